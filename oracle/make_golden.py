@@ -1,0 +1,80 @@
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Runs only where /root/reference exists (it does not
+travel to the GPU box); the fixtures it writes are committed.
+
+    python oracle/make_golden.py
+
+For every case in oracle/params.py::CASES it loads the unmodified reference
+module by file path (vit.py / simple_vit.py import only torch + einops;
+importing the package would pull torchvision via __init__.py:5 -> dino.py:9),
+constructs the model, loads the deterministic state_dict, runs
+forward + ``loss_fn`` + backward in fp32 on the CPU and stores
+
+    logits            the model output
+    grad::<key>       d loss / d parameter for every state_dict key
+    loss              the scalar
+
+Weights and inputs are NOT stored: they are regenerated from the seed by
+oracle/params.py (numpy RNG, platform independent).
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle.params import CASES, make_images, make_params  # noqa: E402
+from oracle.vit_oracle import loss_fn  # noqa: E402
+
+REF = "/root/reference/vit_pytorch"
+
+
+def load_ref(name: str):
+    spec = importlib.util.spec_from_file_location(f"_ref_{name}", os.path.join(REF, f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def run_reference(kind: str, cfg: dict, params, img):
+    mod = load_ref("vit" if kind == "vit" else "simple_vit")
+    cls = mod.ViT if kind == "vit" else mod.SimpleViT
+    model = cls(**cfg)
+    missing = model.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.train()  # dropout p = 0 in every case, so train == eval numerically
+    out = model(img)
+    loss = loss_fn(out)
+    loss.backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+    return out.detach(), loss.detach(), grads
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)  # fixed reduction order
+    outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for name, case in CASES.items():
+        params = make_params(case["kind"], case["cfg"], case["seed"])
+        img = make_images(case["cfg"], case["batch"], case["seed"] + 1000, case.get("image"))
+        out, loss, grads = run_reference(case["kind"], case["cfg"], params, img)
+        blob = {"logits": out.numpy(), "loss": loss.numpy()}
+        for k, g in grads.items():
+            blob["grad::" + k] = g.numpy()
+        path = os.path.join(outdir, name + ".npz")
+        np.savez(path, **blob)
+        print(f"{name}: logits {tuple(out.shape)} loss {float(loss):.6f} "
+              f"{len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main()

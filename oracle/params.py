@@ -1,0 +1,127 @@
+"""Deterministic, torch-RNG-independent weights and inputs for parity tests.
+
+TEST INFRASTRUCTURE ONLY (see oracle/vit_oracle.py header).
+
+The reference constructors draw weights from torch's global RNG, which cannot be
+replayed on the GPU box (the reference is absent there).  Parity fixtures
+therefore use weights generated HERE from a numpy ``default_rng(seed)`` stream
+and loaded into the reference with ``load_state_dict`` by ``make_golden.py``.
+The key names and shapes are the ``state_dict`` contract of the reference
+(vit.py:99-116, simple_vit.py:90-108); distributions
+mimic the reference's defaults (Linear: U(-1/sqrt(fan_in), 1/sqrt(fan_in));
+cls/pos: N(0,1)) except that LayerNorm affine parameters are perturbed away
+from (1, 0) so that their gradients and the affine path are exercised.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+
+def _pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def param_shapes(kind: str, cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict key -> shape, in the reference's registration order."""
+    ih, iw = _pair(cfg["image_size"])
+    ph, pw = _pair(cfg["patch_size"])
+    ch = cfg.get("channels", 3)
+    D, depth, heads = cfg["dim"], cfg["depth"], cfg["heads"]
+    dh = cfg.get("dim_head", 64)
+    F = cfg["mlp_dim"]
+    C = cfg["num_classes"]
+    I = heads * dh
+    P = ch * ph * pw
+    Np = (ih // ph) * (iw // pw)
+    simple = kind == "simple_vit"
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    if not simple:
+        ncls = 1 if cfg.get("pool", "cls") == "cls" else 0
+        s["cls_token"] = (ncls, D)
+        s["pos_embedding"] = (Np + ncls, D)
+    s["to_patch_embedding.1.weight"] = (P,)
+    s["to_patch_embedding.1.bias"] = (P,)
+    s["to_patch_embedding.2.weight"] = (D, P)
+    s["to_patch_embedding.2.bias"] = (D,)
+    s["to_patch_embedding.3.weight"] = (D,)
+    s["to_patch_embedding.3.bias"] = (D,)
+    s["transformer.norm.weight"] = (D,)
+    s["transformer.norm.bias"] = (D,)
+    for i in range(depth):
+        a = f"transformer.layers.{i}.0."
+        f = f"transformer.layers.{i}.1."
+        s[a + "norm.weight"] = (D,)
+        s[a + "norm.bias"] = (D,)
+        s[a + "to_qkv.weight"] = (3 * I, D)
+        if simple:
+            s[a + "to_out.weight"] = (D, I)
+        elif not (heads == 1 and dh == D):
+            s[a + "to_out.0.weight"] = (D, I)
+            s[a + "to_out.0.bias"] = (D,)
+        s[f + "net.0.weight"] = (D,)
+        s[f + "net.0.bias"] = (D,)
+        s[f + "net.1.weight"] = (F, D)
+        s[f + "net.1.bias"] = (F,)
+        second = "net.3." if simple else "net.4."
+        s[f + second + "weight"] = (D, F)
+        s[f + second + "bias"] = (D,)
+    if simple:
+        s["linear_head.weight"] = (C, D)
+        s["linear_head.bias"] = (C,)
+    elif C > 0:
+        s["mlp_head.weight"] = (C, D)
+        s["mlp_head.bias"] = (C,)
+    return s
+
+
+def make_params(kind: str, cfg: dict, seed: int) -> Dict[str, torch.Tensor]:
+    rng = np.random.default_rng(seed)
+    out: Dict[str, torch.Tensor] = OrderedDict()
+    for name, shape in param_shapes(kind, cfg).items():
+        n = int(np.prod(shape)) if len(shape) else 1
+        if name in ("cls_token", "pos_embedding"):
+            a = rng.standard_normal(n)
+        elif len(shape) == 2:  # Linear weight (out, in)
+            bound = 1.0 / np.sqrt(shape[1])
+            a = rng.uniform(-bound, bound, n)
+        elif name.endswith("norm.weight") or name.endswith("net.0.weight") or \
+                name in ("to_patch_embedding.1.weight", "to_patch_embedding.3.weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(n)  # LayerNorm gamma
+        elif name.endswith("norm.bias") or name.endswith("net.0.bias") or \
+                name in ("to_patch_embedding.1.bias", "to_patch_embedding.3.bias"):
+            a = 0.1 * rng.standard_normal(n)  # LayerNorm beta
+        else:  # Linear bias
+            a = rng.uniform(-0.05, 0.05, n)
+        out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape)).clone()
+    return out
+
+
+def make_images(cfg: dict, batch: int, seed: int, image_size=None) -> torch.Tensor:
+    ih, iw = _pair(image_size if image_size is not None else cfg["image_size"])
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((batch, cfg.get("channels", 3), ih, iw)).astype(np.float32)
+    return torch.from_numpy(a)
+
+
+# The parity cases.  cfg1 is BASELINE.json configs[0].
+CASES = {
+    "cfg1_simple_vit_tiny": dict(
+        kind="simple_vit", batch=8, seed=0,
+        cfg=dict(image_size=32, patch_size=4, num_classes=10, dim=64, depth=2, heads=4, mlp_dim=128)),
+    "vit_cls_tiny": dict(
+        kind="vit", batch=3, seed=1,
+        cfg=dict(image_size=32, patch_size=8, num_classes=7, dim=32, depth=2, heads=2, dim_head=16,
+                 mlp_dim=64, pool="cls")),
+    "vit_mean_rect": dict(  # non-square image/patch, mean pool, dim_head != dim/heads
+        kind="vit", batch=2, seed=2,
+        cfg=dict(image_size=(24, 32), patch_size=(4, 8), num_classes=5, dim=48, depth=1, heads=3,
+                 dim_head=8, mlp_dim=40, pool="mean")),
+    "vit_tokens_small_input": dict(  # num_classes=0 -> tokens out; input smaller than image_size (vit.py:125-127)
+        kind="vit", batch=2, seed=3, image=(16, 24),
+        cfg=dict(image_size=32, patch_size=8, num_classes=0, dim=32, depth=1, heads=2, dim_head=16,
+                 mlp_dim=48, pool="cls")),
+}

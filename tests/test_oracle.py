@@ -1,0 +1,103 @@
+"""CPU: the oracle restatement must reproduce the reference's own outputs (tests/golden/*.npz,
+written by oracle/make_golden.py from /root/reference) and its explicit backward formulas must
+agree with autograd of its forward."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as O
+from oracle.params import CASES, make_images, make_params
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REL_TOL_FP32 = 2e-6   # fp32 oracle vs fp32 reference (different op order only)
+REL_TOL_FP64 = 2e-6   # fp64 oracle vs fp32 reference: bounded by the reference's own fp32 rounding
+
+
+def rel_l2(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    d = (a - b).norm()
+    n = b.norm()
+    return float(d / n) if n > 0 else float(d)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_oracle_matches_reference_golden(name, dtype):
+    case = CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000, case.get("image"))
+    out, grads = O.run_fwd_bwd(case["kind"], case["cfg"], params, img, dtype=dtype)
+    tol = REL_TOL_FP32 if dtype == torch.float32 else REL_TOL_FP64
+    assert out.shape == gold["logits"].shape
+    assert rel_l2(out, torch.from_numpy(gold["logits"])) <= tol
+    for k in params:
+        g_ref = torch.from_numpy(gold["grad::" + k])
+        assert grads[k].shape == g_ref.shape, k
+        if g_ref.numel() == 0:
+            continue
+        # gradient tolerance: relative to the gradient's own norm, a few ulps of fp32 accumulation
+        assert rel_l2(grads[k], g_ref) <= 2e-5, (k, rel_l2(grads[k], g_ref))
+
+
+def test_patchify_is_channel_fastest():
+    img = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    x = O.patchify(img, 2, 3)  # h=2, w=2 patches of 2x3
+    assert x.shape == (2, 4, 18)
+    # patch (h=1, w=0): rows 2..3, cols 0..2 ; element (i=1,j=2,c=1) -> index (1*3+2)*3+1
+    assert x[1, 2, (1 * 3 + 2) * 3 + 1] == img[1, 1, 2 + 1, 0 + 2]
+
+
+def test_sincos_table_properties():
+    pe = O.posemb_sincos_2d(3, 5, 16)
+    assert pe.shape == (15, 16) and pe.dtype == torch.float32
+    # token (y=0,x=0): sin=0, cos=1 in both halves
+    assert torch.allclose(pe[0], torch.tensor([0.] * 4 + [1.] * 4 + [0.] * 4 + [1.] * 4))
+    # x is the column index and comes first: token 1 = (y=0, x=1)
+    assert torch.allclose(pe[1, 0], torch.sin(torch.tensor(1.0)))
+    assert torch.allclose(pe[5, 8], torch.sin(torch.tensor(1.0)))  # token 5 = (y=1,x=0) -> y block
+
+
+def _autograd(fn, *xs):
+    xs = [x.clone().double().requires_grad_(True) for x in xs]
+    out = fn(*xs)
+    g = torch.randn_like(out)
+    out.backward(g)
+    return g, [x.grad for x in xs]
+
+
+def test_layer_norm_bwd_formula():
+    torch.manual_seed(0)
+    x = torch.randn(5, 7, 24).double(); w = torch.randn(24).double(); b = torch.randn(24).double()
+    g, (dx, dw, db) = _autograd(lambda x, w, b: O.layer_norm_fwd(x, w, b)[0], x, w, b)
+    _, mean, rstd = O.layer_norm_fwd(x, w, b)
+    dx2, dw2, db2 = O.layer_norm_bwd(g, x, w, mean, rstd)
+    assert rel_l2(dx2, dx) < 1e-12 and rel_l2(dw2, dw) < 1e-12 and rel_l2(db2, db) < 1e-12
+
+
+def test_gelu_bwd_formula():
+    torch.manual_seed(1)
+    x = torch.randn(1000).double() * 3
+    g, (dx,) = _autograd(O.gelu_fwd, x)
+    assert rel_l2(O.gelu_bwd(g, x), dx) < 1e-12
+    # and the forward is torch's exact-erf GELU
+    assert rel_l2(O.gelu_fwd(x), torch.nn.functional.gelu(x)) < 1e-15
+
+
+def test_linear_bwd_formula():
+    torch.manual_seed(2)
+    x = torch.randn(4, 9, 6).double(); w = torch.randn(5, 6).double(); b = torch.randn(5).double()
+    g, (dx, dw, db) = _autograd(O.linear_fwd, x, w, b)
+    dx2, dw2, db2 = O.linear_bwd(g, x, w, True)
+    assert rel_l2(dx2, dx) < 1e-12 and rel_l2(dw2, dw) < 1e-12 and rel_l2(db2, db) < 1e-12
+
+
+def test_attention_core_bwd_formula():
+    torch.manual_seed(3)
+    q, k, v = (torch.randn(2, 3, 11, 8).double() for _ in range(3))
+    scale = 8 ** -0.5
+    g, (dq, dk, dv) = _autograd(lambda q, k, v: O.attention_core_fwd(q, k, v, scale)[0], q, k, v)
+    dq2, dk2, dv2 = O.attention_core_bwd(g, q, k, v, scale)
+    assert rel_l2(dq2, dq) < 1e-12 and rel_l2(dk2, dk) < 1e-12 and rel_l2(dv2, dv) < 1e-12
