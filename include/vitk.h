@@ -1,0 +1,178 @@
+/* vitk.h -- C-ABI of libvitk.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * ViT / SimpleViT encoder forward + backward hot path.
+ *
+ * The reference (lucidrains/vit-pytorch) has NO native layer and NO FFI: its hot path is
+ * Python calling torch.nn / einops.  The "FFI the reference would bind" is
+ * therefore the set of ATen ops its hot path dispatches; each entry point below names the
+ * reference call site(s) (file:line under /root/reference/vit_pytorch/) it replaces.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, int64 sizes, a dtype tag, and the hipStream_t (passed as
+ *     void*) to enqueue on.  No torch types.  Nothing here allocates, frees or synchronises;
+ *     kernels are enqueued on `stream` and the call returns.  Never uses the null stream
+ *     unless the caller passes it.
+ *   - return value: 0 = OK; < 0 = argument/shape/alignment error detected on the host before
+ *     any launch (VITK_E_*); > 0 = hipError_t from the launch.  vitk_last_error() returns a
+ *     thread-local human readable string for the last non-zero return on this thread.
+ *   - thread safety: re-entrant; no global mutable state (error string is thread-local).
+ *     Callable from the autograd worker thread.
+ *   - dtype tags: VITK_F32 = 0, VITK_BF16 = 1.  "T" below means the model dtype.
+ *   - all matrices are row-major with explicit leading dimensions (in elements).
+ */
+#ifndef VITK_H
+#define VITK_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITK_VERSION 100
+
+#define VITK_F32 0
+#define VITK_BF16 1
+
+#define VITK_E_ARG (-1)      /* null pointer / bad enum */
+#define VITK_E_SHAPE (-2)    /* unsupported extent */
+#define VITK_E_ALIGN (-3)    /* pointer or leading dimension not aligned as required */
+#define VITK_E_DTYPE (-4)    /* unsupported dtype combination */
+
+int vitk_version(void);
+const char* vitk_last_error(void);
+
+/* A row map sends logical row r to physical row (r / group) * gstride + (r % group) + offset.
+ * Identity: group = 0 (treated as "no map").  Used to read the cls rows of a (B,N,D) tensor
+ * (group 1, gstride N) or to write patch rows behind a cls slot (group Np, gstride N, offset 1). */
+typedef struct vitk_rowmap { int64_t group, gstride, offset; } vitk_rowmap;
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm  (replaces nn.LayerNorm at vit.py:19,39,69,101,103 / simple_vit.py:29,42,67,92,94)
+ *   y[omap(r), :] = (x[imap(r), :] - mean_r) * rstd_r * w + b  (+ add[(r % add_group) + add_off, :])
+ *   mean/rstd (f32, indexed by logical r) are saved for backward.  Biased variance, eps in sqrt.
+ *   `add` (nullable, dtype wdt, ld = D) fuses the positional-embedding add of vit.py:127 /
+ *   simple_vit.py:114.  D % 4 == 0, D <= 4096.
+ * ------------------------------------------------------------------------------------------ */
+int vitk_layernorm_fwd(const void* x, int xdt, const void* w, const void* b, int wdt,
+                       void* y, int ydt, float* mean, float* rstd,
+                       int64_t rows, int64_t D, float eps,
+                       vitk_rowmap imap, vitk_rowmap omap,
+                       const void* add, int64_t add_group, int64_t add_off, void* stream);
+
+/* LayerNorm backward.
+ *   g   = dy[dymap(r)] * w ; xhat = (x[xmap(r)] - mean_r) * rstd_r
+ *   dx  = rstd_r * (g - mean(g) - xhat * mean(g * xhat))            (+ gin[dxmap(r)] if gin)
+ *   written to dx_f32[dxmap(r)] and/or dx_T[dxmap(r)] (either may be null; both null = only dw/db)
+ *   dw/db partial column sums go to `partials` (f32, 2 * nblk * D, nblk = vitk_layernorm_bwd_blocks());
+ *   finish with vitk_colsum_partials.  If colsum_dx != 0 a third slab (column sums of the value
+ *   written to dx, i.e. the bias gradient of the Linear that produced the residual branch) is
+ *   also accumulated: partials has 3 * nblk * D floats.
+ */
+int64_t vitk_layernorm_bwd_blocks(int64_t rows);
+int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int xdt, const void* w, int wdt,
+                       const float* mean, const float* rstd,
+                       const float* gin, float* dx_f32, void* dx_t, int dxtdt,
+                       float* partials, int colsum_dx,
+                       int64_t rows, int64_t D,
+                       vitk_rowmap dymap, vitk_rowmap xmap, vitk_rowmap dxmap, void* stream);
+
+/* out[c] (dtype odt) = (accumulate ? out[c] : 0) + sum_{p < nparts} partials[p * ld + c], c < cols */
+int vitk_colsum_partials(const float* partials, int64_t nparts, int64_t ld, int64_t cols,
+                         void* out, int odt, int accumulate, void* stream);
+
+/* Column sums of a (rows x cols) matrix (bias gradients: db = colsum(dY); pos/cls gradients:
+ * sum over the batch of a (B, N*D) view).  ws: f32 workspace of vitk_colsum_ws_floats() floats. */
+int64_t vitk_colsum_ws_floats(int64_t rows, int64_t cols);
+int vitk_colsum(const void* x, int xdt, int64_t rows, int64_t cols, int64_t ld,
+                void* out, int odt, int accumulate, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMMs (replace nn.Linear at vit.py:20,23,44,47,102 and their autograd)
+ * ------------------------------------------------------------------------------------------ */
+#define VITK_EPI_NONE 0        /* C = acc                                  (C: bf16)            */
+#define VITK_EPI_BIAS 1        /* C = acc + bias[n]                                             */
+#define VITK_EPI_BIAS_GELU 2   /* aux = acc + bias (pre-activation, bf16); C = gelu_erf(aux)    */
+#define VITK_EPI_RESID 3       /* Cf32 = resid_f32 + acc (+ bias[n] if bias)  (C: f32)          */
+#define VITK_EPI_GELU_BWD 4    /* C = acc * gelu'(aux[m][n])   (aux = saved pre-activation)     */
+
+/* C[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  A, W bf16, K-contiguous ("NT").
+ * Requirements: K % 32 == 0; lda, ldw % 8 == 0; N % 4 == 0; pointers 16-byte aligned.
+ * bias: bf16 [N] or null.  resid: f32 [M, ldc].  aux: bf16 [M, ldc].                          */
+int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
+                      void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                      int epilogue, const void* bias, const float* resid, void* aux, void* stream);
+
+/* dW[N,K] = sum_m dY[m,N]^T X[m,K]  ("TN": both operands are read with the reduction index as
+ * the strided one).  Split over M into `splits` slabs of f32 partials (ws: splits*N*K floats),
+ * then reduced into dW (dtype odt, ld = ldo; accumulate: dW += ...).  N % 8 == 0, K % 8 == 0.  */
+int64_t vitk_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
+int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int64_t ldx,
+                      void* dW, int odt, int64_t ldo, int accumulate,
+                      int64_t M, int64_t N, int64_t K, float* ws, int64_t splits, void* stream);
+
+/* Generic strided batched GEMM for everything the fast kernels do not cover (f32 validation
+ * mode, odd extents, the materialising attention path needed by forward hooks on `attend`):
+ *   C[b1,b2][m][n] = alpha * sum_k A[b1,b2][m][k] * B[b1,b2][k][n] + beta * C (+ bias[n])
+ * every operand addressed as base + b1*s_b1 + b2*s_b2 + row*s_row + col*s_col (element strides),
+ * dtypes f32 or bf16 per operand, f32 accumulation.                                            */
+typedef struct vitk_mat { const void* p; int dt; int64_t s_b1, s_b2, s_row, s_col; } vitk_mat;
+int vitk_gemm_generic(vitk_mat A, vitk_mat B, vitk_mat C, const void* bias, int bias_dt,
+                      int64_t nb1, int64_t nb2, int64_t M, int64_t N, int64_t K,
+                      float alpha, float beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention core  (replaces vit.py:57-62: matmul(q,k^T)*scale -> softmax -> matmul(attn,v))
+ * Fused, never materialises the N x N matrix.  bf16, dim_head == 64.
+ * q/k/v/o addressed as base + b*s_b + h*s_h + n*s_n + d (element strides, d contiguous), so the
+ * merged (B, N, 3*h*d) output of the to_qkv GEMM is consumed in place (no head-split copies:
+ * replaces the three rearranges of vit.py:55 and the merge of vit.py:63).
+ * lse: f32 (B, H, N) row log-sum-exp of the scaled scores, saved for backward.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vitk_bhnd { void* p; int64_t s_b, s_h, s_n; } vitk_bhnd;
+int vitk_attn_fwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, float* lse,
+                       int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream);
+/* delta: f32 (B,H,N) scratch (rowsum(dO*O)), written by the call. */
+int vitk_attn_bwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_bhnd dout,
+                       const float* lse, float* delta,
+                       vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv,
+                       int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream);
+
+/* Materialising path pieces (nn.Softmax at vit.py:41,59; needed when `attend` has forward hooks,
+ * for dim_head != 64 and for f32 validation mode): row softmax of scale*s and its backward.  */
+int vitk_softmax_fwd(const void* s, void* p, int dt, int64_t rows, int64_t cols, float scale, void* stream);
+/* ds = scale * p * (dp - rowsum(dp * p)) */
+int vitk_softmax_bwd(const void* p, const void* dp, void* ds, int dt, int64_t rows, int64_t cols,
+                     float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise / data movement
+ * ------------------------------------------------------------------------------------------ */
+/* Rearrange 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit.py:100): out[(b*h*w), p1*p2*c]        */
+int vitk_patchify(const void* img, void* out, int dt, int64_t B, int64_t C, int64_t H, int64_t W,
+                  int64_t p1, int64_t p2, void* stream);
+/* y = gelu_erf(x) (vit.py:21) ; dx = dy * gelu'(x) */
+int vitk_gelu_fwd(const void* x, void* y, int dt, int64_t n, void* stream);
+int vitk_gelu_bwd(const void* dy, const void* x, void* dx, int dt, int64_t n, void* stream);
+/* out[r, :] = a[r, :] + b[r, :] (+ bias[:]) ; a f32 or T, b T, out f32 or T (residual adds)   */
+int vitk_add_rows(const void* a, int adt, const void* b, int bdt, const void* bias, int biasdt,
+                  void* out, int odt, int64_t rows, int64_t cols, void* stream);
+/* dtype conversion / copy, n elements */
+int vitk_cast(const void* x, int xdt, void* y, int ydt, int64_t n, void* stream);
+/* x[b, 0:ncls, :] = cls[0:ncls, :] + pos[0:ncls, :] for every b (vit.py:122-127); x f32 or T   */
+int vitk_write_cls_rows(void* x, int xdt, const void* cls, const void* pos, int pdt,
+                        int64_t B, int64_t N, int64_t D, int64_t ncls, void* stream);
+/* out[b, :] = mean_n x[b, n, :] (vit.py:135 pool='mean') ; dx[b, n, :] = dout[b, :] / N          */
+int vitk_mean_pool_fwd(const void* x, int xdt, void* out, int odt, int64_t B, int64_t N, int64_t D, void* stream);
+int vitk_mean_pool_bwd(const void* dout, int ddt, void* dx, int xdt, int64_t B, int64_t N, int64_t D, void* stream);
+/* Counter-based dropout (nn.Dropout at vit.py:22,24,42,48,109): y = x * keep / (1-p); mask u8. */
+int vitk_dropout_fwd(const void* x, void* y, uint8_t* mask, int dt, int64_t n, float p,
+                     uint64_t seed, uint64_t offset, void* stream);
+int vitk_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dt, int64_t n, float p, void* stream);
+/* 2-D transpose out[c][r] = in[r][c] (weights: W^T for the dX GEMMs) */
+int vitk_transpose(const void* in, void* out, int dt, int64_t rows, int64_t cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITK_H */

@@ -1,0 +1,400 @@
+"""GPU: every libvitk kernel, called through the C-ABI, against a plain PyTorch reference of the
+same op evaluated in fp32/fp64 on the same inputs.  Tolerances are stated per test: f32 kernels are
+held to f32 round-off, bf16 kernels to bf16 output rounding (2^-8 relative) around an f32-accumulated
+result."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from vit_pytorch_amd import kernels as K  # noqa: E402
+from vit_pytorch_amd import _lib as L  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+F32 = torch.float32
+
+
+def rel(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    n = b.norm().item()
+    return (a - b).norm().item() / (n if n > 0 else 1.0)
+
+
+def maxabs(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+def rnd(*shape, dtype=F32, scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xffff))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("xdt,ydt,wdt", [(F32, F32, F32), (F32, BF, BF), (F32, F32, BF), (BF, BF, BF), (BF, F32, BF)])
+@pytest.mark.parametrize("rows,D", [(37, 64), (1000, 768), (50, 1024), (9, 1280), (5, 3072), (6, 48)])
+def test_layernorm_fwd(xdt, ydt, wdt, rows, D):
+    x = rnd(rows, D, dtype=xdt, seed=1) * 2 + 0.5
+    w = (1 + 0.1 * rnd(D, seed=2)).to(wdt); b = (0.1 * rnd(D, seed=3)).to(wdt)
+    y = torch.empty(rows, D, dtype=ydt, device=DEV)
+    mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+    K.layernorm_fwd(x, w, b, y, mean, rstd, rows, D)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5)
+    tol = 2e-6 if ydt == F32 else 4e-3
+    assert rel(y, ref) < tol
+    assert rel(mean, x.double().mean(-1)) < 1e-5
+    assert rel(rstd, 1 / torch.sqrt(x.double().var(-1, unbiased=False) + 1e-5)) < 1e-5
+
+
+def test_layernorm_fwd_rowmaps_and_posadd():
+    B, Np, D = 3, 6, 64
+    N = Np + 1
+    x = rnd(B * Np, D, dtype=BF, seed=4)
+    w = rnd(D, dtype=BF, seed=5); b = rnd(D, dtype=BF, seed=6)
+    pos = rnd(N, D, dtype=BF, seed=7)
+    out = torch.zeros(B, N, D, device=DEV)
+    mean = torch.empty(B * Np, device=DEV); rstd = torch.empty(B * Np, device=DEV)
+    K.layernorm_fwd(x, w, b, out, mean, rstd, B * Np, D, omap=L.RowMap(Np, N, 1), add=pos, add_group=Np, add_off=1)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float()).view(B, Np, D) + pos.float()[1:]
+    assert rel(out[:, 1:], ref) < 2e-6
+    assert out[:, 0].abs().max().item() == 0
+    # read only the cls rows of a (B,N,D) tensor
+    xs = rnd(B, N, D, seed=8)
+    y = torch.empty(B, D, dtype=BF, device=DEV)
+    m2 = torch.empty(B, device=DEV); r2 = torch.empty(B, device=DEV)
+    K.layernorm_fwd(xs, w, b, y, m2, r2, B, D, imap=L.RowMap(1, N, 0))
+    ref = torch.nn.functional.layer_norm(xs[:, 0], (D,), w.float(), b.float())
+    assert rel(y, ref) < 4e-3
+
+
+@pytest.mark.parametrize("dydt,xdt,wdt", [(F32, F32, F32), (BF, F32, BF), (BF, BF, BF), (F32, F32, BF)])
+@pytest.mark.parametrize("rows,D", [(333, 768), (40, 64), (7, 1280), (2100, 256)])
+def test_layernorm_bwd(dydt, xdt, wdt, rows, D):
+    x = rnd(rows, D, dtype=xdt, seed=11) * 1.5 + 0.3
+    dy = rnd(rows, D, dtype=dydt, seed=12)
+    w = (1 + 0.2 * rnd(D, seed=13)).to(wdt); b = (0.1 * rnd(D, seed=14)).to(wdt)
+    gin = rnd(rows, D, seed=15)
+    xd = x.double().requires_grad_(True); wd = w.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(xd, (D,), wd, bd, 1e-5)
+    yref.backward(dy.double())
+    mean = x.double().mean(-1).float(); rstd = (1 / torch.sqrt(x.double().var(-1, unbiased=False) + 1e-5)).float()
+    nblk = K.layernorm_bwd_blocks(rows)
+    partials = torch.empty(3 * nblk * D, device=DEV)
+    dxf = torch.empty(rows, D, device=DEV)
+    dxt = torch.empty(rows, D, dtype=wdt, device=DEV)
+    K.layernorm_bwd(dy, x, w, mean, rstd, gin, dxf, dxt, partials, True, rows, D)
+    dw = torch.empty(D, dtype=wdt, device=DEV); db = torch.empty(D, dtype=wdt, device=DEV); dc = torch.empty(D, device=DEV)
+    K.colsum_partials(partials, nblk, D, D, dw)
+    K.colsum_partials(partials[nblk * D:], nblk, D, D, db)
+    K.colsum_partials(partials[2 * nblk * D:], nblk, D, D, dc)
+    dx_ref = xd.grad + gin.double()
+    assert rel(dxf, dx_ref) < 3e-6
+    assert rel(dxt, dx_ref) < (3e-6 if wdt == F32 else 4e-3)
+    tolw = 1e-5 if wdt == F32 else 5e-3
+    assert rel(dw, wd.grad) < tolw and rel(db, bd.grad) < tolw
+    assert rel(dc, dx_ref.sum(0)) < 1e-4
+
+
+def test_layernorm_bwd_maps():
+    # dy rows are the cls rows result (B rows), x rows are strided in (B,N,D), dx scattered to row 0 of each image
+    B, N, D = 4, 5, 64
+    xs = rnd(B, N, D, seed=21)
+    dy = rnd(B, D, dtype=BF, seed=22)
+    w = rnd(D, dtype=BF, seed=23)
+    mean = xs[:, 0].mean(-1).contiguous(); rstd = (1 / torch.sqrt(xs[:, 0].var(-1, unbiased=False) + 1e-5)).contiguous()
+    nblk = K.layernorm_bwd_blocks(B)
+    partials = torch.empty(2 * nblk * D, device=DEV)
+    dx = torch.zeros(B, N, D, device=DEV)
+    m = L.RowMap(1, N, 0)
+    K.layernorm_bwd(dy, xs, w, mean, rstd, None, dx, None, partials, False, B, D, xmap=m, dxmap=m)
+    xd = xs[:, 0].double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (D,), w.double(), None, 1e-5).backward(dy.double())
+    assert rel(dx[:, 0], xd.grad) < 3e-6
+    assert dx[:, 1:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("rows,cols,xdt,odt", [(1000, 768, BF, BF), (257, 3072, BF, F32), (256, 197 * 64, F32, F32), (3, 8, F32, BF), (300, 10, BF, F32), (17, 7, F32, F32)])
+def test_colsum(rows, cols, xdt, odt):
+    x = rnd(rows, cols, dtype=xdt, seed=31)
+    ws = torch.empty(K.colsum_ws_floats(rows, cols), device=DEV)
+    out = torch.empty(cols, dtype=odt, device=DEV)
+    K.colsum(x, rows, cols, cols, out, ws)
+    assert rel(out, x.double().sum(0)) < (1e-5 if odt == F32 else 4e-3)
+    K.colsum(x, rows, cols, cols, out, ws, accumulate=True)
+    assert rel(out, 2 * x.double().sum(0)) < (1e-5 if odt == F32 else 8e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(128, 128, 32), (256, 384, 64), (197 * 3, 768, 768), (1000, 2304, 768), (130, 132, 96), (64, 64, 64), (50432 // 8, 768, 3072)]
+
+
+@pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
+def test_gemm_nt_plain_and_bias(M, N, Kd):
+    A = rnd(M, Kd, dtype=BF, seed=41); W = rnd(N, Kd, dtype=BF, seed=42) * (Kd ** -0.5)
+    bias = rnd(N, dtype=BF, seed=43)
+    ref = A.double() @ W.double().t()
+    C = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt_bf16(A, Kd, W, Kd, C, N, M, N, Kd)
+    assert rel(C, ref) < 4e-3, "plain"
+    # exactness up to bf16 output rounding: compare with the bf16-rounded f32 result
+    assert maxabs(C, ref.float().to(BF)) <= 2 * 2 ** -8 * ref.abs().max().item()
+    K.gemm_nt_bf16(A, Kd, W, Kd, C, N, M, N, Kd, L.EPI_BIAS, bias=bias)
+    assert rel(C, ref + bias.double()) < 4e-3, "bias"
+
+
+@pytest.mark.parametrize("M,N,Kd", [(197 * 2, 768, 768), (300, 3072, 768), (256, 768, 3072)])
+def test_gemm_nt_epilogues(M, N, Kd):
+    A = rnd(M, Kd, dtype=BF, seed=44); W = rnd(N, Kd, dtype=BF, seed=45) * (Kd ** -0.5)
+    bias = rnd(N, dtype=BF, seed=46)
+    ref = A.double() @ W.double().t()
+    # bias + gelu, saving the pre-activation
+    C = torch.empty(M, N, dtype=BF, device=DEV); aux = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt_bf16(A, Kd, W, Kd, C, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    pre = ref + bias.double()
+    assert rel(aux, pre) < 4e-3
+    assert rel(C, torch.nn.functional.gelu(pre)) < 4e-3
+    # residual (f32 stream), with and without bias
+    resid = rnd(M, N, seed=47)
+    out = torch.empty(M, N, device=DEV)
+    K.gemm_nt_bf16(A, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid)
+    assert rel(out, resid.double() + pre) < 1e-5
+    K.gemm_nt_bf16(A, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, resid=resid)
+    assert rel(out, resid.double() + ref) < 1e-5
+    # in-place residual (out aliases resid) is what the engine does
+    r2 = resid.clone()
+    K.gemm_nt_bf16(A, Kd, W, Kd, r2, N, M, N, Kd, L.EPI_RESID, resid=r2)
+    assert rel(r2, resid.double() + ref) < 1e-5
+    # gelu backward epilogue
+    h = rnd(M, N, dtype=BF, seed=48)
+    K.gemm_nt_bf16(A, Kd, W, Kd, C, N, M, N, Kd, L.EPI_GELU_BWD, aux=h)
+    hd = h.double().requires_grad_(True)
+    torch.nn.functional.gelu(hd).backward(ref)
+    assert rel(C, hd.grad) < 4e-3
+
+
+def test_gemm_nt_rejects_bad_shapes():
+    A = rnd(64, 40, dtype=BF); W = rnd(64, 40, dtype=BF); C = torch.empty(64, 64, dtype=BF, device=DEV)
+    with pytest.raises(L.VitkError):
+        K.gemm_nt_bf16(A, 40, W, 40, C, 64, 64, 64, 40)  # K % 32 != 0
+
+
+@pytest.mark.parametrize("M,N,Kd", [(64, 128, 128), (1000, 768, 768), (197 * 16, 2304, 768), (333, 136, 72), (197 * 8, 768, 3072), (5000, 64, 256)])
+@pytest.mark.parametrize("odt", [BF, F32])
+def test_gemm_tn(M, N, Kd, odt):
+    dY = rnd(M, N, dtype=BF, seed=51) * (M ** -0.5); X = rnd(M, Kd, dtype=BF, seed=52)
+    ref = dY.double().t() @ X.double()
+    splits = K.gemm_tn_splits(M, N, Kd)
+    ws = torch.empty(splits * N * Kd, device=DEV)
+    dW = torch.empty(N, Kd, dtype=odt, device=DEV)
+    K.gemm_tn_bf16(dY, N, X, Kd, dW, Kd, M, N, Kd, ws, splits)
+    assert rel(dW, ref) < (1e-5 if odt == F32 else 4e-3)
+    K.gemm_tn_bf16(dY, N, X, Kd, dW, Kd, M, N, Kd, ws, splits, accumulate=True)
+    assert rel(dW, 2 * ref) < (1e-5 if odt == F32 else 8e-3)
+
+
+def test_gemm_tn_strided_operands():
+    # dY is a column slice of a wider matrix (the merged dqkv buffer), X likewise
+    M, N, Kd = 700, 128, 64
+    big = rnd(M, 3 * N, dtype=BF, seed=53); xb = rnd(M, 2 * Kd, dtype=BF, seed=54)
+    ref = big[:, N:2 * N].double().t() @ xb[:, Kd:].double()
+    splits = 3
+    ws = torch.empty(splits * N * Kd, device=DEV)
+    dW = torch.empty(N, Kd, device=DEV)
+    dYv = big[:, N:2 * N]; Xv = xb[:, Kd:]
+    check = L.load().vitk_gemm_tn_bf16(dYv.data_ptr(), 3 * N, Xv.data_ptr(), 2 * Kd, dW.data_ptr(), L.F32, Kd, 0, M, N, Kd,
+                                       ws.data_ptr(), splits, torch.cuda.current_stream().cuda_stream)
+    assert check == 0
+    assert rel(dW, ref) < 1e-5
+
+
+@pytest.mark.parametrize("adt,bdt,cdt", [(F32, F32, F32), (BF, BF, BF), (BF, BF, F32)])
+def test_gemm_generic_variants(adt, bdt, cdt):
+    M, N, Kd = 70, 45, 33
+    A = rnd(M, Kd, dtype=adt, seed=61); Bm = rnd(Kd, N, dtype=bdt, seed=62); bias = rnd(N, dtype=cdt, seed=63)
+    C = torch.empty(M, N, dtype=cdt, device=DEV)
+    tol = 1e-5 if cdt == F32 and adt == F32 else (1e-5 if cdt == F32 else 4e-3)
+    # NN
+    K.gemm_generic(K.mat(A, Kd, 1), K.mat(Bm, N, 1), K.mat(C, N, 1), M, N, Kd, bias=bias)
+    assert rel(C, A.double() @ Bm.double() + bias.double()) < tol
+    # NT: B given as (N, K) row-major
+    Bt = Bm.t().contiguous()
+    K.gemm_generic(K.mat(A, Kd, 1), K.mat(Bt, 1, Kd), K.mat(C, N, 1), M, N, Kd)
+    assert rel(C, A.double() @ Bm.double()) < tol
+    # TN: A given as (K, M) row-major, with alpha/beta
+    At = A.t().contiguous()
+    C0 = rnd(M, N, dtype=cdt, seed=64)
+    C.copy_(C0)
+    K.gemm_generic(K.mat(At, 1, M), K.mat(Bm, N, 1), K.mat(C, N, 1), M, N, Kd, alpha=0.5, beta=2.0)
+    assert rel(C, 0.5 * (A.double() @ Bm.double()) + 2 * C0.double()) < (tol * 3)
+
+
+def test_gemm_generic_batched_heads():
+    # scores[b,h] = q[b,:,h,:] @ k[b,:,h,:]^T read in place from a merged (B, N, 3*H*d) tensor
+    B, H, N, d = 2, 3, 19, 16
+    I = H * d
+    qkv = rnd(B, N, 3 * I, seed=65)
+    S = torch.empty(B, H, N, N, device=DEV)
+    K.gemm_generic(K.mat(qkv, 3 * I, 1, N * 3 * I, d), K.mat(qkv, 1, 3 * I, N * 3 * I, d, offset=I),
+                   K.mat(S, N, 1, H * N * N, N * N), N, N, d, nb1=B, nb2=H)
+    q = qkv[..., :I].view(B, N, H, d).permute(0, 2, 1, 3); k = qkv[..., I:2 * I].view(B, N, H, d).permute(0, 2, 1, 3)
+    assert rel(S, q.double() @ k.double().transpose(-1, -2)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, N, H, d, scale, do=None):
+    I = H * d
+    q, k, v = (qkv[..., i * I:(i + 1) * I].reshape(B, N, H, d).permute(0, 2, 1, 3).double() for i in range(3))
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    s = (q @ k.transpose(-1, -2)) * scale
+    p = torch.softmax(s, -1)
+    o = p @ v
+    om = o.permute(0, 2, 1, 3).reshape(B, N, I)
+    lse = torch.logsumexp(s, -1)
+    if do is None:
+        return om.detach(), lse.detach()
+    om.backward(do.double())
+    g = [t.grad.permute(0, 2, 1, 3).reshape(B, N, I) for t in (q, k, v)]
+    return om.detach(), lse.detach(), torch.cat(g, -1)
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 64), (3, 1, 50), (1, 4, 17), (2, 2, 256), (1, 1, 1)])
+def test_attention_fwd_bwd(B, H, N):
+    d = 64
+    I = H * d
+    scale = d ** -0.5
+    qkv = rnd(B, N, 3 * I, dtype=BF, seed=71) * 1.5
+    do = rnd(B, N, I, dtype=BF, seed=72)
+    o = torch.empty(B, N, I, dtype=BF, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    sb, sh, sn = N * 3 * I, d, 3 * I
+    q_ = K.bhnd(qkv, sb, sh, sn); k_ = K.bhnd(qkv, sb, sh, sn, offset=I); v_ = K.bhnd(qkv, sb, sh, sn, offset=2 * I)
+    o_ = K.bhnd(o, N * I, d, I)
+    K.attn_fwd_bf16(q_, k_, v_, o_, lse, B, H, N, d, scale)
+    oref, lref, gref = _attn_ref(qkv, B, N, H, d, scale, do)
+    assert rel(o, oref) < 6e-3, rel(o, oref)
+    assert maxabs(lse, lref) < 2e-3
+    dqkv = torch.zeros(B, N, 3 * I, dtype=BF, device=DEV)
+    delta = torch.empty(B, H, N, device=DEV)
+    K.attn_bwd_bf16(q_, k_, v_, o_, K.bhnd(do, N * I, d, I), lse, delta, K.bhnd(dqkv, sb, sh, sn),
+                    K.bhnd(dqkv, sb, sh, sn, offset=I), K.bhnd(dqkv, sb, sh, sn, offset=2 * I), B, H, N, d, scale)
+    for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
+        r = rel(dqkv[..., sl], gref[..., sl])
+        assert r < 1.2e-2, (name, r)
+
+
+def test_attention_online_softmax_rescale_branch():
+    # force the running max to jump late: one key (in the last 32-key step) dominates one query row
+    B, H, N, d = 1, 1, 197, 64
+    scale = d ** -0.5
+    qkv = rnd(B, N, 3 * d, dtype=BF, seed=73) * 0.5
+    qkv[0, 5, :d] = 4.0           # query 5
+    qkv[0, 190, d:2 * d] = 4.0    # key 190 -> raw score 1024*scale = 128 for (5,190)
+    o = torch.empty(B, N, d, dtype=BF, device=DEV); lse = torch.empty(B, H, N, device=DEV)
+    sb, sh, sn = N * 3 * d, d, 3 * d
+    K.attn_fwd_bf16(K.bhnd(qkv, sb, sh, sn), K.bhnd(qkv, sb, sh, sn, offset=d), K.bhnd(qkv, sb, sh, sn, offset=2 * d),
+                    K.bhnd(o, N * d, d, d), lse, B, H, N, d, scale)
+    oref, lref = _attn_ref(qkv, B, N, H, d, scale)
+    assert torch.isfinite(o.float()).all()
+    assert rel(o, oref) < 6e-3
+    assert maxabs(lse, lref) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+def test_softmax_fwd_bwd(dtype):
+    rows, cols, scale = 77, 197, 0.125
+    s = rnd(rows, cols, dtype=dtype, seed=81) * 4
+    p = torch.empty_like(s)
+    K.softmax_fwd(s, p, rows, cols, scale)
+    sd = s.double().requires_grad_(True)
+    pref = torch.softmax(sd * scale, -1)
+    assert rel(p, pref) < (2e-6 if dtype == F32 else 4e-3)
+    dp = rnd(rows, cols, dtype=dtype, seed=82)
+    ds = torch.empty_like(s)
+    K.softmax_bwd(p, dp, ds, rows, cols, scale)
+    # reference backward evaluated at the kernel's own p (so bf16 rounding of p is not counted twice)
+    pd = p.double()
+    dsref = scale * pd * (dp.double() - (dp.double() * pd).sum(-1, keepdim=True))
+    assert rel(ds, dsref) < (3e-6 if dtype == F32 else 6e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("B,C,H,W,p1,p2", [(2, 3, 32, 32, 4, 4), (1, 3, 224, 224, 16, 16), (2, 1, 24, 32, 4, 8), (1, 3, 64, 64, 32, 32)])
+def test_patchify(dtype, B, C, H, W, p1, p2):
+    img = rnd(B, C, H, W, dtype=dtype, seed=91)
+    h, w = H // p1, W // p2
+    out = torch.empty(B * h * w, p1 * p2 * C, dtype=dtype, device=DEV)
+    K.patchify(img, out, B, C, H, W, p1, p2)
+    ref = img.reshape(B, C, h, p1, w, p2).permute(0, 2, 4, 3, 5, 1).reshape(B * h * w, p1 * p2 * C)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+def test_gelu(dtype):
+    x = rnd(1000, 64, dtype=dtype, seed=92) * 3
+    y = torch.empty_like(x)
+    K.gelu_fwd(x, y)
+    xd = x.double().requires_grad_(True)
+    yr = torch.nn.functional.gelu(xd)
+    assert rel(y, yr) < (2e-6 if dtype == F32 else 4e-3)
+    dy = rnd(1000, 64, dtype=dtype, seed=93)
+    yr.backward(dy.double())
+    dx = torch.empty_like(x)
+    K.gelu_bwd(dy, x, dx)
+    assert rel(dx, xd.grad) < (3e-6 if dtype == F32 else 4e-3)
+
+
+def test_add_rows_cast_cls_meanpool_transpose():
+    rows, cols = 50, 64
+    a = rnd(rows, cols, seed=94); b = rnd(rows, cols, dtype=BF, seed=95); bias = rnd(cols, dtype=BF, seed=96)
+    out = torch.empty(rows, cols, device=DEV)
+    K.add_rows(a, b, bias, out, rows, cols)
+    assert rel(out, a.double() + b.double() + bias.double()) < 1e-6
+    outb = torch.empty(rows, cols, dtype=BF, device=DEV)
+    K.add_rows(a, b, None, outb, rows, cols)
+    assert rel(outb, a.double() + b.double()) < 4e-3
+    # cast
+    x = rnd(1003, seed=97); y = torch.empty(1003, dtype=BF, device=DEV)
+    K.cast(x, y)
+    assert torch.equal(y, x.to(BF))
+    z = torch.empty(1003, device=DEV)
+    K.cast(y, z)
+    assert torch.equal(z, y.float())
+    # cls rows
+    B, N, D = 3, 5, 64
+    xs = torch.zeros(B, N, D, device=DEV); cls = rnd(1, D, dtype=BF, seed=98); pos = rnd(N, D, dtype=BF, seed=99)
+    K.write_cls_rows(xs, cls, pos, B, N, D, 1)
+    assert rel(xs[:, 0], (cls.float() + pos.float()[0:1]).expand(B, D)) < 1e-7
+    assert xs[:, 1:].abs().max().item() == 0
+    # mean pool
+    xt = rnd(B, N, D, dtype=BF, seed=100); mp = torch.empty(B, D, dtype=BF, device=DEV)
+    K.mean_pool_fwd(xt, mp, B, N, D)
+    assert rel(mp, xt.double().mean(1)) < 4e-3
+    dmp = rnd(B, D, dtype=BF, seed=101); dxs = torch.empty(B, N, D, device=DEV)
+    K.mean_pool_bwd(dmp, dxs, B, N, D)
+    assert rel(dxs, (dmp.double() / N).unsqueeze(1).expand(B, N, D)) < 1e-6
+    # transpose
+    w = rnd(70, 45, dtype=BF, seed=102); wt = torch.empty(45, 70, dtype=BF, device=DEV)
+    K.transpose(w, wt, 70, 45)
+    assert torch.equal(wt, w.t().contiguous())
+
+
+def test_dropout_statistics_and_backward():
+    n, p = 1 << 20, 0.1
+    x = torch.ones(n, dtype=BF, device=DEV)
+    y = torch.empty_like(x); mask = torch.empty(n, dtype=torch.uint8, device=DEV)
+    K.dropout_fwd(x, y, mask, p, 1234, 0)
+    keep = mask.float().mean().item()
+    assert abs(keep - (1 - p)) < 3e-3
+    assert rel(y, mask.float() / (1 - p)) < 4e-3
+    y2 = torch.empty_like(x); m2 = torch.empty_like(mask)
+    K.dropout_fwd(x, y2, m2, p, 1234, 0)
+    assert torch.equal(mask, m2)                      # reproducible from (seed, offset)
+    K.dropout_fwd(x, y2, m2, p, 1234, n)
+    assert not torch.equal(mask, m2)                  # a different offset is a different stream
+    dy = rnd(n, dtype=BF, seed=103); dx = torch.empty_like(dy)
+    K.dropout_bwd(dy, mask, dx, p)
+    assert rel(dx, dy.float() * mask.float() / (1 - p)) < 4e-3

@@ -1,0 +1,191 @@
+"""GPU parity of the drop-in modules against (a) the golden vectors produced by the reference
+itself (tests/golden, oracle/make_golden.py) and (b) the CPU oracle run live on the same
+deterministic weights/inputs.
+
+Tolerances (floating point, stated here as the task requires):
+  * f32 mode (params float32; same host logic, f32 kernels): logits and every parameter gradient
+    within 1e-3 relative L2 of the reference (north_star's bound); measured ~1e-6..1e-5.
+  * bf16 mode (production): the reference's OWN bf16 run deviates from its f32 run by 3.6e-3
+    (autocast) .. 9.3e-3 (pure bf16) on ViT-B/16 logits, so 1e-3 is not a
+    physical bound for any bf16 pipeline.  Gate: error vs the f32 oracle <= 1.5x the error of the
+    oracle's own pure-bf16 CPU run on the same inputs (+1e-3 absolute slack), for logits and for
+    the concatenated gradient vector.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vit_oracle as O  # noqa: E402
+from oracle.params import CASES, make_images, make_params  # noqa: E402
+from vit_pytorch_amd import SimpleViT, ViT  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
+    n = b.norm().item()
+    return (a - b).norm().item() / (n if n > 0 else 1.0)
+
+
+def build(kind, cfg, params, dtype):
+    cls = ViT if kind == "vit" else SimpleViT
+    m = cls(**cfg)
+    m.load_state_dict(params, strict=True)
+    return m.to(DEV, dtype=dtype)
+
+
+def run_mine(kind, cfg, params, img, dtype):
+    m = build(kind, cfg, params, dtype)
+    out = m(img.to(DEV, dtype=dtype))
+    O.loss_fn(out).backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+    return out, grads
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_f32_mode_matches_reference_golden(name):
+    case = CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000, case.get("image"))
+    out, grads = run_mine(case["kind"], case["cfg"], params, img, torch.float32)
+    assert tuple(out.shape) == gold["logits"].shape
+    e = rel(out, torch.from_numpy(gold["logits"]))
+    assert e <= 1e-3, e
+    assert e <= 5e-5, f"f32 mode should be round-off close, got {e}"
+    for k in params:
+        g_ref = torch.from_numpy(gold["grad::" + k])
+        if g_ref.numel() == 0:
+            assert grads[k].numel() == 0
+            continue
+        eg = rel(grads[k], g_ref)
+        assert eg <= 1e-3, (k, eg)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_bf16_mode_vs_oracle(name):
+    case = CASES[name]
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000, case.get("image"))
+    ref_out, ref_g = O.run_fwd_bwd(case["kind"], case["cfg"], params, img, torch.float32)
+    bf_out, bf_g = O.run_fwd_bwd(case["kind"], case["cfg"], params, img, torch.bfloat16)   # the reference's own bf16 behaviour
+    out, grads = run_mine(case["kind"], case["cfg"], params, img, torch.bfloat16)
+    keys = [k for k in params if params[k].numel()]
+    cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
+    e_mine, e_ref = rel(out, ref_out), rel(bf_out, ref_out)
+    g_mine, g_ref = rel(cat(grads), cat(ref_g)), rel(cat(bf_g), cat(ref_g))
+    print(f"{name}: logits err mine {e_mine:.2e} vs reference-bf16 {e_ref:.2e}; grads mine {g_mine:.2e} vs {g_ref:.2e}")
+    assert e_mine <= 1.5 * e_ref + 1e-3, (e_mine, e_ref)
+    assert g_mine <= 1.5 * g_ref + 1e-3, (g_mine, g_ref)
+
+
+VITB_SMALL = dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=2, heads=12, mlp_dim=3072)
+
+
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vit_b16_width_depth2_vs_oracle(kind, dtype):
+    """BASELINE config 2's layer shapes (N=197, D=768, h=12, F=3072: the MFMA fast path in bf16)
+    at depth 2 / batch 4 so the CPU oracle finishes in seconds."""
+    cfg = dict(VITB_SMALL)
+    params = make_params(kind, cfg, 7)
+    img = make_images(cfg, 4, 1007)
+    ref_out, ref_g = O.run_fwd_bwd(kind, cfg, params, img, torch.float32)
+    out, grads = run_mine(kind, cfg, params, img, dtype)
+    keys = list(params)
+    cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
+    e, g = rel(out, ref_out), rel(cat(grads), cat(ref_g))
+    if dtype == torch.float32:
+        assert e <= 1e-3 and g <= 1e-3, (e, g)
+        worst = max(rel(grads[k], ref_g[k]) for k in keys)
+        assert worst <= 1e-3, worst
+    else:
+        bf_out, bf_g = O.run_fwd_bwd(kind, cfg, params, img, torch.bfloat16)
+        e_ref, g_ref = rel(bf_out, ref_out), rel(cat(bf_g), cat(ref_g))
+        print(f"{kind} bf16 depth2: logits {e:.2e} (reference-bf16 {e_ref:.2e}); grads {g:.2e} (reference-bf16 {g_ref:.2e})")
+        assert e <= 1.5 * e_ref + 1e-3, (e, e_ref)
+        assert g <= 1.5 * g_ref + 1e-3, (g, g_ref)
+        # no gradient tensor may be grossly off (catches a wrong-but-small tensor hidden in the concatenation)
+        for k in keys:
+            assert rel(grads[k], ref_g[k]) <= 0.12, (k, rel(grads[k], ref_g[k]))
+
+
+def test_full_config2_size_properties():
+    """ViT-B/16, depth 12, bf16 at batch 64: size-independent properties instead of an oracle run.
+    (1) run-to-run bitwise determinism of logits and gradients; (2) permuting the batch permutes
+    the logits bit-exactly and leaves every gradient unchanged up to f32 summation order."""
+    cfg = dict(VITB_SMALL, depth=12)
+    torch.manual_seed(0)
+    m = ViT(**cfg).to(DEV, dtype=torch.bfloat16)
+    img = torch.randn(64, 3, 224, 224, device=DEV).to(torch.bfloat16)
+
+    def step(x):
+        m.zero_grad(set_to_none=True)
+        out = m(x)
+        O.loss_fn(out).backward()
+        return out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    o1, g1 = step(img)
+    o2, g2 = step(img)
+    assert torch.isfinite(o1.float()).all()
+    assert torch.equal(o1, o2)
+    for k in g1:
+        assert torch.isfinite(g1[k].float()).all(), k
+        assert torch.equal(g1[k], g2[k]), k
+    perm = torch.randperm(64, device=DEV)
+    o3, g3 = step(img[perm])
+    assert torch.equal(o3, o1[perm])
+    for k in g1:
+        assert rel(g3[k], g1[k]) <= 2e-2, (k, rel(g3[k], g1[k]))
+
+
+def test_reference_unit_test_verbatim():
+    """tests/test_vit.py:4-20 of the reference, on the GPU: train mode, dropout 0.1, shape check."""
+    v = ViT(image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=6, heads=16, mlp_dim=2048,
+            dropout=0.1, emb_dropout=0.1).to(DEV)
+    img = torch.randn(1, 3, 256, 256, device=DEV)
+    preds = v(img)
+    assert preds.shape == (1, 1000), 'correct logits outputted'
+    preds.float().square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in v.parameters())
+
+
+def test_hooks_and_submodules_match_fused_path():
+    """Recorder-style forward hook on `attend` (recorder.py:26-29) forces the materialising path;
+    its result and gradients must agree with the fused path, and the hook must see (b,h,n,n)."""
+    case = CASES["vit_cls_tiny"]
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000)
+    out_f, g_f = run_mine("vit", case["cfg"], params, img, torch.float32)
+    m = build("vit", case["cfg"], params, torch.float32)
+    seen = []
+    hs = [layer[0].attend.register_forward_hook(lambda mod, i, o: seen.append(o.detach())) for layer in m.transformer.layers]
+    out_h = m(img.to(DEV))
+    O.loss_fn(out_h).backward()
+    assert len(seen) == case["cfg"]["depth"]
+    n = (32 // 8) ** 2 + 1
+    assert tuple(seen[0].shape) == (case["batch"], case["cfg"]["heads"], n, n)
+    assert torch.allclose(seen[0].sum(-1), torch.ones_like(seen[0].sum(-1)), atol=1e-5)
+    assert rel(out_h, out_f) < 1e-5
+    for k, p in m.named_parameters():
+        if p.numel():
+            assert rel(p.grad, g_f[k]) < 1e-4, k
+    for h in hs:
+        h.remove()
+    # sub-modules are callable on their own (mae.py:74, simmim.py:70, mpp.py:169 do this)
+    tokens = m.to_patch_embedding(img.to(DEV))
+    assert tuple(tokens.shape) == (case["batch"], n - 1, case["cfg"]["dim"])
+    y = m.transformer(tokens)
+    assert tuple(y.shape) == tuple(tokens.shape)
+
+
+def test_cpu_input_fails_loudly():
+    m = ViT(**CASES["vit_cls_tiny"]["cfg"])
+    with pytest.raises(RuntimeError, match="HIP"):
+        m(torch.randn(1, 3, 32, 32))

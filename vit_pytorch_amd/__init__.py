@@ -1,0 +1,17 @@
+"""vit_pytorch_amd: MI355X-native drop-in for vit_pytorch.ViT / vit_pytorch.SimpleViT.
+
+Mirrors the export surface of the reference package (vit_pytorch/__init__.py:1-5 exports
+ViT and SimpleViT; MAE and Dino are out of scope).
+"""
+__version__ = "0.1.0"
+
+
+def __getattr__(name):
+    # lazy: importing the package must not require torch.cuda or the built library
+    if name in ("ViT", "Transformer", "Attention", "FeedForward"):
+        from . import vit as _v
+        return getattr(_v, name)
+    if name == "SimpleViT":
+        from .simple_vit import SimpleViT
+        return SimpleViT
+    raise AttributeError(name)

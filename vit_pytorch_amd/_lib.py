@@ -1,0 +1,100 @@
+"""ctypes binding of libvitk.so (include/vitk.h).  No torch types cross this boundary.
+
+The product path has NO fallback: if the library is missing this module raises at
+import of the first kernel call site, with the command that builds it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvitk.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3, 4
+VITK_VERSION = 100
+
+
+class RowMap(C.Structure):
+    _fields_ = [("group", C.c_int64), ("gstride", C.c_int64), ("offset", C.c_int64)]
+
+
+class Mat(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("dt", C.c_int), ("s_b1", C.c_int64), ("s_b2", C.c_int64),
+                ("s_row", C.c_int64), ("s_col", C.c_int64)]
+
+
+class BHND(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("s_b", C.c_int64), ("s_h", C.c_int64), ("s_n", C.c_int64)]
+
+
+IDENT = RowMap(0, 0, 0)
+
+_vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/vitk.h one to one (tests/test_abi.py checks the
+# header against this table and against the exported symbols).
+SIGNATURES = {
+    "vitk_version": (_i, []),
+    "vitk_last_error": (C.c_char_p, []),
+    "vitk_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i64, _f, RowMap, RowMap, _vp, _i64, _i64, _vp]),
+    "vitk_layernorm_bwd_blocks": (_i64, [_i64]),
+    "vitk_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i64, RowMap, RowMap, RowMap, _vp]),
+    "vitk_colsum_partials": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _i, _vp]),
+    "vitk_colsum_ws_floats": (_i64, [_i64, _i64]),
+    "vitk_colsum": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _vp, _vp]),
+    "vitk_gemm_nt_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
+    "vitk_gemm_tn_splits": (_i64, [_i64, _i64, _i64]),
+    "vitk_gemm_tn_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "vitk_gemm_generic": (_i, [Mat, Mat, Mat, _vp, _i, _i64, _i64, _i64, _i64, _i64, _f, _f, _vp]),
+    "vitk_attn_fwd_bf16": (_i, [BHND, BHND, BHND, BHND, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_attn_bwd_bf16": (_i, [BHND, BHND, BHND, BHND, BHND, _vp, _vp, BHND, BHND, BHND, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_softmax_fwd": (_i, [_vp, _vp, _i, _i64, _i64, _f, _vp]),
+    "vitk_softmax_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _f, _vp]),
+    "vitk_patchify": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "vitk_gelu_fwd": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "vitk_gelu_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
+    "vitk_add_rows": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i64, _vp]),
+    "vitk_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
+    "vitk_write_cls_rows": (_i, [_vp, _i, _vp, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
+    "vitk_mean_pool_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),
+    "vitk_mean_pool_bwd": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),
+    "vitk_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _u64, _u64, _vp]),
+    "vitk_dropout_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp]),
+    "vitk_transpose": (_i, [_vp, _vp, _i, _i64, _i64, _vp]),
+}
+
+_lib = None
+
+
+class VitkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libvitk.so once.  Raises VitkError (never falls back) if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitkError(
+            f"{LIB_PATH} not found: the HIP kernel library is not built. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python -m vit_pytorch_amd._build`). There is no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.vitk_version()
+    if v != VITK_VERSION:
+        raise VitkError(f"libvitk.so version {v} != binding version {VITK_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().vitk_last_error().decode("utf-8", "replace")
+        raise VitkError(f"{what}: vitk error {rc}: {msg}")

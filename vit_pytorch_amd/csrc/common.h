@@ -1,0 +1,86 @@
+// common.h -- shared device/host helpers for libvitk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/vitk.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------
+void vitk_set_error(const char* fmt, ...);
+#define VITK_FAIL(code, ...) do { vitk_set_error(__VA_ARGS__); return (code); } while (0)
+#define VITK_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); \
+    if (e__ != hipSuccess) { vitk_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return (int)e__; } } while (0)
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+// ---- bf16 <-> f32 (device) ---------------------------------------------------------------
+// round-to-nearest-even, NaN preserved: what torch's .to(bfloat16) does.
+__device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
+__device__ __forceinline__ __bf16 f2bf(float f) { return (__bf16)f; }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__bf16>(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// 4-element vector load/store as f32x4 (16 B for f32, 8 B for bf16). p must be aligned to the
+// vector size.
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<__bf16>(const __bf16* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, f32x4 v) {
+    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// ---- wave reductions (wave = 64) --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- math ------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = __expf(-0.5f * x * x) * 0.39894228040143267794f;
+    return cdf + x * pdf;
+}
+
+// ---- row map (see vitk.h) ---------------------------------------------------------------
+struct RowMap { long long group, gstride, offset; };
+__device__ __forceinline__ long long map_row(const RowMap& m, long long r) {
+    if (m.group <= 0) return r;
+    return (r / m.group) * m.gstride + (r % m.group) + m.offset;
+}
+static inline RowMap to_map(vitk_rowmap m) { return RowMap{(long long)m.group, (long long)m.gstride, (long long)m.offset}; }
+
+// dtype dispatch helpers (host)
+#define VITK_DISPATCH_DT(dt, T, ...) \
+    if ((dt) == VITK_F32) { using T = float; __VA_ARGS__; } \
+    else if ((dt) == VITK_BF16) { using T = __bf16; __VA_ARGS__; } \
+    else VITK_FAIL(VITK_E_DTYPE, "bad dtype tag %d", (int)(dt))

@@ -1,0 +1,310 @@
+// elementwise.hip -- data movement and element-wise kernels (HBM-bound), plus version / error API.
+#include "common.h"
+#include <string.h>
+
+// ---- error string (thread-local) ---------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vitk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" int vitk_version(void) { return VITK_VERSION; }
+extern "C" const char* vitk_last_error(void) { return g_err; }
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline unsigned ew_blocks(long long work_items, int per_block = EW_THREADS) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b > 16384) b = 16384;  // grid-stride beyond that
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// Rearrange 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit.py:100): one wave per patch row, iterating
+// in DESTINATION order so the write is fully coalesced; the gather reads hit L2 (each source line
+// is touched by the p2*c consecutive destination elements of a patch row).
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ img, T* __restrict__ out, long long rows,
+                                                        int C, int H, int W, int p1, int p2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hp = H / p1, wp = W / p2;
+    const int P = p1 * p2 * C;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+        const long long b = row / (hp * wp);
+        const int hw = (int)(row % (hp * wp));
+        const int ph = hw / wp, pw = hw % wp;
+        const T* src = img + b * (long long)C * H * W + (long long)(ph * p1) * W + pw * p2;
+        T* dst = out + row * (long long)P;
+        for (int e = lane; e < P; e += 64) {
+            const int c = e % C;
+            const int ij = e / C;
+            const int j = ij % p2, i = ij / p2;
+            dst[e] = src[(long long)c * H * W + (long long)i * W + j];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 v = load4<T>(x + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        store4<T>(y + 4 * i, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
+                                                        long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 g = load4<T>(dy + 4 * i);
+        const f32x4 v = load4<T>(x + 4 * i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = g[e] * gelu_erf_grad(v[e]);
+        store4<T>(dx + 4 * i, o);
+    }
+}
+
+template <typename AT, typename BT, typename OT>
+__global__ __launch_bounds__(256) void add_rows_kernel(const AT* __restrict__ a, const BT* __restrict__ b,
+                                                        const BT* __restrict__ bias, OT* __restrict__ out, long long rows,
+                                                        int cols4) {
+    const long long n4 = rows * cols4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 v = load4<AT>(a + 4 * i) + load4<BT>(b + 4 * i);
+        if (bias) v += load4<BT>(bias + 4 * (i % cols4));
+        store4<OT>(out + 4 * i, v);
+    }
+}
+
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void cast_kernel(const XT* __restrict__ x, YT* __restrict__ y, long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        store4<YT>(y + 4 * i, load4<XT>(x + 4 * i));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = from_f32<YT>(to_f32<XT>(x[n4 * 4 + threadIdx.x]));
+}
+
+template <typename XT, typename PT>
+__global__ __launch_bounds__(256) void write_cls_kernel(XT* __restrict__ x, const PT* __restrict__ cls, const PT* __restrict__ pos,
+                                                         long long B, long long N, int D, int ncls) {
+    const long long total = B * ncls * D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int d = (int)(i % D);
+        const long long t = i / D;
+        const int c = (int)(t % ncls);
+        const long long b = t / ncls;
+        x[(b * N + c) * D + d] = from_f32<XT>(to_f32<PT>(cls[c * D + d]) + to_f32<PT>(pos[c * D + d]));
+    }
+}
+
+// out[b, d] = mean_n x[b, n, d]; thread per (b, 4 columns)
+template <typename XT, typename OT>
+__global__ __launch_bounds__(256) void mean_pool_fwd_kernel(const XT* __restrict__ x, OT* __restrict__ out, long long B,
+                                                             int N, int D4) {
+    const long long total = B * D4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / D4;
+        const int c = (int)(i % D4);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < N; ++n) s += load4<XT>(x + ((b * N + n) * D4 + c) * 4);
+        s *= (1.0f / (float)N);
+        store4<OT>(out + i * 4, s);
+    }
+}
+template <typename DT, typename XT>
+__global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const DT* __restrict__ dout, XT* __restrict__ dx, long long B,
+                                                             int N, int D4) {
+    const long long total = B * N * D4;
+    const float inv = 1.0f / (float)N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const long long b = i / ((long long)N * D4);
+        store4<XT>(dx + i * 4, load4<DT>(dout + (b * D4 + c) * 4) * inv);
+    }
+}
+
+// Counter-based RNG for dropout: a 64-bit mix (splitmix64 finaliser) of (seed, offset + index).
+// Stateless, so forward and backward agree through the stored u8 mask and the stream of keep
+// decisions is reproducible from (seed, offset) alone.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ mask,
+                                                           long long n, float p, unsigned long long seed,
+                                                           unsigned long long offset) {
+    const float scale = 1.0f / (1.0f - p);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned long long r = mix64(seed ^ mix64(offset + (unsigned long long)i));
+        const float u = (float)(r >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
+        const bool keep = u >= p;
+        mask[i] = keep ? 1 : 0;
+        y[i] = from_f32<T>(keep ? to_f32<T>(x[i]) * scale : 0.f);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                           T* __restrict__ dx, long long n, float p) {
+    const float scale = 1.0f / (1.0f - p);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dx[i] = from_f32<T>(mask[i] ? to_f32<T>(dy[i]) * scale : 0.f);
+}
+
+// 32x32 LDS-tiled transpose
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int rows, int cols) {
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * k][tx] = in[(long long)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) out[(long long)c * rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+}  // namespace
+
+extern "C" int vitk_patchify(const void* img, void* out, int dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p1,
+                             int64_t p2, void* stream) {
+    if (!img || !out) VITK_FAIL(VITK_E_ARG, "patchify: null pointer");
+    if (B <= 0 || C <= 0 || p1 <= 0 || p2 <= 0 || H % p1 || W % p2) VITK_FAIL(VITK_E_SHAPE, "patchify: image not divisible by patch");
+    const long long rows = B * (H / p1) * (W / p2);
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((patchify_kernel<T>), dim3(ew_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)img, (T*)out, rows, (int)C, (int)H, (int)W, (int)p1, (int)p2));
+    VITK_CHECK_LAUNCH("patchify");
+    return 0;
+}
+
+extern "C" int vitk_gelu_fwd(const void* x, void* y, int dt, int64_t n, void* stream) {
+    if (!x || !y) VITK_FAIL(VITK_E_ARG, "gelu_fwd: null pointer");
+    if (n <= 0 || (n & 3)) VITK_FAIL(VITK_E_SHAPE, "gelu_fwd: n %% 4 != 0");
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((gelu_fwd_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)x, (T*)y, (long long)(n / 4)));
+    VITK_CHECK_LAUNCH("gelu_fwd");
+    return 0;
+}
+extern "C" int vitk_gelu_bwd(const void* dy, const void* x, void* dx, int dt, int64_t n, void* stream) {
+    if (!dy || !x || !dx) VITK_FAIL(VITK_E_ARG, "gelu_bwd: null pointer");
+    if (n <= 0 || (n & 3)) VITK_FAIL(VITK_E_SHAPE, "gelu_bwd: n %% 4 != 0");
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)dy, (const T*)x, (T*)dx, (long long)(n / 4)));
+    VITK_CHECK_LAUNCH("gelu_bwd");
+    return 0;
+}
+
+extern "C" int vitk_add_rows(const void* a, int adt, const void* b, int bdt, const void* bias, int biasdt, void* out, int odt,
+                             int64_t rows, int64_t cols, void* stream) {
+    if (!a || !b || !out) VITK_FAIL(VITK_E_ARG, "add_rows: null pointer");
+    if (rows <= 0 || cols <= 0 || (cols & 3)) VITK_FAIL(VITK_E_SHAPE, "add_rows: cols %% 4 != 0");
+    if (bias && biasdt != bdt) VITK_FAIL(VITK_E_DTYPE, "add_rows: bias dtype must equal b dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = ew_blocks(rows * cols / 4);
+#define ADD_CASE(AT, BT, OT) hipLaunchKernelGGL((add_rows_kernel<AT, BT, OT>), dim3(blocks), dim3(256), 0, st, (const AT*)a, \
+        (const BT*)b, (const BT*)bias, (OT*)out, (long long)rows, (int)(cols / 4))
+    if (adt == VITK_F32 && bdt == VITK_F32 && odt == VITK_F32) ADD_CASE(float, float, float);
+    else if (adt == VITK_F32 && bdt == VITK_BF16 && odt == VITK_F32) ADD_CASE(float, __bf16, float);
+    else if (adt == VITK_F32 && bdt == VITK_BF16 && odt == VITK_BF16) ADD_CASE(float, __bf16, __bf16);
+    else if (adt == VITK_BF16 && bdt == VITK_BF16 && odt == VITK_BF16) ADD_CASE(__bf16, __bf16, __bf16);
+    else if (adt == VITK_BF16 && bdt == VITK_BF16 && odt == VITK_F32) ADD_CASE(__bf16, __bf16, float);
+    else VITK_FAIL(VITK_E_DTYPE, "add_rows: unsupported dtype combination");
+#undef ADD_CASE
+    VITK_CHECK_LAUNCH("add_rows");
+    return 0;
+}
+
+extern "C" int vitk_cast(const void* x, int xdt, void* y, int ydt, int64_t n, void* stream) {
+    if (!x || !y) VITK_FAIL(VITK_E_ARG, "cast: null pointer");
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = ew_blocks((n + 3) / 4);
+    if (xdt == VITK_F32 && ydt == VITK_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, (long long)n);
+    else if (xdt == VITK_F32 && ydt == VITK_BF16) hipLaunchKernelGGL((cast_kernel<float, __bf16>), dim3(blocks), dim3(256), 0, st, (const float*)x, (__bf16*)y, (long long)n);
+    else if (xdt == VITK_BF16 && ydt == VITK_F32) hipLaunchKernelGGL((cast_kernel<__bf16, float>), dim3(blocks), dim3(256), 0, st, (const __bf16*)x, (float*)y, (long long)n);
+    else if (xdt == VITK_BF16 && ydt == VITK_BF16) hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)x, (__bf16*)y, (long long)n);
+    else VITK_FAIL(VITK_E_DTYPE, "cast: bad dtype");
+    VITK_CHECK_LAUNCH("cast");
+    return 0;
+}
+
+extern "C" int vitk_write_cls_rows(void* x, int xdt, const void* cls, const void* pos, int pdt, int64_t B, int64_t N, int64_t D,
+                                   int64_t ncls, void* stream) {
+    if (ncls == 0) return 0;
+    if (!x || !cls || !pos) VITK_FAIL(VITK_E_ARG, "write_cls_rows: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = ew_blocks(B * ncls * D);
+    if (xdt == VITK_F32 && pdt == VITK_F32) hipLaunchKernelGGL((write_cls_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (float*)x, (const float*)cls, (const float*)pos, (long long)B, (long long)N, (int)D, (int)ncls);
+    else if (xdt == VITK_F32 && pdt == VITK_BF16) hipLaunchKernelGGL((write_cls_kernel<float, __bf16>), dim3(blocks), dim3(256), 0, st, (float*)x, (const __bf16*)cls, (const __bf16*)pos, (long long)B, (long long)N, (int)D, (int)ncls);
+    else if (xdt == VITK_BF16 && pdt == VITK_BF16) hipLaunchKernelGGL((write_cls_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), 0, st, (__bf16*)x, (const __bf16*)cls, (const __bf16*)pos, (long long)B, (long long)N, (int)D, (int)ncls);
+    else VITK_FAIL(VITK_E_DTYPE, "write_cls_rows: bad dtype combination");
+    VITK_CHECK_LAUNCH("write_cls_rows");
+    return 0;
+}
+
+extern "C" int vitk_mean_pool_fwd(const void* x, int xdt, void* out, int odt, int64_t B, int64_t N, int64_t D, void* stream) {
+    if (!x || !out) VITK_FAIL(VITK_E_ARG, "mean_pool_fwd: null pointer");
+    if (B <= 0 || N <= 0 || D <= 0 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "mean_pool_fwd: D %% 4 != 0");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = ew_blocks(B * D / 4);
+    if (xdt == VITK_F32 && odt == VITK_F32) hipLaunchKernelGGL((mean_pool_fwd_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)out, (long long)B, (int)N, (int)(D / 4));
+    else if (xdt == VITK_BF16 && odt == VITK_BF16) hipLaunchKernelGGL((mean_pool_fwd_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)x, (__bf16*)out, (long long)B, (int)N, (int)(D / 4));
+    else if (xdt == VITK_F32 && odt == VITK_BF16) hipLaunchKernelGGL((mean_pool_fwd_kernel<float, __bf16>), dim3(blocks), dim3(256), 0, st, (const float*)x, (__bf16*)out, (long long)B, (int)N, (int)(D / 4));
+    else VITK_FAIL(VITK_E_DTYPE, "mean_pool_fwd: bad dtype combination");
+    VITK_CHECK_LAUNCH("mean_pool_fwd");
+    return 0;
+}
+extern "C" int vitk_mean_pool_bwd(const void* dout, int ddt, void* dx, int xdt, int64_t B, int64_t N, int64_t D, void* stream) {
+    if (!dout || !dx) VITK_FAIL(VITK_E_ARG, "mean_pool_bwd: null pointer");
+    if (B <= 0 || N <= 0 || D <= 0 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "mean_pool_bwd: D %% 4 != 0");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = ew_blocks(B * N * D / 4);
+    if (ddt == VITK_F32 && xdt == VITK_F32) hipLaunchKernelGGL((mean_pool_bwd_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)dout, (float*)dx, (long long)B, (int)N, (int)(D / 4));
+    else if (ddt == VITK_BF16 && xdt == VITK_BF16) hipLaunchKernelGGL((mean_pool_bwd_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)dout, (__bf16*)dx, (long long)B, (int)N, (int)(D / 4));
+    else if (ddt == VITK_BF16 && xdt == VITK_F32) hipLaunchKernelGGL((mean_pool_bwd_kernel<__bf16, float>), dim3(blocks), dim3(256), 0, st, (const __bf16*)dout, (float*)dx, (long long)B, (int)N, (int)(D / 4));
+    else VITK_FAIL(VITK_E_DTYPE, "mean_pool_bwd: bad dtype combination");
+    VITK_CHECK_LAUNCH("mean_pool_bwd");
+    return 0;
+}
+
+extern "C" int vitk_dropout_fwd(const void* x, void* y, uint8_t* mask, int dt, int64_t n, float p, uint64_t seed, uint64_t offset,
+                                void* stream) {
+    if (!x || !y || !mask) VITK_FAIL(VITK_E_ARG, "dropout_fwd: null pointer");
+    if (n <= 0 || !(p >= 0.f && p < 1.f)) VITK_FAIL(VITK_E_SHAPE, "dropout_fwd: need n > 0 and 0 <= p < 1");
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((dropout_fwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)x, (T*)y, mask, (long long)n, p, (unsigned long long)seed,
+                                                (unsigned long long)offset));
+    VITK_CHECK_LAUNCH("dropout_fwd");
+    return 0;
+}
+extern "C" int vitk_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dt, int64_t n, float p, void* stream) {
+    if (!dy || !dx || !mask) VITK_FAIL(VITK_E_ARG, "dropout_bwd: null pointer");
+    if (n <= 0 || !(p >= 0.f && p < 1.f)) VITK_FAIL(VITK_E_SHAPE, "dropout_bwd: need n > 0 and 0 <= p < 1");
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((dropout_bwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)dy, mask, (T*)dx, (long long)n, p));
+    VITK_CHECK_LAUNCH("dropout_bwd");
+    return 0;
+}
+
+extern "C" int vitk_transpose(const void* in, void* out, int dt, int64_t rows, int64_t cols, void* stream) {
+    if (!in || !out) VITK_FAIL(VITK_E_ARG, "transpose: null pointer");
+    if (rows <= 0 || cols <= 0 || (rows + 31) / 32 > 65535) VITK_FAIL(VITK_E_SHAPE, "transpose: bad shape");
+    const dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
+                                                (T*)out, (int)rows, (int)cols));
+    VITK_CHECK_LAUNCH("transpose");
+    return 0;
+}

@@ -1,0 +1,341 @@
+// gemm_bf16.hip -- bf16 MFMA GEMMs for gfx950 (MI355X).
+//
+// Replace nn.Linear (vit.py:20,23,44,47,102; simple_vit.py:30,32,47,48,93) forward and autograd.
+//
+//   NT  C[M,N]  = A[M,K] . W[N,K]^T   (+ fused epilogue)      forward Linear, and dX with W^T
+//   TN  dW[N,K] = dY[M,N]^T . X[M,K]  (split over M)          weight gradients
+//
+// Design (MFMA-bound, f32 accumulation, v_mfma_f32_16x16x32_bf16):
+//  * 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 MFMA fragments.
+//  * NT: K-step 32, operands go HBM -> LDS with global_load_lds dwordx4 (no VGPR round trip),
+//    two LDS stages, one barrier per K-step.  The LDS image is lane-linear (DMA constraint), so
+//    the bank swizzle is applied to the per-lane SOURCE address and to the ds_read_b128 address
+//    (same involution on both sides).
+//  * The MFMA "A" operand is the W fragment and "B" the activation fragment, so a lane ends up
+//    holding 4 CONSECUTIVE output columns of one output row: every epilogue store is an 8-byte
+//    (bf16) or 16-byte (f32) vector store and bias / GELU / residual / GELU' are applied in
+//    registers -- the activation tensor is written exactly once.
+//  * TN: the reduction index (token row m) is the strided one in both operands; tiles are staged
+//    row-major through registers into padded LDS rows and read with ds_read_b64_tr_b16 (hardware
+//    transpose read) to form MFMA fragments.  Split-M slabs of f32 partials + a deterministic
+//    reduce (no atomics), which also converts to the gradient dtype / accumulates.
+//  * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs walks a contiguous run of tiles
+//    (n fastest), so the activation panel a tile row shares is fetched into one L2, not eight.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int NT_BK = 32;
+constexpr int NT_TILE_BYTES = 128 * NT_BK * 2;           // 8 KiB per operand tile
+constexpr int NT_STAGE_BYTES = 2 * NT_TILE_BYTES;        // A + W
+constexpr int NXCD = 8;
+
+__device__ __forceinline__ int xcd_swizzle(int b, int nwg) {
+    const int q = nwg / NXCD, r = nwg % NXCD;
+    const int xcd = b % NXCD, idx = b / NXCD;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// permutation f = [0,2,3,1]: logical 16-byte chunk g of row i sits at position g ^ f[(i>>2)&3].
+// Makes every ds_read_b128 lane group of the 64-byte-row image hit 16 distinct bank slots.
+__device__ __forceinline__ int swz_f(int x) { return (0x1320 >> (4 * (x & 3))) & 3; }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(
+    const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ W, long long ldw,
+    void* __restrict__ Cv, long long ldc, int M, int N, int K,
+    const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
+    int tiles_n, int nwg) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * NT_STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wg = xcd_swizzle(blockIdx.x, nwg);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses (constant over the K loop except the k offset) ----
+    const int srow = lane >> 2;                 // row inside a 16-row group
+    const int spos = lane & 3;                  // 16-byte slot inside the 64-byte row
+    const int schunk = spos ^ swz_f(lane >> 4); // logical k-chunk this lane fetches
+    const __bf16* a_src[2];
+    const __bf16* w_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rg = wave * 2 + j;
+        int ar = m0 + rg * 16 + srow; ar = ar < M ? ar : M - 1;
+        int wr = n0 + rg * 16 + srow; wr = wr < N ? wr : N - 1;
+        a_src[j] = A + (long long)ar * lda + schunk * 8;
+        w_src[j] = W + (long long)wr * ldw + schunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = lds + buf * NT_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rg = wave * 2 + j;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + kt * NT_BK),
+                                             (void __attribute__((address_space(3)))*)(base + rg * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + kt * NT_BK),
+                                             (void __attribute__((address_space(3)))*)(base + NT_TILE_BYTES + rg * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses ----
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fpos = fg ^ swz_f(fi >> 2);
+    const int a_off = (wm * 64 + fi) * 64 + fpos * 16;                   // + fm*16*64
+    const int w_off = NT_TILE_BYTES + (wn * 64 + fi) * 64 + fpos * 16;   // + fn*16*64
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = K / NT_BK;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();  // own DMA landed (vmcnt(0)) + everyone's; also: all reads of the other stage are done
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        const char* base = lds + (t & 1) * NT_STAGE_BYTES;
+        bf16x8 xf[4], wf[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + f * 1024);
+            wf[f] = *reinterpret_cast<const bf16x8*>(base + w_off + f * 1024);
+        }
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm)
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[fm], acc[fn][fm], 0, 0, 0);
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = ..+(lane&15), n = ..+4*(lane>>4) ----
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+        const int m = m0 + wm * 64 + fm * 16 + fi;
+        if (m >= M) continue;
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            const int n = n0 + wn * 64 + fn * 16 + 4 * fg;
+            if (n >= N) continue;
+            f32x4 v = acc[fn][fm];
+            const long long o = (long long)m * ldc + n;
+            if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU) {
+                v += load4<__bf16>(bias + n);
+            }
+            if constexpr (EPI == VITK_EPI_NONE || EPI == VITK_EPI_BIAS) {
+                store4<__bf16>(reinterpret_cast<__bf16*>(Cv) + o, v);
+            } else if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+                store4<__bf16>(aux + o, v);
+                f32x4 gq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gq[e] = gelu_erf(v[e]);
+                store4<__bf16>(reinterpret_cast<__bf16*>(Cv) + o, gq);
+            } else if constexpr (EPI == VITK_EPI_RESID) {
+                if (bias) v += load4<__bf16>(bias + n);
+                v += *reinterpret_cast<const f32x4*>(resid + o);
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + o) = v;
+            } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                const f32x4 h = load4<__bf16>(aux + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(h[e]);
+                store4<__bf16>(reinterpret_cast<__bf16*>(Cv) + o, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN: dW[n][k] = sum_m dY[m][n] * X[m][k]
+// ------------------------------------------------------------------------------------------
+constexpr int TN_BKM = 32;                 // token rows per step
+constexpr int TN_LD = 288;                 // bytes per LDS row: 256 data + 32 pad (8 consecutive rows -> 64 distinct banks)
+constexpr int TN_TILE_BYTES = TN_BKM * TN_LD;
+constexpr int TN_STAGE_BYTES = 2 * TN_TILE_BYTES;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off) {
+    // two transpose reads: token rows {4g..4g+3} and {16+4g..16+4g+3} of one 16-column block
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off + 16 * TN_LD));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(
+    const __bf16* __restrict__ dY, long long ldy, const __bf16* __restrict__ X, long long ldx,
+    float* __restrict__ ws, int M, int N, int K, int rows_per_split, int tiles_k, int nwg) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * TN_STAGE_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int wg = xcd_swizzle(blockIdx.x, nwg);
+    const int tn = wg / tiles_k, tk = wg % tiles_k;
+    const int n0 = tn * BN, k0 = tk * BM;
+    const int split = blockIdx.y;
+    const int mbeg = split * rows_per_split;
+    int mend = mbeg + rows_per_split; mend = mend < M ? mend : M;
+
+    // staging: 512 16-byte chunks per operand tile, 2 per thread
+    int srow[2], scol[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int c = tid + 256 * j; srow[j] = c >> 4; scol[j] = (c & 15) * 8; }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 ry[2], rx[2];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = mb + srow[j];
+            const bool mv = m < mend;
+            ry[j] = (mv && n0 + scol[j] < N) ? *reinterpret_cast<const bf16x8*>(dY + (long long)m * ldy + n0 + scol[j]) : zero8;
+            rx[j] = (mv && k0 + scol[j] < K) ? *reinterpret_cast<const bf16x8*>(X + (long long)m * ldx + k0 + scol[j]) : zero8;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = lds + buf * TN_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<bf16x8*>(base + srow[j] * TN_LD + scol[j] * 2) = ry[j];
+            *reinterpret_cast<bf16x8*>(base + TN_TILE_BYTES + srow[j] * TN_LD + scol[j] * 2) = rx[j];
+        }
+    };
+
+    const int fi = lane & 15, fg = lane >> 4;
+    // transpose-read address of this lane inside a 16-column block: row 4g + (i>>2), 4 columns at (i&3)*4
+    const int tr_off = (4 * fg + (fi >> 2)) * TN_LD + (fi & 3) * 8;
+    const int y_off = tr_off + wn * 128;                    // + fn*32 bytes
+    const int x_off = TN_TILE_BYTES + tr_off + wk * 128;    // + fk*32 bytes
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (mend - mbeg + TN_BKM - 1) / TN_BKM;
+    if (nsteps > 0) {
+        gload(mbeg);
+        lstore(0);
+        __syncthreads();
+        for (int t = 0; t < nsteps; ++t) {
+            if (t + 1 < nsteps) gload(mbeg + (t + 1) * TN_BKM);
+            const char* base = lds + (t & 1) * TN_STAGE_BYTES;
+            bf16x8 yf[4], xf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                yf[f] = tr_frag(base, y_off + f * 32);
+                xf[f] = tr_frag(base, x_off + f * 32);
+            }
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                for (int fk = 0; fk < 4; ++fk)
+                    acc[fn][fk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[fn], xf[fk], acc[fn][fk], 0, 0, 0);
+            if (t + 1 < nsteps) lstore((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // partial tile -> ws[split][n][k]; D row = n (4g + r), D col = k (lane & 15)
+    float* out = ws + (long long)split * N * K;
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 64 + fn * 16 + 4 * fg + r;
+            if (n >= N) continue;
+#pragma unroll
+            for (int fk = 0; fk < 4; ++fk) {
+                const int k = k0 + wk * 64 + fk * 16 + fi;
+                if (k < K) out[(long long)n * K + k] = acc[fn][fk][r];
+            }
+        }
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, long long NK, int K,
+                                                         OT* __restrict__ out, long long ldo, int accumulate) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= NK) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
+    for (int p = 1; p < splits; ++p) s += *reinterpret_cast<const f32x4*>(ws + (long long)p * NK + i4);
+    const long long n = i4 / K, k = i4 % K;  // K % 4 == 0 -> the 4 elements share a row
+    OT* o = out + n * ldo + k;
+    if (accumulate) s += load4<OT>(o);
+    store4<OT>(o, s);
+}
+
+}  // namespace
+
+extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                 int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux,
+                                 void* stream) {
+    if (!A || !W || !C) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || (K % NT_BK) || (N & 3) || M > (1 << 30) || N > (1 << 30))
+        VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: need K %% 32 == 0 and N %% 4 == 0 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+    if ((lda & 7) || (ldw & 7) || (ldc & 3) || !aligned16(A) || !aligned16(W) || !aligned16(C) || (bias && !aligned8(bias)) ||
+        (resid && !aligned16(resid)) || (aux && !aligned8(aux)))
+        VITK_FAIL(VITK_E_ALIGN, "gemm_nt_bf16: lda/ldw %% 8, ldc %% 4 and 16-byte aligned pointers required");
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+    const long long nwg = (long long)tiles_m * tiles_n;
+    if (nwg > 0x7fffffffLL) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+#define NT_LAUNCH(E) hipLaunchKernelGGL((gemm_nt_kernel<E>), dim3((unsigned)nwg), dim3(256), 0, st, (const __bf16*)A, (long long)lda, \
+        (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg)
+    switch (epilogue) {
+        case VITK_EPI_NONE: NT_LAUNCH(VITK_EPI_NONE); break;
+        case VITK_EPI_BIAS:
+            if (!bias) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS needs bias");
+            NT_LAUNCH(VITK_EPI_BIAS); break;
+        case VITK_EPI_BIAS_GELU:
+            if (!bias || !aux) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS_GELU needs bias and aux");
+            NT_LAUNCH(VITK_EPI_BIAS_GELU); break;
+        case VITK_EPI_RESID:
+            if (!resid) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_RESID needs resid");
+            NT_LAUNCH(VITK_EPI_RESID); break;
+        case VITK_EPI_GELU_BWD:
+            if (!aux) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_GELU_BWD needs aux");
+            NT_LAUNCH(VITK_EPI_GELU_BWD); break;
+        default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: bad epilogue %d", epilogue);
+    }
+#undef NT_LAUNCH
+    VITK_CHECK_LAUNCH("gemm_nt_bf16");
+    return 0;
+}
+
+extern "C" int64_t vitk_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ((N + BN - 1) / BN) * ((K + BM - 1) / BM);
+    int64_t s = (768 + tiles - 1) / tiles;            // aim for ~3 blocks per CU
+    const int64_t max_by_rows = (M + 255) / 256;      // at least 8 steps of 32 rows per split
+    if (s > max_by_rows) s = max_by_rows;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int64_t ldx, void* dW, int odt, int64_t ldo,
+                                 int accumulate, int64_t M, int64_t N, int64_t K, float* ws, int64_t splits, void* stream) {
+    if (!dY || !X || !dW || !ws) VITK_FAIL(VITK_E_ARG, "gemm_tn_bf16: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || splits < 1 || splits > 65535 || M > (1 << 30))
+        VITK_FAIL(VITK_E_SHAPE, "gemm_tn_bf16: need N %% 8 == 0, K %% 8 == 0 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+    if ((ldy & 7) || (ldx & 7) || (ldo & 3) || !aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws))
+        VITK_FAIL(VITK_E_ALIGN, "gemm_tn_bf16: ldy/ldx %% 8, ldo %% 4 and 16-byte aligned pointers required");
+    const int tiles_n = (int)((N + BN - 1) / BN), tiles_k = (int)((K + BM - 1) / BM);
+    const int nwg = tiles_n * tiles_k;
+    long long rps = (M + splits - 1) / splits;
+    rps = (rps + TN_BKM - 1) / TN_BKM * TN_BKM;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nwg, (unsigned)splits), dim3(256), 0, st, (const __bf16*)dY, (long long)ldy,
+                       (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
+    VITK_CHECK_LAUNCH("gemm_tn_bf16");
+    const long long NK = (long long)N * K;
+    const unsigned blocks = (unsigned)((NK / 4 + 255) / 256);
+    VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((tn_reduce_kernel<OT>), dim3(blocks), dim3(256), 0, st, ws, (int)splits, NK, (int)K,
+                                                  (OT*)dW, (long long)ldo, accumulate));
+    VITK_CHECK_LAUNCH("gemm_tn_reduce");
+    return 0;
+}

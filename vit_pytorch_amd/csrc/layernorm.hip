@@ -1,0 +1,345 @@
+// layernorm.hip -- LayerNorm forward/backward and column-sum reductions for gfx950.
+//
+// Replaces nn.LayerNorm (vit.py:19,39,69,101,103; simple_vit.py:29,42,67,92,94) and its autograd.
+// HBM-bound: one wave64 per row, the row lives in registers (4 elements per lane per chunk,
+// 16-byte loads for f32 / 8-byte for bf16), statistics by wave shuffles, f32 arithmetic.
+// Algorithmic bytes per row: D*(sizeof(x)+sizeof(y)) forward; backward reads dy and x and
+// writes dx (f32 and/or T).
+#include "common.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_WAVES = LN_THREADS / WAVE;
+
+template <typename XT, typename YT, typename WT, int MAXC>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
+    const XT* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b,
+    YT* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    long long rows, int D, float eps, RowMap imap, RowMap omap,
+    const WT* __restrict__ add, long long add_group, long long add_off) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nchunk = D >> 2;
+    const float invD = 1.0f / (float)D;
+
+    f32x4 wv[MAXC], bv[MAXC];
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nchunk) {
+            wv[t] = load4<WT>(w + 4 * c);
+            bv[t] = b ? load4<WT>(b + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    for (long long row = (long long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long long)gridDim.x * LN_WAVES) {
+        const XT* xr = x + map_row(imap, row) * (long long)D;
+        f32x4 v[MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nchunk) {
+                v[t] = load4<XT>(xr + 4 * c);
+                s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+            }
+        }
+        const float mean = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[t][e] - mean; q += d * d; }
+            }
+        }
+        const float var = wave_sum(q) * invD;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        YT* yr = y + map_row(omap, row) * (long long)D;
+        const WT* ar = add ? add + ((add_group > 0 ? row % add_group : row) + add_off) * (long long)D : nullptr;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nchunk) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[t][e] - mean) * rstd * wv[t][e] + bv[t][e];
+                if (ar) { const f32x4 a = load4<WT>(ar + 4 * c); o += a; }
+                store4<YT>(yr + 4 * c, o);
+            }
+        }
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+}
+
+// Backward.  DXT is the dtype of the optional second dx output (dx_t).
+template <typename DYT, typename XT, typename WT, typename DXT, int MAXC>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
+    const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
+    float* __restrict__ partials, int colsum_dx,
+    long long rows, int D, RowMap dymap, RowMap xmap, RowMap dxmap) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nchunk = D >> 2;
+    const float invD = 1.0f / (float)D;
+    const bool want_dx = (dx_f32 != nullptr) || (dx_t != nullptr);
+
+    f32x4 wv[MAXC], acc_w[MAXC], acc_b[MAXC], acc_x[MAXC];
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nchunk) wv[t] = load4<WT>(w + 4 * c);
+        acc_w[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc_b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc_x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long long row = (long long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long long)gridDim.x * LN_WAVES) {
+        const DYT* dyr = dy + map_row(dymap, row) * (long long)D;
+        const XT* xr = x + map_row(xmap, row) * (long long)D;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        f32x4 g[MAXC], xh[MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nchunk) {
+                const f32x4 d = load4<DYT>(dyr + 4 * c);
+                const f32x4 xv = load4<XT>(xr + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[t][e] = (xv[e] - mean) * rstd;
+                    g[t][e] = d[e] * wv[t][e];
+                    s1 += g[t][e];
+                    s2 += g[t][e] * xh[t][e];
+                    acc_w[t][e] += d[e] * xh[t][e];
+                    acc_b[t][e] += d[e];
+                }
+            }
+        }
+        if (want_dx) {
+            const float c1 = wave_sum(s1) * invD;
+            const float c2 = wave_sum(s2) * invD;
+            const long long orow = map_row(dxmap, row);
+#pragma unroll
+            for (int t = 0; t < MAXC; ++t) {
+                const int c = lane + 64 * t;
+                if (c < nchunk) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2);
+                    if (gin) { const f32x4 gi = *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c); o += gi; }
+                    if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow * D + 4 * c) = o;
+                    if (dx_t) store4<DXT>(dx_t + orow * D + 4 * c, o);
+                    if (colsum_dx) acc_x[t] += o;
+                }
+            }
+        }
+    }
+    // block reduce the per-wave column accumulators through LDS, one slab at a time
+    __shared__ f32x4 red[LN_WAVES][64];
+    const int nslab = colsum_dx ? 3 : 2;
+    for (int slab = 0; slab < nslab; ++slab) {
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            if (64 * t < nchunk) {  // uniform across the block
+                const f32x4 a = slab == 0 ? acc_w[t] : (slab == 1 ? acc_b[t] : acc_x[t]);
+                red[wave][lane] = a;
+                __syncthreads();
+                if (wave == 0) {
+                    const int c = lane + 64 * t;
+                    if (c < nchunk) {
+                        f32x4 sum = red[0][lane];
+#pragma unroll
+                        for (int wv_ = 1; wv_ < LN_WAVES; ++wv_) sum += red[wv_][lane];
+                        *reinterpret_cast<f32x4*>(partials + ((long long)slab * gridDim.x + blockIdx.x) * D + 4 * c) = sum;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// out[c] = (acc ? out[c] : 0) + sum_p partials[p*ld + c]
+template <typename OT>
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partials, long long nparts,
+                                                               long long ld, long long cols, OT* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const long long c = (long long)blockIdx.x * 64 + cx;
+    float s = 0.f;
+    if (c < cols) for (long long p = ph; p < nparts; p += 4) s += partials[p * ld + c];
+    red[ph][cx] = s;
+    __syncthreads();
+    if (ph == 0 && c < cols) {
+        float t = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+        if (accumulate) t += to_f32<OT>(out[c]);
+        out[c] = from_f32<OT>(t);
+    }
+}
+
+// stage 1 of a general column sum: block = 64 column-quads x 4 row phases over a 256-row slab.
+constexpr int CS_ROWS = 256;
+template <typename XT>
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const XT* __restrict__ x, long long rows, long long cols,
+                                                             long long ld, float* __restrict__ ws) {
+    __shared__ f32x4 red[4][64];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const long long c4 = ((long long)blockIdx.x * 64 + cx) * 4;
+    const long long r0 = (long long)blockIdx.y * CS_ROWS;
+    const long long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < cols) for (long long r = r0 + ph; r < r1; r += 4) s += load4<XT>(x + r * ld + c4);
+    red[ph][cx] = s;
+    __syncthreads();
+    if (ph == 0 && c4 < cols) {
+        const f32x4 t = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+        *reinterpret_cast<f32x4*>(ws + (long long)blockIdx.y * cols + c4) = t;
+    }
+}
+
+// scalar variant for widths that are not a multiple of 4 (e.g. num_classes = 10)
+template <typename XT>
+__global__ __launch_bounds__(256) void colsum_stage1_scalar_kernel(const XT* __restrict__ x, long long rows, long long cols,
+                                                                    long long ld, float* __restrict__ ws) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const long long c = (long long)blockIdx.x * 64 + cx;
+    const long long r0 = (long long)blockIdx.y * CS_ROWS;
+    const long long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+    float s = 0.f;
+    if (c < cols) for (long long r = r0 + ph; r < r1; r += 4) s += to_f32<XT>(x[r * ld + c]);
+    red[ph][cx] = s;
+    __syncthreads();
+    if (ph == 0 && c < cols) ws[(long long)blockIdx.y * cols + c] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+
+template <typename XT, typename YT, typename WT>
+int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, long long rows, int D,
+                  float eps, RowMap im, RowMap om, const void* add, long long ag, long long ao, hipStream_t st) {
+    const int nchunk = D / 4;
+    const int maxc = (nchunk + 63) / 64;
+    long long blocks = (rows + LN_WAVES - 1) / LN_WAVES;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+#define LN_FWD_CASE(MC) hipLaunchKernelGGL((ln_fwd_kernel<XT, YT, WT, MC>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, \
+        (const XT*)x, (const WT*)w, (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao)
+    if (maxc <= 1) LN_FWD_CASE(1);
+    else if (maxc <= 3) LN_FWD_CASE(3);
+    else if (maxc <= 4) LN_FWD_CASE(4);
+    else if (maxc <= 5) LN_FWD_CASE(5);
+    else if (maxc <= 8) LN_FWD_CASE(8);
+    else LN_FWD_CASE(16);
+#undef LN_FWD_CASE
+    VITK_CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+
+template <typename DYT, typename XT, typename WT, typename DXT>
+int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const float* gin,
+                  float* dxf, void* dxt, float* partials, int colsum_dx, long long rows, int D, RowMap dm, RowMap xm,
+                  RowMap om, hipStream_t st) {
+    const int nchunk = D / 4;
+    const int maxc = (nchunk + 63) / 64;
+    const long long blocks = vitk_layernorm_bwd_blocks(rows);
+#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, \
+        (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om)
+    if (maxc <= 1) LN_BWD_CASE(1);
+    else if (maxc <= 3) LN_BWD_CASE(3);
+    else if (maxc <= 4) LN_BWD_CASE(4);
+    else if (maxc <= 5) LN_BWD_CASE(5);
+    else if (maxc <= 8) LN_BWD_CASE(8);
+    else LN_BWD_CASE(16);
+#undef LN_BWD_CASE
+    VITK_CHECK_LAUNCH("layernorm_bwd");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vitk_layernorm_fwd(const void* x, int xdt, const void* w, const void* b, int wdt, void* y, int ydt,
+                                  float* mean, float* rstd, int64_t rows, int64_t D, float eps, vitk_rowmap imap,
+                                  vitk_rowmap omap, const void* add, int64_t add_group, int64_t add_off, void* stream) {
+    if (!x || !w || !y || !mean || !rstd) VITK_FAIL(VITK_E_ARG, "layernorm_fwd: null pointer");
+    if (rows < 0 || D <= 0 || (D & 3) || D > 4096) VITK_FAIL(VITK_E_SHAPE, "layernorm_fwd: need D %% 4 == 0 and D <= 4096, got D=%lld", (long long)D);
+    if (rows == 0) return 0;
+    if (!aligned16(x) || !aligned16(y) || !aligned8(w) || (b && !aligned8(b)) || (add && !aligned8(add)))
+        VITK_FAIL(VITK_E_ALIGN, "layernorm_fwd: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const RowMap im = to_map(imap), om = to_map(omap);
+    if (wdt == VITK_F32) {
+        if (xdt != VITK_F32 || ydt != VITK_F32) VITK_FAIL(VITK_E_DTYPE, "layernorm_fwd: f32 params need f32 x/y");
+        return launch_ln_fwd<float, float, float>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
+    }
+    if (wdt != VITK_BF16) VITK_FAIL(VITK_E_DTYPE, "layernorm_fwd: bad wdt");
+    if (xdt == VITK_F32 && ydt == VITK_BF16) return launch_ln_fwd<float, __bf16, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
+    if (xdt == VITK_F32 && ydt == VITK_F32) return launch_ln_fwd<float, float, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
+    if (xdt == VITK_BF16 && ydt == VITK_BF16) return launch_ln_fwd<__bf16, __bf16, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
+    if (xdt == VITK_BF16 && ydt == VITK_F32) return launch_ln_fwd<__bf16, float, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
+    VITK_FAIL(VITK_E_DTYPE, "layernorm_fwd: bad dtype combination");
+}
+
+extern "C" int64_t vitk_layernorm_bwd_blocks(int64_t rows) {
+    int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+extern "C" int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int xdt, const void* w, int wdt,
+                                  const float* mean, const float* rstd, const float* gin, float* dx_f32, void* dx_t,
+                                  int dxtdt, float* partials, int colsum_dx, int64_t rows, int64_t D, vitk_rowmap dymap,
+                                  vitk_rowmap xmap, vitk_rowmap dxmap, void* stream) {
+    if (!dy || !x || !w || !mean || !rstd || !partials) VITK_FAIL(VITK_E_ARG, "layernorm_bwd: null pointer");
+    if (rows <= 0 || D <= 0 || (D & 3) || D > 4096) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd: need rows > 0, D %% 4 == 0, D <= 4096");
+    if (!aligned16(dy) || !aligned16(x) || (gin && !aligned16(gin)) || (dx_f32 && !aligned16(dx_f32)) || (dx_t && !aligned16(dx_t)))
+        VITK_FAIL(VITK_E_ALIGN, "layernorm_bwd: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const RowMap dm = to_map(dymap), xm = to_map(xmap), om = to_map(dxmap);
+    if (wdt == VITK_F32) {
+        if (dydt != VITK_F32 || xdt != VITK_F32 || (dx_t && dxtdt != VITK_F32)) VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: f32 params need f32 tensors");
+        return launch_ln_bwd<float, float, float, float>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
+    }
+    if (wdt != VITK_BF16) VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: bad wdt");
+    if (dx_t && dxtdt != VITK_BF16) VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: dx_t must be bf16 with bf16 params");
+    if (dydt == VITK_BF16 && xdt == VITK_F32) return launch_ln_bwd<__bf16, float, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
+    if (dydt == VITK_BF16 && xdt == VITK_BF16) return launch_ln_bwd<__bf16, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
+    if (dydt == VITK_F32 && xdt == VITK_F32) return launch_ln_bwd<float, float, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
+    if (dydt == VITK_F32 && xdt == VITK_BF16) return launch_ln_bwd<float, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
+    VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: bad dtype combination");
+}
+
+extern "C" int vitk_colsum_partials(const float* partials, int64_t nparts, int64_t ld, int64_t cols, void* out, int odt,
+                                    int accumulate, void* stream) {
+    if (!partials || !out) VITK_FAIL(VITK_E_ARG, "colsum_partials: null pointer");
+    if (cols <= 0 || nparts <= 0) VITK_FAIL(VITK_E_SHAPE, "colsum_partials: empty");
+    const unsigned blocks = (unsigned)((cols + 63) / 64);
+    VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((colsum_partials_kernel<OT>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                                  partials, (long long)nparts, (long long)ld, (long long)cols, (OT*)out, accumulate));
+    VITK_CHECK_LAUNCH("colsum_partials");
+    return 0;
+}
+
+extern "C" int64_t vitk_colsum_ws_floats(int64_t rows, int64_t cols) { return ((rows + CS_ROWS - 1) / CS_ROWS) * cols; }
+
+extern "C" int vitk_colsum(const void* x, int xdt, int64_t rows, int64_t cols, int64_t ld, void* out, int odt,
+                           int accumulate, float* ws, void* stream) {
+    if (!x || !out || !ws) VITK_FAIL(VITK_E_ARG, "colsum: null pointer");
+    if (rows <= 0 || cols <= 0 || ld < cols) VITK_FAIL(VITK_E_SHAPE, "colsum: bad shape");
+    const long long rb = (rows + CS_ROWS - 1) / CS_ROWS;
+    if (rb > 65535) VITK_FAIL(VITK_E_SHAPE, "colsum: too many rows");
+    if ((cols & 3) == 0 && (ld & 3) == 0 && aligned16(x) && aligned16(ws)) {
+        const dim3 grid((unsigned)((cols / 4 + 63) / 64), (unsigned)rb);
+        VITK_DISPATCH_DT(xdt, XT, hipLaunchKernelGGL((colsum_stage1_kernel<XT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                      (const XT*)x, (long long)rows, (long long)cols, (long long)ld, ws));
+    } else {
+        const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)rb);
+        VITK_DISPATCH_DT(xdt, XT, hipLaunchKernelGGL((colsum_stage1_scalar_kernel<XT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                      (const XT*)x, (long long)rows, (long long)cols, (long long)ld, ws));
+    }
+    VITK_CHECK_LAUNCH("colsum_stage1");
+    return vitk_colsum_partials(ws, rb, cols, cols, out, odt, accumulate, stream);
+}

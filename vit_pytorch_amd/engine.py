@@ -1,0 +1,353 @@
+"""Fused forward/backward of the ViT encoder as three torch.autograd.Functions.
+
+    PatchEmbedFn   img -> x0        vit.py:99-104 + :122-128   (patchify, LN, Linear, LN, cls, +pos)
+    TransformerFn  x0  -> tokens    vit.py:78-83               (depth x [attn + x ; ff + x], final LN)
+    HeadFn         tokens -> logits vit.py:135-138             (pool, Linear)
+
+Each Function runs the whole stage on libvitk kernels (vit_pytorch_amd.ops), keeps what backward
+needs, and its backward produces the gradients of every parameter of the stage.  Backward is
+entered from autograd's device thread; all launches go to that thread's current stream.
+
+Data flow per transformer layer (T = model dtype, residual stream x in f32):
+
+    a1  = LN1(x)                        T   (M, D)      stats1
+    qkv = a1 Wqkv^T                     T   (M, 3I)     merged layout, never split
+    o   = softmax(scale q k^T) v        T   (M, I)      lse (B,H,N)
+    x2  = x + o Wout^T + bout           f32 (M, D)      fused residual epilogue
+    a2  = LN2(x2)                       T               stats2
+    pre = a2 W1^T + b1 ; act = gelu     T   (M, F) x2   fused bias+GELU epilogue
+    x3  = x2 + act W2^T + b2            f32             fused residual epilogue
+
+A GradSink (see parallel.py) may be installed to place parameter gradients into one flat
+buffer and to be told when the transformer's gradients are complete (data-parallel overlap).
+"""
+from __future__ import annotations
+
+import threading
+from typing import List, Optional
+
+import torch
+
+from . import kernels as K
+from . import ops
+from ._lib import RowMap, VitkError
+
+Tensor = torch.Tensor
+F32 = torch.float32
+
+_sink_local = threading.local()
+_sink_global = [None]
+
+
+def set_grad_sink(sink):
+    """Install (or clear with None) the object that receives parameter-gradient buffers."""
+    _sink_global[0] = sink
+
+
+def _sink():
+    return _sink_global[0]
+
+
+def _grad_buf(param: Tensor) -> Tensor:
+    s = _sink()
+    if s is not None:
+        buf = s.buffer_for(param)
+        if buf is not None:
+            return buf
+    return torch.empty_like(param, memory_format=torch.contiguous_format)
+
+
+def _check_dims(D: int, what: str):
+    if D % 4 != 0:
+        raise VitkError(f"{what}: feature dimension {D} must be a multiple of 4 for the HIP kernels")
+
+
+LAYER_NPARAM = 10  # ln1_w, ln1_b, Wqkv, Wout, bout, ln2_w, ln2_b, W1, b1, W2, b2 -> see pack order below
+
+
+def pack_layer_params(attn, ff) -> List[Optional[Tensor]]:
+    """Fixed argument order of one layer for TransformerFn (None where the module has no tensor)."""
+    to_out = attn.to_out
+    if isinstance(to_out, torch.nn.Identity):
+        wout, bout = None, None
+    elif isinstance(to_out, torch.nn.Linear):      # SimpleViT: bias-free Linear (simple_vit.py:48)
+        wout, bout = to_out.weight, to_out.bias
+    else:                                          # ViT: Sequential(Linear, Dropout) (vit.py:46-49)
+        wout, bout = to_out[0].weight, to_out[0].bias
+    lins = [m for m in ff.net if isinstance(m, torch.nn.Linear)]
+    return [attn.norm.weight, attn.norm.bias, attn.to_qkv.weight, wout, bout,
+            ff.net[0].weight, ff.net[0].bias, lins[0].weight, lins[0].bias, lins[1].weight, lins[1].bias]
+
+
+NLP = 11  # tensors per layer in pack_layer_params
+
+
+class TransformerFn(torch.autograd.Function):
+    """Transformer.forward (vit.py:78-83 / simple_vit.py:74-78), dropout = 0."""
+
+    @staticmethod
+    def forward(ctx, x, heads: int, dim_head: int, norm_w, norm_b, *lp):
+        K.require_device(x, norm_w)
+        depth = len(lp) // NLP
+        T = norm_w.dtype
+        B, N, D = x.shape
+        M = B * N
+        _check_dims(D, "Transformer")
+        I = heads * dim_head
+        scale = dim_head ** -0.5
+        x = x.contiguous()
+        if x.dtype == F32:
+            xs = x
+        else:
+            xs = ops.empty((B, N, D), F32, x)
+            K.cast(x, xs)
+        saved = []
+        for li in range(depth):
+            ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
+            a1 = ops.empty((M, D), T, xs)
+            st1 = ops.ln_fwd(xs, ln1w, ln1b, M, D, a1)
+            qkv = ops.linear_fwd(a1, wqkv, None, M)
+            o, att_saved = ops.attn_fwd(qkv, B, N, heads, dim_head, scale)
+            if wout is not None:
+                x2 = ops.linear_fwd(o, wout, bout, M, resid=xs)
+            else:  # to_out = Identity (heads == 1 and dim_head == dim, vit.py:34,49)
+                x2 = ops.empty((M, D), F32, xs)
+                K.add_rows(xs, o, None, x2, M, D)
+            a2 = ops.empty((M, D), T, xs)
+            st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2)
+            act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True)
+            x3 = ops.linear_fwd(act, w2, b2, M, resid=x2)
+            saved.append((xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act))
+            xs = x3
+        y = ops.empty((B, N, D), T, xs)
+        stf = ops.ln_fwd(xs, norm_w, norm_b, M, D, y)
+        ctx.saved = saved
+        ctx.x_last = xs
+        ctx.stf = stf
+        ctx.meta = (heads, dim_head, depth, B, N, D, x.dtype)
+        ctx.save_for_backward(norm_w, norm_b, *[t for t in lp if t is not None])
+        ctx.lp_mask = [t is not None for t in lp]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        heads, dim_head, depth, B, N, D, in_dtype = ctx.meta
+        sv = list(ctx.saved_tensors)
+        norm_w, norm_b = sv[0], sv[1]
+        it = iter(sv[2:])
+        lp = [next(it) if m else None for m in ctx.lp_mask]
+        T = norm_w.dtype
+        bf = T != F32
+        M = B * N
+        scale = dim_head ** -0.5
+        dy = dy.contiguous()
+        grads: List[Optional[Tensor]] = [None] * len(lp)
+
+        def newg():
+            g32 = ops.empty((M, D), F32, dy)
+            return g32, (ops.empty((M, D), T, dy) if bf else None)
+
+        # final LayerNorm (vit.py:83)
+        g, gb = newg()
+        dnw, dnb = _grad_buf(norm_w), _grad_buf(norm_b)
+        dcol = ops.empty((D,), T, dy)  # colsum of g == bias gradient of the last layer's second FF Linear
+        ops.ln_bwd(dy, ctx.x_last, norm_w, ctx.stf[0], ctx.stf[1], M, D, dx_f32=g, dx_t=gb, dw=dnw, db=dnb, dcol=dcol)
+        ctx.x_last = None
+        for li in reversed(range(depth)):
+            ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
+            xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act = ctx.saved[li]
+            ctx.saved[li] = None
+            gT = gb if bf else g
+            base = li * NLP
+            # ---- feed-forward branch (vit.py:18-25) ----
+            dw2 = _grad_buf(w2)
+            ops.linear_dw(gT, act, M, dw2)
+            grads[base + 9] = dw2
+            if b2 is not None:
+                db2 = _grad_buf(b2)
+                K.cast(dcol, db2)
+                grads[base + 10] = db2
+            dpre = ops.linear_dx(gT, w2, M, gelu_pre=pre)
+            dw1 = _grad_buf(w1)
+            db1 = _grad_buf(b1) if b1 is not None else None
+            ops.linear_dw(dpre, a2, M, dw1, db1)
+            grads[base + 7], grads[base + 8] = dw1, db1
+            da2 = ops.linear_dx(dpre, w1, M)
+            del dpre, pre, act
+            g2, g2b = newg()
+            dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
+            dcol2 = ops.empty((D,), T, dy)
+            ops.ln_bwd(da2, x2, ln2w, st2[0], st2[1], M, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2w, db=dl2b, dcol=dcol2)
+            grads[base + 5], grads[base + 6] = dl2w, dl2b
+            del da2, g, gb
+            g2T = g2b if bf else g2
+            # ---- attention branch (vit.py:51-64) ----
+            if wout is not None:
+                dwo = _grad_buf(wout)
+                ops.linear_dw(g2T, o, M, dwo)
+                grads[base + 3] = dwo
+                if bout is not None:
+                    dbo = _grad_buf(bout)
+                    K.cast(dcol2, dbo)
+                    grads[base + 4] = dbo
+                do = ops.linear_dx(g2T, wout, M)
+            else:
+                do = g2T
+            dqkv = ops.attn_bwd(qkv, o, do, att_saved, B, N, heads, dim_head, scale)
+            dwq = _grad_buf(wqkv)
+            ops.linear_dw(dqkv, a1, M, dwq)
+            grads[base + 2] = dwq
+            da1 = ops.linear_dx(dqkv, wqkv, M)
+            del dqkv, do, qkv, o
+            g1, g1b = newg()
+            dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
+            dcol = ops.empty((D,), T, dy)
+            ops.ln_bwd(da1, xs, ln1w, st1[0], st1[1], M, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1w, db=dl1b, dcol=dcol)
+            grads[base + 0], grads[base + 1] = dl1w, dl1b
+            g, gb = g1, g1b
+            del g2, g2b, da1
+        s = _sink()
+        if s is not None:
+            s.stage_done("transformer")
+        if in_dtype == F32:
+            dx = g.view(B, N, D)
+        else:
+            dx = (gb if gb is not None else g).view(B, N, D)
+        return (dx, None, None, dnw, dnb, *grads)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """to_patch_embedding + cls token + positional embedding (vit.py:99-104, :122-128;
+    simple_vit.py:90-95, :113-114).  Output: float32 residual stream (B, N, D)."""
+
+    @staticmethod
+    def forward(ctx, img, p1: int, p2: int, ln1w, ln1b, w, b, ln2w, ln2b, cls, pos):
+        K.require_device(img, w)
+        T = w.dtype
+        if img.dtype != T:
+            raise VitkError(f"input dtype {img.dtype} != parameter dtype {T} (same rule as the reference nn.Linear)")
+        img = img.contiguous()
+        B, C, H, W = img.shape
+        if H % p1 or W % p2:
+            raise VitkError("Image dimensions must be divisible by the patch size.")
+        Np = (H // p1) * (W // p2)
+        P = C * p1 * p2
+        D = w.shape[0]
+        _check_dims(D, "patch embedding (dim)")
+        _check_dims(P, "patch embedding (patch_dim)")
+        ncls = cls.shape[0] if cls is not None else 0
+        N = Np + ncls
+        if pos is not None and pos.shape[0] < N:
+            raise VitkError(f"sequence of {N} tokens exceeds the positional table ({pos.shape[0]} rows)")
+        Mp = B * Np
+        patches = ops.empty((Mp, P), T, img)
+        K.patchify(img, patches, B, C, H, W, p1, p2)
+        pn = ops.empty((Mp, P), T, img)
+        st1 = ops.ln_fwd(patches, ln1w, ln1b, Mp, P, pn)
+        y = ops.linear_fwd(pn, w, b, Mp)
+        x0 = ops.empty((B, N, D), F32, img)
+        st2 = ops.ln_fwd(y, ln2w, ln2b, Mp, D, x0, omap=RowMap(Np, N, ncls), add=pos, add_group=Np, add_off=ncls)
+        if ncls:
+            K.write_cls_rows(x0, cls, pos, B, N, D, ncls)
+        ctx.save_for_backward(ln1w, ln1b, w, ln2w, ln2b, *([b] if b is not None else []))
+        ctx.inter = (patches, st1, pn, y, st2)
+        ctx.meta = (B, Np, N, P, D, ncls, b is not None, cls is not None, pos is not None and pos.requires_grad,
+                    pos.shape if pos is not None else None)
+        return x0
+
+    @staticmethod
+    def backward(ctx, g):
+        sv = ctx.saved_tensors
+        ln1w, ln1b, w, ln2w, ln2b = sv[:5]
+        bparam = sv[5] if len(sv) > 5 else None
+        patches, st1, pn, y, st2 = ctx.inter
+        ctx.inter = None
+        B, Np, N, P, D, ncls, has_b, has_cls, pos_grad, pos_shape = ctx.meta
+        T = w.dtype
+        Mp = B * Np
+        g = g.contiguous()
+        if g.dtype != F32:
+            g32 = ops.empty((B, N, D), F32, g)
+            K.cast(g, g32)
+            g = g32
+        dpos = dcls = None
+        if pos_grad or has_cls:
+            # d pos[n] = sum_b g[b, n] ; d cls = d pos[0:ncls]   (x[b,n] = tok[b,n] + pos[n]; x[b,0] = cls + pos[0])
+            gsum = ops.empty((N * D,), T, g)
+            ops.colsum(g, B, N * D, gsum)
+            gsum = gsum.view(N, D)
+            if pos_grad:
+                dpos = torch.zeros(pos_shape, dtype=T, device=g.device) if pos_shape[0] != N else None
+                if dpos is None:
+                    dpos = gsum
+                else:
+                    K.cast(gsum, dpos[:N])
+            if has_cls and ncls:
+                dcls = ops.empty((ncls, D), T, g)
+                K.cast(gsum[:ncls], dcls)
+            elif has_cls:
+                dcls = ops.empty((0, D), T, g)
+        # LN(dim) backward: dy rows are the patch rows of g (behind the cls slot)
+        dyp = ops.empty((Mp, D), T, g)
+        dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
+        ops.ln_bwd(g, y, ln2w, st2[0], st2[1], Mp, D, dx_t=dyp if T != F32 else None, dx_f32=dyp if T == F32 else None,
+                   dw=dl2w, db=dl2b, dymap=RowMap(Np, N, ncls))
+        dw = _grad_buf(w)
+        db = _grad_buf(bparam) if has_b else None
+        ops.linear_dw(dyp, pn, Mp, dw, db)
+        dpn = ops.linear_dx(dyp, w, Mp)
+        dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
+        ops.ln_bwd(dpn, patches, ln1w, st1[0], st1[1], Mp, P, dw=dl1w, db=dl1b)  # the image needs no gradient
+        s = _sink()
+        if s is not None:
+            s.stage_done("patch_embed")
+        return (None, None, None, dl1w, dl1b, dw, db, dl2w, dl2b, dcls, dpos)
+
+
+class HeadFn(torch.autograd.Function):
+    """pool ('cls' -> row 0, 'mean' -> mean over tokens) + Linear head (vit.py:135-138)."""
+
+    @staticmethod
+    def forward(ctx, y, pool_mean: bool, w, b):
+        K.require_device(y, w)
+        B, N, D = y.shape
+        T = w.dtype
+        C = w.shape[0]
+        y = y.contiguous()
+        logits = ops.empty((B, C), T, y)
+        if pool_mean:
+            pooled = ops.empty((B, D), T, y)
+            K.mean_pool_fwd(y, pooled, B, N, D)
+            K.gemm_generic(K.mat(pooled, D, 1), K.mat(w, 1, D), K.mat(logits, C, 1), B, C, D, bias=b)
+            ctx.pooled = pooled
+        else:  # row 0 of every image read in place through the row stride N*D
+            K.gemm_generic(K.mat(y, N * D, 1), K.mat(w, 1, D), K.mat(logits, C, 1), B, C, D, bias=b)
+            ctx.pooled = None
+        ctx.save_for_backward(y, w, *([b] if b is not None else []))
+        ctx.meta = (B, N, D, C, pool_mean, b is not None)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        y, w = ctx.saved_tensors[:2]
+        B, N, D, C, pool_mean, has_b = ctx.meta
+        T = w.dtype
+        dl = dl.contiguous()
+        dw = _grad_buf(w)
+        db = _grad_buf(ctx.saved_tensors[2]) if has_b else None
+        dy = torch.zeros((B, N, D), dtype=T, device=dl.device) if not pool_mean else ops.empty((B, N, D), T, dl)
+        if pool_mean:
+            pooled = ctx.pooled
+            K.gemm_generic(K.mat(dl, 1, C), K.mat(pooled, D, 1), K.mat(dw, D, 1), C, D, B)
+            dpooled = ops.empty((B, D), T, dl)
+            K.gemm_generic(K.mat(dl, C, 1), K.mat(w, D, 1), K.mat(dpooled, D, 1), B, D, C)
+            K.mean_pool_bwd(dpooled, dy, B, N, D)
+        else:
+            K.gemm_generic(K.mat(dl, 1, C), K.mat(y, N * D, 1), K.mat(dw, D, 1), C, D, B)
+            K.gemm_generic(K.mat(dl, C, 1), K.mat(w, D, 1), K.mat(dy, N * D, 1), B, D, C)  # writes row 0 of each image
+        if has_b:
+            ops.colsum(dl, B, C, db)
+        s = _sink()
+        if s is not None:
+            s.stage_done("head")
+        return dy, None, dw, db

@@ -1,0 +1,362 @@
+"""Fine-grained autograd Functions and nn.Module shells (one per torch.nn op the reference uses).
+
+These make every SUB-module of the drop-in callable on its own, exactly like the reference's
+(`vit.to_patch_embedding(img)`, `vit.transformer(tokens)`, `Attention(x)`, forward hooks on
+`Attention.attend` used by recorder.py:26-29, `to_latent` hooks used by dino.py:138-151), and
+they are the path taken when dropout is active in training.  They run the same libvitk
+kernels as the fused engine, one op at a time; the fused engine (engine.py) is the fast path.
+
+The Module shells subclass the torch.nn classes of the reference so `state_dict()` keys, shapes
+and `isinstance` checks are unchanged; only `forward` is replaced.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from . import ops
+from ._lib import VitkError
+
+Tensor = torch.Tensor
+F32 = torch.float32
+
+
+def _rows(x: Tensor):
+    D = x.shape[-1]
+    return x.numel() // D, D
+
+
+def _to(x: Tensor, dtype) -> Tensor:
+    """dtype conversion on the device through vitk_cast (no torch compute)."""
+    x = x.contiguous()
+    if x.dtype == dtype:
+        return x
+    y = torch.empty_like(x, dtype=dtype)
+    K.cast(x, y)
+    return y
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        K.require_device(x, w)
+        x = x.contiguous()
+        rows, D = _rows(x)
+        if D % 4:
+            raise VitkError(f"LayerNorm width {D} must be a multiple of 4")
+        if w.dtype == F32 and x.dtype != F32:
+            x = _to(x, F32)
+        y = torch.empty(x.shape, dtype=w.dtype, device=x.device)
+        mean, rstd = ops.ln_fwd(x, w, b, rows, D, y)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        rows, D = _rows(x)
+        T = w.dtype
+        dy = _to(dy, T)
+        dx32 = torch.empty(x.shape, dtype=F32, device=x.device)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(w) if ctx.has_b else None
+        dbuf = db if db is not None else torch.empty_like(w)
+        ops.ln_bwd(dy, x, w, mean, rstd, rows, D, dx_f32=dx32, dw=dw, db=dbuf)
+        return _to(dx32, x.dtype), dw, db
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        K.require_device(x, w)
+        if x.dtype != w.dtype:
+            raise VitkError(f"Linear: input dtype {x.dtype} != weight dtype {w.dtype}")
+        x = x.contiguous()
+        M, Kd = _rows(x)
+        y = ops.linear_fwd(x, w, b, M)
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        M, Kd = _rows(x)
+        dy = _to(dy, w.dtype)
+        dw = torch.empty_like(w)
+        db = torch.empty(w.shape[0], dtype=w.dtype, device=w.device) if ctx.has_b else None
+        ops.linear_dw(dy, x, M, dw, db)
+        dx = ops.linear_dx(dy, w, M).view(x.shape) if ctx.needs_input_grad[0] else None
+        return dx, dw, db
+
+
+class GELUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        K.require_device(x)
+        x = x.contiguous()
+        if x.numel() % 4:
+            raise VitkError("GELU: element count must be a multiple of 4")
+        y = torch.empty_like(x)
+        K.gelu_fwd(x, y)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        K.gelu_bwd(_to(dy, x.dtype), x, dx)
+        return dx
+
+
+class SoftmaxFn(torch.autograd.Function):
+    """nn.Softmax(dim=-1) (vit.py:41,59)."""
+
+    @staticmethod
+    def forward(ctx, s):
+        K.require_device(s)
+        s = s.contiguous()
+        rows, cols = _rows(s)
+        p = torch.empty_like(s)
+        K.softmax_fwd(s, p, rows, cols, 1.0)
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        rows, cols = _rows(p)
+        ds = torch.empty_like(p)
+        K.softmax_bwd(p, _to(dp, p.dtype), ds, rows, cols, 1.0)
+        return ds
+
+
+class AddFn(torch.autograd.Function):
+    """a + b with both of one shape (the residual adds of vit.py:80-81)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        K.require_device(a, b)
+        if a.shape != b.shape or a.dtype != b.dtype:
+            raise VitkError("AddFn: operands must have one shape and dtype")
+        a = a.contiguous(); b = b.contiguous()
+        rows, D = _rows(a)
+        if D % 4:
+            raise VitkError("AddFn: last dimension must be a multiple of 4")
+        out = torch.empty_like(a)
+        K.add_rows(a, b, None, out, rows, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout in training mode (vit.py:22,24,42,48,109): counter-based mask, reproducible fwd<->bwd."""
+    _offset = [0]
+
+    @staticmethod
+    def forward(ctx, x, p: float):
+        K.require_device(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        seed = int(torch.initial_seed()) & 0x7fffffffffffffff
+        off = DropoutFn._offset[0]
+        DropoutFn._offset[0] += x.numel()
+        K.dropout_fwd(x, y, mask, p, seed, off)
+        ctx.save_for_backward(mask)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        K.dropout_bwd(dy, mask, dx, ctx.p)
+        return dx, None
+
+
+class PatchifyFn(torch.autograd.Function):
+    """Rearrange 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit.py:100)."""
+
+    @staticmethod
+    def forward(ctx, img, p1: int, p2: int):
+        K.require_device(img)
+        img = img.contiguous()
+        B, C, H, W = img.shape
+        if H % p1 or W % p2:
+            raise VitkError("Image dimensions must be divisible by the patch size.")
+        out = torch.empty((B, (H // p1) * (W // p2), p1 * p2 * C), dtype=img.dtype, device=img.device)
+        K.patchify(img, out, B, C, H, W, p1, p2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.needs_input_grad[0]:
+            raise VitkError("gradient with respect to the input image is not implemented")
+        return None, None, None
+
+
+class ScoresFn(torch.autograd.Function):
+    """dots = (q k^T) * scale over the merged qkv tensor (vit.py:54-57): (B,N,3I) -> (B,H,N,N)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads: int, scale: float):
+        K.require_device(qkv)
+        qkv = qkv.contiguous()
+        B, N, I3 = qkv.shape
+        I = I3 // 3
+        d = I // heads
+        S = torch.empty((B, heads, N, N), dtype=qkv.dtype, device=qkv.device)
+        K.gemm_generic(K.mat(qkv, I3, 1, N * I3, d), K.mat(qkv, 1, I3, N * I3, d, offset=I),
+                       K.mat(S, N, 1, heads * N * N, N * N), N, N, d, nb1=B, nb2=heads, alpha=scale)
+        ctx.save_for_backward(qkv)
+        ctx.meta = (heads, scale)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        (qkv,) = ctx.saved_tensors
+        heads, scale = ctx.meta
+        B, N, I3 = qkv.shape
+        I = I3 // 3
+        d = I // heads
+        dS = _to(dS, qkv.dtype)
+        dqkv = torch.zeros_like(qkv)  # the v third receives no gradient from here
+        sm = K.mat(dS, N, 1, heads * N * N, N * N)
+        smT = K.mat(dS, 1, N, heads * N * N, N * N)
+        K.gemm_generic(sm, K.mat(qkv, I3, 1, N * I3, d, offset=I), K.mat(dqkv, I3, 1, N * I3, d), N, d, N,
+                       nb1=B, nb2=heads, alpha=scale)
+        K.gemm_generic(smT, K.mat(qkv, I3, 1, N * I3, d), K.mat(dqkv, I3, 1, N * I3, d, offset=I), N, d, N,
+                       nb1=B, nb2=heads, alpha=scale)
+        return dqkv, None, None
+
+
+class AttnValuesFn(torch.autograd.Function):
+    """out = attn @ v, merged back to 'b n (h d)' (vit.py:62-63): (B,H,N,N),(B,N,3I) -> (B,N,I)."""
+
+    @staticmethod
+    def forward(ctx, attn, qkv, heads: int):
+        K.require_device(attn, qkv)
+        attn = attn.contiguous(); qkv = qkv.contiguous()
+        B, N, I3 = qkv.shape
+        I = I3 // 3
+        d = I // heads
+        o = torch.empty((B, N, I), dtype=qkv.dtype, device=qkv.device)
+        K.gemm_generic(K.mat(attn, N, 1, heads * N * N, N * N), K.mat(qkv, I3, 1, N * I3, d, offset=2 * I),
+                       K.mat(o, I, 1, N * I, d), N, d, N, nb1=B, nb2=heads)
+        ctx.save_for_backward(attn, qkv)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        attn, qkv = ctx.saved_tensors
+        heads = ctx.heads
+        B, N, I3 = qkv.shape
+        I = I3 // 3
+        d = I // heads
+        do = _to(do, qkv.dtype)
+        dom = K.mat(do, I, 1, N * I, d)
+        dattn = torch.empty_like(attn)
+        K.gemm_generic(dom, K.mat(qkv, 1, I3, N * I3, d, offset=2 * I), K.mat(dattn, N, 1, heads * N * N, N * N),
+                       N, N, d, nb1=B, nb2=heads)
+        dqkv = torch.zeros_like(qkv)
+        K.gemm_generic(K.mat(attn, 1, N, heads * N * N, N * N), dom, K.mat(dqkv, I3, 1, N * I3, d, offset=2 * I),
+                       N, d, N, nb1=B, nb2=heads)
+        return dattn, dqkv, None
+
+
+class FusedAttnFn(torch.autograd.Function):
+    """The fused attention core on the merged qkv tensor: (B,N,3I) -> (B,N,I)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads: int, scale: float):
+        K.require_device(qkv)
+        qkv = qkv.contiguous()
+        B, N, I3 = qkv.shape
+        d = I3 // 3 // heads
+        o, saved = ops.attn_fwd(qkv.view(B * N, I3), B, N, heads, d, scale)
+        ctx.save_for_backward(qkv, o, saved)
+        ctx.meta = (heads, scale)
+        return o.view(B, N, I3 // 3)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, saved = ctx.saved_tensors
+        heads, scale = ctx.meta
+        B, N, I3 = qkv.shape
+        d = I3 // 3 // heads
+        dqkv = ops.attn_bwd(qkv.view(B * N, I3), o, _to(do, qkv.dtype).view(B * N, I3 // 3), saved, B, N, heads, d, scale)
+        return dqkv.view(B, N, I3), None, None
+
+
+class MeanTokensFn(torch.autograd.Function):
+    """x.mean(dim=1) (vit.py:135, simple_vit.py:117)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        K.require_device(x)
+        x = x.contiguous()
+        B, N, D = x.shape
+        out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+        K.mean_pool_fwd(x, out, B, N, D)
+        ctx.shape = (B, N, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((B, N, D), dtype=g.dtype, device=g.device)
+        K.mean_pool_bwd(g, dx, B, N, D)
+        return dx
+
+
+# ---- nn.Module shells (same classes / state_dict keys as the reference's children) -------------
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return LayerNormFn.apply(x, self.weight, self.bias)
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return LinearFn.apply(x, self.weight, self.bias)
+
+
+class GELU(nn.GELU):
+    def forward(self, x):
+        return GELUFn.apply(x)
+
+
+class Softmax(nn.Softmax):
+    def forward(self, x):
+        assert self.dim in (-1, x.dim() - 1)
+        return SoftmaxFn.apply(x)
+
+
+class Dropout(nn.Dropout):
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        return DropoutFn.apply(x, float(self.p))
+
+
+class Patchify(nn.Module):
+    """Stands where the reference has einops' Rearrange (to_patch_embedding[0]); no parameters."""
+
+    def __init__(self, p1: int, p2: int):
+        super().__init__()
+        self.p1, self.p2 = p1, p2
+
+    def forward(self, img):
+        return PatchifyFn.apply(img, self.p1, self.p2)
+
+    def extra_repr(self):
+        return f"'b c (h p1) (w p2) -> b (h w) (p1 p2 c)', p1={self.p1}, p2={self.p2}"

@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the C-ABI (one Python function per libvitk entry point).
+
+torch is used here only as the owner of device memory and of the current HIP stream
+(``torch.cuda.current_stream().cuda_stream`` is the ``hipStream_t`` on ROCm builds); every
+computation happens inside libvitk.so.  All functions enqueue on the CURRENT stream and
+return immediately.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import BF16, F32, IDENT, BHND, Mat, RowMap, check
+
+Tensor = torch.Tensor
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return F32
+    if d == torch.bfloat16:
+        return BF16
+    raise L.VitkError(f"unsupported dtype {d}: libvitk computes in float32 or bfloat16")
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*ts: Tensor):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.VitkError(
+                "vit_pytorch_amd runs on an AMD GPU (HIP) only: got a tensor on "
+                f"{t.device}. Move the module and its input to 'cuda'. There is no CPU path.")
+
+
+def _c(t: Tensor) -> Tensor:
+    assert t.is_contiguous(), "libvitk wrappers take contiguous tensors"
+    return t
+
+
+# ---- LayerNorm -------------------------------------------------------------------------------
+def layernorm_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], y: Tensor, mean: Tensor, rstd: Tensor,
+                  rows: int, D: int, eps: float = 1e-5, imap: RowMap = IDENT, omap: RowMap = IDENT,
+                  add: Optional[Tensor] = None, add_group: int = 0, add_off: int = 0):
+    lib = L.load()
+    check(lib.vitk_layernorm_fwd(_p(x), dt(x), _p(w), _p(b), dt(w), _p(y), dt(y), _p(mean), _p(rstd),
+                                 rows, D, eps, imap, omap, _p(add), add_group, add_off, _stream()),
+          "layernorm_fwd")
+
+
+def layernorm_bwd_blocks(rows: int) -> int:
+    return int(L.load().vitk_layernorm_bwd_blocks(rows))
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, gin: Optional[Tensor],
+                  dx_f32: Optional[Tensor], dx_t: Optional[Tensor], partials: Tensor, colsum_dx: bool,
+                  rows: int, D: int, dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT):
+    lib = L.load()
+    check(lib.vitk_layernorm_bwd(_p(dy), dt(dy), _p(x), dt(x), _p(w), dt(w), _p(mean), _p(rstd), _p(gin),
+                                 _p(dx_f32), _p(dx_t), dt(dx_t) if dx_t is not None else F32, _p(partials),
+                                 1 if colsum_dx else 0, rows, D, dymap, xmap, dxmap, _stream()),
+          "layernorm_bwd")
+
+
+def colsum_partials(partials: Tensor, nparts: int, ld: int, cols: int, out: Tensor, accumulate: bool = False):
+    check(L.load().vitk_colsum_partials(_p(partials), nparts, ld, cols, _p(out), dt(out), int(accumulate), _stream()),
+          "colsum_partials")
+
+
+def colsum_ws_floats(rows: int, cols: int) -> int:
+    return int(L.load().vitk_colsum_ws_floats(rows, cols))
+
+
+def colsum(x: Tensor, rows: int, cols: int, ld: int, out: Tensor, ws: Tensor, accumulate: bool = False):
+    check(L.load().vitk_colsum(_p(x), dt(x), rows, cols, ld, _p(out), dt(out), int(accumulate), _p(ws), _stream()),
+          "colsum")
+
+
+# ---- GEMMs -----------------------------------------------------------------------------------
+def gemm_nt_bf16(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
+                 epilogue: int = L.EPI_NONE, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
+                 aux: Optional[Tensor] = None):
+    check(L.load().vitk_gemm_nt_bf16(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, epilogue, _p(bias), _p(resid),
+                                     _p(aux), _stream()), "gemm_nt_bf16")
+
+
+def gemm_tn_splits(M: int, N: int, K: int) -> int:
+    return int(L.load().vitk_gemm_tn_splits(M, N, K))
+
+
+def gemm_tn_bf16(dY: Tensor, ldy: int, X: Tensor, ldx: int, dW: Tensor, ldo: int, M: int, N: int, K: int,
+                 ws: Tensor, splits: int, accumulate: bool = False):
+    check(L.load().vitk_gemm_tn_bf16(_p(dY), ldy, _p(X), ldx, _p(dW), dt(dW), ldo, int(accumulate), M, N, K,
+                                     _p(ws), splits, _stream()), "gemm_tn_bf16")
+
+
+def mat(t: Tensor, s_row: int, s_col: int, s_b1: int = 0, s_b2: int = 0, offset: int = 0) -> Mat:
+    return Mat(t.data_ptr() + offset * t.element_size(), dt(t), s_b1, s_b2, s_row, s_col)
+
+
+def gemm_generic(A: Mat, B: Mat, Cm: Mat, M: int, N: int, K: int, nb1: int = 1, nb2: int = 1,
+                 bias: Optional[Tensor] = None, alpha: float = 1.0, beta: float = 0.0):
+    check(L.load().vitk_gemm_generic(A, B, Cm, _p(bias), dt(bias) if bias is not None else F32, nb1, nb2, M, N, K,
+                                     alpha, beta, _stream()), "gemm_generic")
+
+
+# ---- attention -------------------------------------------------------------------------------
+def bhnd(t: Tensor, s_b: int, s_h: int, s_n: int, offset: int = 0) -> BHND:
+    return BHND(t.data_ptr() + offset * t.element_size(), s_b, s_h, s_n)
+
+
+def attn_fwd_bf16(q: BHND, k: BHND, v: BHND, o: BHND, lse: Tensor, B: int, H: int, N: int, d: int, scale: float):
+    check(L.load().vitk_attn_fwd_bf16(q, k, v, o, _p(lse), B, H, N, d, scale, _stream()), "attn_fwd_bf16")
+
+
+def attn_bwd_bf16(q: BHND, k: BHND, v: BHND, o: BHND, dout: BHND, lse: Tensor, delta: Tensor, dq: BHND, dk: BHND,
+                  dv: BHND, B: int, H: int, N: int, d: int, scale: float):
+    check(L.load().vitk_attn_bwd_bf16(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, B, H, N, d, scale, _stream()),
+          "attn_bwd_bf16")
+
+
+def softmax_fwd(s: Tensor, p: Tensor, rows: int, cols: int, scale: float):
+    check(L.load().vitk_softmax_fwd(_p(s), _p(p), dt(s), rows, cols, scale, _stream()), "softmax_fwd")
+
+
+def softmax_bwd(p: Tensor, dp: Tensor, ds: Tensor, rows: int, cols: int, scale: float):
+    check(L.load().vitk_softmax_bwd(_p(p), _p(dp), _p(ds), dt(p), rows, cols, scale, _stream()), "softmax_bwd")
+
+
+# ---- element-wise ------------------------------------------------------------------------------
+def patchify(img: Tensor, out: Tensor, B: int, C: int, H: int, W: int, p1: int, p2: int):
+    check(L.load().vitk_patchify(_p(img), _p(out), dt(img), B, C, H, W, p1, p2, _stream()), "patchify")
+
+
+def gelu_fwd(x: Tensor, y: Tensor):
+    check(L.load().vitk_gelu_fwd(_p(x), _p(y), dt(x), x.numel(), _stream()), "gelu_fwd")
+
+
+def gelu_bwd(dy: Tensor, x: Tensor, dx: Tensor):
+    check(L.load().vitk_gelu_bwd(_p(dy), _p(x), _p(dx), dt(x), x.numel(), _stream()), "gelu_bwd")
+
+
+def add_rows(a: Tensor, b: Tensor, bias: Optional[Tensor], out: Tensor, rows: int, cols: int):
+    check(L.load().vitk_add_rows(_p(a), dt(a), _p(b), dt(b), _p(bias), dt(bias) if bias is not None else dt(b),
+                                 _p(out), dt(out), rows, cols, _stream()), "add_rows")
+
+
+def cast(x: Tensor, y: Tensor):
+    check(L.load().vitk_cast(_p(x), dt(x), _p(y), dt(y), x.numel(), _stream()), "cast")
+
+
+def write_cls_rows(x: Tensor, cls: Tensor, pos: Tensor, B: int, N: int, D: int, ncls: int):
+    check(L.load().vitk_write_cls_rows(_p(x), dt(x), _p(cls), _p(pos), dt(pos), B, N, D, ncls, _stream()),
+          "write_cls_rows")
+
+
+def mean_pool_fwd(x: Tensor, out: Tensor, B: int, N: int, D: int):
+    check(L.load().vitk_mean_pool_fwd(_p(x), dt(x), _p(out), dt(out), B, N, D, _stream()), "mean_pool_fwd")
+
+
+def mean_pool_bwd(dout: Tensor, dx: Tensor, B: int, N: int, D: int):
+    check(L.load().vitk_mean_pool_bwd(_p(dout), dt(dout), _p(dx), dt(dx), B, N, D, _stream()), "mean_pool_bwd")
+
+
+def dropout_fwd(x: Tensor, y: Tensor, mask: Tensor, p: float, seed: int, offset: int):
+    check(L.load().vitk_dropout_fwd(_p(x), _p(y), _p(mask), dt(x), x.numel(), p, seed, offset, _stream()), "dropout_fwd")
+
+
+def dropout_bwd(dy: Tensor, mask: Tensor, dx: Tensor, p: float):
+    check(L.load().vitk_dropout_bwd(_p(dy), _p(mask), _p(dx), dt(dy), dy.numel(), p, _stream()), "dropout_bwd")
+
+
+def transpose(x: Tensor, out: Tensor, rows: int, cols: int):
+    check(L.load().vitk_transpose(_p(x), _p(out), dt(x), rows, cols, _stream()), "transpose")

@@ -1,0 +1,206 @@
+"""Host-side op layer: shape logic + kernel selection on top of the C-ABI wrappers.
+
+Every function here ends in libvitk kernels (fast bf16 MFMA kernels when the extents allow,
+otherwise the generic coverage kernels).  No torch compute ops are used on the data path;
+torch only allocates buffers (``torch.empty``) and carries the stream.
+
+dtype policy
+  * model dtype T = dtype of the parameters: torch.bfloat16 (production) or torch.float32
+    (validation mode: same host logic, f32 kernels).
+  * the residual stream and its gradient are always float32 (also in bf16 mode); everything
+    that feeds a GEMM is T.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+from ._lib import IDENT, RowMap
+
+Tensor = torch.Tensor
+BF16 = torch.bfloat16
+F32 = torch.float32
+LN_EPS = 1e-5
+
+
+def empty(shape, dtype, like: Tensor) -> Tensor:
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ---- LayerNorm ---------------------------------------------------------------------------------
+def ln_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], rows: int, D: int, out: Tensor,
+           imap: RowMap = IDENT, omap: RowMap = IDENT, add: Optional[Tensor] = None,
+           add_group: int = 0, add_off: int = 0) -> Tuple[Tensor, Tensor]:
+    """nn.LayerNorm(D) over `rows` logical rows (vit.py:19,39,69,101,103). Returns (mean, rstd)."""
+    mean = empty((rows,), F32, x)
+    rstd = empty((rows,), F32, x)
+    K.layernorm_fwd(x, w, b, out, mean, rstd, rows, D, LN_EPS, imap, omap, add, add_group, add_off)
+    return mean, rstd
+
+
+def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, rows: int, D: int, *,
+           gin: Optional[Tensor] = None, dx_f32: Optional[Tensor] = None, dx_t: Optional[Tensor] = None,
+           dw: Optional[Tensor] = None, db: Optional[Tensor] = None, dcol: Optional[Tensor] = None,
+           dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT):
+    """LayerNorm backward; dw/db/dcol are (D,) outputs of dtype T (dcol = column sums of dx)."""
+    nblk = K.layernorm_bwd_blocks(rows)
+    nslab = 3 if dcol is not None else 2
+    partials = empty((nslab * nblk * D,), F32, x)
+    K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap)
+    if dw is not None:
+        K.colsum_partials(partials, nblk, D, D, dw)
+    if db is not None:
+        K.colsum_partials(partials[nblk * D:], nblk, D, D, db)
+    if dcol is not None:
+        K.colsum_partials(partials[2 * nblk * D:], nblk, D, D, dcol)
+
+
+# ---- column sums (bias / pos / cls gradients) -----------------------------------------------------
+def colsum(x: Tensor, rows: int, cols: int, out: Tensor, accumulate: bool = False):
+    ws = empty((K.colsum_ws_floats(rows, cols),), F32, x)
+    K.colsum(x, rows, cols, cols, out, ws, accumulate)
+
+
+# ---- Linear --------------------------------------------------------------------------------------
+def _fast_nt(x: Tensor, N: int, Kd: int) -> bool:
+    return x.dtype == BF16 and Kd % 32 == 0 and N % 4 == 0
+
+
+def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bool = False,
+               resid: Optional[Tensor] = None, out_dtype=None):
+    """y = x @ W^T + b  (vit.py:20,23,44,47,102).  x: (M,K) T contiguous; W: (N,K) T.
+
+    gelu=True  -> returns (gelu(y), y)         (vit.py:20-21 fused)
+    resid      -> returns resid + y as float32 (the `+ x` of vit.py:80-81 fused), new buffer
+    """
+    N, Kd = W.shape
+    T = x.dtype
+    if resid is not None:
+        out = empty((M, N), F32, x)
+        if _fast_nt(x, N, Kd):
+            K.gemm_nt_bf16(x, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid)
+        else:
+            y = empty((M, N), T, x)
+            K.gemm_generic(K.mat(x, Kd, 1), K.mat(W, 1, Kd), K.mat(y, N, 1), M, N, Kd, bias=bias)
+            K.add_rows(resid, y, None, out, M, N)
+        return out
+    if gelu:
+        act = empty((M, N), T, x)
+        pre = empty((M, N), T, x)
+        if _fast_nt(x, N, Kd) and bias is not None:
+            K.gemm_nt_bf16(x, Kd, W, Kd, act, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=pre)
+        else:
+            K.gemm_generic(K.mat(x, Kd, 1), K.mat(W, 1, Kd), K.mat(pre, N, 1), M, N, Kd, bias=bias)
+            K.gelu_fwd(pre, act)
+        return act, pre
+    y = empty((M, N), out_dtype or T, x)
+    if _fast_nt(x, N, Kd) and y.dtype == BF16:
+        K.gemm_nt_bf16(x, Kd, W, Kd, y, N, M, N, Kd, L.EPI_BIAS if bias is not None else L.EPI_NONE, bias=bias)
+    else:
+        K.gemm_generic(K.mat(x, Kd, 1), K.mat(W, 1, Kd), K.mat(y, N, 1), M, N, Kd, bias=bias)
+    return y
+
+
+def transpose_weight(W: Tensor) -> Tensor:
+    N, Kd = W.shape
+    Wt = empty((Kd, N), W.dtype, W)
+    K.transpose(W, Wt, N, Kd)
+    return Wt
+
+
+def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = None) -> Tensor:
+    """dX = dY @ W  (optionally * gelu'(pre): the GELU backward fused as an epilogue)."""
+    N, Kd = W.shape
+    T = dy.dtype
+    dx = empty((M, Kd), T, dy)
+    if T == BF16 and N % 32 == 0 and Kd % 4 == 0:
+        Wt = transpose_weight(W)  # (K, N): makes dX an NT GEMM with reduction dim N contiguous
+        if gelu_pre is not None:
+            K.gemm_nt_bf16(dy, N, Wt, N, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, aux=gelu_pre)
+        else:
+            K.gemm_nt_bf16(dy, N, Wt, N, dx, Kd, M, Kd, N)
+    else:
+        K.gemm_generic(K.mat(dy, N, 1), K.mat(W, Kd, 1), K.mat(dx, Kd, 1), M, Kd, N)
+        if gelu_pre is not None:
+            K.gelu_bwd(dx, gelu_pre, dx)
+    return dx
+
+
+def linear_dw(dy: Tensor, x: Tensor, M: int, dW: Tensor, db: Optional[Tensor] = None,
+              ldy: Optional[int] = None, ldx: Optional[int] = None):
+    """dW = dY^T X (reduced over the M token rows), db = colsum(dY).  dW: (N,K) of dtype T."""
+    N, Kd = dW.shape
+    ldy = ldy or N
+    ldx = ldx or Kd
+    if dy.dtype == BF16 and N % 8 == 0 and Kd % 8 == 0 and ldy % 8 == 0 and ldx % 8 == 0:
+        splits = K.gemm_tn_splits(M, N, Kd)
+        ws = empty((splits * N * Kd,), F32, dy)
+        K.gemm_tn_bf16(dy, ldy, x, ldx, dW, Kd, M, N, Kd, ws, splits)
+    else:
+        K.gemm_generic(K.mat(dy, 1, ldy), K.mat(x, ldx, 1), K.mat(dW, Kd, 1), N, Kd, M)
+    if db is not None:
+        assert ldy == N
+        colsum(dy, M, N, db)
+
+
+# ---- attention core --------------------------------------------------------------------------------
+def attn_fast_ok(T, N: int, d: int) -> bool:
+    return T == BF16 and d == 64 and 1 <= N <= 480
+
+
+def attn_fwd(qkv: Tensor, B: int, N: int, H: int, d: int, scale: float):
+    """softmax(scale * q k^T) v on the merged (B*N, 3*H*d) to_qkv output (vit.py:54-63).
+    Returns (o (B*N, H*d), saved) where saved is lse (fused) or the attention matrix P."""
+    I = H * d
+    T = qkv.dtype
+    o = empty((B * N, I), T, qkv)
+    sb, sh, sn = N * 3 * I, d, 3 * I
+    if attn_fast_ok(T, N, d):
+        lse = empty((B, H, N), F32, qkv)
+        K.attn_fwd_bf16(K.bhnd(qkv, sb, sh, sn), K.bhnd(qkv, sb, sh, sn, offset=I), K.bhnd(qkv, sb, sh, sn, offset=2 * I),
+                        K.bhnd(o, N * I, d, I), lse, B, H, N, d, scale)
+        return o, lse
+    # materialising path: S = q k^T ; P = softmax(scale*S) ; O = P v   (batched over (B, H) in place)
+    S = empty((B, H, N, N), T, qkv)
+    K.gemm_generic(K.mat(qkv, sn, 1, sb, sh), K.mat(qkv, 1, sn, sb, sh, offset=I), K.mat(S, N, 1, H * N * N, N * N),
+                   N, N, d, nb1=B, nb2=H)
+    P = empty((B, H, N, N), T, qkv)
+    K.softmax_fwd(S, P, B * H * N, N, scale)
+    K.gemm_generic(K.mat(P, N, 1, H * N * N, N * N), K.mat(qkv, sn, 1, sb, sh, offset=2 * I), K.mat(o, I, 1, N * I, d),
+                   N, d, N, nb1=B, nb2=H)
+    return o, P
+
+
+def attn_bwd(qkv: Tensor, o: Tensor, do: Tensor, saved: Tensor, B: int, N: int, H: int, d: int, scale: float) -> Tensor:
+    """Returns dqkv (B*N, 3*H*d) in the merged layout (it is the dY of the to_qkv GEMM)."""
+    I = H * d
+    T = qkv.dtype
+    dqkv = empty((B * N, 3 * I), T, qkv)
+    sb, sh, sn = N * 3 * I, d, 3 * I
+    if attn_fast_ok(T, N, d):
+        delta = empty((B, H, N), F32, qkv)
+        K.attn_bwd_bf16(K.bhnd(qkv, sb, sh, sn), K.bhnd(qkv, sb, sh, sn, offset=I), K.bhnd(qkv, sb, sh, sn, offset=2 * I),
+                        K.bhnd(o, N * I, d, I), K.bhnd(do, N * I, d, I), saved, delta,
+                        K.bhnd(dqkv, sb, sh, sn), K.bhnd(dqkv, sb, sh, sn, offset=I), K.bhnd(dqkv, sb, sh, sn, offset=2 * I),
+                        B, H, N, d, scale)
+        return dqkv
+    P = saved
+    pm = K.mat(P, N, 1, H * N * N, N * N)
+    pmT = K.mat(P, 1, N, H * N * N, N * N)
+    dom = K.mat(do, I, 1, N * I, d)
+    # dV = P^T dO
+    K.gemm_generic(pmT, dom, K.mat(dqkv, sn, 1, sb, sh, offset=2 * I), N, d, N, nb1=B, nb2=H)
+    # dP = dO V^T ; dS = scale * P * (dP - rowsum(dP*P))
+    dP = empty((B, H, N, N), T, qkv)
+    K.gemm_generic(dom, K.mat(qkv, 1, sn, sb, sh, offset=2 * I), K.mat(dP, N, 1, H * N * N, N * N), N, N, d, nb1=B, nb2=H)
+    dS = dP
+    K.softmax_bwd(P, dP, dS, B * H * N, N, scale)
+    # dQ = dS K ; dK = dS^T Q
+    K.gemm_generic(K.mat(dS, N, 1, H * N * N, N * N), K.mat(qkv, sn, 1, sb, sh, offset=I), K.mat(dqkv, sn, 1, sb, sh),
+                   N, d, N, nb1=B, nb2=H)
+    K.gemm_generic(K.mat(dS, 1, N, H * N * N, N * N), K.mat(qkv, sn, 1, sb, sh), K.mat(dqkv, sn, 1, sb, sh, offset=I),
+                   N, d, N, nb1=B, nb2=H)
+    return dqkv

@@ -1,0 +1,230 @@
+"""Drop-in for vit_pytorch/vit.py (FeedForward :15-28, Attention :30-64, Transformer :66-83,
+ViT :85-138): same constructors, module tree, children order, parameter names and shapes,
+same forward() contract -- executed by hand-written gfx950 kernels (libvitk) on an MI355X.
+
+There is no CPU path: calling forward() on CPU tensors raises (vit_pytorch_amd._lib.VitkError).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from torch.nn import Module, ModuleList
+
+from . import engine as E
+from . import functional as Fn
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def _has_fwd_hooks(m: Module) -> bool:
+    return bool(m._forward_hooks) or bool(m._forward_pre_hooks)
+
+
+class FeedForward(Module):
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(
+            Fn.LayerNorm(dim),
+            Fn.Linear(dim, hidden_dim),
+            Fn.GELU(),
+            Fn.Dropout(dropout),
+            Fn.Linear(hidden_dim, dim),
+            Fn.Dropout(dropout),
+        )
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class Attention(Module):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        project_out = not (heads == 1 and dim_head == dim)
+
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+
+        self.norm = Fn.LayerNorm(dim)
+
+        self.attend = Fn.Softmax(dim=-1)
+        self.dropout = Fn.Dropout(dropout)
+
+        self.to_qkv = Fn.Linear(dim, inner_dim * 3, bias=False)
+
+        self.to_out = nn.Sequential(
+            Fn.Linear(inner_dim, dim),
+            Fn.Dropout(dropout),
+        ) if project_out else nn.Identity()
+
+    def _needs_attention_matrix(self) -> bool:
+        # forward hooks on `attend` (recorder.py:26-29) or active attention dropout need the N x N matrix
+        return _has_fwd_hooks(self.attend) or (self.training and self.dropout.p > 0.)
+
+    def forward(self, x):
+        x = self.norm(x)
+        qkv = self.to_qkv(x)  # (b, n, 3*h*d): q | k | v, each '(h d)' with h outer -- consumed in place
+        if self._needs_attention_matrix():
+            dots = Fn.ScoresFn.apply(qkv, self.heads, self.scale)   # matmul(q, k^T) * scale  (vit.py:57)
+            attn = self.attend(dots)
+            attn = self.dropout(attn)
+            out = Fn.AttnValuesFn.apply(attn, qkv, self.heads)      # matmul(attn, v) + merge heads (vit.py:62-63)
+        else:
+            out = Fn.FusedAttnFn.apply(qkv, self.heads, self.scale)
+        return self.to_out(out)
+
+
+class Transformer(Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.norm = Fn.LayerNorm(dim)
+        self.layers = ModuleList([])
+        self._heads, self._dim_head = heads, dim_head
+
+        for _ in range(depth):
+            self.layers.append(ModuleList([
+                Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout),
+                FeedForward(dim, mlp_dim, dropout=dropout),
+            ]))
+
+    def _fusable(self) -> bool:
+        """The fused engine covers the block when nothing needs to observe or perturb its inside."""
+        for attn, ff in self.layers:
+            if attn._needs_attention_matrix() or _has_fwd_hooks(attn) or _has_fwd_hooks(ff):
+                return False
+            if self.training and any(isinstance(m, nn.Dropout) and m.p > 0. for m in list(ff.net) + list(attn.modules())):
+                return False
+            if any(_has_fwd_hooks(m) for m in list(attn.modules()) + list(ff.modules())):
+                return False
+        return not _has_fwd_hooks(self.norm)
+
+    def forward(self, x):
+        if self._fusable():
+            params = []
+            for attn, ff in self.layers:
+                params += E.pack_layer_params(attn, ff)
+            return E.TransformerFn.apply(x, self._heads, self._dim_head, self.norm.weight, self.norm.bias, *params)
+        x = Fn._to(x, self.norm.weight.dtype)
+        for attn, ff in self.layers:
+            x = Fn.AddFn.apply(attn(x), x)
+            x = Fn.AddFn.apply(ff(x), x)
+        return self.norm(x)
+
+
+class ViT(Module):
+    def __init__(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool='cls', channels=3,
+                 dim_head=64, dropout=0., emb_dropout=0.):
+        super().__init__()
+        image_height, image_width = pair(image_size)
+        self.patch_size = patch_height, patch_width = pair(patch_size)
+
+        assert image_height % patch_height == 0 and image_width % patch_width == 0, 'Image dimensions must be divisible by the patch size.'
+
+        num_patches = (image_height // patch_height) * (image_width // patch_width)
+        patch_dim = channels * patch_height * patch_width
+
+        assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        num_cls_tokens = 1 if pool == 'cls' else 0
+
+        self.to_patch_embedding = nn.Sequential(
+            Fn.Patchify(patch_height, patch_width),
+            Fn.LayerNorm(patch_dim),
+            Fn.Linear(patch_dim, dim),
+            Fn.LayerNorm(dim),
+        )
+
+        self.cls_token = nn.Parameter(torch.randn(num_cls_tokens, dim))
+        self.pos_embedding = nn.Parameter(torch.randn(num_patches + num_cls_tokens, dim))
+
+        self.dropout = Fn.Dropout(emb_dropout)
+
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+
+        self.pool = pool
+        self.to_latent = nn.Identity()
+
+        self.mlp_head = Fn.Linear(dim, num_classes) if num_classes > 0 else None
+
+    def _embed_fusable(self) -> bool:
+        pe = self.to_patch_embedding
+        if any(_has_fwd_hooks(m) for m in pe.modules()):
+            return False
+        return not (self.training and self.dropout.p > 0.) and not _has_fwd_hooks(self.dropout)
+
+    def forward(self, img):
+        pe = self.to_patch_embedding
+        if self._embed_fusable():
+            x = E.PatchEmbedFn.apply(img, pe[0].p1, pe[0].p2, pe[1].weight, pe[1].bias, pe[2].weight, pe[2].bias,
+                                     pe[3].weight, pe[3].bias, self.cls_token, self.pos_embedding)
+        else:
+            x = pe(img)
+            x = _prepend_cls_add_pos(x, self.cls_token, self.pos_embedding)
+            x = self.dropout(x)
+
+        x = self.transformer(x)
+
+        if self.mlp_head is None:
+            return x
+
+        head_plain = not (_has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.mlp_head))
+        if head_plain:
+            return E.HeadFn.apply(x, self.pool == 'mean', self.mlp_head.weight, self.mlp_head.bias)
+        x = Fn.MeanTokensFn.apply(x) if self.pool == 'mean' else _ClsRowFn.apply(x)
+        x = self.to_latent(x)
+        return self.mlp_head(x)
+
+
+class _ClsRowFn(torch.autograd.Function):
+    """x[:, 0] (vit.py:135) as a strided device copy (no compute)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return x[:, 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        dx = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        dx[:, 0].copy_(g)
+        return dx
+
+
+class _ClsPosFn(torch.autograd.Function):
+    """cat(cls, x) + pos[:seq] (vit.py:122-127) for the non-fused embedding path."""
+
+    @staticmethod
+    def forward(ctx, x, cls, pos):
+        from . import kernels as K
+        x = x.contiguous()
+        B, Np, D = x.shape
+        ncls = cls.shape[0]
+        N = Np + ncls
+        out = torch.empty((B, N, D), dtype=x.dtype, device=x.device)
+        posN = pos[:N].contiguous()
+        # token rows: out[b, ncls + p] = x[b, p] + pos[ncls + p]; written through a strided view of `out`
+        for b in range(B):  # B strided row blocks (this is the slow observability path, not the fused one)
+            K.add_rows(x[b], posN[ncls:], None, out[b, ncls:], Np, D)
+        if ncls:
+            K.write_cls_rows(out, cls, posN, B, N, D, ncls)
+        ctx.meta = (B, Np, N, D, ncls, pos.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        from . import kernels as K
+        B, Np, N, D, ncls, pos_shape = ctx.meta
+        g = g.contiguous()
+        gsum = torch.empty((N, D), dtype=g.dtype, device=g.device)
+        ops.colsum(g, B, N * D, gsum)
+        dpos = torch.zeros(pos_shape, dtype=g.dtype, device=g.device)
+        K.cast(gsum, dpos[:N])
+        dcls = gsum[:ncls].contiguous()
+        dx = g[:, ncls:].contiguous()
+        return dx, dcls, dpos
+
+
+def _prepend_cls_add_pos(x, cls, pos):
+    return _ClsPosFn.apply(x, cls, pos)
