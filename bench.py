@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, measured on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+            --master-port P bench.py --gpus N --steps K --warmup W)
+
+Workload ("step"): one forward + loss + backward of ViT-B/16 224x224, bf16, batch 256 PER GPU
+(BASELINE.json configs[1]) on synthetic on-device images and labels, random-init
+weights; when N > 1 the step includes the data-parallel gradient all-reduce (RCCL) overlapped with the
+patch-embedding backward.  Optimizer excluded (the north star names fwd+bwd).  Weak scaling:
+per-GPU batch fixed, `value` = images/s summed over all GPUs.
+
+Timed region: W warm-up steps, then barrier + torch.cuda.synchronize(), exactly K steps,
+synchronize + barrier; the time is the MAX over ranks.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      the dominant kernel class (the NT MFMA GEMM; timed instance = the FF1 GEMM with the fused
+                bias+GELU epilogue, 50,432 x 3072 x 768): algorithmic FLOPs per launch / mean launch duration
+                measured live with HIP events on the launch stream; peak = 2516.6 TFLOP/s dense bf16 MFMA.
+  model         whole-step algorithmic TFLOP/s (105.383 GF/img for ViT-B/16) and its fraction of peak.
+  cpu_baseline  the CPU oracle (oracle/vit_oracle.py, kind "port") timed on this host's cores on a bounded
+                sample of the same workload (same model, f32, small batch), rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+CONFIGS = {
+    # name: (ctor kwargs, per-GPU batch)
+    "vit_b16": (dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072), 256),
+    "vit_l16": (dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096), 128),
+}
+
+
+def fwd_gflop_per_image(cfg) -> float:
+    """fwd = 2 Np P D + depth (2 N D 3I + 4 h N^2 dh + 2 N I D + 4 N D F) + 2 D C; fwd+bwd = 3x."""
+    ph = cfg["patch_size"]
+    Np = (cfg["image_size"] // ph) ** 2
+    P = 3 * ph * ph
+    D, depth, h, F, C = cfg["dim"], cfg["depth"], cfg["heads"], cfg["mlp_dim"], cfg["num_classes"]
+    dh = cfg.get("dim_head", 64)
+    I = h * dh
+    N = Np + 1
+    f = 2 * Np * P * D + depth * (2 * N * D * 3 * I + 4 * h * N * N * dh + 2 * N * I * D + 4 * N * D * F) + 2 * D * C
+    return f / 1e9
+
+
+def time_dominant_kernel(M: int, D: int, F: int, iters: int = 30):
+    """Mean duration of the FF1 NT GEMM (+bias+GELU epilogue) launch, HIP events on the launch stream."""
+    from vit_pytorch_amd import _lib as L, kernels as K
+    dev = "cuda"
+    A = torch.randn(M, D, device=dev).to(torch.bfloat16)
+    W = (torch.randn(F, D, device=dev) * D ** -0.5).to(torch.bfloat16)
+    b = torch.randn(F, device=dev).to(torch.bfloat16)
+    C = torch.empty(M, F, dtype=torch.bfloat16, device=dev)
+    aux = torch.empty(M, F, dtype=torch.bfloat16, device=dev)
+    run = lambda: K.gemm_nt_bf16(A, D, W, D, C, F, M, F, D, L.EPI_BIAS_GELU, bias=b, aux=aux)
+    for _ in range(3):
+        run()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        run()
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * F * D
+    return ms, flops
+
+
+def cpu_baseline(cfg, budget_s: float = 20.0):
+    """The oracle (a port of the reference algorithm) on the host cores, bounded to ~budget_s."""
+    from oracle import vit_oracle as O
+    from oracle.params import make_images, make_params
+    threads = torch.get_num_threads()
+    params = make_params("vit", cfg, 0)
+    B = 8
+    img = make_images(cfg, B, 1)
+    p = {k: v.clone().requires_grad_(v.numel() > 0) for k, v in params.items()}
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        out = O.vit_fwd(img, p, patch_size=cfg["patch_size"], depth=cfg["depth"], heads=cfg["heads"],
+                        dim_head=cfg.get("dim_head", 64), pool="cls", num_classes=cfg["num_classes"])
+        O.loss_fn(out).backward()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/vit_oracle.py ViT-B/16 fwd+bwd f32, batch {B}, {n} steps in {dt:.1f} s "
+                      f"on {threads} threads of {os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="vit_b16", choices=list(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (invalidates the headline number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from vit_pytorch_amd import ViT
+    from vit_pytorch_amd.parallel import DataParallel
+
+    cfg, batch = CONFIGS[args.config]
+    if args.batch:
+        batch = args.batch
+    torch.manual_seed(0)  # identical init on every rank (DataParallel also broadcasts rank 0's)
+    model = ViT(**cfg).to(dev, dtype=torch.bfloat16)
+    dp = DataParallel(model)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1 + rank)
+    img = torch.randn(batch, 3, cfg["image_size"], cfg["image_size"], device=dev, generator=g).to(torch.bfloat16)
+    labels = torch.randint(0, cfg["num_classes"], (batch,), device=dev, generator=g)
+
+    def step():
+        logits = dp(img)
+        loss = torch.nn.functional.cross_entropy(logits.float(), labels)
+        dp.backward(loss)  # zeroes .grad, backward, overlapped all-reduce when world > 1
+        return loss
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        total_imgs = batch * world * args.steps
+        value = total_imgs / dt
+        gf = 3.0 * fwd_gflop_per_image(cfg)
+        N = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
+        kms, kflops = time_dominant_kernel(batch * N, cfg["dim"], cfg["mlp_dim"])
+        ach = kflops / (kms * 1e-3) / 1e12
+        line = {
+            "metric": "images/sec (fwd+bwd) ViT-B/16 224^2 bf16" if args.config == "vit_b16" else f"images/sec (fwd+bwd) {args.config} bf16",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (randn images, randint labels, random-init weights)",
+            "config": {"workload": f"{args.config} fwd+bwd, batch {batch}/GPU, 224x224, cross-entropy loss, no optimizer"
+                                   + (", flat-buffer RCCL all-reduce overlapped with patch-embed backward" if world > 1 else ""),
+                       "global_batch": batch * world, "per_gpu_batch": batch, "seq_len": N, "parallelism": f"dp{world}"},
+            "per_gpu_images_per_s": round(value / world, 2),
+            "model": {"gflop_per_image_fwd_bwd": round(gf, 3), "tflops_per_gpu": round(value / world * gf / 1e3, 2),
+                      "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_BIAS_GELU> (FF1 50432x3072x768 at batch 256)",
+                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(kms, 4), "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,7 @@ def load():
             f"{LIB_PATH} not found: the HIP kernel library is not built. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `python -m vit_pytorch_amd._build`). There is no CPU/eager fallback.")
+    import torch  # noqa: F401  -- torch must load ITS HIP runtime first; a second runtime copy cannot see the device
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

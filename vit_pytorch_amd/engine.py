@@ -150,7 +150,7 @@ class TransformerFn(torch.autograd.Function):
         # final LayerNorm (vit.py:83)
         g, gb = newg()
         dnw, dnb = _grad_buf(norm_w), _grad_buf(norm_b)
-        dcol = ops.empty((D,), T, dy)  # colsum of g == bias gradient of the last layer's second FF Linear
+        dcol = ops.empty((D,), F32, dy)  # colsum of g == bias gradient of the last layer's second FF Linear
         ops.ln_bwd(dy, ctx.x_last, norm_w, ctx.stf[0], ctx.stf[1], M, D, dx_f32=g, dx_t=gb, dw=dnw, db=dnb, dcol=dcol)
         ctx.x_last = None
         for li in reversed(range(depth)):
@@ -176,7 +176,7 @@ class TransformerFn(torch.autograd.Function):
             del dpre, pre, act
             g2, g2b = newg()
             dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
-            dcol2 = ops.empty((D,), T, dy)
+            dcol2 = ops.empty((D,), F32, dy)
             ops.ln_bwd(da2, x2, ln2w, st2[0], st2[1], M, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2w, db=dl2b, dcol=dcol2)
             grads[base + 5], grads[base + 6] = dl2w, dl2b
             del da2, g, gb
@@ -201,7 +201,7 @@ class TransformerFn(torch.autograd.Function):
             del dqkv, do, qkv, o
             g1, g1b = newg()
             dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
-            dcol = ops.empty((D,), T, dy)
+            dcol = ops.empty((D,), F32, dy)
             ops.ln_bwd(da1, xs, ln1w, st1[0], st1[1], M, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1w, db=dl1b, dcol=dcol)
             grads[base + 0], grads[base + 1] = dl1w, dl1b
             g, gb = g1, g1b
@@ -251,6 +251,7 @@ class PatchEmbedFn(torch.autograd.Function):
             K.write_cls_rows(x0, cls, pos, B, N, D, ncls)
         ctx.save_for_backward(ln1w, ln1b, w, ln2w, ln2b, *([b] if b is not None else []))
         ctx.inter = (patches, st1, pn, y, st2)
+        ctx.cls_pos = (cls, pos)
         ctx.meta = (B, Np, N, P, D, ncls, b is not None, cls is not None, pos is not None and pos.requires_grad,
                     pos.shape if pos is not None else None)
         return x0
@@ -271,22 +272,20 @@ class PatchEmbedFn(torch.autograd.Function):
             K.cast(g, g32)
             g = g32
         dpos = dcls = None
+        cls_p, pos_p = ctx.cls_pos
         if pos_grad or has_cls:
             # d pos[n] = sum_b g[b, n] ; d cls = d pos[0:ncls]   (x[b,n] = tok[b,n] + pos[n]; x[b,0] = cls + pos[0])
-            gsum = ops.empty((N * D,), T, g)
+            gsum = ops.empty((N, D), T, g)
             ops.colsum(g, B, N * D, gsum)
-            gsum = gsum.view(N, D)
             if pos_grad:
-                dpos = torch.zeros(pos_shape, dtype=T, device=g.device) if pos_shape[0] != N else None
-                if dpos is None:
-                    dpos = gsum
-                else:
-                    K.cast(gsum, dpos[:N])
-            if has_cls and ncls:
-                dcls = ops.empty((ncls, D), T, g)
-                K.cast(gsum[:ncls], dcls)
-            elif has_cls:
-                dcls = ops.empty((0, D), T, g)
+                dpos = _grad_buf(pos_p)
+                if pos_shape[0] != N:
+                    dpos[N:].zero_()  # rows of the table this (smaller) input never touched (vit.py:125-127)
+                K.cast(gsum, dpos[:N])
+            if has_cls:
+                dcls = _grad_buf(cls_p)
+                if ncls:
+                    K.cast(gsum[:ncls], dcls)
         # LN(dim) backward: dy rows are the patch rows of g (behind the cls slot)
         dyp = ops.empty((Mp, D), T, g)
         dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)

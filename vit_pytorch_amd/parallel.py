@@ -1,0 +1,186 @@
+"""Data-parallel training step: one process per GPU, one flat gradient buffer, RCCL over xGMI.
+
+The reference has no distributed code; its only training script gets data parallelism from
+accelerate -> torch DDP (train_vit_decorr.py:74-78,109: bucketed all-reduce, 25 MiB buckets,
+hooks per parameter).  This is the MI355X-first replacement for that step:
+
+  * every parameter gradient is written by the backward kernels DIRECTLY into one flat buffer
+    (engine.set_grad_sink), laid out in reverse-readiness order: head, final norm, layers
+    depth-1 .. 0, then the patch-embedding stage (cls, pos, patch Linear, LayerNorms);
+  * when the transformer stage's backward has been enqueued, ONE all-reduce of the big
+    segment (everything but the patch-embedding stage: >99% of the bytes) is launched on a side
+    stream behind an event, so it overlaps the patch-embedding backward (north_star); the small
+    patch-embedding segment follows as a second collective when its gradients are enqueued;
+  * xGMI is point-to-point (7 links/GPU): a few large collectives beat many 25 MiB buckets, so
+    there is no bucketing at all -- 173 MB (ViT-B bf16) / 609 MB (ViT-L) go out as one message
+    and RCCL picks its algorithm for the fully connected 8-GPU node.
+
+`torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" on CPU for tests) is the transport.
+Models that are not vit_pytorch_amd modules work too (no overlap: flatten after backward).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import engine as E
+
+
+def _ordered_params(model: torch.nn.Module) -> (List[torch.nn.Parameter], int):
+    """Parameters in reverse-readiness order and the index where the late (patch-embed) stage starts."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    late_names = ("to_patch_embedding", "cls_token", "pos_embedding")
+    named = list(model.named_parameters())
+    if not any(n.startswith(late_names) for n, _ in named):
+        return params, len(params)
+    early, late = [], []
+    for n, p in named:
+        if not p.requires_grad:
+            continue
+        (late if n.startswith(late_names) else early).append((n, p))
+
+    def key(item):
+        n = item[0]
+        if n.startswith(("mlp_head", "linear_head")):
+            return (0, 0)
+        if n.startswith("transformer.norm"):
+            return (1, 0)
+        if n.startswith("transformer.layers."):
+            return (2, -int(n.split(".")[2]))
+        return (3, 0)
+
+    early.sort(key=key)
+    return [p for _, p in early] + [p for _, p in late], len(early)
+
+
+class FlatGradSink:
+    """Owns the flat gradient buffer; handed to the engine as the gradient sink."""
+
+    def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True):
+        self.model = model
+        self.group = process_group
+        self.average = average
+        self.params, self.n_early = _ordered_params(model)
+        p0 = self.params[0]
+        self.dtype, self.device = p0.dtype, p0.device
+        assert all(p.dtype == self.dtype and p.device == self.device for p in self.params), \
+            "one dtype/device for all parameters"
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 7) // 8 * 8  # keep every slice 16-byte aligned for the kernels
+        self.offsets = offs
+        self.total = total
+        self.boundary = offs[self.n_early] if self.n_early < len(self.params) else total
+        self.flat = torch.zeros(total, dtype=self.dtype, device=self.device)
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
+        self._by_ptr: Dict[int, int] = {p.data_ptr(): i for i, p in enumerate(self.params) if p.numel()}
+        self._filled = set()
+        self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._early_launched = False
+        self._late_launched = False
+        self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    # ---- engine-facing ------------------------------------------------------------------------
+    def buffer_for(self, param: torch.Tensor) -> Optional[torch.Tensor]:
+        i = self._by_ptr.get(param.data_ptr())
+        if i is None:
+            return None
+        self._filled.add(i)
+        return self.views[i]
+
+    def stage_done(self, stage: str):
+        """Called from inside backward (autograd thread) when a stage's gradients are enqueued."""
+        if self.world == 1:
+            return
+        if stage == "transformer" and not self._early_launched and self.boundary > 0:
+            self._launch(self.flat[:self.boundary])
+            self._early_launched = True
+        elif stage == "patch_embed" and not self._late_launched and self.boundary < self.total:
+            self._launch(self.flat[self.boundary:])
+            self._late_launched = True
+
+    def _launch(self, seg: torch.Tensor):
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self._allreduce(seg)
+        else:
+            self._allreduce(seg)
+
+    def _allreduce(self, seg: torch.Tensor):
+        if self.average and dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                seg.div_(self.world)
+
+    # ---- step-facing ----------------------------------------------------------------------------
+    def begin_step(self):
+        self._filled.clear()
+        self._early_launched = self._late_launched = False
+        for p in self.params:
+            p.grad = None
+        E.set_grad_sink(self)
+
+    def finish_step(self):
+        """After loss.backward(): make every p.grad the (reduced) flat view."""
+        E.set_grad_sink(None)
+        # gradients autograd produced outside the sink (foreign modules / non-fused paths): copy in
+        missing = False
+        for i, p in enumerate(self.params):
+            if i not in self._filled:
+                if p.grad is not None and p.grad.data_ptr() != self.views[i].data_ptr():
+                    self.views[i].copy_(p.grad)
+                elif p.grad is None:
+                    self.views[i].zero_()
+                missing = True
+        if self.world > 1:
+            if missing or not self._early_launched:
+                # no overlap possible: one collective over whatever has not been reduced yet
+                if self.side is not None:
+                    torch.cuda.current_stream(self.device).wait_stream(self.side)
+                if not self._early_launched and not self._late_launched:
+                    self._allreduce(self.flat)
+                else:
+                    if not self._early_launched and self.boundary > 0:
+                        self._allreduce(self.flat[:self.boundary])
+                    if not self._late_launched and self.boundary < self.total:
+                        self._allreduce(self.flat[self.boundary:])
+            if self.side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self.side)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+
+class DataParallel(torch.nn.Module):
+    """Wrap a model for one-process-per-GPU data parallelism.
+
+        dp = DataParallel(model)          # after dist.init_process_group(...)
+        loss = loss_fn(dp(x), y)
+        dp.backward(loss)                 # backward + overlapped all-reduce; p.grad are views of dp.sink.flat
+        optimizer.step()
+    """
+
+    def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True, broadcast: bool = True):
+        super().__init__()
+        self.module = model
+        self.sink = FlatGradSink(model, process_group, average)
+        if broadcast and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            for p in model.parameters():
+                dist.broadcast(p.data, src=0, group=process_group)
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+    def backward(self, loss: torch.Tensor):
+        self.sink.begin_step()
+        try:
+            loss.backward()
+        finally:
+            self.sink.finish_step()
