@@ -77,6 +77,11 @@ int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int xdt, const v
                        int64_t rows, int64_t D,
                        vitk_rowmap dymap, vitk_rowmap xmap, vitk_rowmap dxmap, void* stream);
 
+/* One-launch finish of vitk_layernorm_bwd: dw, db (dtype odt, either may be null) and, if non-null, the f32
+ * column sums dcol of dx, from the `partials` buffer of that call (nblk = vitk_layernorm_bwd_blocks(rows)). */
+int vitk_layernorm_bwd_finalize(const float* partials, int64_t nblk, int64_t D, void* dw, void* db, int odt,
+                                float* dcol, void* stream);
+
 /* out[c] (dtype odt) = (accumulate ? out[c] : 0) + sum_{p < nparts} partials[p * ld + c], c < cols */
 int vitk_colsum_partials(const float* partials, int64_t nparts, int64_t ld, int64_t cols,
                          void* out, int odt, int accumulate, void* stream);

@@ -128,7 +128,7 @@ def test_colsum(rows, cols, xdt, odt):
 
 
 # ---------------------------------------------------------------------------------------------
-GEMM_SHAPES = [(128, 128, 32), (256, 384, 64), (197 * 3, 768, 768), (1000, 2304, 768), (130, 132, 96), (64, 64, 64), (50432 // 8, 768, 3072)]
+GEMM_SHAPES = [(1024, 256, 64), (2500, 768, 768), (1300, 520, 128), (128, 128, 32), (256, 384, 64), (197 * 3, 768, 768), (1000, 2304, 768), (130, 132, 96), (64, 64, 64), (50432 // 8, 768, 3072)]
 
 
 @pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
@@ -145,7 +145,7 @@ def test_gemm_nt_plain_and_bias(M, N, Kd):
     assert rel(C, ref + bias.double()) < 4e-3, "bias"
 
 
-@pytest.mark.parametrize("M,N,Kd", [(197 * 2, 768, 768), (300, 3072, 768), (256, 768, 3072)])
+@pytest.mark.parametrize("M,N,Kd", [(197 * 2, 768, 768), (300, 3072, 768), (256, 768, 3072), (1100, 768, 768), (1576, 1032, 192)])
 def test_gemm_nt_epilogues(M, N, Kd):
     A = rnd(M, Kd, dtype=BF, seed=44); W = rnd(N, Kd, dtype=BF, seed=45) * (Kd ** -0.5)
     bias = rnd(N, dtype=BF, seed=46)
@@ -181,7 +181,7 @@ def test_gemm_nt_rejects_bad_shapes():
         K.gemm_nt_bf16(A, 40, W, 40, C, 64, 64, 64, 40)  # K % 32 != 0
 
 
-@pytest.mark.parametrize("M,N,Kd", [(64, 128, 128), (1000, 768, 768), (197 * 16, 2304, 768), (333, 136, 72), (197 * 8, 768, 3072), (5000, 64, 256)])
+@pytest.mark.parametrize("M,N,Kd", [(4096, 256, 256), (5000, 768, 768), (6304, 2304, 768), (4500, 264, 520), (64, 128, 128), (1000, 768, 768), (197 * 16, 2304, 768), (333, 136, 72), (197 * 8, 768, 3072), (5000, 64, 256)])
 @pytest.mark.parametrize("odt", [BF, F32])
 def test_gemm_tn(M, N, Kd, odt):
     dY = rnd(M, N, dtype=BF, seed=51) * (M ** -0.5); X = rnd(M, Kd, dtype=BF, seed=52)

@@ -64,12 +64,24 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- math ------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = __expf(-0.5f * x * x) * 0.39894228040143267794f;
-    return cdf + x * pdf;
+// Exact-erf GELU (nn.GELU() default, vit.py:21).  Phi(x) = 0.5*erfc(-x/sqrt2) is evaluated with the
+// Abramowitz-Stegun 7.1.26 rational form of erfc (|abs err| <= 1.5e-7, i.e. f32 round-off class; no
+// cancellation in the negative tail because erfc is formed directly): 1 rcp + 1 exp2 + ~8 FMA instead of
+// the ~40-instruction libm erff.  The same exp(-x^2/2) serves the Gaussian density in the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);   // exp(-z^2) = exp(-x^2/2)
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float half_erfc = 0.5f * p * t * e;           // 0.5 * erfc(|x|/sqrt2)
+    cdf = x < 0.f ? half_erfc : 1.0f - half_erfc;
+    pdf = e * 0.39894228040143267794f;
 }
+__device__ __forceinline__ float gelu_erf(float x) { float c, p; gelu_parts(x, c, p); return x * c; }
+__device__ __forceinline__ float gelu_erf_grad(float x) { float c, p; gelu_parts(x, c, p); return fmaf(x, p, c); }
 
 // ---- row map (see vitk.h) ---------------------------------------------------------------
 struct RowMap { long long group, gstride, offset; };

@@ -22,6 +22,7 @@
 //  * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs walks a contiguous run of tiles
 //    (n fastest), so the activation panel a tile row shares is fetched into one L2, not eight.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -269,6 +270,299 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     store4<OT>(o, s);
 }
 
+
+// ==========================================================================================
+// 256 x 256 x 64 tiles, 8 waves (2 x 4), one workgroup per CU (128 KiB LDS, two stages).
+// Per MFMA the 128^2 tile moves ~2x the LDS bytes (both DMA writes and fragment reads) and is
+// LDS-bound on gfx950; a 128x64 wave tile needs 12 ds_read_b128 per 32 MFMAs instead of 8 per 16.
+// ==========================================================================================
+constexpr int L_BM = 256, L_BN = 256, L_BK = 64;
+constexpr int L_TILE_BYTES = 256 * L_BK * 2;      // 32 KiB per operand tile (128-byte rows)
+constexpr int L_STAGE_BYTES = 2 * L_TILE_BYTES;   // A + W
+constexpr int L_LDS_BYTES = 2 * L_STAGE_BYTES;    // 128 KiB
+
+// 128-byte rows: logical 16-byte chunk c (0..7) of row r sits at position c ^ ((r >> 1) & 7);
+// every ds_read_b128 lane group then covers all 16 slots of the 256-byte bank row exactly once.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(
+    const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ W, long long ldw,
+    void* __restrict__ Cv, long long ldc, int M, int N, int K,
+    const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
+    int tiles_n, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wg = xcd_swizzle(blockIdx.x, nwg);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int m0 = tm * L_BM, n0 = tn * L_BN;
+
+    // staging: a wave-instruction fills 8 rows x 128 B; wave w owns row groups 4w..4w+3 of each operand
+    const int srow = lane >> 3, spos = lane & 7;
+    const __bf16* a_src[4];
+    const __bf16* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + srow;          // row inside the tile
+        const int chunk = spos ^ ((r >> 1) & 7);
+        int ar = m0 + r; ar = ar < M ? ar : M - 1;
+        int wr = n0 + r; wr = wr < N ? wr : N - 1;
+        a_src[j] = A + (long long)ar * lda + chunk * 8;
+        w_src[j] = W + (long long)wr * ldw + chunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = lds + buf * L_STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + kt * L_BK),
+                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + kt * L_BK),
+                                             (void __attribute__((address_space(3)))*)(base + L_TILE_BYTES + j * 1024), 16, 0, 0);
+        }
+    };
+
+    const int fi = lane & 15, fg = lane >> 4;
+    const int sw = (fi >> 1) & 7;
+    const int a_row = (wm * 128 + fi) * 128;                    // + fm * 2048
+    const int w_row = L_TILE_BYTES + (wn * 64 + fi) * 128;      // + fn * 2048
+    const int pos0 = ((0 + fg) ^ sw) * 16, pos1 = ((4 + fg) ^ sw) * 16;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Main loop: two LDS stages, one barrier per 64-deep K-tile; the DMA of tile t+1 flies during the
+    // 64 MFMAs per wave of tile t.  (Measured alternatives that did NOT pay on these shapes: counted vmcnt
+    // with an LDS-DMA L2 prefetch two tiles ahead; hand-ordered fragment double-buffering; a 4-wave
+    // 256x128 tile with 3 stages and two workgroups per CU -- see DESIGN.md.)
+    const int nt = K / L_BK;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        const char* base = lds + (t & 1) * L_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pos = ks ? pos1 : pos0;
+            bf16x8 wf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(base + w_row + f * 2048 + pos);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 xf[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_row + (h * 4 + f) * 2048 + pos);
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[fn][h * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][h * 4 + f], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: accumulators -> (wave-private 16 KiB of the now idle LDS) -> full-line global I/O ----
+    // A lane holds 4 consecutive columns of 32 scattered (row, 16-col block) pairs; stored directly that is
+    // 32-byte pieces of 16 rows per instruction (measured: ~30% of the kernel).  Re-staged through LDS every
+    // global store (and every residual / pre-activation load) is 16 B per lane and 128 B contiguous per row.
+    __syncthreads();  // every wave is done reading the operand stages
+    char* ep = lds + wave * 16384;
+    const int mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
+    if constexpr (EPI == VITK_EPI_RESID) {
+        const int rr = lane >> 4, rc = lane & 15;      // read-back: 4 rows x 16 chunks of 4 floats
+        const int ncol = ncol0 + rc * 4;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (bias && ncol < N) b4 = load4<__bf16>(bias + ncol);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int f4 = 0; f4 < 4; ++f4) {
+                const int row = f4 * 16 + fi;
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn) {
+                    const int c16 = fn * 4 + fg;
+                    *reinterpret_cast<f32x4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16)) = acc[fn][hh * 4 + f4];
+                }
+            }
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int row = j * 4 + rr;
+                f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 256 + ((rc ^ (row & 15)) * 16));
+                const int m = mrow0 + hh * 64 + row;
+                if (m < M && ncol < N) {
+                    const long long o = (long long)m * ldc + ncol;
+                    v += b4;
+                    v += *reinterpret_cast<const f32x4*>(resid + o);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + o) = v;
+                }
+            }
+        }
+    } else {
+        f32x4 b4[4];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            b4[fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU) {
+                const int n = ncol0 + fn * 16 + 4 * fg;
+                if (n < N) b4[fn] = load4<__bf16>(bias + n);
+            }
+        }
+#pragma unroll
+        for (int fm = 0; fm < 8; ++fm) {
+            const int row = fm * 16 + fi;
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn) {
+                const int c16 = fn * 2 + (fg >> 1);
+                const f32x4 v = acc[fn][fm] + b4[fn];
+                const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fg & 1) * 8) = pk;
+            }
+        }
+        const int rr = lane >> 3, rc = lane & 7;       // read-back: 8 rows x 8 chunks of 8 bf16
+        const int ncol = ncol0 + rc * 8;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int row = j * 8 + rr;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row * 128 + ((rc ^ (row & 7)) * 16));
+            const int m = mrow0 + row;
+            if (m < M && ncol < N) {
+                const long long o = (long long)m * ldc + ncol;
+                if constexpr (EPI == VITK_EPI_NONE || EPI == VITK_EPI_BIAS) {
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = v;
+                } else if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+                    *reinterpret_cast<bf16x8*>(aux + o) = v;
+                    bf16x8 g8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g8[e] = (__bf16)gelu_erf((float)v[e]);
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
+                } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                    const bf16x8 h8 = *reinterpret_cast<const bf16x8*>(aux + o);
+                    bf16x8 g8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g8[e] = (__bf16)((float)v[e] * gelu_erf_grad((float)h8[e]));
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
+                }
+            }
+        }
+    }
+}
+
+// TN 256 x 256 output tile, 64 token rows per step, register-staged into padded rows (544 B:
+// 8 consecutive rows hit 8 disjoint 32-byte bank windows for the transpose reads).
+constexpr int LT_BKM = 64;
+constexpr int LT_LD = 544;
+constexpr int LT_TILE_BYTES = LT_BKM * LT_LD;       // 34,816
+constexpr int LT_STAGE_BYTES = 2 * LT_TILE_BYTES;
+constexpr int LT_LDS_BYTES = 2 * LT_STAGE_BYTES;    // 139,264
+
+__device__ __forceinline__ bf16x8 tr_frag_ld(const char* tile, int off, int ld) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off + 16 * ld));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(
+    const __bf16* __restrict__ dY, long long ldy, const __bf16* __restrict__ X, long long ldx,
+    float* __restrict__ ws, int M, int N, int K, int rows_per_split, int tiles_k, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave >> 2, wk = wave & 3;   // wave tile: 128 (n) x 64 (k)
+    const int wg = xcd_swizzle(blockIdx.x, nwg);
+    const int tn = wg / tiles_k, tk = wg % tiles_k;
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int split = blockIdx.y;
+    const int mbeg = split * rows_per_split;
+    int mend = mbeg + rows_per_split; mend = mend < M ? mend : M;
+
+    int srow[4], scol[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = tid + 512 * j; srow[j] = c >> 5; scol[j] = (c & 31) * 8; }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 ry[4], rx[4];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mb + srow[j];
+            const bool mv = m < mend;
+            ry[j] = (mv && n0 + scol[j] < N) ? *reinterpret_cast<const bf16x8*>(dY + (long long)m * ldy + n0 + scol[j]) : zero8;
+            rx[j] = (mv && k0 + scol[j] < K) ? *reinterpret_cast<const bf16x8*>(X + (long long)m * ldx + k0 + scol[j]) : zero8;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = lds + buf * LT_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<bf16x8*>(base + srow[j] * LT_LD + scol[j] * 2) = ry[j];
+            *reinterpret_cast<bf16x8*>(base + LT_TILE_BYTES + srow[j] * LT_LD + scol[j] * 2) = rx[j];
+        }
+    };
+
+    const int fi = lane & 15, fg = lane >> 4;
+    const int tr_off = (4 * fg + (fi >> 2)) * LT_LD + (fi & 3) * 8;
+    const int y_off = tr_off + wn * 256;                     // + fn*32 bytes ; + ks*32 rows
+    const int x_off = LT_TILE_BYTES + tr_off + wk * 128;     // + fk*32 bytes
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (mend - mbeg + LT_BKM - 1) / LT_BKM;
+    if (nsteps > 0) {
+        gload(mbeg);
+        lstore(0);
+        __syncthreads();
+        for (int t = 0; t < nsteps; ++t) {
+            if (t + 1 < nsteps) gload(mbeg + (t + 1) * LT_BKM);
+            const char* base = lds + (t & 1) * LT_STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xf[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) xf[f] = tr_frag_ld(base, x_off + ks * 32 * LT_LD + f * 32, LT_LD);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bf16x8 yf[4];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) yf[f] = tr_frag_ld(base, y_off + ks * 32 * LT_LD + (h * 4 + f) * 32, LT_LD);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int fk = 0; fk < 4; ++fk)
+                            acc[h * 4 + f][fk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[f], xf[fk], acc[h * 4 + f][fk], 0, 0, 0);
+                }
+            }
+            if (t + 1 < nsteps) lstore((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+    float* out = ws + (long long)split * N * K;
+#pragma unroll
+    for (int fn = 0; fn < 8; ++fn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 128 + fn * 16 + 4 * fg + r;
+            if (n >= N) continue;
+#pragma unroll
+            for (int fk = 0; fk < 4; ++fk) {
+                const int k = k0 + wk * 64 + fk * 16 + fi;
+                if (k < K) out[(long long)n * K + k] = acc[fn][fk][r];
+            }
+        }
+}
+
+template <typename Kern>
+int set_max_lds(Kern kernel, int bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 }  // namespace
 
 extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
@@ -280,12 +574,22 @@ extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
     if ((lda & 7) || (ldw & 7) || (ldc & 3) || !aligned16(A) || !aligned16(W) || !aligned16(C) || (bias && !aligned8(bias)) ||
         (resid && !aligned16(resid)) || (aux && !aligned8(aux)))
         VITK_FAIL(VITK_E_ALIGN, "gemm_nt_bf16: lda/ldw %% 8, ldc %% 4 and 16-byte aligned pointers required");
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+    const bool large = (K % L_BK == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux)) && !getenv("VITK_NO_256");
+    const int tbm = large ? L_BM : BM, tbn = large ? L_BN : BN;
+    const int tiles_m = (int)((M + tbm - 1) / tbm), tiles_n = (int)((N + tbn - 1) / tbn);
     const long long nwg = (long long)tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: grid too large");
     hipStream_t st = (hipStream_t)stream;
-#define NT_LAUNCH(E) hipLaunchKernelGGL((gemm_nt_kernel<E>), dim3((unsigned)nwg), dim3(256), 0, st, (const __bf16*)A, (long long)lda, \
-        (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg)
+#define NT_LAUNCH(E) do { \
+    if (large) { \
+        static const int rc__ = set_max_lds(gemm_nt256_kernel<E>, L_LDS_BYTES); \
+        if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", L_LDS_BYTES); \
+        hipLaunchKernelGGL((gemm_nt256_kernel<E>), dim3((unsigned)nwg), dim3(512), L_LDS_BYTES, st, (const __bf16*)A, (long long)lda, \
+            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg); \
+    } else { \
+        hipLaunchKernelGGL((gemm_nt_kernel<E>), dim3((unsigned)nwg), dim3(256), 0, st, (const __bf16*)A, (long long)lda, \
+            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg); \
+    } } while (0)
     switch (epilogue) {
         case VITK_EPI_NONE: NT_LAUNCH(VITK_EPI_NONE); break;
         case VITK_EPI_BIAS:
@@ -307,7 +611,18 @@ extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
     return 0;
 }
 
+static bool tn_large(int64_t M, int64_t N, int64_t K) { return M >= 4096 && N >= 256 && K >= 256 && !getenv("VITK_NO_256"); }
+
 extern "C" int64_t vitk_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
+    if (tn_large(M, N, K)) {
+        const int64_t tiles = ((N + 255) / 256) * ((K + 255) / 256);
+        int64_t s = (256 + tiles / 2) / tiles;            // ~one workgroup per CU
+        const int64_t max_by_rows = (M + 511) / 512;      // at least 8 steps of 64 rows per split
+        if (s > max_by_rows) s = max_by_rows;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
+        return s;
+    }
     const int64_t tiles = ((N + BN - 1) / BN) * ((K + BM - 1) / BM);
     int64_t s = (768 + tiles - 1) / tiles;            // aim for ~3 blocks per CU
     const int64_t max_by_rows = (M + 255) / 256;      // at least 8 steps of 32 rows per split
@@ -324,13 +639,24 @@ extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int
         VITK_FAIL(VITK_E_SHAPE, "gemm_tn_bf16: need N %% 8 == 0, K %% 8 == 0 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
     if ((ldy & 7) || (ldx & 7) || (ldo & 3) || !aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws))
         VITK_FAIL(VITK_E_ALIGN, "gemm_tn_bf16: ldy/ldx %% 8, ldo %% 4 and 16-byte aligned pointers required");
-    const int tiles_n = (int)((N + BN - 1) / BN), tiles_k = (int)((K + BM - 1) / BM);
-    const int nwg = tiles_n * tiles_k;
-    long long rps = (M + splits - 1) / splits;
-    rps = (rps + TN_BKM - 1) / TN_BKM * TN_BKM;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nwg, (unsigned)splits), dim3(256), 0, st, (const __bf16*)dY, (long long)ldy,
-                       (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
+    if (tn_large(M, N, K)) {
+        const int tiles_n = (int)((N + 255) / 256), tiles_k = (int)((K + 255) / 256);
+        const int nwg = tiles_n * tiles_k;
+        long long rps = (M + splits - 1) / splits;
+        rps = (rps + LT_BKM - 1) / LT_BKM * LT_BKM;
+        static const int rc__ = set_max_lds(gemm_tn256_kernel, LT_LDS_BYTES);
+        if (rc__ != 0) VITK_FAIL(rc__, "gemm_tn_bf16: cannot enable %d B of LDS", LT_LDS_BYTES);
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3((unsigned)nwg, (unsigned)splits), dim3(512), LT_LDS_BYTES, st, (const __bf16*)dY,
+                           (long long)ldy, (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
+    } else {
+        const int tiles_n = (int)((N + BN - 1) / BN), tiles_k = (int)((K + BM - 1) / BM);
+        const int nwg = tiles_n * tiles_k;
+        long long rps = (M + splits - 1) / splits;
+        rps = (rps + TN_BKM - 1) / TN_BKM * TN_BKM;
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nwg, (unsigned)splits), dim3(256), 0, st, (const __bf16*)dY, (long long)ldy,
+                           (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
+    }
     VITK_CHECK_LAUNCH("gemm_tn_bf16");
     const long long NK = (long long)N * K;
     const unsigned blocks = (unsigned)((NK / 4 + 255) / 256);

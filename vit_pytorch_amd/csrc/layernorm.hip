@@ -181,6 +181,33 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
     }
 }
 
+// LayerNorm-backward finalize: reduce the 2 or 3 partial slabs of one ln_bwd launch in ONE kernel
+// (1024 threads = 64 columns x 16 partial phases; dw/db in the parameter dtype, dcol in f32).
+template <typename OT>
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int D,
+                                                                OT* __restrict__ dw, OT* __restrict__ db, float* __restrict__ dcol) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int slab = blockIdx.y;
+    const float* src = partials + (long long)slab * nblk * D;
+    float s = 0.f;
+    if (c < D) {
+#pragma unroll 4
+        for (int p = ph; p < nblk; p += 16) s += src[(long long)p * D + c];
+    }
+    red[ph][cx] = s;
+    __syncthreads();
+    if (ph == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        if (slab == 0) { if (dw) dw[c] = from_f32<OT>(t); }
+        else if (slab == 1) { if (db) db[c] = from_f32<OT>(t); }
+        else if (dcol) dcol[c] = t;
+    }
+}
+
 // stage 1 of a general column sum: block = 64 column-quads x 4 row phases over a 256-row slab.
 constexpr int CS_ROWS = 256;
 template <typename XT>
@@ -310,6 +337,17 @@ extern "C" int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int x
     if (dydt == VITK_F32 && xdt == VITK_F32) return launch_ln_bwd<float, float, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
     if (dydt == VITK_F32 && xdt == VITK_BF16) return launch_ln_bwd<float, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
     VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: bad dtype combination");
+}
+
+extern "C" int vitk_layernorm_bwd_finalize(const float* partials, int64_t nblk, int64_t D, void* dw, void* db, int odt,
+                                           float* dcol, void* stream) {
+    if (!partials) VITK_FAIL(VITK_E_ARG, "layernorm_bwd_finalize: null pointer");
+    if (nblk <= 0 || D <= 0) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd_finalize: empty");
+    const dim3 grid((unsigned)((D + 63) / 64), dcol ? 3u : 2u);
+    VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((ln_bwd_finalize_kernel<OT>), grid, dim3(1024), 0, (hipStream_t)stream, partials,
+                                                  (int)nblk, (int)D, (OT*)dw, (OT*)db, dcol));
+    VITK_CHECK_LAUNCH("layernorm_bwd_finalize");
+    return 0;
 }
 
 extern "C" int vitk_colsum_partials(const float* partials, int64_t nparts, int64_t ld, int64_t cols, void* out, int odt,

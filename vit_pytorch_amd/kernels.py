@@ -71,6 +71,12 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
           "layernorm_bwd")
 
 
+def layernorm_bwd_finalize(partials: Tensor, nblk: int, D: int, dw: Optional[Tensor], db: Optional[Tensor],
+                           dcol: Optional[Tensor], odt: int):
+    check(L.load().vitk_layernorm_bwd_finalize(_p(partials), nblk, D, _p(dw), _p(db), odt, _p(dcol), _stream()),
+          "layernorm_bwd_finalize")
+
+
 def colsum_partials(partials: Tensor, nparts: int, ld: int, cols: int, out: Tensor, accumulate: bool = False):
     check(L.load().vitk_colsum_partials(_p(partials), nparts, ld, cols, _p(out), dt(out), int(accumulate), _stream()),
           "colsum_partials")

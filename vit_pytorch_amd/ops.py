@@ -45,17 +45,13 @@ def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, rows: i
            gin: Optional[Tensor] = None, dx_f32: Optional[Tensor] = None, dx_t: Optional[Tensor] = None,
            dw: Optional[Tensor] = None, db: Optional[Tensor] = None, dcol: Optional[Tensor] = None,
            dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT):
-    """LayerNorm backward; dw/db/dcol are (D,) outputs of dtype T (dcol = column sums of dx)."""
+    """LayerNorm backward; dw/db are (D,) outputs of dtype T, dcol (D,) float32 = column sums of dx."""
     nblk = K.layernorm_bwd_blocks(rows)
     nslab = 3 if dcol is not None else 2
     partials = empty((nslab * nblk * D,), F32, x)
     K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap)
-    if dw is not None:
-        K.colsum_partials(partials, nblk, D, D, dw)
-    if db is not None:
-        K.colsum_partials(partials[nblk * D:], nblk, D, D, db)
-    if dcol is not None:
-        K.colsum_partials(partials[2 * nblk * D:], nblk, D, D, dcol)
+    assert dcol is None or dcol.dtype == F32
+    K.layernorm_bwd_finalize(partials, nblk, D, dw, db, dcol, K.dt(w))
 
 
 # ---- column sums (bias / pos / cls gradients) -----------------------------------------------------
