@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library loads without a GPU and exports exactly what include/vitk.h declares;
+host-side argument validation works without launching anything."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from vit_pytorch_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vitk.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(vitk_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        out[name] = n
+    return out
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return L.load()
+
+
+def test_header_binding_and_exports_agree(lib):
+    hdr = header_functions()
+    assert len(hdr) >= 28
+    assert set(hdr) == set(L.SIGNATURES), set(hdr) ^ set(L.SIGNATURES)
+    for name, nargs in hdr.items():
+        assert hasattr(lib, name), f"{name} not exported by libvitk.so"
+        assert len(L.SIGNATURES[name][1]) == nargs, (name, nargs, len(L.SIGNATURES[name][1]))
+
+
+def test_version_and_no_torch_symbols(lib):
+    assert lib.vitk_version() == L.VITK_VERSION
+    # the boundary is plain C: the library must not depend on libtorch / libc10
+    import subprocess
+    deps = subprocess.run(["ldd", L.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libtorch" not in deps and "libc10" not in deps
+    assert "libamdhip64" in deps
+
+
+def test_host_side_validation_without_gpu(lib):
+    # bad shapes / null pointers are rejected on the host with a negative code and a message; nothing is launched
+    rc = lib.vitk_gemm_nt_bf16(None, 64, None, 64, None, 64, 64, 64, 64, 0, None, None, None, None)
+    assert rc == -1 and b"null" in lib.vitk_last_error()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p = (p + 255) // 256 * 256
+    rc = lib.vitk_gemm_nt_bf16(p, 40, p, 40, p, 64, 64, 64, 40, 0, None, None, None, None)   # K % 32 != 0
+    assert rc == -2 and b"K % 32" in lib.vitk_last_error()
+    rc = lib.vitk_layernorm_fwd(p, 0, p, p, 0, p, 0, p, p, 4, 30, 1e-5, L.IDENT, L.IDENT, None, 0, 0, None)  # D % 4 != 0
+    assert rc == -2
+    q = L.BHND(p, 64, 64, 64)
+    rc = lib.vitk_attn_fwd_bf16(q, q, q, q, p, 1, 1, 16, 80, 0.1, None)  # dim_head != 64 on the fused path
+    assert rc == -2 and b"dim_head" in lib.vitk_last_error()
+    assert lib.vitk_gemm_tn_splits(50432, 2304, 768) >= 1
+    assert lib.vitk_layernorm_bwd_blocks(50432) == 512
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.VitkError, match="not built"):
+        L.load()

@@ -1,0 +1,96 @@
+"""CPU: drop-in contract of the modules (constructor, module tree, state_dict) and host-side logic."""
+import pytest
+import torch
+
+import bench
+from oracle import vit_oracle as O
+from oracle.params import CASES, make_params, param_shapes
+from vit_pytorch_amd import SimpleViT, ViT
+from vit_pytorch_amd import simple_vit as SV
+from vit_pytorch_amd import vit as V
+from vit_pytorch_amd._lib import VitkError
+from vit_pytorch_amd.parallel import FlatGradSink, _ordered_params
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_state_dict_contract(name):
+    c = CASES[name]
+    m = (ViT if c["kind"] == "vit" else SimpleViT)(**c["cfg"])
+    sd = m.state_dict()
+    exp = param_shapes(c["kind"], c["cfg"])
+    assert list(sd.keys()) == list(exp.keys())          # names AND registration order
+    for k in sd:
+        assert tuple(sd[k].shape) == exp[k], k
+    m.load_state_dict(make_params(c["kind"], c["cfg"], 0), strict=True)
+
+
+def test_module_tree_matches_reference_shape():
+    v = ViT(image_size=32, patch_size=8, num_classes=10, dim=32, depth=2, heads=2, mlp_dim=64)
+    assert [n for n, _ in v.named_children()] == ["to_patch_embedding", "dropout", "transformer", "to_latent", "mlp_head"]
+    s = SimpleViT(image_size=32, patch_size=8, num_classes=10, dim=32, depth=2, heads=2, mlp_dim=64)
+    assert [n for n, _ in s.named_children()] == ["to_patch_embedding", "transformer", "to_latent", "linear_head"]
+    # consumers index into these (mae.py:28-31, recorder.py:26-29, dino.py:138-140, accept_video_wrapper.py:72-74)
+    assert len(v.to_patch_embedding) == 4 and isinstance(v.to_patch_embedding[1], torch.nn.LayerNorm)
+    assert isinstance(v.to_patch_embedding[2], torch.nn.Linear) and v.to_patch_embedding[2].weight.shape == (32, 192)
+    assert v.patch_size == (8, 8) and v.pool == "cls"
+    attn, ff = v.transformer.layers[0]
+    assert isinstance(attn.attend, torch.nn.Softmax) and isinstance(attn.to_out, torch.nn.Sequential)
+    assert attn.to_qkv.bias is None and isinstance(ff.net[2], torch.nn.GELU)
+    assert list(v.children())[-2] is v.to_latent
+    assert "pos_embedding" not in s.state_dict() and s.pos_embedding.shape == (16, 32)   # plain tensor attribute
+    # to_out collapses to Identity iff heads == 1 and dim_head == dim (vit.py:34,49)
+    a = V.Attention(16, heads=1, dim_head=16)
+    assert isinstance(a.to_out, torch.nn.Identity)
+    t = V.Transformer(16, 1, 2, 8, 32)                   # vit.Transformer(dim, depth, heads, dim_head, mlp_dim)
+    assert len(t.layers) == 1
+
+
+def test_constructor_assertions_and_tuple_sizes():
+    with pytest.raises(AssertionError, match="divisible"):
+        ViT(image_size=30, patch_size=8, num_classes=2, dim=8, depth=1, heads=1, mlp_dim=8)
+    with pytest.raises(AssertionError, match="pool type"):
+        ViT(image_size=32, patch_size=8, num_classes=2, dim=8, depth=1, heads=1, mlp_dim=8, pool="max")
+    with pytest.raises(AssertionError, match="multiple of 4"):
+        SimpleViT(image_size=32, patch_size=8, num_classes=2, dim=10, depth=1, heads=1, mlp_dim=8)
+    m = ViT(image_size=(24, 32), patch_size=(4, 8), num_classes=0, dim=8, depth=1, heads=1, mlp_dim=8, pool="mean")
+    assert m.mlp_head is None and m.cls_token.shape == (0, 8) and m.pos_embedding.shape == (24, 8)
+    assert V.pair(3) == (3, 3) and V.pair((2, 5)) == (2, 5)
+
+
+def test_sincos_table_equals_oracle():
+    assert torch.equal(SV.posemb_sincos_2d(3, 5, 16), O.posemb_sincos_2d(3, 5, 16))
+
+
+def test_cpu_tensors_raise_never_fall_back():
+    m = SimpleViT(image_size=32, patch_size=8, num_classes=10, dim=32, depth=1, heads=2, mlp_dim=64)
+    with pytest.raises(VitkError, match="HIP"):
+        m(torch.randn(2, 3, 32, 32))
+    with pytest.raises(VitkError, match="HIP"):
+        m.transformer(torch.randn(2, 16, 32))
+    with pytest.raises(VitkError, match="HIP"):
+        m.to_patch_embedding(torch.randn(2, 3, 32, 32))
+
+
+def test_flop_model_matches_survey_table():
+    assert abs(3 * bench.fwd_gflop_per_image(bench.CONFIGS["vit_b16"][0]) - 105.383) < 1e-3
+    assert abs(3 * bench.fwd_gflop_per_image(bench.CONFIGS["vit_l16"][0]) - 369.328) < 1e-3
+
+
+def test_flat_gradient_layout_is_reverse_readiness():
+    m = ViT(image_size=32, patch_size=8, num_classes=10, dim=32, depth=3, heads=2, mlp_dim=64)
+    names = {id(p): n for n, p in m.named_parameters()}
+    params, n_early = _ordered_params(m)
+    order = [names[id(p)] for p in params]
+    assert order[0].startswith("mlp_head") and order[2].startswith("transformer.norm")
+    layer_of = [int(n.split(".")[2]) for n in order if n.startswith("transformer.layers.")]
+    assert layer_of == sorted(layer_of, reverse=True)                     # depth-1 ... 0
+    late = order[n_early:]
+    assert late and all(n.startswith(("to_patch_embedding", "cls_token", "pos_embedding")) for n in late)
+    sink = FlatGradSink(m)
+    assert sink.total % 8 == 0 and all(o % 8 == 0 for o in sink.offsets)  # 16-byte aligned slices for the kernels
+    assert sink.boundary == sink.offsets[n_early]
+    w = m.transformer.layers[1][1].net[1].weight
+    buf = sink.buffer_for(w)
+    idx = [i for i, q in enumerate(params) if q is w][0]
+    assert buf.shape == w.shape and buf.data_ptr() == sink.views[idx].data_ptr()
+    assert sink.buffer_for(torch.zeros(3)) is None

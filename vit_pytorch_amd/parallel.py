@@ -131,29 +131,28 @@ class FlatGradSink:
     def finish_step(self):
         """After loss.backward(): make every p.grad the (reduced) flat view."""
         E.set_grad_sink(None)
-        # gradients autograd produced outside the sink (foreign modules / non-fused paths): copy in
-        missing = False
-        for i, p in enumerate(self.params):
-            if i not in self._filled:
-                if p.grad is not None and p.grad.data_ptr() != self.views[i].data_ptr():
-                    self.views[i].copy_(p.grad)
-                elif p.grad is None:
-                    self.views[i].zero_()
-                missing = True
+        # gradients autograd produced outside the sink (foreign modules / non-fused paths): copy them in
+        missing = [i for i in range(len(self.params)) if i not in self._filled]
+        for i in missing:
+            p = self.params[i]
+            if p.grad is not None and p.grad.data_ptr() != self.views[i].data_ptr():
+                self.views[i].copy_(p.grad)
+            elif p.grad is None:
+                self.views[i].zero_()
         if self.world > 1:
-            if missing or not self._early_launched:
-                # no overlap possible: one collective over whatever has not been reduced yet
-                if self.side is not None:
-                    torch.cuda.current_stream(self.device).wait_stream(self.side)
-                if not self._early_launched and not self._late_launched:
-                    self._allreduce(self.flat)
-                else:
-                    if not self._early_launched and self.boundary > 0:
-                        self._allreduce(self.flat[:self.boundary])
-                    if not self._late_launched and self.boundary < self.total:
-                        self._allreduce(self.flat[self.boundary:])
+            early_was, late_was = self._early_launched, self._late_launched
             if self.side is not None:
                 torch.cuda.current_stream(self.device).wait_stream(self.side)
+            if not early_was and not late_was:
+                self._allreduce(self.flat)                       # nothing went out during backward: one collective
+            else:
+                if not early_was and self.boundary > 0:
+                    self._allreduce(self.flat[:self.boundary])
+                if not late_was and self.boundary < self.total:
+                    self._allreduce(self.flat[self.boundary:])
+                for i in missing:                                # arrived after their segment had already gone out
+                    if (early_was if i < self.n_early else late_was) and self.params[i].numel():
+                        self._allreduce(self.views[i])
         for p, v in zip(self.params, self.views):
             p.grad = v
 
