@@ -28,6 +28,8 @@
 namespace {
 
 constexpr int AT_LD = 160;  // bytes per LDS row: 64 bf16 + 32 B pad
+constexpr int AT_THREADS = 512;  // 8 waves per (batch, head): query / key tiles are dealt round-robin to the waves
+constexpr int AT_WAVES = AT_THREADS / 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -35,7 +37,7 @@ struct BHND { __bf16* p; long long s_b, s_h, s_n; };
 
 __device__ __forceinline__ void fill_tile(char* tile, const __bf16* src, long long s_n, int N, int rows_pad, int tid) {
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int c = tid; c < rows_pad * 8; c += 256) {
+    for (int c = tid; c < rows_pad * 8; c += AT_THREADS) {
         const int row = c >> 3, col8 = c & 7;
         const bf16x8 v = row < N ? *reinterpret_cast<const bf16x8*>(src + (long long)row * s_n + col8 * 8) : zero8;
         *reinterpret_cast<bf16x8*>(tile + row * AT_LD + col8 * 16) = v;
@@ -66,7 +68,7 @@ __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b) {
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(BHND q, BHND k, BHND v, BHND o, float* __restrict__ lse,
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BHND v, BHND o, float* __restrict__ lse,
                                                         int H, int N, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(BHND q, BHND k, BHND v, B
 
     const int nqt = (N + 15) >> 4, nks = rows_pad >> 5;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += AT_WAVES) {
         const int qi = qt * 16 + fi;
         const int qrow = qi < N ? qi : N - 1;
         const __bf16* qp = q.p + b * q.s_b + h * q.s_h + (long long)qrow * q.s_n;
@@ -107,12 +109,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(BHND q, BHND k, BHND v, B
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx);
-            const float alpha = exp2f(m - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             float ps = 0.f;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { st[hh][r] = exp2f(st[hh][r] - m_new); ps += st[hh][r]; }
+                for (int r = 0; r < 4; ++r) { st[hh][r] = __builtin_amdgcn_exp2f(st[hh][r] - m_new); ps += st[hh][r]; }
             lsum = lsum * alpha + ps;
             m = m_new;
             const bf16x8 pb = pack8(st[0], st[1]);
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(BHND q, BHND k, BHND v, B
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BHND q, BHND k, BHND v, BHND o, BHND dout,
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k, BHND v, BHND o, BHND dout,
                                                            const float* __restrict__ lse, float* __restrict__ delta,
                                                            BHND dq, int H, int N, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BHND q, BHND k, BHND v
     const int nqt = (N + 15) >> 4, nks = rows_pad >> 5;
     const float scale_log2e = scale * LOG2E;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += AT_WAVES) {
         const int qi = qt * 16 + fi;
         const int qrow = qi < N ? qi : N - 1;
         const __bf16* qp = q.p + b * q.s_b + h * q.s_h + (long long)qrow * q.s_n;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BHND q, BHND k, BHND v
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = row0 + 4 * fg + r;
-                    const float p = key < N ? exp2f(st[r] * scale_log2e - l2) : 0.f;
+                    const float p = key < N ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - l2) : 0.f;
                     ds[hh][r] = p * (dp[r] - dl) * scale;
                 }
             }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BHND q, BHND k, BHND v
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BHND q, BHND k, BHND v, BHND dout,
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k, BHND v, BHND dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             BHND dk, BHND dv, int H, int N, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BHND q, BHND k, BHND 
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     fill_tile(Qs, q.p + b * q.s_b + h * q.s_h, q.s_n, N, rows_pad, tid);
     fill_tile(Ds, dout.p + b * dout.s_b + h * dout.s_h, dout.s_n, N, rows_pad, tid);
-    for (int r = tid; r < rows_pad; r += 256) {
+    for (int r = tid; r < rows_pad; r += AT_THREADS) {
         lse_s[r] = r < N ? lse[(long long)bh * N + r] * LOG2E : 0.f;
         del_s[r] = r < N ? delta[(long long)bh * N + r] : 0.f;
     }
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BHND q, BHND k, BHND 
     const int nkt = (N + 15) >> 4, nqs = rows_pad >> 5;
     const float scale_log2e = scale * LOG2E;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = wave; kt < nkt; kt += AT_WAVES) {
         const int ki = kt * 16 + fi;
         const int krow = ki < N ? ki : N - 1;
         const __bf16* kp = k.p + b * k.s_b + h * k.s_h + (long long)krow * k.s_n;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BHND q, BHND k, BHND 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qidx = row0 + 4 * fg + r;
-                    p[hh][r] = qidx < N ? exp2f(st[r] * scale_log2e - l4[r]) : 0.f;
+                    p[hh][r] = qidx < N ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - l4[r]) : 0.f;
                     ds[hh][r] = p[hh][r] * (dp[r] - d4[r]) * scale;
                 }
             }
@@ -327,7 +329,7 @@ extern "C" int vitk_attn_fwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bh
     const int rows_pad = (int)((N + 31) / 32 * 32);
     const size_t lds = (size_t)2 * rows_pad * AT_LD;
     SET_LDS(attn_fwd_kernel, "attn_fwd_bf16");
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(256), lds, (hipStream_t)stream, to_bhnd(q), to_bhnd(k),
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(AT_THREADS), lds, (hipStream_t)stream, to_bhnd(q), to_bhnd(k),
                        to_bhnd(v), to_bhnd(o), lse, (int)H, (int)N, scale * LOG2E);
     VITK_CHECK_LAUNCH("attn_fwd_bf16");
     return 0;
@@ -346,10 +348,10 @@ extern "C" int vitk_attn_bwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bh
     SET_LDS(attn_bwd_dq_kernel, "attn_bwd_dq");
     SET_LDS(attn_bwd_dkv_kernel, "attn_bwd_dkv");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(256), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v),
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(AT_THREADS), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v),
                        to_bhnd(o), to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale);
     VITK_CHECK_LAUNCH("attn_bwd_dq");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(256), lds2, st, to_bhnd(q), to_bhnd(k), to_bhnd(v),
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(AT_THREADS), lds2, st, to_bhnd(q), to_bhnd(k), to_bhnd(v),
                        to_bhnd(dout), lse, delta, to_bhnd(dk), to_bhnd(dv), (int)H, (int)N, scale);
     VITK_CHECK_LAUNCH("attn_bwd_dkv");
     return 0;

@@ -11,6 +11,10 @@ namespace {
 
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / WAVE;
+// backward is latency-bound (3 input streams per row): 8 waves per block, up to 1024 blocks = 32 waves per CU
+constexpr int LNB_THREADS = 512;
+constexpr int LNB_WAVES = LNB_THREADS / WAVE;
+constexpr int LNB_MAX_BLOCKS = 1024;
 
 template <typename XT, typename YT, typename WT, int MAXC>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 
 // Backward.  DXT is the dtype of the optional second dx output (dx_t).
 template <typename DYT, typename XT, typename WT, typename DXT, int MAXC>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
+__global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
     const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
         acc_b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc_x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (long long row = (long long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long long)gridDim.x * LN_WAVES) {
+    for (long long row = (long long)blockIdx.x * LNB_WAVES + wave; row < rows; row += (long long)gridDim.x * LNB_WAVES) {
         const DYT* dyr = dy + map_row(dymap, row) * (long long)D;
         const XT* xr = x + map_row(xmap, row) * (long long)D;
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
         }
     }
     // block reduce the per-wave column accumulators through LDS, one slab at a time
-    __shared__ f32x4 red[LN_WAVES][64];
+    __shared__ f32x4 red[LNB_WAVES][64];
     const int nslab = colsum_dx ? 3 : 2;
     for (int slab = 0; slab < nslab; ++slab) {
 #pragma unroll
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
                     if (c < nchunk) {
                         f32x4 sum = red[0][lane];
 #pragma unroll
-                        for (int wv_ = 1; wv_ < LN_WAVES; ++wv_) sum += red[wv_][lane];
+                        for (int wv_ = 1; wv_ < LNB_WAVES; ++wv_) sum += red[wv_][lane];
                         *reinterpret_cast<f32x4*>(partials + ((long long)slab * gridDim.x + blockIdx.x) * D + 4 * c) = sum;
                     }
                 }
@@ -272,7 +276,7 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
     const int nchunk = D / 4;
     const int maxc = (nchunk + 63) / 64;
     const long long blocks = vitk_layernorm_bwd_blocks(rows);
-#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, \
+#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC>), dim3((unsigned)blocks), dim3(LNB_THREADS), 0, st, \
         (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om)
     if (maxc <= 1) LN_BWD_CASE(1);
     else if (maxc <= 3) LN_BWD_CASE(3);
@@ -310,8 +314,8 @@ extern "C" int vitk_layernorm_fwd(const void* x, int xdt, const void* w, const v
 }
 
 extern "C" int64_t vitk_layernorm_bwd_blocks(int64_t rows) {
-    int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
-    if (blocks > 512) blocks = 512;
+    int64_t blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
+    if (blocks > LNB_MAX_BLOCKS) blocks = LNB_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
     return blocks;
 }

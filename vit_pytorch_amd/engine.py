@@ -57,6 +57,61 @@ def _grad_buf(param: Tensor) -> Tensor:
     return torch.empty_like(param, memory_format=torch.contiguous_format)
 
 
+def _ret(g: Optional[Tensor]) -> Optional[Tensor]:
+    """What backward hands to autograd for a parameter gradient.  A gradient that already sits in the
+    sink's flat buffer is NOT returned (autograd would clone the view into a fresh .grad tensor: one
+    device copy per parameter per step); the sink assigns p.grad itself in finish_step()."""
+    s = _sink()
+    if g is not None and s is not None and s.owns(g):
+        return None
+    return g
+
+
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (device.type, device.index)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+class _Fork:
+    """Run weight-gradient GEMMs on a side stream, concurrently with the dX chain of the main stream.
+
+    Within one layer's backward the dW GEMMs (TN) depend on tensors the chain has already produced but
+    nothing on the chain depends on them, so they can fill the CUs the chain leaves idle (the tail of
+    every 591-tile N=768 GEMM on 256 CUs, the HBM-bound LayerNorm/attention phases).  `run` orders the
+    side stream behind everything enqueued so far, `record_stream`s the inputs so the caching allocator
+    does not recycle them early, and `join` makes the main stream wait for the side work."""
+
+    def __init__(self, device):
+        import os
+        self.enabled = device.type == "cuda" and os.environ.get("VITK_DW_STREAM", "1") != "0"
+        if self.enabled:
+            self.main = torch.cuda.current_stream(device)
+            self.side = _side_stream(device)
+
+    def run(self, fn, *tensors):
+        if not self.enabled:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
+
+    def join(self):
+        if self.enabled:
+            self.main.wait_stream(self.side)
+
+
 def _check_dims(D: int, what: str):
     if D % 4 != 0:
         raise VitkError(f"{what}: feature dimension {D} must be a multiple of 4 for the HIP kernels")
@@ -147,6 +202,7 @@ class TransformerFn(torch.autograd.Function):
             g32 = ops.empty((M, D), F32, dy)
             return g32, (ops.empty((M, D), T, dy) if bf else None)
 
+        fork = _Fork(dy.device)
         # final LayerNorm (vit.py:83)
         g, gb = newg()
         dnw, dnb = _grad_buf(norm_w), _grad_buf(norm_b)
@@ -161,7 +217,7 @@ class TransformerFn(torch.autograd.Function):
             base = li * NLP
             # ---- feed-forward branch (vit.py:18-25) ----
             dw2 = _grad_buf(w2)
-            ops.linear_dw(gT, act, M, dw2)
+            fork.run(lambda: ops.linear_dw(gT, act, M, dw2), gT, act, dw2)
             grads[base + 9] = dw2
             if b2 is not None:
                 db2 = _grad_buf(b2)
@@ -170,7 +226,7 @@ class TransformerFn(torch.autograd.Function):
             dpre = ops.linear_dx(gT, w2, M, gelu_pre=pre)
             dw1 = _grad_buf(w1)
             db1 = _grad_buf(b1) if b1 is not None else None
-            ops.linear_dw(dpre, a2, M, dw1, db1)
+            fork.run(lambda: ops.linear_dw(dpre, a2, M, dw1, db1), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
             da2 = ops.linear_dx(dpre, w1, M)
             del dpre, pre, act
@@ -184,7 +240,7 @@ class TransformerFn(torch.autograd.Function):
             # ---- attention branch (vit.py:51-64) ----
             if wout is not None:
                 dwo = _grad_buf(wout)
-                ops.linear_dw(g2T, o, M, dwo)
+                fork.run(lambda: ops.linear_dw(g2T, o, M, dwo), g2T, o, dwo)
                 grads[base + 3] = dwo
                 if bout is not None:
                     dbo = _grad_buf(bout)
@@ -195,7 +251,7 @@ class TransformerFn(torch.autograd.Function):
                 do = g2T
             dqkv = ops.attn_bwd(qkv, o, do, att_saved, B, N, heads, dim_head, scale)
             dwq = _grad_buf(wqkv)
-            ops.linear_dw(dqkv, a1, M, dwq)
+            fork.run(lambda: ops.linear_dw(dqkv, a1, M, dwq), dqkv, a1, dwq)
             grads[base + 2] = dwq
             da1 = ops.linear_dx(dqkv, wqkv, M)
             del dqkv, do, qkv, o
@@ -206,6 +262,7 @@ class TransformerFn(torch.autograd.Function):
             grads[base + 0], grads[base + 1] = dl1w, dl1b
             g, gb = g1, g1b
             del g2, g2b, da1
+        fork.join()
         s = _sink()
         if s is not None:
             s.stage_done("transformer")
@@ -213,7 +270,7 @@ class TransformerFn(torch.autograd.Function):
             dx = g.view(B, N, D)
         else:
             dx = (gb if gb is not None else g).view(B, N, D)
-        return (dx, None, None, dnw, dnb, *grads)
+        return (dx, None, None, _ret(dnw), _ret(dnb), *[_ret(t) for t in grads])
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -300,7 +357,7 @@ class PatchEmbedFn(torch.autograd.Function):
         s = _sink()
         if s is not None:
             s.stage_done("patch_embed")
-        return (None, None, None, dl1w, dl1b, dw, db, dl2w, dl2b, dcls, dpos)
+        return (None, None, None, _ret(dl1w), _ret(dl1b), _ret(dw), _ret(db), _ret(dl2w), _ret(dl2b), _ret(dcls), _ret(dpos))
 
 
 class HeadFn(torch.autograd.Function):
@@ -349,4 +406,4 @@ class HeadFn(torch.autograd.Function):
         s = _sink()
         if s is not None:
             s.stage_done("head")
-        return dy, None, dw, db
+        return dy, None, _ret(dw), _ret(db)

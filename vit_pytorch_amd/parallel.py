@@ -77,6 +77,7 @@ class FlatGradSink:
         self.flat = torch.zeros(total, dtype=self.dtype, device=self.device)
         self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
         self._by_ptr: Dict[int, int] = {p.data_ptr(): i for i, p in enumerate(self.params) if p.numel()}
+        self._view_ptrs = {v.data_ptr() for v, p in zip(self.views, self.params) if p.numel()}
         self._filled = set()
         self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._early_launched = False
@@ -90,6 +91,9 @@ class FlatGradSink:
             return None
         self._filled.add(i)
         return self.views[i]
+
+    def owns(self, t: torch.Tensor) -> bool:
+        return t.data_ptr() in self._view_ptrs
 
     def stage_done(self, stage: str):
         """Called from inside backward (autograd thread) when a stage's gradients are enqueued."""
