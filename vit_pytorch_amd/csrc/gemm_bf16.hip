@@ -450,6 +450,220 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
     }
 }
 
+// ==========================================================================================
+// Ping-pong variant of the 256 x 256 NT kernel.
+// The two waves that share a SIMD (wave w and w+4) are put in different GROUPS that run the same
+// instruction stream one barrier-slot apart: while group A issues its 16 MFMAs of a sub-step, group B
+// reads its fragments from LDS and issues LDS-DMA for a future K-step, and vice versa.  The MFMA pipe of
+// every SIMD then always has exactly one wave feeding it instead of two waves reading LDS together and
+// then queueing on the pipe together.  K-step 32, FOUR 32 KiB stages: the DMA of K-step j+3 is issued
+// during K-step j (counted vmcnt: never drained inside the loop).
+//   slot (barrier interval) c:   4j     4j+1    4j+2    4j+3    4j+4
+//   group A:                    R0(j)   M0(j)   R1(j)   M1(j)   R0(j+1)
+//   group B:                    M1(j-1) R0(j)   M0(j)   R1(j)   M1(j)
+// R0 = read W(4) + X[0..3](4) fragments, issue 2 DMA; R1 = read X[4..7], issue 2 DMA, counted wait for
+// K-step j+1; M0/M1 = 16 MFMAs each.  LDS hazards: a stage is re-filled (K-step j+3 -> stage (j-1)&3) only
+// after the barrier that follows the last read of K-step j-1 (reads are retired with lgkmcnt(0) BEFORE
+// the barrier that ends an R slot); a stage is read only after every wave's counted vmcnt + a barrier.
+// (A coarser split -- one R and one M slot per K-step, 12 reads / 32 MFMAs -- measured 3-5% slower.)
+// ==========================================================================================
+constexpr int P_BK = 32, P_STAGES = 4;
+constexpr int P_TILE_BYTES = 256 * P_BK * 2;          // 16 KiB per operand per stage (64-byte rows)
+constexpr int P_STAGE_BYTES = 2 * P_TILE_BYTES;       // 32 KiB
+constexpr int P_LDS_BYTES = P_STAGES * P_STAGE_BYTES; // 128 KiB
+
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
+    const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ W, long long ldw,
+    void* __restrict__ Cv, long long ldc, int M, int N, int K,
+    const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
+    int tiles_n, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool grp_b = wave >= 4;
+    const int wg = xcd_swizzle(blockIdx.x, nwg);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int m0 = tm * L_BM, n0 = tn * L_BN;
+
+    // staging: 64-byte rows, a wave-instruction fills 16 rows; wave w owns row groups 2w, 2w+1 of each operand
+    const int srow = lane >> 2, spos = lane & 3;
+    const int schunk = spos ^ swz_f(lane >> 4);
+    const __bf16* a_src[2];
+    const __bf16* w_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int ar = m0 + (wave * 2 + j) * 16 + srow; ar = ar < M ? ar : M - 1;
+        int wr = n0 + (wave * 2 + j) * 16 + srow; wr = wr < N ? wr : N - 1;
+        a_src[j] = A + (long long)ar * lda + schunk * 8;
+        w_src[j] = W + (long long)wr * ldw + schunk * 8;
+    }
+    auto stage_a = [&](int kt) {
+        char* base = lds + (kt & 3) * P_STAGE_BYTES + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + kt * P_BK),
+                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
+    };
+    auto stage_w = [&](int kt) {
+        char* base = lds + (kt & 3) * P_STAGE_BYTES + P_TILE_BYTES + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + kt * P_BK),
+                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
+    };
+
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fpos = fg ^ swz_f(fi >> 2);
+    const int a_off = (wm * 128 + fi) * 64 + fpos * 16;                    // + fm * 1024
+    const int w_off = P_TILE_BYTES + (wn * 64 + fi) * 64 + fpos * 16;      // + fn * 1024
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = K / P_BK;
+    // prologue: K-steps 0..2 in flight, K-step 0 landed
+    stage_a(0); stage_w(0);
+    if (nt > 1) { stage_a(1); stage_w(1); }
+    if (nt > 2) { stage_a(2); stage_w(2); }
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    if (grp_b) PP_BARRIER();   // group B runs one slot behind group A
+
+    for (int j = 0; j < nt; ++j) {
+        const char* base = lds + (j & 3) * P_STAGE_BYTES;
+        const bool more = j + 3 < nt;
+        bf16x8 wf[4], xf[4];
+        // ---- R0 ----
+#pragma unroll
+        for (int f = 0; f < 4; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(base + w_off + f * 1024);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + f * 1024);
+        if (more) stage_a(j + 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        // ---- M0 ----
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][f], 0, 0, 0);
+        PP_BARRIER();
+        // ---- R1 ----
+#pragma unroll
+        for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
+        if (more) stage_w(j + 3);
+        // this wave's DMA of K-step j+1 must have landed before the barrier that precedes its first read
+        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        // ---- M1 ----
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][4 + f], 0, 0, 0);
+        PP_BARRIER();
+    }
+    if (!grp_b) PP_BARRIER();  // pairs with group B's extra barrier
+
+    // ---- epilogue: accumulators -> (wave-private 16 KiB of the now idle LDS) -> full-line global I/O ----
+    // A lane holds 4 consecutive columns of 32 scattered (row, 16-col block) pairs; stored directly that is
+    // 32-byte pieces of 16 rows per instruction (measured: ~30% of the kernel).  Re-staged through LDS every
+    // global store (and every residual / pre-activation load) is 16 B per lane and 128 B contiguous per row.
+    __syncthreads();  // every wave is done reading the operand stages
+    char* ep = lds + wave * 16384;
+    const int mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
+    if constexpr (EPI == VITK_EPI_RESID) {
+        const int rr = lane >> 4, rc = lane & 15;      // read-back: 4 rows x 16 chunks of 4 floats
+        const int ncol = ncol0 + rc * 4;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (bias && ncol < N) b4 = load4<__bf16>(bias + ncol);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int f4 = 0; f4 < 4; ++f4) {
+                const int row = f4 * 16 + fi;
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn) {
+                    const int c16 = fn * 4 + fg;
+                    *reinterpret_cast<f32x4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16)) = acc[fn][hh * 4 + f4];
+                }
+            }
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int row = j * 4 + rr;
+                f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 256 + ((rc ^ (row & 15)) * 16));
+                const int m = mrow0 + hh * 64 + row;
+                if (m < M && ncol < N) {
+                    const long long o = (long long)m * ldc + ncol;
+                    v += b4;
+                    v += *reinterpret_cast<const f32x4*>(resid + o);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + o) = v;
+                }
+            }
+        }
+    } else {
+        f32x4 b4[4];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            b4[fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU) {
+                const int n = ncol0 + fn * 16 + 4 * fg;
+                if (n < N) b4[fn] = load4<__bf16>(bias + n);
+            }
+        }
+#pragma unroll
+        for (int fm = 0; fm < 8; ++fm) {
+            const int row = fm * 16 + fi;
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn) {
+                const int c16 = fn * 2 + (fg >> 1);
+                const f32x4 v = acc[fn][fm] + b4[fn];
+                const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fg & 1) * 8) = pk;
+            }
+        }
+        const int rr = lane >> 3, rc = lane & 7;       // read-back: 8 rows x 8 chunks of 8 bf16
+        const int ncol = ncol0 + rc * 8;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int row = j * 8 + rr;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row * 128 + ((rc ^ (row & 7)) * 16));
+            const int m = mrow0 + row;
+            if (m < M && ncol < N) {
+                const long long o = (long long)m * ldc + ncol;
+                if constexpr (EPI == VITK_EPI_NONE || EPI == VITK_EPI_BIAS) {
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = v;
+                } else if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+                    *reinterpret_cast<bf16x8*>(aux + o) = v;
+                    bf16x8 g8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g8[e] = (__bf16)gelu_erf((float)v[e]);
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
+                } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                    const bf16x8 h8 = *reinterpret_cast<const bf16x8*>(aux + o);
+                    bf16x8 g8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g8[e] = (__bf16)((float)v[e] * gelu_erf_grad((float)h8[e]));
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
+                }
+            }
+        }
+    }
+}
+
 // TN 256 x 256 output tile, 64 token rows per step, register-staged into padded rows (544 B:
 // 8 consecutive rows hit 8 disjoint 32-byte bank windows for the transpose reads).
 constexpr int LT_BKM = 64;
@@ -580,8 +794,14 @@ extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
     const long long nwg = (long long)tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: grid too large");
     hipStream_t st = (hipStream_t)stream;
+    const bool pp = large && !(getenv("VITK_NT_PP") && getenv("VITK_NT_PP")[0] == '0');
 #define NT_LAUNCH(E) do { \
-    if (large) { \
+    if (pp) { \
+        static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E>, P_LDS_BYTES); \
+        if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", P_LDS_BYTES); \
+        hipLaunchKernelGGL((gemm_nt256pp_kernel<E>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, (const __bf16*)A, (long long)lda, \
+            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg); \
+    } else if (large) { \
         static const int rc__ = set_max_lds(gemm_nt256_kernel<E>, L_LDS_BYTES); \
         if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", L_LDS_BYTES); \
         hipLaunchKernelGGL((gemm_nt256_kernel<E>), dim3((unsigned)nwg), dim3(512), L_LDS_BYTES, st, (const __bf16*)A, (long long)lda, \
