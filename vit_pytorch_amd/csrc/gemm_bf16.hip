@@ -552,11 +552,13 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PP_BARRIER();
         // ---- M0 ----
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
             for (int f = 0; f < 4; ++f)
                 acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][f], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         PP_BARRIER();
         // ---- R1 ----
 #pragma unroll
@@ -569,11 +571,13 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PP_BARRIER();
         // ---- M1 ----
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
             for (int f = 0; f < 4; ++f)
                 acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][4 + f], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         PP_BARRIER();
     }
     if (!grp_b) PP_BARRIER();  // pairs with group B's extra barrier
