@@ -175,10 +175,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
-    const int wg = xcd_swizzle(blockIdx.x, nwg);
+    const int lin = xcd_swizzle(blockIdx.x, (int)gridDim.x);   // (split, tile) jointly, split-major (see gemm_tn256_kernel)
+    const int split = lin / nwg;
+    const int wg = lin % nwg;
     const int tn = wg / tiles_k, tk = wg % tiles_k;
     const int n0 = tn * BN, k0 = tk * BM;
-    const int split = blockIdx.y;
     const int mbeg = split * rows_per_split;
     int mend = mbeg + rows_per_split; mend = mend < M ? mend : M;
 
@@ -691,10 +692,14 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wn = wave >> 2, wk = wave & 3;   // wave tile: 128 (n) x 64 (k)
-    const int wg = xcd_swizzle(blockIdx.x, nwg);
+    // XCD-aware order over (split, tile) JOINTLY, split-major: each XCD gets a contiguous run of tiles of (mostly)
+    // ONE M-split, i.e. workgroups that read the same dY / X rows at the same time, so a 64-row slice is fetched
+    // from HBM once per XCD and shared through its L2 (measured before: 40% L2 hits, ~1 GB fabric reads / call).
+    const int lin = xcd_swizzle(blockIdx.x, (int)gridDim.x);
+    const int split = lin / nwg;
+    const int wg = lin % nwg;
     const int tn = wg / tiles_k, tk = wg % tiles_k;
     const int n0 = tn * 256, k0 = tk * 256;
-    const int split = blockIdx.y;
     const int mbeg = split * rows_per_split;
     int mend = mbeg + rows_per_split; mend = mend < M ? mend : M;
 
@@ -871,14 +876,14 @@ extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int
         rps = (rps + LT_BKM - 1) / LT_BKM * LT_BKM;
         static const int rc__ = set_max_lds(gemm_tn256_kernel, LT_LDS_BYTES);
         if (rc__ != 0) VITK_FAIL(rc__, "gemm_tn_bf16: cannot enable %d B of LDS", LT_LDS_BYTES);
-        hipLaunchKernelGGL(gemm_tn256_kernel, dim3((unsigned)nwg, (unsigned)splits), dim3(512), LT_LDS_BYTES, st, (const __bf16*)dY,
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3((unsigned)(nwg * splits)), dim3(512), LT_LDS_BYTES, st, (const __bf16*)dY,
                            (long long)ldy, (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
     } else {
         const int tiles_n = (int)((N + BN - 1) / BN), tiles_k = (int)((K + BM - 1) / BM);
         const int nwg = tiles_n * tiles_k;
         long long rps = (M + splits - 1) / splits;
         rps = (rps + TN_BKM - 1) / TN_BKM * TN_BKM;
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nwg, (unsigned)splits), dim3(256), 0, st, (const __bf16*)dY, (long long)ldy,
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(nwg * splits)), dim3(256), 0, st, (const __bf16*)dY, (long long)ldy,
                            (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
     }
     VITK_CHECK_LAUNCH("gemm_tn_bf16");
