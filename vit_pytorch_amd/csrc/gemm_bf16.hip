@@ -38,6 +38,20 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Grouped tile order: walk the n-tiles in groups of `gn` (m fastest across the group, n fastest inside it), so
+// the ~32 tiles an XCD runs at once cover (32/gn) activation panels x gn weight panels instead of ~3 x all.
+// Fabric bytes ~ A_total * tiles_n / gn + W_panel * gn * tiles / 32: for N = 3072, K = 768 (W = 4.7 MB > L2)
+// gn = 6 reads 328 MB instead of 425 MB (measured 485 MB with the plain n-fastest order).
+__device__ __forceinline__ void grouped_tile(int wg, int tiles_m, int tiles_n, int gn, int& tm, int& tn) {
+    const int per_group = gn * tiles_m;
+    const int g = wg / per_group;
+    const int r = wg - g * per_group;
+    const int rem = tiles_n - g * gn;
+    const int w = rem < gn ? rem : gn;
+    tm = r / w;
+    tn = g * gn + (r - tm * w);
+}
+
 // permutation f = [0,2,3,1]: logical 16-byte chunk g of row i sits at position g ^ f[(i>>2)&3].
 // Makes every ds_read_b128 lane group of the 64-byte-row image hit 16 distinct bank slots.
 __device__ __forceinline__ int swz_f(int x) { return (0x1320 >> (4 * (x & 3))) & 3; }
@@ -273,183 +287,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 
 
 // ==========================================================================================
-// 256 x 256 x 64 tiles, 8 waves (2 x 4), one workgroup per CU (128 KiB LDS, two stages).
+// 256 x 256 tiles, 8 waves (2 x 4), one workgroup per CU (128 KiB LDS).
 // Per MFMA the 128^2 tile moves ~2x the LDS bytes (both DMA writes and fragment reads) and is
 // LDS-bound on gfx950; a 128x64 wave tile needs 12 ds_read_b128 per 32 MFMAs instead of 8 per 16.
 // ==========================================================================================
 constexpr int L_BM = 256, L_BN = 256, L_BK = 64;
-constexpr int L_TILE_BYTES = 256 * L_BK * 2;      // 32 KiB per operand tile (128-byte rows)
-constexpr int L_STAGE_BYTES = 2 * L_TILE_BYTES;   // A + W
-constexpr int L_LDS_BYTES = 2 * L_STAGE_BYTES;    // 128 KiB
-
-// 128-byte rows: logical 16-byte chunk c (0..7) of row r sits at position c ^ ((r >> 1) & 7);
-// every ds_read_b128 lane group then covers all 16 slots of the 256-byte bank row exactly once.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt256_kernel(
-    const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ W, long long ldw,
-    void* __restrict__ Cv, long long ldc, int M, int N, int K,
-    const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
-    int tiles_n, int nwg) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int wg = xcd_swizzle(blockIdx.x, nwg);
-    const int tm = wg / tiles_n, tn = wg % tiles_n;
-    const int m0 = tm * L_BM, n0 = tn * L_BN;
-
-    // staging: a wave-instruction fills 8 rows x 128 B; wave w owns row groups 4w..4w+3 of each operand
-    const int srow = lane >> 3, spos = lane & 7;
-    const __bf16* a_src[4];
-    const __bf16* w_src[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 8 + srow;          // row inside the tile
-        const int chunk = spos ^ ((r >> 1) & 7);
-        int ar = m0 + r; ar = ar < M ? ar : M - 1;
-        int wr = n0 + r; wr = wr < N ? wr : N - 1;
-        a_src[j] = A + (long long)ar * lda + chunk * 8;
-        w_src[j] = W + (long long)wr * ldw + chunk * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        char* base = lds + buf * L_STAGE_BYTES + wave * 4096;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + kt * L_BK),
-                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + kt * L_BK),
-                                             (void __attribute__((address_space(3)))*)(base + L_TILE_BYTES + j * 1024), 16, 0, 0);
-        }
-    };
-
-    const int fi = lane & 15, fg = lane >> 4;
-    const int sw = (fi >> 1) & 7;
-    const int a_row = (wm * 128 + fi) * 128;                    // + fm * 2048
-    const int w_row = L_TILE_BYTES + (wn * 64 + fi) * 128;      // + fn * 2048
-    const int pos0 = ((0 + fg) ^ sw) * 16, pos1 = ((4 + fg) ^ sw) * 16;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Main loop: two LDS stages, one barrier per 64-deep K-tile; the DMA of tile t+1 flies during the
-    // 64 MFMAs per wave of tile t.  (Measured alternatives that did NOT pay on these shapes: counted vmcnt
-    // with an LDS-DMA L2 prefetch two tiles ahead; hand-ordered fragment double-buffering; a 4-wave
-    // 256x128 tile with 3 stages and two workgroups per CU -- see DESIGN.md.)
-    const int nt = K / L_BK;
-    stage(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        __syncthreads();
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-        const char* base = lds + (t & 1) * L_STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int pos = ks ? pos1 : pos0;
-            bf16x8 wf[4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(base + w_row + f * 2048 + pos);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bf16x8 xf[4];
-#pragma unroll
-                for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_row + (h * 4 + f) * 2048 + pos);
-#pragma unroll
-                for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        acc[fn][h * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][h * 4 + f], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- epilogue: accumulators -> (wave-private 16 KiB of the now idle LDS) -> full-line global I/O ----
-    // A lane holds 4 consecutive columns of 32 scattered (row, 16-col block) pairs; stored directly that is
-    // 32-byte pieces of 16 rows per instruction (measured: ~30% of the kernel).  Re-staged through LDS every
-    // global store (and every residual / pre-activation load) is 16 B per lane and 128 B contiguous per row.
-    __syncthreads();  // every wave is done reading the operand stages
-    char* ep = lds + wave * 16384;
-    const int mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
-    if constexpr (EPI == VITK_EPI_RESID) {
-        const int rr = lane >> 4, rc = lane & 15;      // read-back: 4 rows x 16 chunks of 4 floats
-        const int ncol = ncol0 + rc * 4;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (bias && ncol < N) b4 = load4<__bf16>(bias + ncol);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-            for (int f4 = 0; f4 < 4; ++f4) {
-                const int row = f4 * 16 + fi;
-#pragma unroll
-                for (int fn = 0; fn < 4; ++fn) {
-                    const int c16 = fn * 4 + fg;
-                    *reinterpret_cast<f32x4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16)) = acc[fn][hh * 4 + f4];
-                }
-            }
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                const int row = j * 4 + rr;
-                f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 256 + ((rc ^ (row & 15)) * 16));
-                const int m = mrow0 + hh * 64 + row;
-                if (m < M && ncol < N) {
-                    const long long o = (long long)m * ldc + ncol;
-                    v += b4;
-                    v += *reinterpret_cast<const f32x4*>(resid + o);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + o) = v;
-                }
-            }
-        }
-    } else {
-        f32x4 b4[4];
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) {
-            b4[fn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU) {
-                const int n = ncol0 + fn * 16 + 4 * fg;
-                if (n < N) b4[fn] = load4<__bf16>(bias + n);
-            }
-        }
-#pragma unroll
-        for (int fm = 0; fm < 8; ++fm) {
-            const int row = fm * 16 + fi;
-#pragma unroll
-            for (int fn = 0; fn < 4; ++fn) {
-                const int c16 = fn * 2 + (fg >> 1);
-                const f32x4 v = acc[fn][fm] + b4[fn];
-                const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fg & 1) * 8) = pk;
-            }
-        }
-        const int rr = lane >> 3, rc = lane & 7;       // read-back: 8 rows x 8 chunks of 8 bf16
-        const int ncol = ncol0 + rc * 8;
-#pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-            const int row = j * 8 + rr;
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row * 128 + ((rc ^ (row & 7)) * 16));
-            const int m = mrow0 + row;
-            if (m < M && ncol < N) {
-                const long long o = (long long)m * ldc + ncol;
-                if constexpr (EPI == VITK_EPI_NONE || EPI == VITK_EPI_BIAS) {
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = v;
-                } else if constexpr (EPI == VITK_EPI_BIAS_GELU) {
-                    *reinterpret_cast<bf16x8*>(aux + o) = v;
-                    bf16x8 g8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) g8[e] = (__bf16)gelu_erf((float)v[e]);
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
-                } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
-                    const bf16x8 h8 = *reinterpret_cast<const bf16x8*>(aux + o);
-                    bf16x8 g8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) g8[e] = (__bf16)((float)v[e] * gelu_erf_grad((float)h8[e]));
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
-                }
-            }
-        }
-    }
-}
 
 // ==========================================================================================
 // Ping-pong variant of the 256 x 256 NT kernel.
@@ -475,12 +317,12 @@ constexpr int P_LDS_BYTES = P_STAGES * P_STAGE_BYTES; // 128 KiB
 
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int EPI>
+template <int EPI, int FM>
 __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ W, long long ldw,
     void* __restrict__ Cv, long long ldc, int M, int N, int K,
     const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
-    int tiles_n, int nwg) {
+    int tiles_n, int nwg, int group_n) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -488,8 +330,10 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     const int wm = wave >> 2, wn = wave & 3;
     const bool grp_b = wave >= 4;
     const int wg = xcd_swizzle(blockIdx.x, nwg);
-    const int tm = wg / tiles_n, tn = wg % tiles_n;
-    const int m0 = tm * L_BM, n0 = tn * L_BN;
+    int tm, tn;
+    grouped_tile(wg, nwg / tiles_n, tiles_n, group_n, tm, tn);
+    constexpr int WROWS = 16 * FM;            // rows per wave (FM = 8: 256-row tile, FM = 7: 224-row tile)
+    const int m0 = tm * (2 * WROWS), n0 = tn * L_BN;
 
     // staging: 64-byte rows, a wave-instruction fills 16 rows; wave w owns row groups 2w, 2w+1 of each operand
     const int srow = lane >> 2, spos = lane & 3;
@@ -520,14 +364,14 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
 
     const int fi = lane & 15, fg = lane >> 4;
     const int fpos = fg ^ swz_f(fi >> 2);
-    const int a_off = (wm * 128 + fi) * 64 + fpos * 16;                    // + fm * 1024
+    const int a_off = (wm * WROWS + fi) * 64 + fpos * 16;                  // + fm * 1024
     const int w_off = P_TILE_BYTES + (wn * 64 + fi) * 64 + fpos * 16;      // + fn * 1024
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][FM];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = K / P_BK;
     // prologue: K-steps 0..2 in flight, K-step 0 landed
@@ -563,7 +407,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         PP_BARRIER();
         // ---- R1 ----
 #pragma unroll
-        for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
+        for (int f = 0; f < FM - 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
         if (more) stage_w(j + 3);
         // this wave's DMA of K-step j+1 must have landed before the barrier that precedes its first read
         if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -576,7 +420,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < FM - 4; ++f)
                 acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][4 + f], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_BARRIER();
@@ -584,12 +428,12 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     if (!grp_b) PP_BARRIER();  // pairs with group B's extra barrier
 
     // ---- epilogue: accumulators -> (wave-private 16 KiB of the now idle LDS) -> full-line global I/O ----
-    // A lane holds 4 consecutive columns of 32 scattered (row, 16-col block) pairs; stored directly that is
+    // A lane holds 4 consecutive columns of 4*FM scattered (row, 16-col block) pairs; stored directly that is
     // 32-byte pieces of 16 rows per instruction (measured: ~30% of the kernel).  Re-staged through LDS every
     // global store (and every residual / pre-activation load) is 16 B per lane and 128 B contiguous per row.
     __syncthreads();  // every wave is done reading the operand stages
     char* ep = lds + wave * 16384;
-    const int mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
+    const int mrow0 = m0 + wm * WROWS, ncol0 = n0 + wn * 64;
     if constexpr (EPI == VITK_EPI_RESID) {
         const int rr = lane >> 4, rc = lane & 15;      // read-back: 4 rows x 16 chunks of 4 floats
         const int ncol = ncol0 + rc * 4;
@@ -597,17 +441,20 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         if (bias && ncol < N) b4 = load4<__bf16>(bias + ncol);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
+            constexpr int NF0 = 4, NF1 = FM - 4;
+            const int nf = hh ? NF1 : NF0;
 #pragma unroll
             for (int f4 = 0; f4 < 4; ++f4) {
-                const int row = f4 * 16 + fi;
+                if (f4 < nf) {
+                    const int row = f4 * 16 + fi;
 #pragma unroll
-                for (int fn = 0; fn < 4; ++fn) {
-                    const int c16 = fn * 4 + fg;
-                    *reinterpret_cast<f32x4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16)) = acc[fn][hh * 4 + f4];
+                    for (int fn = 0; fn < 4; ++fn) {
+                        const int c16 = fn * 4 + fg;
+                        *reinterpret_cast<f32x4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16)) = acc[fn][hh * 4 + f4 < FM ? hh * 4 + f4 : 0];
+                    }
                 }
             }
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < nf * 4; ++j) {
                 const int row = j * 4 + rr;
                 f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 256 + ((rc ^ (row & 15)) * 16));
                 const int m = mrow0 + hh * 64 + row;
@@ -630,7 +477,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
             }
         }
 #pragma unroll
-        for (int fm = 0; fm < 8; ++fm) {
+        for (int fm = 0; fm < FM; ++fm) {
             const int row = fm * 16 + fi;
 #pragma unroll
             for (int fn = 0; fn < 4; ++fn) {
@@ -642,8 +489,8 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         }
         const int rr = lane >> 3, rc = lane & 7;       // read-back: 8 rows x 8 chunks of 8 bf16
         const int ncol = ncol0 + rc * 8;
-#pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
+#pragma unroll 2
+        for (int j = 0; j < 2 * FM; ++j) {
             const int row = j * 8 + rr;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row * 128 + ((rc ^ (row & 7)) * 16));
             const int m = mrow0 + row;
@@ -798,24 +645,37 @@ extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
         (resid && !aligned16(resid)) || (aux && !aligned8(aux)))
         VITK_FAIL(VITK_E_ALIGN, "gemm_nt_bf16: lda/ldw %% 8, ldc %% 4 and 16-byte aligned pointers required");
     const bool large = (K % L_BK == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux)) && !getenv("VITK_NO_256");
-    const int tbm = large ? L_BM : BM, tbn = large ? L_BN : BN;
+    // Tile height: 256 rows (8 m-fragments per wave) or 224 (7).  One workgroup per CU, so the grid is
+    // quantised in rounds of 256 tiles: pick the height whose (rounds x height) is smaller -- e.g. M = 50,432,
+    // N = 768: 591 tiles of 256 rows need 3 rounds for 2.31 rounds of work, 678 tiles of 224 rows need 3
+    // rounds of 7/8-size tiles (-12.5 %).
+    int fm = 8;
+    if (large) {
+        const long long tn_ = (N + L_BN - 1) / L_BN;
+        const long long t8 = ((M + 255) / 256) * tn_, t7 = ((M + 223) / 224) * tn_;
+        const long long cost8 = ((t8 + 255) / 256) * 8, cost7 = ((t7 + 255) / 256) * 7;
+        if (cost7 * 10 <= cost8 * 9) fm = 7;   // only when it buys >= 10 %: the shorter tile re-uses each W fragment 7x instead of 8x
+        if (getenv("VITK_NT_FM")) fm = atoi(getenv("VITK_NT_FM")) == 7 ? 7 : 8;
+    }
+    const int tbm = large ? 32 * fm : BM, tbn = large ? L_BN : BN;
     const int tiles_m = (int)((M + tbm - 1) / tbm), tiles_n = (int)((N + tbn - 1) / tbn);
     const long long nwg = (long long)tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    const bool pp = large && !(getenv("VITK_NT_PP") && getenv("VITK_NT_PP")[0] == '0');
-#define NT_LAUNCH(E) do { \
-    if (pp) { \
-        static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E>, P_LDS_BYTES); \
+    int group_n = tiles_n;                                  // n-tiles per group of the grouped tile order
+    if (large && tiles_n > 8) group_n = (tiles_n + (tiles_n + 5) / 6 - 1) / ((tiles_n + 5) / 6);
+    if (getenv("VITK_GROUP_N")) group_n = atoi(getenv("VITK_GROUP_N")) > 0 ? atoi(getenv("VITK_GROUP_N")) : tiles_n;
+    if (group_n > tiles_n) group_n = tiles_n;
+#define NT_LAUNCH_PP(E, F) do { \
+        static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E, F>, P_LDS_BYTES); \
         if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", P_LDS_BYTES); \
-        hipLaunchKernelGGL((gemm_nt256pp_kernel<E>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, (const __bf16*)A, (long long)lda, \
-            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg); \
-    } else if (large) { \
-        static const int rc__ = set_max_lds(gemm_nt256_kernel<E>, L_LDS_BYTES); \
-        if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", L_LDS_BYTES); \
-        hipLaunchKernelGGL((gemm_nt256_kernel<E>), dim3((unsigned)nwg), dim3(512), L_LDS_BYTES, st, (const __bf16*)A, (long long)lda, \
-            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg); \
-    } else { \
+        hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, (const __bf16*)A, (long long)lda, \
+            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n); \
+    } while (0)
+#define NT_LAUNCH(E) do { \
+    if (large && fm == 7) NT_LAUNCH_PP(E, 7); \
+    else if (large) NT_LAUNCH_PP(E, 8); \
+    else { \
         hipLaunchKernelGGL((gemm_nt_kernel<E>), dim3((unsigned)nwg), dim3(256), 0, st, (const __bf16*)A, (long long)lda, \
             (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg); \
     } } while (0)
@@ -836,6 +696,7 @@ extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
         default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: bad epilogue %d", epilogue);
     }
 #undef NT_LAUNCH
+#undef NT_LAUNCH_PP
     VITK_CHECK_LAUNCH("gemm_nt_bf16");
     return 0;
 }
