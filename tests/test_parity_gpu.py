@@ -189,3 +189,53 @@ def test_cpu_input_fails_loudly():
     m = ViT(**CASES["vit_cls_tiny"]["cfg"])
     with pytest.raises(RuntimeError, match="HIP"):
         m(torch.randn(1, 3, 32, 32))
+
+
+def test_batch_of_one_and_odd_batch():
+    """Edge extents: a single image, and a batch that leaves ragged tails in every tile (M = 3 * 197)."""
+    cfg = dict(VITB_SMALL, depth=1)
+    params = make_params("vit", cfg, 11)
+    for b in (1, 3):
+        img = make_images(cfg, b, 2000 + b)
+        ref_out, ref_g = O.run_fwd_bwd("vit", cfg, params, img, torch.float32)
+        out, grads = run_mine("vit", cfg, params, img, torch.float32)
+        assert rel(out, ref_out) <= 1e-3
+        assert max(rel(grads[k], ref_g[k]) for k in params) <= 1e-3
+
+
+def test_vit_l16_width_bf16_runs_fast_path():
+    """BASELINE config 3's layer shapes (D=1024, h=16, F=4096) at depth 2 / batch 8, bf16, vs the f32 oracle."""
+    cfg = dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=2, heads=16, mlp_dim=4096)
+    params = make_params("vit", cfg, 13)
+    img = make_images(cfg, 8, 1013)
+    ref_out, ref_g = O.run_fwd_bwd("vit", cfg, params, img, torch.float32)
+    bf_out, bf_g = O.run_fwd_bwd("vit", cfg, params, img, torch.bfloat16)
+    out, grads = run_mine("vit", cfg, params, img, torch.bfloat16)
+    keys = list(params)
+    cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
+    e, e_ref = rel(out, ref_out), rel(bf_out, ref_out)
+    g, g_ref = rel(cat(grads), cat(ref_g)), rel(cat(bf_g), cat(ref_g))
+    print(f"vit-L width bf16: logits {e:.2e} (reference-bf16 {e_ref:.2e}); grads {g:.2e} (reference-bf16 {g_ref:.2e})")
+    assert e <= 1.5 * e_ref + 1e-3 and g <= 1.5 * g_ref + 1e-3
+
+
+def test_dropout_training_path_statistics():
+    """dropout > 0 in train mode takes the op-by-op path; eval mode must equal the fused path exactly."""
+    case = CASES["vit_cls_tiny"]
+    cfg = dict(case["cfg"], dropout=0.2, emb_dropout=0.1)
+    params = make_params("vit", case["cfg"], case["seed"])
+    img = make_images(cfg, case["batch"], 77).to(DEV)
+    m = ViT(**cfg)
+    m.load_state_dict(params)
+    m = m.to(DEV)
+    m.eval()
+    out_eval = m(img)
+    out_ref, _ = run_mine("vit", case["cfg"], params, img.cpu(), torch.float32)
+    assert rel(out_eval, out_ref) < 1e-5
+    m.train()
+    torch.manual_seed(5)
+    o1 = m(img); o2 = m(img)
+    assert not torch.equal(o1, o2)                      # fresh masks every call
+    assert rel(o1, out_eval) > 1e-3                     # dropout is active
+    o1.float().square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.numel())
