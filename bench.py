@@ -83,6 +83,18 @@ def time_dominant_kernel(M: int, D: int, F: int, iters: int = 30):
     return ms, flops
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the timed kernel, from the committed PMC collection (profiles/r01_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note
+    of MI355X_MICROARCH.md).  Counters cannot be collected from inside this process; null if the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            ks = json.load(f)["kernels"]
+        return next(v["traffic_bytes"] for k, v in ks.items() if "EPI_BIAS_GELU" in k)
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, budget_s: float = 20.0):
     """The oracle (a port of the reference algorithm) on the host cores, bounded to ~budget_s."""
     from oracle import vit_oracle as O
@@ -196,7 +208,8 @@ def main():
                       "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_BIAS_GELU> (FF1 50432x3072x768 at batch 256)",
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(kms, 4), "traffic": None},
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(kms, 4),
+                         "traffic": pmc_traffic_bytes()},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
