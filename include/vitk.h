@@ -143,6 +143,32 @@ int vitk_attn_bwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_
                        vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv,
                        int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream);
 
+/* Variable-length (packed) attention -- the NaViT path (na_vit.py:115-169: F.scaled_dot_product_attention with a dense
+ * boolean "same image & key not padding" mask, :335-337; and the attention pool :371-387).  Tokens of all images are
+ * packed without padding into (T, H*d) matrices addressed as p + n*s_n + h*s_h + d; attention runs per segment
+ * (= image): query rows [cu_q[s], cu_q[s+1]) against key rows [cu_k[s], cu_k[s+1]).  No mask is materialised.
+ * blk_seg/blk_r0 (int32, device): for every 128-row block of the launch, its segment and its first row inside the
+ * segment (query blocks for fwd and dQ, key blocks for dK/dV).  lse, delta: f32 (H, tq_total).  bf16, d == 64. */
+typedef struct vitk_hnd { void* p; int64_t s_h, s_n; } vitk_hnd;
+int vitk_attn_varlen_fwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse,
+                              const int32_t* cu_q, const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0,
+                              int64_t nblk, int64_t tq_total, int64_t H, int64_t d, float scale, void* stream);
+int vitk_attn_varlen_bwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, vitk_hnd dout, const float* lse, float* delta,
+                              vitk_hnd dq, vitk_hnd dk, vitk_hnd dv, const int32_t* cu_q, const int32_t* cu_k,
+                              const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
+                              const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk,
+                              int64_t tq_total, int64_t H, int64_t d, float scale, void* stream);
+
+/* NaViT q/k normalisation (RMSNorm, na_vit.py:93-101): y = x / max(||x||, 1e-12) * sqrt(d) * gamma[h, :] for every
+ * (token, head); x, y viewed (T, H, 64) with token strides ldx / ldy.  rnorm: f32 (T*H) saved for backward.
+ * Backward also needs `partials`: f32 workspace of vitk_rmsnorm_heads_rows(T, H) * 64 floats.                  */
+int64_t vitk_rmsnorm_heads_rows(int64_t T, int64_t H);
+int vitk_rmsnorm_heads_fwd(const void* x, int64_t ldx, const void* gamma, void* y, int64_t ldy, float* rnorm, int dt,
+                           int64_t T, int64_t H, int64_t d, void* stream);
+int vitk_rmsnorm_heads_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma, const float* rnorm,
+                           void* dx, int64_t lddx, void* dgamma, float* partials, int dt,
+                           int64_t T, int64_t H, int64_t d, void* stream);
+
 /* Materialising path pieces (nn.Softmax at vit.py:41,59; needed when `attend` has forward hooks,
  * for dim_head != 64 and for f32 validation mode): row softmax of scale*s and its backward.  */
 int vitk_softmax_fwd(const void* s, void* p, int dt, int64_t rows, int64_t cols, float scale, void* stream);
@@ -156,6 +182,17 @@ int vitk_softmax_bwd(const void* p, const void* dp, void* ds, int dt, int64_t ro
 /* Rearrange 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit.py:100): out[(b*h*w), p1*p2*c]        */
 int vitk_patchify(const void* img, void* out, int dt, int64_t B, int64_t C, int64_t H, int64_t W,
                   int64_t p1, int64_t p2, void* stream);
+/* NaViT patch extraction of ONE image, 'c (h p1) (w p2) -> (h w) (c p1 p2)' (na_vit.py:300): out rows
+ * [row0, row0 + h*w) of a (T, C*p*p) matrix (leading dimension ld).                                           */
+int vitk_patchify_cpp(const void* img, void* out, int dt, int64_t C, int64_t H, int64_t W, int64_t p,
+                      int64_t row0, int64_t ld, void* stream);
+/* out[t, :] = x[t, :] + A[ia[t], :] + B[ib[t], :]   (factorised 2-d positional embedding, na_vit.py:354-359)     */
+int vitk_gather_add2(const void* x, const void* A, const int32_t* ia, const void* B, const int32_t* ib, void* out, int dt,
+                     int64_t T, int64_t D, void* stream);
+/* out[i, :] = sum_{j in [ptr[i], ptr[i+1])} g[rows[j], :]  -- deterministic segmented row sum in CSR form (gradient of
+ * the embedding gathers above; also a row gather when every segment has one entry).  g: gdt, out: odt.          */
+int vitk_csr_rowsum(const void* g, int gdt, const int32_t* ptr, const int32_t* rows, void* out, int odt,
+                    int64_t nseg, int64_t D, void* stream);
 /* y = gelu_erf(x) (vit.py:21) ; dx = dy * gelu'(x) */
 int vitk_gelu_fwd(const void* x, void* y, int dt, int64_t n, void* stream);
 int vitk_gelu_bwd(const void* dy, const void* x, void* dx, int dt, int64_t n, void* stream);

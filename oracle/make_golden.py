@@ -31,7 +31,7 @@ sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from oracle.params import CASES, make_images, make_params  # noqa: E402
+from oracle.params import CASES, NAVIT_CASES, make_images, make_navit_images, make_navit_params, make_params  # noqa: E402
 from oracle.vit_oracle import loss_fn  # noqa: E402
 
 REF = "/root/reference/vit_pytorch"
@@ -76,5 +76,26 @@ def main():
               f"{len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def main_navit():
+    outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    mod = load_ref("na_vit")
+    for name, case in NAVIT_CASES.items():
+        params = make_navit_params(case["cfg"], case["seed"])
+        images = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
+        model = mod.NaViT(**case["cfg"])
+        model.load_state_dict(params, strict=True)
+        model.eval()  # no token dropout / dropout in the parity case
+        out = model(images)
+        loss = loss_fn(out)
+        loss.backward()
+        blob = {"logits": out.detach().numpy(), "loss": loss.detach().numpy()}
+        for k, p in model.named_parameters():
+            blob["grad::" + k] = p.grad.numpy()
+        path = os.path.join(outdir, name + ".npz")
+        np.savez(path, **blob)
+        print(f"{name}: logits {tuple(out.shape)} loss {float(loss):.6f} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 if __name__ == "__main__":
     main()
+    main_navit()

@@ -125,3 +125,76 @@ CASES = {
         cfg=dict(image_size=32, patch_size=8, num_classes=0, dim=32, depth=1, heads=2, dim_head=16,
                  mlp_dim=48, pool="cls")),
 }
+
+
+# ---- NaViT (BASELINE config 4) --------------------------------------------------------------------------------
+def navit_param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict key -> shape of na_vit.NaViT in registration order (buffers `beta` included)."""
+    ih, iw = _pair(cfg["image_size"])
+    ps = cfg["patch_size"]
+    ch = cfg.get("channels", 3)
+    D, depth, heads, F, C = cfg["dim"], cfg["depth"], cfg["heads"], cfg["mlp_dim"], cfg["num_classes"]
+    dh = cfg.get("dim_head", 64)
+    I = heads * dh
+    P = ch * ps * ps
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["pos_embed_height"] = (ih // ps, D)
+    s["pos_embed_width"] = (iw // ps, D)
+    s["attn_pool_queries"] = (D,)
+    s["to_patch_embedding.0.gamma"] = (P,); s["to_patch_embedding.0.beta"] = (P,)
+    s["to_patch_embedding.1.weight"] = (D, P); s["to_patch_embedding.1.bias"] = (D,)
+    s["to_patch_embedding.2.gamma"] = (D,); s["to_patch_embedding.2.beta"] = (D,)
+
+    def attn(prefix):
+        s[prefix + "norm.gamma"] = (D,); s[prefix + "norm.beta"] = (D,)
+        s[prefix + "q_norm.gamma"] = (heads, 1, dh)
+        s[prefix + "k_norm.gamma"] = (heads, 1, dh)
+        s[prefix + "to_q.weight"] = (I, D)
+        s[prefix + "to_kv.weight"] = (2 * I, D)
+        s[prefix + "to_out.0.weight"] = (D, I)
+
+    for i in range(depth):
+        attn(f"transformer.layers.{i}.0.")
+        f = f"transformer.layers.{i}.1."
+        s[f + "0.gamma"] = (D,); s[f + "0.beta"] = (D,)
+        s[f + "1.weight"] = (F, D); s[f + "1.bias"] = (F,)
+        s[f + "4.weight"] = (D, F); s[f + "4.bias"] = (D,)
+    s["transformer.norm.gamma"] = (D,); s["transformer.norm.beta"] = (D,)
+    attn("attn_pool.")
+    s["mlp_head.0.gamma"] = (D,); s["mlp_head.0.beta"] = (D,)
+    s["mlp_head.1.weight"] = (C, D)
+    return s
+
+
+def make_navit_params(cfg: dict, seed: int) -> Dict[str, torch.Tensor]:
+    rng = np.random.default_rng(seed)
+    out: Dict[str, torch.Tensor] = OrderedDict()
+    for name, shape in navit_param_shapes(cfg).items():
+        n = int(np.prod(shape))
+        if name.endswith(".beta"):
+            a = np.zeros(n)                                   # registered buffer, always zero (na_vit.py:86)
+        elif name.startswith("pos_embed") or name == "attn_pool_queries":
+            a = rng.standard_normal(n)
+        elif name.endswith("gamma"):
+            a = 1.0 + 0.1 * rng.standard_normal(n)
+        elif len(shape) == 2:
+            bound = 1.0 / np.sqrt(shape[1])
+            a = rng.uniform(-bound, bound, n)
+        else:
+            a = rng.uniform(-0.05, 0.05, n)
+        out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape)).clone()
+    return out
+
+
+def make_navit_images(cfg: dict, sizes, seed: int):
+    """sizes: list (packs) of lists of (H, W).  Returns nested lists of (C, H, W) float32 images."""
+    rng = np.random.default_rng(seed)
+    ch = cfg.get("channels", 3)
+    return [[torch.from_numpy(rng.standard_normal((ch, h, w)).astype(np.float32)) for (h, w) in pack] for pack in sizes]
+
+
+NAVIT_CASES = {
+    "navit_two_packs": dict(
+        seed=5, sizes=[[(32, 48), (16, 16), (64, 24)], [(40, 40), (8, 56)]],
+        cfg=dict(image_size=64, patch_size=8, num_classes=7, dim=64, depth=2, heads=2, mlp_dim=96)),
+}

@@ -1,0 +1,151 @@
+"""GPU: NaViT path (BASELINE config 4): variable-length attention kernels against a per-image
+PyTorch reference, and the drop-in NaViT module against the reference's golden outputs and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import navit_oracle as NO  # noqa: E402
+from oracle.params import NAVIT_CASES, make_navit_images, make_navit_params  # noqa: E402
+from vit_pytorch_amd import kernels as K  # noqa: E402
+from vit_pytorch_amd.na_vit import NaViT, Segments  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
+    n = b.norm().item()
+    return (a - b).norm().item() / (n if n > 0 else 1.0)
+
+
+@pytest.mark.parametrize("lens", [[197], [16, 300, 1, 129, 64], [1600, 7], [128, 128, 256]])
+@pytest.mark.parametrize("H", [1, 3])
+def test_varlen_attention_fwd_bwd(lens, H):
+    d, I = 64, H * 64
+    T = sum(lens)
+    g = torch.Generator().manual_seed(len(lens) * 7 + H)
+    q = (torch.randn(T, I, generator=g)).to(BF).to(DEV)
+    kv = (torch.randn(T, 2 * I, generator=g)).to(BF).to(DEV)
+    do = torch.randn(T, I, generator=g).to(BF).to(DEV)
+    segs = Segments(lens, lens, torch.device(DEV))
+    o = torch.empty(T, I, dtype=BF, device=DEV); lse = torch.empty(H, T, device=DEV)
+    scale = 0.2
+    K.attn_varlen_fwd_bf16(K.hnd(q, d, I), K.hnd(kv, d, 2 * I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), lse, segs.cu_q,
+                           segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, T, H, d, scale)
+    dq = torch.zeros_like(q); dkv = torch.zeros_like(kv); delta = torch.empty(H, T, device=DEV)
+    K.attn_varlen_bwd_bf16(K.hnd(q, d, I), K.hnd(kv, d, 2 * I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), K.hnd(do, d, I), lse, delta,
+                           K.hnd(dq, d, I), K.hnd(dkv, d, 2 * I), K.hnd(dkv, d, 2 * I, offset=I), segs.cu_q, segs.cu_k, segs.qblk_seg,
+                           segs.qblk_r0, segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, T, H, d, scale)
+    # reference: independent attention per image
+    qd = q.double().requires_grad_(True); kvd = kv.double().requires_grad_(True)
+    outs, start = [], 0
+    for n in lens:
+        qs = qd[start:start + n].view(n, H, d).transpose(0, 1)
+        ks = kvd[start:start + n, :I].view(n, H, d).transpose(0, 1)
+        vs = kvd[start:start + n, I:].view(n, H, d).transpose(0, 1)
+        p = torch.softmax(qs @ ks.transpose(-1, -2) * scale, -1)
+        outs.append((p @ vs).transpose(0, 1).reshape(n, I))
+        start += n
+    oref = torch.cat(outs)
+    oref.backward(do.double())
+    assert rel(o, oref) < 6e-3
+    assert rel(dq, qd.grad) < 1.2e-2
+    assert rel(dkv, kvd.grad) < 1.2e-2
+
+
+def test_attention_pool_geometry_one_query_per_image():
+    H, d = 2, 64
+    I = H * d
+    lens = [24, 4, 300]
+    T = sum(lens); S = len(lens)
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(S, I, generator=g).to(BF).to(DEV); kv = torch.randn(T, 2 * I, generator=g).to(BF).to(DEV)
+    segs = Segments([1] * S, lens, torch.device(DEV))
+    o = torch.empty(S, I, dtype=BF, device=DEV); lse = torch.empty(H, S, device=DEV)
+    K.attn_varlen_fwd_bf16(K.hnd(q, d, I), K.hnd(kv, d, 2 * I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), lse, segs.cu_q,
+                           segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, S, H, d, 1.0)
+    start = 0
+    for s, n in enumerate(lens):
+        qs = q[s].double().view(H, 1, d); ks = kv[start:start + n, :I].double().view(n, H, d).transpose(0, 1)
+        vs = kv[start:start + n, I:].double().view(n, H, d).transpose(0, 1)
+        ref = (torch.softmax(qs @ ks.transpose(-1, -2), -1) @ vs).reshape(I)
+        assert rel(o[s], ref) < 6e-3
+        start += n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_rmsnorm_heads(dtype):
+    T, H, d = 37, 3, 64
+    x = torch.randn(T, 2 * H * d).to(dtype).to(DEV)       # read the first half of a wider matrix (like to_kv's output)
+    gamma = (1 + 0.2 * torch.randn(H, d)).to(dtype).to(DEV)
+    y = torch.empty(T, H * d, dtype=dtype, device=DEV); rn = torch.empty(T * H, device=DEV)
+    K.rmsnorm_heads_fwd(x, 2 * H * d, gamma, y, H * d, rn, T, H, d)
+    xd = x[:, :H * d].double().view(T, H, d).requires_grad_(True); gd = gamma.double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xd, dim=-1) * 8.0 * gd
+    tol = 3e-6 if dtype == torch.float32 else 5e-3
+    assert rel(y, ref.reshape(T, H * d)) < tol
+    dy = torch.randn(T, H * d).to(dtype).to(DEV)
+    ref.backward(dy.double().view(T, H, d))
+    dx = torch.zeros(T, 2 * H * d, dtype=dtype, device=DEV); dg = torch.empty(H, d, dtype=dtype, device=DEV)
+    part = torch.empty(K.rmsnorm_heads_rows(T, H) * 64, device=DEV)
+    K.rmsnorm_heads_bwd(dy, H * d, x, 2 * H * d, gamma, rn, dx, 2 * H * d, dg, part, T, H, d)
+    assert rel(dx[:, :H * d], xd.grad.reshape(T, H * d)) < tol * 2
+    assert rel(dg, gd.grad) < tol * 2
+    assert dx[:, H * d:].abs().max().item() == 0
+
+
+def _run_navit(case, dtype):
+    params = make_navit_params(case["cfg"], case["seed"])
+    imgs = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
+    m = NaViT(**case["cfg"])
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV, dtype=dtype).eval()
+    out = m([[im.to(DEV, dtype=dtype) for im in g] for g in imgs])
+    NO.O.loss_fn(out).backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    return out, grads, params, imgs
+
+
+@pytest.mark.parametrize("name", list(NAVIT_CASES))
+def test_navit_f32_matches_reference_golden(name):
+    case = NAVIT_CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    out, grads, _, _ = _run_navit(case, torch.float32)
+    assert tuple(out.shape) == gold["logits"].shape
+    assert rel(out, torch.from_numpy(gold["logits"])) <= 1e-3
+    for k, g in grads.items():
+        assert rel(g, torch.from_numpy(gold["grad::" + k])) <= 1e-3, k
+
+
+@pytest.mark.parametrize("name", list(NAVIT_CASES))
+def test_navit_bf16_vs_oracle(name):
+    case = NAVIT_CASES[name]
+    out, grads, params, imgs = _run_navit(case, BF)
+    ref_out, ref_g = NO.run_fwd_bwd(case["cfg"], params, imgs, torch.float32)
+    bf_out, bf_g = NO.run_fwd_bwd(case["cfg"], params, imgs, BF)
+    keys = list(ref_g)
+    cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
+    e, e_ref = rel(out, ref_out), rel(bf_out, ref_out)
+    g, g_ref = rel(cat(grads), cat(ref_g)), rel(cat(bf_g), cat(ref_g))
+    print(f"{name} bf16: logits {e:.2e} (reference-bf16 {e_ref:.2e}); grads {g:.2e} (reference-bf16 {g_ref:.2e})")
+    assert e <= 1.5 * e_ref + 1e-3 and g <= 1.5 * g_ref + 1e-3
+
+
+def test_navit_grouping_and_token_dropout_run():
+    cfg = dict(NAVIT_CASES["navit_two_packs"]["cfg"], token_dropout_prob=0.25)
+    m = NaViT(**cfg).to(DEV, dtype=BF)
+    imgs = [torch.randn(3, h, w, device=DEV).to(BF) for (h, w) in [(32, 32), (64, 16), (8, 8), (48, 64), (24, 40)]]
+    m.train()
+    out = m(imgs, group_images=True, group_max_seq_len=48)
+    assert out.shape == (5, cfg["num_classes"]) and torch.isfinite(out.float()).all()
+    out.float().square().mean().backward()
+    assert all(torch.isfinite(p.grad.float()).all() for p in m.parameters())
+    m.eval()
+    a = m(imgs); b = m([imgs[:2], imgs[2:]])            # packing must not change the result
+    assert torch.equal(a, b)

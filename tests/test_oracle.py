@@ -101,3 +101,22 @@ def test_attention_core_bwd_formula():
     g, (dq, dk, dv) = _autograd(lambda q, k, v: O.attention_core_fwd(q, k, v, scale)[0], q, k, v)
     dq2, dk2, dv2 = O.attention_core_bwd(g, q, k, v, scale)
     assert rel_l2(dq2, dq) < 1e-12 and rel_l2(dk2, dk) < 1e-12 and rel_l2(dv2, dv) < 1e-12
+
+
+# ---- NaViT (config 4) ----------------------------------------------------------------------------------------
+from oracle import navit_oracle as NO  # noqa: E402
+from oracle.params import NAVIT_CASES, make_navit_images, make_navit_params  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(NAVIT_CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_navit_oracle_matches_reference_golden(name, dtype):
+    case = NAVIT_CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    params = make_navit_params(case["cfg"], case["seed"])
+    imgs = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
+    out, grads = NO.run_fwd_bwd(case["cfg"], params, imgs, dtype)
+    assert out.shape == gold["logits"].shape
+    assert rel_l2(out, torch.from_numpy(gold["logits"])) <= 2e-6
+    for k, g in grads.items():
+        assert rel_l2(g, torch.from_numpy(gold["grad::" + k])) <= 2e-5, k

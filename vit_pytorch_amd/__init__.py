@@ -14,4 +14,7 @@ def __getattr__(name):
     if name == "SimpleViT":
         from .simple_vit import SimpleViT
         return SimpleViT
+    if name == "NaViT":   # reference: `from vit_pytorch.na_vit import NaViT` (README.md:154)
+        from .na_vit import NaViT
+        return NaViT
     raise AttributeError(name)

@@ -25,6 +25,10 @@ class Mat(C.Structure):
                 ("s_row", C.c_int64), ("s_col", C.c_int64)]
 
 
+class HND(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("s_h", C.c_int64), ("s_n", C.c_int64)]
+
+
 class BHND(C.Structure):
     _fields_ = [("p", C.c_void_p), ("s_b", C.c_int64), ("s_h", C.c_int64), ("s_n", C.c_int64)]
 
@@ -51,9 +55,17 @@ SIGNATURES = {
     "vitk_gemm_generic": (_i, [Mat, Mat, Mat, _vp, _i, _i64, _i64, _i64, _i64, _i64, _f, _f, _vp]),
     "vitk_attn_fwd_bf16": (_i, [BHND, BHND, BHND, BHND, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_attn_bwd_bf16": (_i, [BHND, BHND, BHND, BHND, BHND, _vp, _vp, BHND, BHND, BHND, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_attn_varlen_fwd_bf16": (_i, [HND, HND, HND, HND, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_attn_varlen_bwd_bf16": (_i, [HND, HND, HND, HND, HND, _vp, _vp, HND, HND, HND, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_rmsnorm_heads_rows": (_i64, [_i64, _i64]),
+    "vitk_rmsnorm_heads_fwd": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i64, _i64, _i64, _vp]),
+    "vitk_rmsnorm_heads_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i64, _i64, _i64, _vp]),
     "vitk_softmax_fwd": (_i, [_vp, _vp, _i, _i64, _i64, _f, _vp]),
     "vitk_softmax_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _f, _vp]),
     "vitk_patchify": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "vitk_patchify_cpp": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "vitk_gather_add2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
+    "vitk_csr_rowsum": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "vitk_gelu_fwd": (_i, [_vp, _vp, _i, _i64, _vp]),
     "vitk_gelu_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "vitk_add_rows": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i64, _vp]),

@@ -267,6 +267,301 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
     }
 }
 
+// ==========================================================================================
+// Variable-length (packed) attention: the NaViT path (na_vit.py:115-169, 255-402).
+// The reference pads every pack to (b, n) and feeds F.scaled_dot_product_attention a dense boolean
+// (b, 1, n, n) mask "same image AND key not padding" (na_vit.py:335-337).  Here tokens of all images of
+// all packs live UNPADDED in one (T, H*d) matrix and attention is computed per SEGMENT (= image): query
+// rows [cu_q[s], cu_q[s+1]) against key rows [cu_k[s], cu_k[s+1]).  No mask is ever built or read: the
+// block-diagonal structure is the launch geometry.  The attention-pool step (one learned query per image
+// against that image's tokens, na_vit.py:371-387) is the same kernel with cu_q = 0,1,2,...
+// One workgroup = (segment, 128-query block, head); K/V are streamed through LDS in 128-key chunks with the
+// same online-softmax inner step as the fixed-length kernels.
+// ==========================================================================================
+constexpr int VL_QB = 16 * AT_WAVES;   // 128 queries (or keys, in the dK/dV kernel) per workgroup
+constexpr int VL_CH = 128;             // rows per LDS chunk
+
+struct HND { __bf16* p; long long s_h, s_n; };   // element (n, h, d) at p + n*s_n + h*s_h + d
+
+__device__ __forceinline__ void fill_chunk(char* tile, const __bf16* src, long long s_n, int rows, int rows_pad, int tid) {
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = tid; c < rows_pad * 8; c += AT_THREADS) {
+        const int row = c >> 3, col8 = c & 7;
+        const bf16x8 v = row < rows ? *reinterpret_cast<const bf16x8*>(src + (long long)row * s_n + col8 * 8) : zero8;
+        *reinterpret_cast<bf16x8*>(tile + row * AT_LD + col8 * 16) = v;
+    }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
+    HND q, HND k, HND v, HND o, float* __restrict__ lse, const int* __restrict__ cu_q, const int* __restrict__ cu_k,
+    const int* __restrict__ blk_seg, const int* __restrict__ blk_r0, int tq_total, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * AT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    char* Ks = smem;
+    char* Vs = smem + VL_CH * AT_LD;
+    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
+    const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
+    const int ks = cu_k[seg], nk = cu_k[seg + 1] - ks;
+    const int qi = blk_r0[blockIdx.x] + wave * 16 + fi;        // row inside the segment
+    const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nq;
+    const int qrow = qs + (qi < nq ? qi : nq - 1);
+    const __bf16* qp = q.p + (long long)qrow * q.s_n + h * q.s_h;
+    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * fg);
+    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * fg);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lsum = 0.f;
+    f32x4 acc[4] = {z4, z4, z4, z4};
+    for (int c0 = 0; c0 < nk; c0 += VL_CH) {
+        const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
+        const int rows_pad = ((rows + 31) >> 5) << 5;
+        __syncthreads();
+        fill_chunk(Ks, k.p + (long long)(ks + c0) * k.s_n + h * k.s_h, k.s_n, rows, rows_pad, tid);
+        fill_chunk(Vs, v.p + (long long)(ks + c0) * v.s_n + h * v.s_h, v.s_n, rows, rows_pad, tid);
+        __syncthreads();
+        if (!wave_active) continue;
+        for (int s = 0; s < (rows_pad >> 5); ++s) {
+            f32x4 st[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int row0 = s * 32 + hh * 16;
+                st[hh] = MFMA(row_frag(Ks, row0, 0, fi, fg), qf0, z4);
+                st[hh] = MFMA(row_frag(Ks, row0, 1, fi, fg), qf1, st[hh]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = row0 + 4 * fg + r;
+                    st[hh][r] = key < rows ? st[hh][r] * scale_log2e : -INFINITY;
+                    mx = fmaxf(mx, st[hh][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[hh][r] = __builtin_amdgcn_exp2f(st[hh][r] - m_new); ps += st[hh][r]; }
+            lsum = lsum * alpha + ps;
+            m = m_new;
+            const bf16x8 pb = pack8(st[0], st[1]);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                acc[fd] *= alpha;
+                acc[fd] = MFMA(tr_frag(Vs, s * 32, fd * 16, fi, fg), pb, acc[fd]);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (wave_active && qi < nq) {
+        const float inv = 1.0f / lsum;
+        __bf16* op = o.p + (long long)(qs + qi) * o.s_n + h * o.s_h + 4 * fg;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) store4<__bf16>(op + fd * 16, acc[fd] * inv);
+        if (fg == 0) lse[(long long)h * tq_total + qs + qi] = (m + log2f(lsum)) * LN2;
+    }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
+    HND q, HND k, HND v, HND o, HND dout, const float* __restrict__ lse, float* __restrict__ delta, HND dq,
+    const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
+    const int* __restrict__ blk_r0, int tq_total, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * AT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    char* Ks = smem;
+    char* Vs = smem + VL_CH * AT_LD;
+    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
+    const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
+    const int ks = cu_k[seg], nk = cu_k[seg + 1] - ks;
+    const int qi = blk_r0[blockIdx.x] + wave * 16 + fi;
+    const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nq;
+    const int qrow = qs + (qi < nq ? qi : nq - 1);
+    const __bf16* qp = q.p + (long long)qrow * q.s_n + h * q.s_h;
+    const __bf16* dop = dout.p + (long long)qrow * dout.s_n + h * dout.s_h;
+    const __bf16* op = o.p + (long long)qrow * o.s_n + h * o.s_h;
+    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * fg);
+    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * fg);
+    const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * fg);
+    const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * fg);
+    const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(op + 8 * fg);
+    const bf16x8 of1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * fg);
+    float dl = dot8(df0, of0) + dot8(df1, of1);
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (wave_active && qi < nq && fg == 0) delta[(long long)h * tq_total + qs + qi] = dl;
+    const float l2 = lse[(long long)h * tq_total + qrow] * LOG2E;
+    const float scale_log2e = scale * LOG2E;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4] = {z4, z4, z4, z4};
+    for (int c0 = 0; c0 < nk; c0 += VL_CH) {
+        const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
+        const int rows_pad = ((rows + 31) >> 5) << 5;
+        __syncthreads();
+        fill_chunk(Ks, k.p + (long long)(ks + c0) * k.s_n + h * k.s_h, k.s_n, rows, rows_pad, tid);
+        fill_chunk(Vs, v.p + (long long)(ks + c0) * v.s_n + h * v.s_h, v.s_n, rows, rows_pad, tid);
+        __syncthreads();
+        if (!wave_active) continue;
+        for (int s = 0; s < (rows_pad >> 5); ++s) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int row0 = s * 32 + hh * 16;
+                f32x4 st = MFMA(row_frag(Ks, row0, 0, fi, fg), qf0, z4);
+                st = MFMA(row_frag(Ks, row0, 1, fi, fg), qf1, st);
+                f32x4 dp = MFMA(row_frag(Vs, row0, 0, fi, fg), df0, z4);
+                dp = MFMA(row_frag(Vs, row0, 1, fi, fg), df1, dp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = row0 + 4 * fg + r;
+                    const float p = key < rows ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - l2) : 0.f;
+                    ds[hh][r] = p * (dp[r] - dl) * scale;
+                }
+            }
+            const bf16x8 dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) acc[fd] = MFMA(tr_frag(Ks, s * 32, fd * 16, fi, fg), dsb, acc[fd]);
+        }
+    }
+    if (wave_active && qi < nq) {
+        __bf16* dqp = dq.p + (long long)(qs + qi) * dq.s_n + h * dq.s_h + 4 * fg;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) store4<__bf16>(dqp + fd * 16, acc[fd]);
+    }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
+    HND q, HND k, HND v, HND dout, const float* __restrict__ lse, const float* __restrict__ delta, HND dk, HND dv,
+    const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
+    const int* __restrict__ blk_r0, int tq_total, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * AT_LD + 2 * VL_CH * sizeof(float)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    char* Qs = smem;
+    char* Ds = smem + VL_CH * AT_LD;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * VL_CH * AT_LD);
+    float* del_s = lse_s + VL_CH;
+    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
+    const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
+    const int ks = cu_k[seg], nk = cu_k[seg + 1] - ks;
+    const int ki = blk_r0[blockIdx.x] + wave * 16 + fi;        // key row inside the segment
+    const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nk;
+    const int krow = ks + (ki < nk ? ki : nk - 1);
+    const __bf16* kp = k.p + (long long)krow * k.s_n + h * k.s_h;
+    const __bf16* vp = v.p + (long long)krow * v.s_n + h * v.s_h;
+    const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp + 8 * fg);
+    const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * fg);
+    const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + 8 * fg);
+    const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * fg);
+    const float scale_log2e = scale * LOG2E;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accK[4] = {z4, z4, z4, z4}, accV[4] = {z4, z4, z4, z4};
+    for (int c0 = 0; c0 < nq; c0 += VL_CH) {
+        const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
+        const int rows_pad = ((rows + 31) >> 5) << 5;
+        __syncthreads();
+        fill_chunk(Qs, q.p + (long long)(qs + c0) * q.s_n + h * q.s_h, q.s_n, rows, rows_pad, tid);
+        fill_chunk(Ds, dout.p + (long long)(qs + c0) * dout.s_n + h * dout.s_h, dout.s_n, rows, rows_pad, tid);
+        for (int r = tid; r < rows_pad; r += AT_THREADS) {
+            lse_s[r] = r < rows ? lse[(long long)h * tq_total + qs + c0 + r] * LOG2E : 0.f;
+            del_s[r] = r < rows ? delta[(long long)h * tq_total + qs + c0 + r] : 0.f;
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+        for (int s = 0; s < (rows_pad >> 5); ++s) {
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int row0 = s * 32 + hh * 16;
+                f32x4 st = MFMA(row_frag(Qs, row0, 0, fi, fg), kf0, z4);
+                st = MFMA(row_frag(Qs, row0, 1, fi, fg), kf1, st);
+                f32x4 dp = MFMA(row_frag(Ds, row0, 0, fi, fg), vf0, z4);
+                dp = MFMA(row_frag(Ds, row0, 1, fi, fg), vf1, dp);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qidx = row0 + 4 * fg + r;
+                    p[hh][r] = qidx < rows ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - l4[r]) : 0.f;
+                    ds[hh][r] = p[hh][r] * (dp[r] - d4[r]) * scale;
+                }
+            }
+            const bf16x8 pb = pack8(p[0], p[1]);
+            const bf16x8 dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                accV[fd] = MFMA(tr_frag(Ds, s * 32, fd * 16, fi, fg), pb, accV[fd]);
+                accK[fd] = MFMA(tr_frag(Qs, s * 32, fd * 16, fi, fg), dsb, accK[fd]);
+            }
+        }
+    }
+    if (wave_active && ki < nk) {
+        __bf16* dkp = dk.p + (long long)(ks + ki) * dk.s_n + h * dk.s_h + 4 * fg;
+        __bf16* dvp = dv.p + (long long)(ks + ki) * dv.s_n + h * dv.s_h + 4 * fg;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd]); store4<__bf16>(dvp + fd * 16, accV[fd]); }
+    }
+}
+
+// q/k normalisation of NaViT (na_vit.py:93-101): y = x / max(||x||_2, 1e-12) * sqrt(d) * gamma[h, :] per (token, head).
+// x viewed (T, H, 64) with token stride ld; 16 lanes per (token, head), 4 elements per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_heads_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma, T* __restrict__ y,
+                                                                 float* __restrict__ rnorm, long long pairs, int H, long long ldx, long long ldy) {
+    const int sub = threadIdx.x & 15;
+    for (long long pr = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); pr < pairs; pr += (long long)gridDim.x * 16) {
+        const long long t = pr / H; const int h = (int)(pr % H);
+        const f32x4 v = load4<T>(x + t * ldx + h * 64 + sub * 4);
+        float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
+        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        const f32x4 g = load4<T>(gamma + h * 64 + sub * 4);
+        store4<T>(y + t * ldy + h * 64 + sub * 4, v * g * (rn * 8.0f));
+        if (sub == 0) rnorm[pr] = rn;
+    }
+}
+// dx = s*rn*(g*dy - xhat * sum(g*dy*xhat)), xhat = x*rn, s = sqrt(d) = 8; dgamma[h,:] += dy * xhat * s (partials per block)
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_heads_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ gamma,
+                                                                 const float* __restrict__ rnorm, T* __restrict__ dx, float* __restrict__ partials,
+                                                                 long long pairs, int H, long long lddy, long long ldx, long long lddx) {
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    // each 16-lane group accumulates dgamma for the heads it meets; heads cycle with period H over pairs, so a
+    // group that strides by (gridDim*16) pairs keeps a fixed head only if that stride is a multiple of H: enforce it
+    f32x4 accg = {0.f, 0.f, 0.f, 0.f};
+    const long long stride = (long long)gridDim.x * 16;
+    const long long first = (long long)blockIdx.x * 16 + grp;
+    const int h = (int)(first % H);
+    for (long long pr = first; pr < pairs; pr += stride) {
+        const long long t = pr / H;
+        const f32x4 d = load4<T>(dy + t * lddy + h * 64 + sub * 4);
+        const f32x4 v = load4<T>(x + t * ldx + h * 64 + sub * 4);
+        const f32x4 g = load4<T>(gamma + h * 64 + sub * 4);
+        const float rn = rnorm[pr];
+        const f32x4 xh = v * rn;
+        const f32x4 gd = g * d;
+        float dot = gd[0] * xh[0] + gd[1] * xh[1] + gd[2] * xh[2] + gd[3] * xh[3];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
+        store4<T>(dx + t * lddx + h * 64 + sub * 4, (gd - xh * dot) * (rn * 8.0f));
+        accg += d * xh * 8.0f;
+    }
+    // partials[(blockIdx*16 + grp)][64] ; row's head = (blockIdx*16+grp) % H  (stride % H == 0 is guaranteed by the host)
+    *reinterpret_cast<f32x4*>(partials + ((long long)blockIdx.x * 16 + grp) * 64 + sub * 4) = accg;
+}
+// dgamma[h][c] = sum over partial rows r with r % H == h
+template <typename T>
+__global__ __launch_bounds__(64) void rmsnorm_heads_dgamma_kernel(const float* __restrict__ partials, long long nrows, int H, T* __restrict__ dgamma) {
+    const int h = blockIdx.x, c = threadIdx.x;
+    float s = 0.f;
+    for (long long r = h; r < nrows; r += H) s += partials[r * 64 + c];
+    dgamma[h * 64 + c] = from_f32<T>(s);
+}
+
 // ---- materialising pieces: row softmax and its backward (one wave per row, any cols) ----
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ s, T* __restrict__ p, long long rows,
@@ -375,5 +670,82 @@ extern "C" int vitk_softmax_bwd(const void* p, const void* dp, void* ds, int dt,
     VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                                                 (const T*)p, (const T*)dp, (T*)ds, (long long)rows, (int)cols, scale));
     VITK_CHECK_LAUNCH("softmax_bwd");
+    return 0;
+}
+
+namespace {
+HND to_hnd(vitk_hnd t) { return HND{(__bf16*)t.p, (long long)t.s_h, (long long)t.s_n}; }
+bool hnd_ok(vitk_hnd t) { return t.p && aligned16(t.p) && (t.s_h % 8 == 0) && (t.s_n % 8 == 0); }
+}  // namespace
+
+extern "C" int vitk_attn_varlen_fwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse, const int32_t* cu_q,
+                                         const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0, int64_t nblk,
+                                         int64_t tq_total, int64_t H, int64_t d, float scale, void* stream) {
+    if (d != 64) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: needs dim_head == 64 (got %lld)", (long long)d);
+    if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !lse || !cu_q || !cu_k || !blk_seg || !blk_r0)
+        VITK_FAIL(VITK_E_ALIGN, "attn_varlen_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
+    if (nblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: empty problem");
+    hipLaunchKernelGGL(attn_varlen_fwd_kernel, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q),
+                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E);
+    VITK_CHECK_LAUNCH("attn_varlen_fwd_bf16");
+    return 0;
+}
+
+extern "C" int vitk_attn_varlen_bwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, vitk_hnd dout, const float* lse,
+                                         float* delta, vitk_hnd dq, vitk_hnd dk, vitk_hnd dv, const int32_t* cu_q,
+                                         const int32_t* cu_k, const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
+                                         const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk, int64_t tq_total,
+                                         int64_t H, int64_t d, float scale, void* stream) {
+    if (d != 64) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: needs dim_head == 64 (got %lld)", (long long)d);
+    if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !hnd_ok(dout) || !hnd_ok(dq) || !hnd_ok(dk) || !hnd_ok(dv) || !lse ||
+        !delta || !cu_q || !cu_k || !qblk_seg || !qblk_r0 || !kblk_seg || !kblk_r0)
+        VITK_FAIL(VITK_E_ALIGN, "attn_varlen_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
+    if (nqblk <= 0 || nkblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: empty problem");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_varlen_bwd_dq_kernel, dim3((unsigned)nqblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k),
+                       to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale);
+    VITK_CHECK_LAUNCH("attn_varlen_bwd_dq");
+    hipLaunchKernelGGL(attn_varlen_bwd_dkv_kernel, dim3((unsigned)nkblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k),
+                       to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale);
+    VITK_CHECK_LAUNCH("attn_varlen_bwd_dkv");
+    return 0;
+}
+
+extern "C" int64_t vitk_rmsnorm_heads_rows(int64_t T, int64_t H) {
+    // partial rows of the backward kernel: blocks * 16 with (blocks * 16) % H == 0 so every 16-lane group keeps one head
+    const int64_t pairs = T * H;
+    int64_t blocks = (pairs + 15) / 16;
+    if (blocks > 2048) blocks = 2048;
+    int64_t step = H;                      // smallest b with (16 b) % H == 0 is H / gcd(16, H)
+    for (int64_t g = 16; g > 0; g >>= 1) if (H % g == 0) { step = H / g; break; }
+    blocks = (blocks + step - 1) / step * step;
+    return blocks * 16;
+}
+
+extern "C" int vitk_rmsnorm_heads_fwd(const void* x, int64_t ldx, const void* gamma, void* y, int64_t ldy, float* rnorm, int dt,
+                                      int64_t T, int64_t H, int64_t d, void* stream) {
+    if (!x || !gamma || !y || !rnorm) VITK_FAIL(VITK_E_ARG, "rmsnorm_heads_fwd: null pointer");
+    if (d != 64 || T <= 0 || H <= 0 || (ldx & 3) || (ldy & 3)) VITK_FAIL(VITK_E_SHAPE, "rmsnorm_heads_fwd: needs dim_head == 64");
+    long long blocks = (T * H + 15) / 16; if (blocks > 4096) blocks = 4096;
+    VITK_DISPATCH_DT(dt, Tt, hipLaunchKernelGGL((rmsnorm_heads_fwd_kernel<Tt>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                                 (const Tt*)x, (const Tt*)gamma, (Tt*)y, rnorm, (long long)(T * H), (int)H, (long long)ldx, (long long)ldy));
+    VITK_CHECK_LAUNCH("rmsnorm_heads_fwd");
+    return 0;
+}
+
+extern "C" int vitk_rmsnorm_heads_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma, const float* rnorm,
+                                      void* dx, int64_t lddx, void* dgamma, float* partials, int dt, int64_t T, int64_t H, int64_t d,
+                                      void* stream) {
+    if (!dy || !x || !gamma || !rnorm || !dx || !dgamma || !partials) VITK_FAIL(VITK_E_ARG, "rmsnorm_heads_bwd: null pointer");
+    if (d != 64 || T <= 0 || H <= 0) VITK_FAIL(VITK_E_SHAPE, "rmsnorm_heads_bwd: needs dim_head == 64");
+    const long long nrows = vitk_rmsnorm_heads_rows(T, H);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(partials, 0, (size_t)nrows * 64 * sizeof(float), st) != hipSuccess) VITK_FAIL(1, "rmsnorm_heads_bwd: memset failed");
+    VITK_DISPATCH_DT(dt, Tt, {
+        hipLaunchKernelGGL((rmsnorm_heads_bwd_kernel<Tt>), dim3((unsigned)(nrows / 16)), dim3(256), 0, st, (const Tt*)dy, (const Tt*)x,
+                           (const Tt*)gamma, rnorm, (Tt*)dx, partials, (long long)(T * H), (int)H, (long long)lddy, (long long)ldx, (long long)lddx);
+        hipLaunchKernelGGL((rmsnorm_heads_dgamma_kernel<Tt>), dim3((unsigned)H), dim3(64), 0, st, partials, nrows, (int)H, (Tt*)dgamma);
+    });
+    VITK_CHECK_LAUNCH("rmsnorm_heads_bwd");
     return 0;
 }

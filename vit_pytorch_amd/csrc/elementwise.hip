@@ -177,6 +177,51 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
     }
 }
 
+// NaViT patch order 'c (h p1) (w p2) -> (h w) (c p1 p2)' (na_vit.py:300): element e = (c*p + i)*p + j.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_cpp_kernel(const T* __restrict__ img, T* __restrict__ out, int C, int H, int W, int p,
+                                                            long long row0, long long ld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hp = H / p, wp = W / p;
+    const int P = C * p * p;
+    for (int row = blockIdx.x * 4 + wave; row < hp * wp; row += gridDim.x * 4) {
+        const int ph = row / wp, pw = row % wp;
+        const T* src = img + (long long)(ph * p) * W + pw * p;
+        T* dst = out + (row0 + row) * ld;
+        for (int e = lane; e < P; e += 64) {
+            const int j = e % p;
+            const int ci = e / p;
+            const int i = ci % p, c = ci / p;
+            dst[e] = src[(long long)c * H * W + (long long)i * W + j];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_add2_kernel(const T* __restrict__ x, const T* __restrict__ A, const int* __restrict__ ia,
+                                                           const T* __restrict__ B, const int* __restrict__ ib, T* __restrict__ out,
+                                                           long long Tn, int D4) {
+    const long long n4 = Tn * D4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const long long t = i / D4;
+        const int c = (int)(i % D4);
+        const f32x4 v = load4<T>(x + i * 4) + load4<T>(A + ((long long)ia[t] * D4 + c) * 4) + load4<T>(B + ((long long)ib[t] * D4 + c) * 4);
+        store4<T>(out + i * 4, v);
+    }
+}
+
+template <typename GT, typename OT>
+__global__ __launch_bounds__(256) void csr_rowsum_kernel(const GT* __restrict__ g, const int* __restrict__ ptr, const int* __restrict__ rows,
+                                                          OT* __restrict__ out, int D4) {
+    const int seg = blockIdx.x;
+    const int b = ptr[seg], e = ptr[seg + 1];
+    for (int c = threadIdx.x; c < D4; c += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int j = b; j < e; ++j) s += load4<GT>(g + ((long long)rows[j] * D4 + c) * 4);
+        store4<OT>(out + ((long long)seg * D4 + c) * 4, s);
+    }
+}
+
 }  // namespace
 
 extern "C" int vitk_patchify(const void* img, void* out, int dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p1,
@@ -306,5 +351,41 @@ extern "C" int vitk_transpose(const void* in, void* out, int dt, int64_t rows, i
     VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
                                                 (T*)out, (int)rows, (int)cols));
     VITK_CHECK_LAUNCH("transpose");
+    return 0;
+}
+
+extern "C" int vitk_patchify_cpp(const void* img, void* out, int dt, int64_t C, int64_t H, int64_t W, int64_t p, int64_t row0,
+                                 int64_t ld, void* stream) {
+    if (!img || !out) VITK_FAIL(VITK_E_ARG, "patchify_cpp: null pointer");
+    if (C <= 0 || p <= 0 || H <= 0 || W <= 0 || H % p || W % p) VITK_FAIL(VITK_E_SHAPE, "patchify_cpp: image not divisible by patch");
+    const long long rows = (H / p) * (W / p);
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((patchify_cpp_kernel<T>), dim3(ew_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)img, (T*)out, (int)C, (int)H, (int)W, (int)p, (long long)row0, (long long)ld));
+    VITK_CHECK_LAUNCH("patchify_cpp");
+    return 0;
+}
+
+extern "C" int vitk_gather_add2(const void* x, const void* A, const int32_t* ia, const void* B, const int32_t* ib, void* out, int dt,
+                                int64_t T, int64_t D, void* stream) {
+    if (!x || !A || !ia || !B || !ib || !out) VITK_FAIL(VITK_E_ARG, "gather_add2: null pointer");
+    if (T <= 0 || D <= 0 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "gather_add2: D %% 4 != 0");
+    VITK_DISPATCH_DT(dt, Tt, hipLaunchKernelGGL((gather_add2_kernel<Tt>), dim3(ew_blocks(T * D / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                 (const Tt*)x, (const Tt*)A, ia, (const Tt*)B, ib, (Tt*)out, (long long)T, (int)(D / 4)));
+    VITK_CHECK_LAUNCH("gather_add2");
+    return 0;
+}
+
+extern "C" int vitk_csr_rowsum(const void* g, int gdt, const int32_t* ptr, const int32_t* rows, void* out, int odt, int64_t nseg,
+                               int64_t D, void* stream) {
+    if (!g || !ptr || !rows || !out) VITK_FAIL(VITK_E_ARG, "csr_rowsum: null pointer");
+    if (nseg <= 0 || D <= 0 || (D & 3) || nseg > 0x7fffffff) VITK_FAIL(VITK_E_SHAPE, "csr_rowsum: D %% 4 != 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = (int)(D / 4);
+    if (gdt == VITK_F32 && odt == VITK_F32) hipLaunchKernelGGL((csr_rowsum_kernel<float, float>), dim3((unsigned)nseg), dim3(256), 0, st, (const float*)g, ptr, rows, (float*)out, D4);
+    else if (gdt == VITK_BF16 && odt == VITK_BF16) hipLaunchKernelGGL((csr_rowsum_kernel<__bf16, __bf16>), dim3((unsigned)nseg), dim3(256), 0, st, (const __bf16*)g, ptr, rows, (__bf16*)out, D4);
+    else if (gdt == VITK_F32 && odt == VITK_BF16) hipLaunchKernelGGL((csr_rowsum_kernel<float, __bf16>), dim3((unsigned)nseg), dim3(256), 0, st, (const float*)g, ptr, rows, (__bf16*)out, D4);
+    else if (gdt == VITK_BF16 && odt == VITK_F32) hipLaunchKernelGGL((csr_rowsum_kernel<__bf16, float>), dim3((unsigned)nseg), dim3(256), 0, st, (const __bf16*)g, ptr, rows, (float*)out, D4);
+    else VITK_FAIL(VITK_E_DTYPE, "csr_rowsum: bad dtype");
+    VITK_CHECK_LAUNCH("csr_rowsum");
     return 0;
 }

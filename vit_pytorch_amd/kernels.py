@@ -187,3 +187,51 @@ def dropout_bwd(dy: Tensor, mask: Tensor, dx: Tensor, p: float):
 
 def transpose(x: Tensor, out: Tensor, rows: int, cols: int):
     check(L.load().vitk_transpose(_p(x), _p(out), dt(x), rows, cols, _stream()), "transpose")
+
+
+# ---- NaViT: packed / variable-length path ----------------------------------------------------------
+def hnd(t: Tensor, s_h: int, s_n: int, offset: int = 0) -> L.HND:
+    return L.HND(t.data_ptr() + offset * t.element_size(), s_h, s_n)
+
+
+def attn_varlen_fwd_bf16(q: L.HND, k: L.HND, v: L.HND, o: L.HND, lse: Tensor, cu_q: Tensor, cu_k: Tensor, blk_seg: Tensor,
+                         blk_r0: Tensor, nblk: int, tq_total: int, H: int, d: int, scale: float):
+    check(L.load().vitk_attn_varlen_fwd_bf16(q, k, v, o, _p(lse), _p(cu_q), _p(cu_k), _p(blk_seg), _p(blk_r0), nblk,
+                                             tq_total, H, d, scale, _stream()), "attn_varlen_fwd_bf16")
+
+
+def attn_varlen_bwd_bf16(q: L.HND, k: L.HND, v: L.HND, o: L.HND, dout: L.HND, lse: Tensor, delta: Tensor, dq: L.HND,
+                         dk: L.HND, dv: L.HND, cu_q: Tensor, cu_k: Tensor, qblk_seg: Tensor, qblk_r0: Tensor, nqblk: int,
+                         kblk_seg: Tensor, kblk_r0: Tensor, nkblk: int, tq_total: int, H: int, d: int, scale: float):
+    check(L.load().vitk_attn_varlen_bwd_bf16(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, _p(cu_q), _p(cu_k),
+                                             _p(qblk_seg), _p(qblk_r0), nqblk, _p(kblk_seg), _p(kblk_r0), nkblk,
+                                             tq_total, H, d, scale, _stream()), "attn_varlen_bwd_bf16")
+
+
+def rmsnorm_heads_rows(T: int, H: int) -> int:
+    return int(L.load().vitk_rmsnorm_heads_rows(T, H))
+
+
+def rmsnorm_heads_fwd(x: Tensor, ldx: int, gamma: Tensor, y: Tensor, ldy: int, rnorm: Tensor, T: int, H: int, d: int,
+                      x_off: int = 0):
+    check(L.load().vitk_rmsnorm_heads_fwd(x.data_ptr() + x_off * x.element_size(), ldx, _p(gamma), _p(y), ldy, _p(rnorm),
+                                          dt(x), T, H, d, _stream()), "rmsnorm_heads_fwd")
+
+
+def rmsnorm_heads_bwd(dy: Tensor, lddy: int, x: Tensor, ldx: int, gamma: Tensor, rnorm: Tensor, dx: Tensor, lddx: int,
+                      dgamma: Tensor, partials: Tensor, T: int, H: int, d: int, x_off: int = 0, dx_off: int = 0):
+    check(L.load().vitk_rmsnorm_heads_bwd(_p(dy), lddy, x.data_ptr() + x_off * x.element_size(), ldx, _p(gamma), _p(rnorm),
+                                          dx.data_ptr() + dx_off * dx.element_size(), lddx, _p(dgamma), _p(partials),
+                                          dt(x), T, H, d, _stream()), "rmsnorm_heads_bwd")
+
+
+def patchify_cpp(img: Tensor, out: Tensor, C: int, H: int, W: int, p: int, row0: int, ld: int):
+    check(L.load().vitk_patchify_cpp(_p(img), _p(out), dt(img), C, H, W, p, row0, ld, _stream()), "patchify_cpp")
+
+
+def gather_add2(x: Tensor, A: Tensor, ia: Tensor, B: Tensor, ib: Tensor, out: Tensor, T: int, D: int):
+    check(L.load().vitk_gather_add2(_p(x), _p(A), _p(ia), _p(B), _p(ib), _p(out), dt(x), T, D, _stream()), "gather_add2")
+
+
+def csr_rowsum(g: Tensor, ptr: Tensor, rows: Tensor, out: Tensor, nseg: int, D: int):
+    check(L.load().vitk_csr_rowsum(_p(g), dt(g), _p(ptr), _p(rows), _p(out), dt(out), nseg, D, _stream()), "csr_rowsum")

@@ -1,0 +1,438 @@
+"""Drop-in for vit_pytorch/na_vit.py (NaViT: group_images_by_max_seq_len :38-77, LayerNorm :82-89,
+RMSNorm :93-101, FeedForward :105-113, Attention :115-169, Transformer :171-193, NaViT :195-402) on
+libvitk kernels.
+
+MI355X-first data layout.  The reference pads every pack of images to (b, n, d) and drives
+F.scaled_dot_product_attention with a dense boolean (b, 1, n, n) mask "same image and key is not padding"
+(:335-337), pads positions and image ids (:335-342) and selects the real images at the end with a boolean
+index (:393-396).  Here the tokens of ALL images of ALL packs are kept unpadded in one (T, dim) matrix; the
+only thing attention needs is the list of per-image token ranges, because the mask is block diagonal with
+one block per image: attention is launched per (image, 128-query block, head) (vitk_attn_varlen_*).  The
+attention pool (one learned query per image, :371-387) is the same kernel with one query row per image.
+Results for real tokens are identical to the padded formulation (padded rows never reach an output); packing
+into groups therefore changes nothing numerically and `group_images` is honoured only as an API.
+
+Same constructor, state_dict keys/shapes (gamma/beta LayerNorms, to_q / to_kv, q_norm / k_norm,
+pos_embed_height / pos_embed_width, attn_pool_queries, attn_pool.*, mlp_head.{0,1}) and forward() contract
+(list of images or list of lists -> (total_images, num_classes)).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import torch
+from torch import nn, Tensor
+
+from . import functional as Fn
+from . import kernels as K
+from . import ops
+from ._lib import VitkError
+
+F32 = torch.float32
+
+
+def exists(val):
+    return val is not None
+
+
+def default(val, d):
+    return val if exists(val) else d
+
+
+def always(val):
+    return lambda *args: val
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def divisible_by(numer, denom):
+    return (numer % denom) == 0
+
+
+def group_images_by_max_seq_len(images: List[Tensor], patch_size: int, calc_token_dropout=None, max_seq_len=2048) -> List[List[Tensor]]:
+    """Greedy packing of images into groups whose token count stays <= max_seq_len (na_vit.py:38-77)."""
+    calc_token_dropout = default(calc_token_dropout, always(0.))
+    groups, group, seq_len = [], [], 0
+    if isinstance(calc_token_dropout, (float, int)):
+        calc_token_dropout = always(calc_token_dropout)
+    for image in images:
+        assert isinstance(image, Tensor)
+        image_dims = image.shape[-2:]
+        ph, pw = map(lambda t: t // patch_size, image_dims)
+        image_seq_len = int((ph * pw) * (1 - calc_token_dropout(*image_dims)))
+        assert image_seq_len <= max_seq_len, f'image with dimensions {image_dims} exceeds maximum sequence length'
+        if (seq_len + image_seq_len) > max_seq_len:
+            groups.append(group)
+            group, seq_len = [], 0
+        group.append(image)
+        seq_len += image_seq_len
+    if len(group) > 0:
+        groups.append(group)
+    return groups
+
+
+# ---- segment bookkeeping (host) -------------------------------------------------------------------
+class Segments:
+    """Per-image token ranges of a packed batch, plus the 128-row block tables the varlen kernels walk."""
+    BLOCK = 128
+
+    def __init__(self, q_lens, k_lens, device):
+        self.q_lens, self.k_lens = list(map(int, q_lens)), list(map(int, k_lens))
+        assert len(self.q_lens) == len(self.k_lens)
+        self.nseg = len(self.q_lens)
+        cu_q = np.concatenate([[0], np.cumsum(self.q_lens)]).astype(np.int32)
+        cu_k = np.concatenate([[0], np.cumsum(self.k_lens)]).astype(np.int32)
+        self.cu_q_host, self.cu_k_host = cu_q, cu_k
+        self.tq, self.tk = int(cu_q[-1]), int(cu_k[-1])
+
+        def blocks(lens):
+            seg, r0 = [], []
+            for s, n in enumerate(lens):
+                for b in range(0, max(n, 1), self.BLOCK):
+                    seg.append(s); r0.append(b)
+            return np.asarray(seg, np.int32), np.asarray(r0, np.int32)
+
+        qs, qr = blocks(self.q_lens)
+        ks, kr = blocks(self.k_lens)
+        up = lambda a: torch.from_numpy(a).to(device)
+        self.cu_q, self.cu_k = up(cu_q), up(cu_k)
+        self.qblk_seg, self.qblk_r0, self.kblk_seg, self.kblk_r0 = up(qs), up(qr), up(ks), up(kr)
+        self.nqblk, self.nkblk = len(qs), len(ks)
+
+
+class _QKNormAttnFn(torch.autograd.Function):
+    """q_norm / k_norm (RMSNorm per head) + scaled_dot_product_attention(scale = 1) over segments
+    (na_vit.py:147-168).  q: (Tq, I); kv: (Tk, 2I) = k | v, consumed in place; returns (Tq, I)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, gq, gk, segs: Segments, heads: int):
+        K.require_device(q, kv)
+        q = q.contiguous(); kv = kv.contiguous()
+        Tq, I = q.shape
+        Tk = kv.shape[0]
+        d = I // heads
+        T = q.dtype
+        if d != 64:
+            raise VitkError(f"NaViT attention kernels need dim_head == 64 (got {d})")
+        qn = torch.empty_like(q); kn = torch.empty((Tk, I), dtype=T, device=q.device)
+        rq = torch.empty(Tq * heads, dtype=F32, device=q.device); rk = torch.empty(Tk * heads, dtype=F32, device=q.device)
+        gqf, gkf = gq.reshape(heads, d).contiguous(), gk.reshape(heads, d).contiguous()
+        K.rmsnorm_heads_fwd(q, I, gqf, qn, I, rq, Tq, heads, d)
+        K.rmsnorm_heads_fwd(kv, 2 * I, gkf, kn, I, rk, Tk, heads, d)
+        o = torch.empty((Tq, I), dtype=T, device=q.device)
+        if T == torch.bfloat16:
+            lse = torch.empty((heads, Tq), dtype=F32, device=q.device)
+            K.attn_varlen_fwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), lse,
+                                   segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, Tq, heads, d, 1.0)
+            saved = lse
+        else:  # f32 validation mode: per-segment materialising path on the coverage kernels
+            saved = []
+            for s in range(segs.nseg):
+                q0, nq = int(segs.cu_q_host[s]), segs.q_lens[s]
+                k0, nk = int(segs.cu_k_host[s]), segs.k_lens[s]
+                S = torch.empty((heads, nq, nk), dtype=T, device=q.device)
+                K.gemm_generic(K.mat(qn, I, 1, 0, d, offset=q0 * I), K.mat(kn, 1, I, 0, d, offset=k0 * I),
+                               K.mat(S, nk, 1, 0, nq * nk), nq, nk, d, nb1=1, nb2=heads)
+                P = torch.empty_like(S)
+                K.softmax_fwd(S, P, heads * nq, nk, 1.0)
+                K.gemm_generic(K.mat(P, nk, 1, 0, nq * nk), K.mat(kv, 2 * I, 1, 0, d, offset=k0 * 2 * I + I),
+                               K.mat(o, I, 1, 0, d, offset=q0 * I), nq, d, nk, nb1=1, nb2=heads)
+                saved.append(P)
+        ctx.save_for_backward(q, kv, gqf, gkf, qn, kn, o, rq, rk)
+        ctx.att = saved
+        ctx.meta = (segs, heads, d, gq.shape, gk.shape)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, gqf, gkf, qn, kn, o, rq, rk = ctx.saved_tensors
+        segs, heads, d, gq_shape, gk_shape = ctx.meta
+        Tq, I = q.shape
+        Tk = kv.shape[0]
+        T = q.dtype
+        do = Fn._to(do, T)
+        dqn = torch.empty_like(qn); dkn = torch.empty_like(kn)
+        dkv = torch.empty_like(kv)
+        if T == torch.bfloat16:
+            delta = torch.empty((heads, Tq), dtype=F32, device=q.device)
+            K.attn_varlen_bwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I),
+                                   K.hnd(do, d, I), ctx.att, delta, K.hnd(dqn, d, I), K.hnd(dkn, d, I),
+                                   K.hnd(dkv, d, 2 * I, offset=I), segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0,
+                                   segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, Tq, heads, d, 1.0)
+        else:
+            for s in range(segs.nseg):
+                q0, nq = int(segs.cu_q_host[s]), segs.q_lens[s]
+                k0, nk = int(segs.cu_k_host[s]), segs.k_lens[s]
+                P = ctx.att[s]
+                pm = K.mat(P, nk, 1, 0, nq * nk); pmT = K.mat(P, 1, nk, 0, nq * nk)
+                dom = K.mat(do, I, 1, 0, d, offset=q0 * I)
+                K.gemm_generic(pmT, dom, K.mat(dkv, 2 * I, 1, 0, d, offset=k0 * 2 * I + I), nk, d, nq, nb1=1, nb2=heads)      # dV
+                dP = torch.empty_like(P)
+                K.gemm_generic(dom, K.mat(kv, 1, 2 * I, 0, d, offset=k0 * 2 * I + I), K.mat(dP, nk, 1, 0, nq * nk), nq, nk, d, nb1=1, nb2=heads)
+                K.softmax_bwd(P, dP, dP, heads * nq, nk, 1.0)
+                K.gemm_generic(K.mat(dP, nk, 1, 0, nq * nk), K.mat(kn, I, 1, 0, d, offset=k0 * I), K.mat(dqn, I, 1, 0, d, offset=q0 * I), nq, d, nk, nb1=1, nb2=heads)
+                K.gemm_generic(K.mat(dP, 1, nk, 0, nq * nk), K.mat(qn, I, 1, 0, d, offset=q0 * I), K.mat(dkn, I, 1, 0, d, offset=k0 * I), nk, d, nq, nb1=1, nb2=heads)
+        dq = torch.empty_like(q)
+        dgq = torch.empty_like(gqf); dgk = torch.empty_like(gkf)
+        pq = torch.empty(K.rmsnorm_heads_rows(Tq, heads) * 64, dtype=F32, device=q.device)
+        pk = torch.empty(K.rmsnorm_heads_rows(Tk, heads) * 64, dtype=F32, device=q.device)
+        K.rmsnorm_heads_bwd(dqn, I, q, I, gqf, rq, dq, I, dgq, pq, Tq, heads, d)
+        K.rmsnorm_heads_bwd(dkn, I, kv, 2 * I, gkf, rk, dkv, 2 * I, dgk, pk, Tk, heads, d)
+        return dq, dkv, dgq.view(gq_shape), dgk.view(gk_shape), None, None
+
+
+class _PosEmbedFn(torch.autograd.Function):
+    """x + pos_embed_height[h_idx] + pos_embed_width[w_idx] (na_vit.py:354-359); deterministic backward
+    through CSR lists of the tokens that use each table row."""
+
+    @staticmethod
+    def forward(ctx, x, ph, pw, h_idx, w_idx, h_csr, w_csr):
+        K.require_device(x)
+        x = x.contiguous()
+        T, D = x.shape
+        out = torch.empty_like(x)
+        K.gather_add2(x, ph, h_idx, pw, w_idx, out, T, D)
+        ctx.csr = (h_csr, w_csr, ph.shape, pw.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h_csr, w_csr, ph_shape, pw_shape = ctx.csr
+        g = g.contiguous()
+        D = g.shape[1]
+        dph = torch.empty(ph_shape, dtype=g.dtype, device=g.device)
+        dpw = torch.empty(pw_shape, dtype=g.dtype, device=g.device)
+        K.csr_rowsum(g, h_csr[0], h_csr[1], dph, ph_shape[0], D)
+        K.csr_rowsum(g, w_csr[0], w_csr[1], dpw, pw_shape[0], D)
+        return g, dph, dpw, None, None, None, None
+
+
+class _ExpandRowsFn(torch.autograd.Function):
+    """repeat(vec, 'd -> n d') (na_vit.py:373); backward = column sum."""
+
+    @staticmethod
+    def forward(ctx, vec, n: int, ptr, rows):
+        D = vec.shape[0]
+        out = torch.empty((n, D), dtype=vec.dtype, device=vec.device)
+        K.csr_rowsum(vec.contiguous(), ptr, rows, out, n, D)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        D = g.shape[1]
+        dv = torch.empty(D, dtype=g.dtype, device=g.device)
+        ops.colsum(g, ctx.n, D, dv)
+        return dv, None, None, None
+
+
+# ---- modules (same state_dict as the reference) -----------------------------------------------------
+class LayerNorm(nn.Module):
+    """LayerNorm without a learned bias (na_vit.py:82-89): `gamma` parameter, zero `beta` buffer."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim))
+        self.register_buffer('beta', torch.zeros(dim))
+
+    def forward(self, x):
+        return Fn.LayerNormFn.apply(x, self.gamma, None)
+
+
+class RMSNorm(nn.Module):
+    """q/k normalisation (na_vit.py:93-101); applied inside _QKNormAttnFn."""
+
+    def __init__(self, heads, dim):
+        super().__init__()
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones(heads, 1, dim))
+
+
+def FeedForward(dim, hidden_dim, dropout=0.):
+    return nn.Sequential(
+        LayerNorm(dim),
+        Fn.Linear(dim, hidden_dim),
+        Fn.GELU(),
+        Fn.Dropout(dropout),
+        Fn.Linear(hidden_dim, dim),
+        Fn.Dropout(dropout),
+    )
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.norm = LayerNorm(dim)
+        self.q_norm = RMSNorm(heads, dim_head)
+        self.k_norm = RMSNorm(heads, dim_head)
+        self.dropout_p = dropout
+        self.to_q = Fn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = Fn.Linear(dim, inner_dim * 2, bias=False)
+        self.to_out = nn.Sequential(
+            Fn.Linear(inner_dim, dim, bias=False),
+            Fn.Dropout(dropout),
+        )
+
+    def forward(self, x, segs: Segments, context=None):
+        """x: (Tq, dim) packed query-side tokens; context: (Tk, dim) packed key-side tokens (default: x)."""
+        if self.training and self.dropout_p > 0.:
+            raise VitkError("attention-probability dropout inside the fused NaViT attention is not implemented")
+        x = self.norm(x)
+        kv_input = default(context, x)
+        q = self.to_q(x)
+        kv = self.to_kv(kv_input)
+        out = _QKNormAttnFn.apply(q, kv, self.q_norm.gamma, self.k_norm.gamma, segs, self.heads)
+        return self.to_out(out)
+
+
+class Transformer(nn.Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout),
+                FeedForward(dim, mlp_dim, dropout=dropout),
+            ]))
+        self.norm = LayerNorm(dim)
+
+    def forward(self, x, segs: Segments):
+        for attn, ff in self.layers:
+            x = Fn.AddFn.apply(attn(x, segs), x)
+            x = Fn.AddFn.apply(ff(x), x)
+        return self.norm(x)
+
+
+class NaViT(nn.Module):
+    def __init__(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, channels=3, dim_head=64,
+                 dropout=0., emb_dropout=0., token_dropout_prob=None):
+        super().__init__()
+        image_height, image_width = pair(image_size)
+
+        self.calc_token_dropout = None
+        if callable(token_dropout_prob):
+            self.calc_token_dropout = token_dropout_prob
+        elif isinstance(token_dropout_prob, (float, int)):
+            assert 0. <= token_dropout_prob < 1.
+            token_dropout_prob = float(token_dropout_prob)
+            self.calc_token_dropout = lambda height, width: token_dropout_prob
+
+        assert divisible_by(image_height, patch_size) and divisible_by(image_width, patch_size), 'Image dimensions must be divisible by the patch size.'
+
+        patch_height_dim, patch_width_dim = (image_height // patch_size), (image_width // patch_size)
+        patch_dim = channels * (patch_size ** 2)
+
+        self.channels = channels
+        self.patch_size = patch_size
+
+        self.to_patch_embedding = nn.Sequential(
+            LayerNorm(patch_dim),
+            Fn.Linear(patch_dim, dim),
+            LayerNorm(dim),
+        )
+
+        self.pos_embed_height = nn.Parameter(torch.randn(patch_height_dim, dim))
+        self.pos_embed_width = nn.Parameter(torch.randn(patch_width_dim, dim))
+
+        self.dropout = Fn.Dropout(emb_dropout)
+
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+
+        self.attn_pool_queries = nn.Parameter(torch.randn(dim))
+        self.attn_pool = Attention(dim=dim, dim_head=dim_head, heads=heads)
+
+        self.to_latent = nn.Identity()
+
+        self.mlp_head = nn.Sequential(
+            LayerNorm(dim),
+            Fn.Linear(dim, num_classes, bias=False),
+        )
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, batched_images, group_images=False, group_max_seq_len=2048):
+        p, c, device = self.patch_size, self.channels, self.device
+        has_token_dropout = exists(self.calc_token_dropout) and self.training
+        dtype = self.pos_embed_height.dtype
+
+        if group_images:
+            batched_images = group_images_by_max_seq_len(batched_images, patch_size=p,
+                                                         calc_token_dropout=self.calc_token_dropout if self.training else None,
+                                                         max_seq_len=group_max_seq_len)
+        if torch.is_tensor(batched_images[0]):
+            batched_images = [batched_images]
+        images = [img for group in batched_images for img in group]   # pack-major image order == the reference's output order
+        K.require_device(*images)
+
+        # ---- host side: token counts, positions, (optional) token dropout ----
+        lens, h_list, w_list, keeps = [], [], [], []
+        for image in images:
+            assert image.ndim == 3 and image.shape[0] == c
+            ih, iw = image.shape[-2:]
+            assert divisible_by(ih, p) and divisible_by(iw, p), f'height and width {(ih, iw)} of images must be divisible by patch size {p}'
+            ph, pw = ih // p, iw // p
+            hi = np.repeat(np.arange(ph, dtype=np.int32), pw)
+            wi = np.tile(np.arange(pw, dtype=np.int32), ph)
+            keep = None
+            if has_token_dropout:
+                n = ph * pw
+                num_keep = max(1, int(n * (1 - self.calc_token_dropout(ih, iw))))
+                keep = torch.randn((n,), device=device).topk(num_keep, dim=-1).indices     # na_vit.py:311
+                ki = keep.cpu().numpy()
+                hi, wi = hi[ki], wi[ki]
+            keeps.append(keep)
+            lens.append(len(hi)); h_list.append(hi); w_list.append(wi)
+        T = int(sum(lens))
+        P = c * p * p
+        segs = Segments(lens, lens, device)
+        h_all, w_all = np.concatenate(h_list), np.concatenate(w_list)
+
+        def csr(idx, n):
+            order = np.argsort(idx, kind="stable").astype(np.int32)
+            ptr = np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=n))]).astype(np.int32)
+            return torch.from_numpy(ptr).to(device), torch.from_numpy(order).to(device)
+
+        h_idx, w_idx = torch.from_numpy(h_all).to(device), torch.from_numpy(w_all).to(device)
+        h_csr, w_csr = csr(h_all, self.pos_embed_height.shape[0]), csr(w_all, self.pos_embed_width.shape[0])
+
+        # ---- patches: 'c (h p1) (w p2) -> (h w) (c p1 p2)' written straight into the packed (T, P) matrix ----
+        patches = torch.empty((T, P), dtype=dtype, device=device)
+        row0 = 0
+        for image, keep, n in zip(images, keeps, lens):
+            if image.dtype != dtype:
+                raise VitkError(f"image dtype {image.dtype} != parameter dtype {dtype}")
+            image = image.contiguous()
+            ih, iw = image.shape[-2:]
+            if keep is None:
+                K.patchify_cpp(image, patches, c, ih, iw, p, row0, P)
+            else:
+                full = torch.empty(((ih // p) * (iw // p), P), dtype=dtype, device=device)
+                K.patchify_cpp(image, full, c, ih, iw, p, 0, P)
+                ptr = torch.arange(n + 1, dtype=torch.int32, device=device)
+                K.csr_rowsum(full, ptr, keep.to(torch.int32), patches[row0:row0 + n], n, P)   # row gather
+            row0 += n
+
+        x = self.to_patch_embedding(patches)
+        x = _PosEmbedFn.apply(x, self.pos_embed_height, self.pos_embed_width, h_idx, w_idx, h_csr, w_csr)
+        x = self.dropout(x)
+
+        x = self.transformer(x, segs)
+
+        # ---- attention pooling: one learned query per image against that image's tokens ----
+        nimg = len(images)
+        pool_segs = Segments([1] * nimg, lens, device)
+        ptr = torch.arange(nimg + 1, dtype=torch.int32, device=device)
+        rows = torch.zeros(nimg, dtype=torch.int32, device=device)
+        queries = _ExpandRowsFn.apply(self.attn_pool_queries, nimg, ptr, rows)
+        x = Fn.AddFn.apply(self.attn_pool(queries, pool_segs, context=x), queries)
+
+        x = self.to_latent(x)
+        return self.mlp_head(x)
