@@ -211,6 +211,10 @@ int vitk_mean_pool_bwd(const void* dout, int ddt, void* dx, int xdt, int64_t B, 
 int vitk_dropout_fwd(const void* x, void* y, uint8_t* mask, int dt, int64_t n, float p,
                      uint64_t seed, uint64_t offset, void* stream);
 int vitk_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dt, int64_t n, float p, void* stream);
+/* dst[r, c] = c < cols_copy ? src[r, c] : 0 for c < cols_dst  (zero-pads / strips the K columns of a matrix whose inner
+ * extent is not a multiple of 32, e.g. patch_dim = 588 of ViT-H/14, so that the MFMA GEMMs can take it)          */
+int vitk_copy_cols(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int dt, int64_t rows, int64_t cols_copy,
+                   int64_t cols_dst, void* stream);
 /* 2-D transpose out[c][r] = in[r][c] (weights: W^T for the dX GEMMs) */
 int vitk_transpose(const void* in, void* out, int dt, int64_t rows, int64_t cols, void* stream);
 

@@ -25,9 +25,9 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("lens", [[197], [16, 300, 1, 129, 64], [1600, 7], [128, 128, 256]])
-@pytest.mark.parametrize("H", [1, 3])
-def test_varlen_attention_fwd_bwd(lens, H):
-    d, I = 64, H * 64
+@pytest.mark.parametrize("H,d", [(1, 64), (3, 64), (2, 80)])
+def test_varlen_attention_fwd_bwd(lens, H, d):
+    I = H * d
     T = sum(lens)
     g = torch.Generator().manual_seed(len(lens) * 7 + H)
     q = (torch.randn(T, I, generator=g)).to(BF).to(DEV)

@@ -239,3 +239,36 @@ def test_dropout_training_path_statistics():
     assert rel(o1, out_eval) > 1e-3                     # dropout is active
     o1.float().square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.numel())
+
+
+def test_vit_h14_shapes_bf16_fast_paths():
+    """BASELINE config 5's shapes in bf16 (dim_head 80, N = 577 > 480, patch_dim 588 % 32 != 0): chunked attention
+    kernels with the head dimension padded to 96 inside the MFMA K-steps, K-padded patch GEMM.  depth 1, batch 2."""
+    cfg = dict(image_size=336, patch_size=14, num_classes=1000, dim=1280, depth=1, heads=16, dim_head=80, mlp_dim=5120)
+    params = make_params("vit", cfg, 17)
+    img = make_images(cfg, 2, 1017)
+    ref_out, ref_g = O.run_fwd_bwd("vit", cfg, params, img, torch.float32)
+    bf_out, bf_g = O.run_fwd_bwd("vit", cfg, params, img, torch.bfloat16)
+    out, grads = run_mine("vit", cfg, params, img, torch.bfloat16)
+    keys = list(params)
+    cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
+    e, e_ref = rel(out, ref_out), rel(bf_out, ref_out)
+    g, g_ref = rel(cat(grads), cat(ref_g)), rel(cat(bf_g), cat(ref_g))
+    print(f"vit-H/14 shapes bf16: logits {e:.2e} (reference-bf16 {e_ref:.2e}); grads {g:.2e} (reference-bf16 {g_ref:.2e})")
+    assert e <= 1.5 * e_ref + 1e-3 and g <= 1.5 * g_ref + 1e-3
+    for k in keys:
+        assert rel(grads[k], ref_g[k]) <= 0.15, (k, rel(grads[k], ref_g[k]))
+
+
+def test_long_sequence_dim_head_64_uses_chunked_attention():
+    """N = 577 with dim_head 64 (beyond the whole-head-in-LDS kernels): f32 oracle vs bf16 run, depth 1."""
+    cfg = dict(image_size=384, patch_size=16, num_classes=10, dim=128, depth=1, heads=2, mlp_dim=256)
+    params = make_params("vit", cfg, 19)
+    img = make_images(cfg, 2, 1019)
+    ref_out, ref_g = O.run_fwd_bwd("vit", cfg, params, img, torch.float32)
+    bf_out, bf_g = O.run_fwd_bwd("vit", cfg, params, img, torch.bfloat16)
+    out, grads = run_mine("vit", cfg, params, img, torch.bfloat16)
+    keys = list(params)
+    cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
+    assert rel(out, ref_out) <= 1.5 * rel(bf_out, ref_out) + 1e-3
+    assert rel(cat(grads), cat(ref_g)) <= 1.5 * rel(cat(bf_g), cat(ref_g)) + 1e-3

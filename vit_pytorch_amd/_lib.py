@@ -75,6 +75,7 @@ SIGNATURES = {
     "vitk_mean_pool_bwd": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),
     "vitk_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _u64, _u64, _vp]),
     "vitk_dropout_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp]),
+    "vitk_copy_cols": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _i64, _vp]),
     "vitk_transpose": (_i, [_vp, _vp, _i, _i64, _i64, _vp]),
 }
 

@@ -283,41 +283,83 @@ constexpr int VL_CH = 128;             // rows per LDS chunk
 
 struct HND { __bf16* p; long long s_h, s_n; };   // element (n, h, d) at p + n*s_n + h*s_h + d
 
-__device__ __forceinline__ void fill_chunk(char* tile, const __bf16* src, long long s_n, int rows, int rows_pad, int tid) {
+// Head-dimension traits.  DH = 64: 2 MFMA K-steps, 160-byte LDS rows.  DH = 80 (ViT-H/14, vit.py dim_head=80):
+// the contraction over d is padded to 96 = 3 K-steps with zero columns, LDS rows are 208 bytes (13 x 16: every
+// 16 consecutive rows start in distinct 4-bank windows for ds_read_b128), the output has 5 blocks of 16 columns.
+template <int DH> struct HD {
+    static constexpr int NKS = (DH + 31) / 32;      // MFMA K-steps over d
+    static constexpr int NFD = DH / 16;             // 16-column output blocks
+    static constexpr int LD = DH == 64 ? 160 : 208; // bytes per LDS row
+    static constexpr int NCH = NKS * 4;             // 16-byte chunks per LDS row that are read by fragments
+};
+
+template <int DH>
+__device__ __forceinline__ void fill_chunk_t(char* tile, const __bf16* src, long long s_n, int rows, int rows_pad, int tid) {
+    constexpr int NCH = HD<DH>::NCH, LD = HD<DH>::LD;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int c = tid; c < rows_pad * 8; c += AT_THREADS) {
-        const int row = c >> 3, col8 = c & 7;
-        const bf16x8 v = row < rows ? *reinterpret_cast<const bf16x8*>(src + (long long)row * s_n + col8 * 8) : zero8;
-        *reinterpret_cast<bf16x8*>(tile + row * AT_LD + col8 * 16) = v;
+    for (int c = tid; c < rows_pad * NCH; c += AT_THREADS) {
+        const int row = c / NCH, col8 = c % NCH;
+        const bf16x8 v = (row < rows && col8 * 8 < DH) ? *reinterpret_cast<const bf16x8*>(src + (long long)row * s_n + col8 * 8) : zero8;
+        *reinterpret_cast<bf16x8*>(tile + row * LD + col8 * 16) = v;
     }
 }
+template <int DH>
+__device__ __forceinline__ bf16x8 row_frag_t(const char* tile, int row0, int ks, int fi, int fg) {
+    return *reinterpret_cast<const bf16x8*>(tile + (row0 + fi) * HD<DH>::LD + (ks * 32 + 8 * fg) * 2);
+}
+template <int DH>
+__device__ __forceinline__ bf16x8 tr_frag_t(const char* tile, int row0, int col0, int fi, int fg) {
+    constexpr int LD = HD<DH>::LD;
+    const char* p = tile + (row0 + 4 * fg + (fi >> 2)) * LD + (col0 + (fi & 3) * 4) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * LD));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// one row of a (n, h, d) tensor as NKS register fragments: lane (i, g) holds row[ks*32 + 8g .. +7] (zero beyond DH)
+template <int DH>
+__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[HD<DH>::NKS], const __bf16* rowp, int fg) {
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < HD<DH>::NKS; ++ks) f[ks] = (ks * 32 + 8 * fg < DH) ? *reinterpret_cast<const bf16x8*>(rowp + ks * 32 + 8 * fg) : zero8;
+}
+template <int DH>
+__device__ __forceinline__ f32x4 mfma_over_d(const char* tile, int row0, const bf16x8 (&b)[HD<DH>::NKS], int fi, int fg) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < HD<DH>::NKS; ++ks) acc = MFMA(row_frag_t<DH>(tile, row0, ks, fi, fg), b[ks], acc);
+    return acc;
+}
 
+template <int DH>
 __global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
     HND q, HND k, HND v, HND o, float* __restrict__ lse, const int* __restrict__ cu_q, const int* __restrict__ cu_k,
     const int* __restrict__ blk_seg, const int* __restrict__ blk_r0, int tq_total, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * AT_LD];
+    constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
+    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     char* Ks = smem;
-    char* Vs = smem + VL_CH * AT_LD;
+    char* Vs = smem + VL_CH * LD;
     const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
     const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
-    const int ks = cu_k[seg], nk = cu_k[seg + 1] - ks;
+    const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
     const int qi = blk_r0[blockIdx.x] + wave * 16 + fi;        // row inside the segment
     const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nq;
     const int qrow = qs + (qi < nq ? qi : nq - 1);
-    const __bf16* qp = q.p + (long long)qrow * q.s_n + h * q.s_h;
-    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * fg);
-    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * fg);
+    bf16x8 qf[NKS];
+    load_row_frags<DH>(qf, q.p + (long long)qrow * q.s_n + h * q.s_h, fg);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, lsum = 0.f;
-    f32x4 acc[4] = {z4, z4, z4, z4};
+    f32x4 acc[NFD];
+#pragma unroll
+    for (int fd = 0; fd < NFD; ++fd) acc[fd] = z4;
     for (int c0 = 0; c0 < nk; c0 += VL_CH) {
         const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
         __syncthreads();
-        fill_chunk(Ks, k.p + (long long)(ks + c0) * k.s_n + h * k.s_h, k.s_n, rows, rows_pad, tid);
-        fill_chunk(Vs, v.p + (long long)(ks + c0) * v.s_n + h * v.s_h, v.s_n, rows, rows_pad, tid);
+        fill_chunk_t<DH>(Ks, k.p + (long long)(ks0 + c0) * k.s_n + h * k.s_h, k.s_n, rows, rows_pad, tid);
+        fill_chunk_t<DH>(Vs, v.p + (long long)(ks0 + c0) * v.s_n + h * v.s_h, v.s_n, rows, rows_pad, tid);
         __syncthreads();
         if (!wave_active) continue;
         for (int s = 0; s < (rows_pad >> 5); ++s) {
@@ -326,8 +368,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int row0 = s * 32 + hh * 16;
-                st[hh] = MFMA(row_frag(Ks, row0, 0, fi, fg), qf0, z4);
-                st[hh] = MFMA(row_frag(Ks, row0, 1, fi, fg), qf1, st[hh]);
+                st[hh] = mfma_over_d<DH>(Ks, row0, qf, fi, fg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = row0 + 4 * fg + r;
@@ -348,9 +389,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
             m = m_new;
             const bf16x8 pb = pack8(st[0], st[1]);
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) {
+            for (int fd = 0; fd < NFD; ++fd) {
                 acc[fd] *= alpha;
-                acc[fd] = MFMA(tr_frag(Vs, s * 32, fd * 16, fi, fg), pb, acc[fd]);
+                acc[fd] = MFMA(tr_frag_t<DH>(Vs, s * 32, fd * 16, fi, fg), pb, acc[fd]);
             }
         }
     }
@@ -360,49 +401,50 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
         const float inv = 1.0f / lsum;
         __bf16* op = o.p + (long long)(qs + qi) * o.s_n + h * o.s_h + 4 * fg;
 #pragma unroll
-        for (int fd = 0; fd < 4; ++fd) store4<__bf16>(op + fd * 16, acc[fd] * inv);
+        for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(op + fd * 16, acc[fd] * inv);
         if (fg == 0) lse[(long long)h * tq_total + qs + qi] = (m + log2f(lsum)) * LN2;
     }
 }
 
+template <int DH>
 __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
     HND q, HND k, HND v, HND o, HND dout, const float* __restrict__ lse, float* __restrict__ delta, HND dq,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
     const int* __restrict__ blk_r0, int tq_total, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * AT_LD];
+    constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
+    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     char* Ks = smem;
-    char* Vs = smem + VL_CH * AT_LD;
+    char* Vs = smem + VL_CH * LD;
     const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
     const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
-    const int ks = cu_k[seg], nk = cu_k[seg + 1] - ks;
+    const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
     const int qi = blk_r0[blockIdx.x] + wave * 16 + fi;
     const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nq;
     const int qrow = qs + (qi < nq ? qi : nq - 1);
-    const __bf16* qp = q.p + (long long)qrow * q.s_n + h * q.s_h;
-    const __bf16* dop = dout.p + (long long)qrow * dout.s_n + h * dout.s_h;
-    const __bf16* op = o.p + (long long)qrow * o.s_n + h * o.s_h;
-    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * fg);
-    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * fg);
-    const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * fg);
-    const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * fg);
-    const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(op + 8 * fg);
-    const bf16x8 of1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * fg);
-    float dl = dot8(df0, of0) + dot8(df1, of1);
+    bf16x8 qf[NKS], df[NKS], of[NKS];
+    load_row_frags<DH>(qf, q.p + (long long)qrow * q.s_n + h * q.s_h, fg);
+    load_row_frags<DH>(df, dout.p + (long long)qrow * dout.s_n + h * dout.s_h, fg);
+    load_row_frags<DH>(of, o.p + (long long)qrow * o.s_n + h * o.s_h, fg);
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) dl += dot8(df[ks], of[ks]);
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
     if (wave_active && qi < nq && fg == 0) delta[(long long)h * tq_total + qs + qi] = dl;
     const float l2 = lse[(long long)h * tq_total + qrow] * LOG2E;
     const float scale_log2e = scale * LOG2E;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[4] = {z4, z4, z4, z4};
+    f32x4 acc[NFD];
+#pragma unroll
+    for (int fd = 0; fd < NFD; ++fd) acc[fd] = z4;
     for (int c0 = 0; c0 < nk; c0 += VL_CH) {
         const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
         __syncthreads();
-        fill_chunk(Ks, k.p + (long long)(ks + c0) * k.s_n + h * k.s_h, k.s_n, rows, rows_pad, tid);
-        fill_chunk(Vs, v.p + (long long)(ks + c0) * v.s_n + h * v.s_h, v.s_n, rows, rows_pad, tid);
+        fill_chunk_t<DH>(Ks, k.p + (long long)(ks0 + c0) * k.s_n + h * k.s_h, k.s_n, rows, rows_pad, tid);
+        fill_chunk_t<DH>(Vs, v.p + (long long)(ks0 + c0) * v.s_n + h * v.s_h, v.s_n, rows, rows_pad, tid);
         __syncthreads();
         if (!wave_active) continue;
         for (int s = 0; s < (rows_pad >> 5); ++s) {
@@ -410,10 +452,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int row0 = s * 32 + hh * 16;
-                f32x4 st = MFMA(row_frag(Ks, row0, 0, fi, fg), qf0, z4);
-                st = MFMA(row_frag(Ks, row0, 1, fi, fg), qf1, st);
-                f32x4 dp = MFMA(row_frag(Vs, row0, 0, fi, fg), df0, z4);
-                dp = MFMA(row_frag(Vs, row0, 1, fi, fg), df1, dp);
+                const f32x4 st = mfma_over_d<DH>(Ks, row0, qf, fi, fg);
+                const f32x4 dp = mfma_over_d<DH>(Vs, row0, df, fi, fg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = row0 + 4 * fg + r;
@@ -423,48 +463,49 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
             }
             const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) acc[fd] = MFMA(tr_frag(Ks, s * 32, fd * 16, fi, fg), dsb, acc[fd]);
+            for (int fd = 0; fd < NFD; ++fd) acc[fd] = MFMA(tr_frag_t<DH>(Ks, s * 32, fd * 16, fi, fg), dsb, acc[fd]);
         }
     }
     if (wave_active && qi < nq) {
         __bf16* dqp = dq.p + (long long)(qs + qi) * dq.s_n + h * dq.s_h + 4 * fg;
 #pragma unroll
-        for (int fd = 0; fd < 4; ++fd) store4<__bf16>(dqp + fd * 16, acc[fd]);
+        for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(dqp + fd * 16, acc[fd]);
     }
 }
 
+template <int DH>
 __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
     HND q, HND k, HND v, HND dout, const float* __restrict__ lse, const float* __restrict__ delta, HND dk, HND dv,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
     const int* __restrict__ blk_r0, int tq_total, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * AT_LD + 2 * VL_CH * sizeof(float)];
+    constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
+    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD + 2 * VL_CH * sizeof(float)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     char* Qs = smem;
-    char* Ds = smem + VL_CH * AT_LD;
-    float* lse_s = reinterpret_cast<float*>(smem + 2 * VL_CH * AT_LD);
+    char* Ds = smem + VL_CH * LD;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * VL_CH * LD);
     float* del_s = lse_s + VL_CH;
     const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
     const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
-    const int ks = cu_k[seg], nk = cu_k[seg + 1] - ks;
+    const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
     const int ki = blk_r0[blockIdx.x] + wave * 16 + fi;        // key row inside the segment
     const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nk;
-    const int krow = ks + (ki < nk ? ki : nk - 1);
-    const __bf16* kp = k.p + (long long)krow * k.s_n + h * k.s_h;
-    const __bf16* vp = v.p + (long long)krow * v.s_n + h * v.s_h;
-    const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp + 8 * fg);
-    const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * fg);
-    const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + 8 * fg);
-    const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * fg);
+    const int krow = ks0 + (ki < nk ? ki : nk - 1);
+    bf16x8 kf[NKS], vf[NKS];
+    load_row_frags<DH>(kf, k.p + (long long)krow * k.s_n + h * k.s_h, fg);
+    load_row_frags<DH>(vf, v.p + (long long)krow * v.s_n + h * v.s_h, fg);
     const float scale_log2e = scale * LOG2E;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 accK[4] = {z4, z4, z4, z4}, accV[4] = {z4, z4, z4, z4};
+    f32x4 accK[NFD], accV[NFD];
+#pragma unroll
+    for (int fd = 0; fd < NFD; ++fd) { accK[fd] = z4; accV[fd] = z4; }
     for (int c0 = 0; c0 < nq; c0 += VL_CH) {
         const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
         __syncthreads();
-        fill_chunk(Qs, q.p + (long long)(qs + c0) * q.s_n + h * q.s_h, q.s_n, rows, rows_pad, tid);
-        fill_chunk(Ds, dout.p + (long long)(qs + c0) * dout.s_n + h * dout.s_h, dout.s_n, rows, rows_pad, tid);
+        fill_chunk_t<DH>(Qs, q.p + (long long)(qs + c0) * q.s_n + h * q.s_h, q.s_n, rows, rows_pad, tid);
+        fill_chunk_t<DH>(Ds, dout.p + (long long)(qs + c0) * dout.s_n + h * dout.s_h, dout.s_n, rows, rows_pad, tid);
         for (int r = tid; r < rows_pad; r += AT_THREADS) {
             lse_s[r] = r < rows ? lse[(long long)h * tq_total + qs + c0 + r] * LOG2E : 0.f;
             del_s[r] = r < rows ? delta[(long long)h * tq_total + qs + c0 + r] : 0.f;
@@ -476,10 +517,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int row0 = s * 32 + hh * 16;
-                f32x4 st = MFMA(row_frag(Qs, row0, 0, fi, fg), kf0, z4);
-                st = MFMA(row_frag(Qs, row0, 1, fi, fg), kf1, st);
-                f32x4 dp = MFMA(row_frag(Ds, row0, 0, fi, fg), vf0, z4);
-                dp = MFMA(row_frag(Ds, row0, 1, fi, fg), vf1, dp);
+                const f32x4 st = mfma_over_d<DH>(Qs, row0, kf, fi, fg);
+                const f32x4 dp = mfma_over_d<DH>(Ds, row0, vf, fi, fg);
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
 #pragma unroll
@@ -492,17 +531,17 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
             const bf16x8 pb = pack8(p[0], p[1]);
             const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) {
-                accV[fd] = MFMA(tr_frag(Ds, s * 32, fd * 16, fi, fg), pb, accV[fd]);
-                accK[fd] = MFMA(tr_frag(Qs, s * 32, fd * 16, fi, fg), dsb, accK[fd]);
+            for (int fd = 0; fd < NFD; ++fd) {
+                accV[fd] = MFMA(tr_frag_t<DH>(Ds, s * 32, fd * 16, fi, fg), pb, accV[fd]);
+                accK[fd] = MFMA(tr_frag_t<DH>(Qs, s * 32, fd * 16, fi, fg), dsb, accK[fd]);
             }
         }
     }
     if (wave_active && ki < nk) {
-        __bf16* dkp = dk.p + (long long)(ks + ki) * dk.s_n + h * dk.s_h + 4 * fg;
-        __bf16* dvp = dv.p + (long long)(ks + ki) * dv.s_n + h * dv.s_h + 4 * fg;
+        __bf16* dkp = dk.p + (long long)(ks0 + ki) * dk.s_n + h * dk.s_h + 4 * fg;
+        __bf16* dvp = dv.p + (long long)(ks0 + ki) * dv.s_n + h * dv.s_h + 4 * fg;
 #pragma unroll
-        for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd]); store4<__bf16>(dvp + fd * 16, accV[fd]); }
+        for (int fd = 0; fd < NFD; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd]); store4<__bf16>(dvp + fd * 16, accV[fd]); }
     }
 }
 
@@ -681,11 +720,13 @@ bool hnd_ok(vitk_hnd t) { return t.p && aligned16(t.p) && (t.s_h % 8 == 0) && (t
 extern "C" int vitk_attn_varlen_fwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse, const int32_t* cu_q,
                                          const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0, int64_t nblk,
                                          int64_t tq_total, int64_t H, int64_t d, float scale, void* stream) {
-    if (d != 64) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: needs dim_head == 64 (got %lld)", (long long)d);
+    if (d != 64 && d != 80) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: needs dim_head 64 or 80 (got %lld)", (long long)d);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !lse || !cu_q || !cu_k || !blk_seg || !blk_r0)
         VITK_FAIL(VITK_E_ALIGN, "attn_varlen_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     if (nblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: empty problem");
-    hipLaunchKernelGGL(attn_varlen_fwd_kernel, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q),
+    if (d == 64) hipLaunchKernelGGL(attn_varlen_fwd_kernel<64>, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q),
+                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E);
+    else hipLaunchKernelGGL(attn_varlen_fwd_kernel<80>, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q),
                        to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E);
     VITK_CHECK_LAUNCH("attn_varlen_fwd_bf16");
     return 0;
@@ -696,17 +737,19 @@ extern "C" int vitk_attn_varlen_bwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vit
                                          const int32_t* cu_k, const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
                                          const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk, int64_t tq_total,
                                          int64_t H, int64_t d, float scale, void* stream) {
-    if (d != 64) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: needs dim_head == 64 (got %lld)", (long long)d);
+    if (d != 64 && d != 80) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: needs dim_head 64 or 80 (got %lld)", (long long)d);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !hnd_ok(dout) || !hnd_ok(dq) || !hnd_ok(dk) || !hnd_ok(dv) || !lse ||
         !delta || !cu_q || !cu_k || !qblk_seg || !qblk_r0 || !kblk_seg || !kblk_r0)
         VITK_FAIL(VITK_E_ALIGN, "attn_varlen_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     if (nqblk <= 0 || nkblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: empty problem");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_varlen_bwd_dq_kernel, dim3((unsigned)nqblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k),
-                       to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale);
-    VITK_CHECK_LAUNCH("attn_varlen_bwd_dq");
-    hipLaunchKernelGGL(attn_varlen_bwd_dkv_kernel, dim3((unsigned)nkblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k),
-                       to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale);
+#define VL_BWD(DHV) do { \
+    hipLaunchKernelGGL(attn_varlen_bwd_dq_kernel<DHV>, dim3((unsigned)nqblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k), \
+                       to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale); \
+    hipLaunchKernelGGL(attn_varlen_bwd_dkv_kernel<DHV>, dim3((unsigned)nkblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k), \
+                       to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale); } while (0)
+    if (d == 64) VL_BWD(64); else VL_BWD(80);
+#undef VL_BWD
     VITK_CHECK_LAUNCH("attn_varlen_bwd_dkv");
     return 0;
 }

@@ -222,6 +222,17 @@ __global__ __launch_bounds__(256) void csr_rowsum_kernel(const GT* __restrict__ 
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void copy_cols_kernel(const T* __restrict__ src, long long lds_, T* __restrict__ dst, long long ldd,
+                                                         long long rows, int cols_copy, int cols_dst) {
+    const long long total = rows * cols_dst;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols_dst;
+        const int c = (int)(i % cols_dst);
+        dst[r * ldd + c] = c < cols_copy ? src[r * lds_ + c] : from_f32<T>(0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int vitk_patchify(const void* img, void* out, int dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p1,
@@ -387,5 +398,16 @@ extern "C" int vitk_csr_rowsum(const void* g, int gdt, const int32_t* ptr, const
     else if (gdt == VITK_BF16 && odt == VITK_F32) hipLaunchKernelGGL((csr_rowsum_kernel<__bf16, float>), dim3((unsigned)nseg), dim3(256), 0, st, (const __bf16*)g, ptr, rows, (float*)out, D4);
     else VITK_FAIL(VITK_E_DTYPE, "csr_rowsum: bad dtype");
     VITK_CHECK_LAUNCH("csr_rowsum");
+    return 0;
+}
+
+extern "C" int vitk_copy_cols(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int dt, int64_t rows, int64_t cols_copy,
+                              int64_t cols_dst, void* stream) {
+    if (!src || !dst) VITK_FAIL(VITK_E_ARG, "copy_cols: null pointer");
+    if (rows <= 0 || cols_copy < 0 || cols_dst <= 0 || cols_copy > cols_dst || cols_dst > ld_dst || cols_copy > ld_src)
+        VITK_FAIL(VITK_E_SHAPE, "copy_cols: bad extents");
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((copy_cols_kernel<T>), dim3(ew_blocks(rows * cols_dst)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)src, (long long)ld_src, (T*)dst, (long long)ld_dst, (long long)rows, (int)cols_copy, (int)cols_dst));
+    VITK_CHECK_LAUNCH("copy_cols");
     return 0;
 }

@@ -301,13 +301,21 @@ class PatchEmbedFn(torch.autograd.Function):
         K.patchify(img, patches, B, C, H, W, p1, p2)
         pn = ops.empty((Mp, P), T, img)
         st1 = ops.ln_fwd(patches, ln1w, ln1b, Mp, P, pn)
-        y = ops.linear_fwd(pn, w, b, Mp)
+        # patch_dim that is not a multiple of 32 (ViT-H/14: 3*14*14 = 588): zero-pad the contraction to the MFMA K-step
+        Pp = (P + 31) // 32 * 32 if (T != F32 and P % 32) else P
+        if Pp != P:
+            pn = ops.pad_cols(pn, Mp, P, Pp)
+            w_mm = ops.pad_cols(w, D, P, Pp)
+        else:
+            w_mm = w
+        y = ops.linear_fwd(pn, w_mm, b, Mp)
         x0 = ops.empty((B, N, D), F32, img)
         st2 = ops.ln_fwd(y, ln2w, ln2b, Mp, D, x0, omap=RowMap(Np, N, ncls), add=pos, add_group=Np, add_off=ncls)
         if ncls:
             K.write_cls_rows(x0, cls, pos, B, N, D, ncls)
         ctx.save_for_backward(ln1w, ln1b, w, ln2w, ln2b, *([b] if b is not None else []))
         ctx.inter = (patches, st1, pn, y, st2)
+        ctx.pad = (Pp, w_mm if Pp != P else None)
         ctx.cls_pos = (cls, pos)
         ctx.meta = (B, Np, N, P, D, ncls, b is not None, cls is not None, pos is not None and pos.requires_grad,
                     pos.shape if pos is not None else None)
@@ -350,8 +358,15 @@ class PatchEmbedFn(torch.autograd.Function):
                    dw=dl2w, db=dl2b, dymap=RowMap(Np, N, ncls))
         dw = _grad_buf(w)
         db = _grad_buf(bparam) if has_b else None
-        ops.linear_dw(dyp, pn, Mp, dw, db)
-        dpn = ops.linear_dx(dyp, w, Mp)
+        Pp, w_pad = ctx.pad
+        if Pp != P:
+            dw_pad = ops.empty((D, Pp), T, g)
+            ops.linear_dw(dyp, pn, Mp, dw_pad, db)
+            ops.unpad_cols(dw_pad, D, Pp, P, out=dw)
+            dpn = ops.unpad_cols(ops.linear_dx(dyp, w_pad, Mp), Mp, Pp, P)
+        else:
+            ops.linear_dw(dyp, pn, Mp, dw, db)
+            dpn = ops.linear_dx(dyp, w, Mp)
         dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
         ops.ln_bwd(dpn, patches, ln1w, st1[0], st1[1], Mp, P, dw=dl1w, db=dl1b)  # the image needs no gradient
         s = _sink()

@@ -235,3 +235,7 @@ def gather_add2(x: Tensor, A: Tensor, ia: Tensor, B: Tensor, ib: Tensor, out: Te
 
 def csr_rowsum(g: Tensor, ptr: Tensor, rows: Tensor, out: Tensor, nseg: int, D: int):
     check(L.load().vitk_csr_rowsum(_p(g), dt(g), _p(ptr), _p(rows), _p(out), dt(out), nseg, D, _stream()), "csr_rowsum")
+
+
+def copy_cols(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, cols_copy: int, cols_dst: int):
+    check(L.load().vitk_copy_cols(_p(src), ld_src, _p(dst), ld_dst, dt(src), rows, cols_copy, cols_dst, _stream()), "copy_cols")

@@ -74,33 +74,7 @@ def group_images_by_max_seq_len(images: List[Tensor], patch_size: int, calc_toke
     return groups
 
 
-# ---- segment bookkeeping (host) -------------------------------------------------------------------
-class Segments:
-    """Per-image token ranges of a packed batch, plus the 128-row block tables the varlen kernels walk."""
-    BLOCK = 128
-
-    def __init__(self, q_lens, k_lens, device):
-        self.q_lens, self.k_lens = list(map(int, q_lens)), list(map(int, k_lens))
-        assert len(self.q_lens) == len(self.k_lens)
-        self.nseg = len(self.q_lens)
-        cu_q = np.concatenate([[0], np.cumsum(self.q_lens)]).astype(np.int32)
-        cu_k = np.concatenate([[0], np.cumsum(self.k_lens)]).astype(np.int32)
-        self.cu_q_host, self.cu_k_host = cu_q, cu_k
-        self.tq, self.tk = int(cu_q[-1]), int(cu_k[-1])
-
-        def blocks(lens):
-            seg, r0 = [], []
-            for s, n in enumerate(lens):
-                for b in range(0, max(n, 1), self.BLOCK):
-                    seg.append(s); r0.append(b)
-            return np.asarray(seg, np.int32), np.asarray(r0, np.int32)
-
-        qs, qr = blocks(self.q_lens)
-        ks, kr = blocks(self.k_lens)
-        up = lambda a: torch.from_numpy(a).to(device)
-        self.cu_q, self.cu_k = up(cu_q), up(cu_k)
-        self.qblk_seg, self.qblk_r0, self.kblk_seg, self.kblk_r0 = up(qs), up(qr), up(ks), up(kr)
-        self.nqblk, self.nkblk = len(qs), len(ks)
+from .segments import Segments  # noqa: E402  (re-exported: tests and users import it from here)
 
 
 class _QKNormAttnFn(torch.autograd.Function):

@@ -19,6 +19,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from ._lib import IDENT, RowMap
+from .segments import uniform_segments
 
 Tensor = torch.Tensor
 BF16 = torch.bfloat16
@@ -142,9 +143,28 @@ def linear_dw(dy: Tensor, x: Tensor, M: int, dW: Tensor, db: Optional[Tensor] = 
         colsum(dy, M, N, db)
 
 
+def pad_cols(x: Tensor, rows: int, cols: int, cols_pad: int) -> Tensor:
+    """(rows, cols) -> (rows, cols_pad) with zero columns appended (K padding for the MFMA GEMMs)."""
+    out = empty((rows, cols_pad), x.dtype, x)
+    K.copy_cols(x, cols, out, cols_pad, rows, cols, cols_pad)
+    return out
+
+
+def unpad_cols(x: Tensor, rows: int, cols_pad: int, cols: int, out: Optional[Tensor] = None) -> Tensor:
+    out = out if out is not None else empty((rows, cols), x.dtype, x)
+    K.copy_cols(x, cols_pad, out, cols, rows, cols, cols)
+    return out
+
+
 # ---- attention core --------------------------------------------------------------------------------
 def attn_fast_ok(T, N: int, d: int) -> bool:
+    """whole-head-in-LDS kernels: bf16, dim_head 64, N <= 480"""
     return T == BF16 and d == 64 and 1 <= N <= 480
+
+
+def attn_varlen_ok(T, d: int) -> bool:
+    """chunked kernels (any N): bf16, dim_head 64 or 80 (ViT-H/14: dim_head 80, N = 577)"""
+    return T == BF16 and d in (64, 80)
 
 
 def attn_fwd(qkv: Tensor, B: int, N: int, H: int, d: int, scale: float):
@@ -158,6 +178,12 @@ def attn_fwd(qkv: Tensor, B: int, N: int, H: int, d: int, scale: float):
         lse = empty((B, H, N), F32, qkv)
         K.attn_fwd_bf16(K.bhnd(qkv, sb, sh, sn), K.bhnd(qkv, sb, sh, sn, offset=I), K.bhnd(qkv, sb, sh, sn, offset=2 * I),
                         K.bhnd(o, N * I, d, I), lse, B, H, N, d, scale)
+        return o, lse
+    if attn_varlen_ok(T, d):
+        sg = uniform_segments(B, N, qkv.device)
+        lse = empty((H, B * N), F32, qkv)
+        K.attn_varlen_fwd_bf16(K.hnd(qkv, d, sn), K.hnd(qkv, d, sn, offset=I), K.hnd(qkv, d, sn, offset=2 * I), K.hnd(o, d, I), lse,
+                               sg.cu_q, sg.cu_k, sg.qblk_seg, sg.qblk_r0, sg.nqblk, B * N, H, d, scale)
         return o, lse
     # materialising path: S = q k^T ; P = softmax(scale*S) ; O = P v   (batched over (B, H) in place)
     S = empty((B, H, N, N), T, qkv)
@@ -182,6 +208,14 @@ def attn_bwd(qkv: Tensor, o: Tensor, do: Tensor, saved: Tensor, B: int, N: int, 
                         K.bhnd(o, N * I, d, I), K.bhnd(do, N * I, d, I), saved, delta,
                         K.bhnd(dqkv, sb, sh, sn), K.bhnd(dqkv, sb, sh, sn, offset=I), K.bhnd(dqkv, sb, sh, sn, offset=2 * I),
                         B, H, N, d, scale)
+        return dqkv
+    if attn_varlen_ok(T, d):
+        sg = uniform_segments(B, N, qkv.device)
+        delta = empty((H, B * N), F32, qkv)
+        K.attn_varlen_bwd_bf16(K.hnd(qkv, d, sn), K.hnd(qkv, d, sn, offset=I), K.hnd(qkv, d, sn, offset=2 * I), K.hnd(o, d, I),
+                               K.hnd(do, d, I), saved, delta, K.hnd(dqkv, d, sn), K.hnd(dqkv, d, sn, offset=I),
+                               K.hnd(dqkv, d, sn, offset=2 * I), sg.cu_q, sg.cu_k, sg.qblk_seg, sg.qblk_r0, sg.nqblk,
+                               sg.kblk_seg, sg.kblk_r0, sg.nkblk, B * N, H, d, scale)
         return dqkv
     P = saved
     pm = K.mat(P, N, 1, H * N * N, N * N)
