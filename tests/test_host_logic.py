@@ -79,7 +79,8 @@ def test_flop_model_matches_survey_table():
 def test_flat_gradient_layout_is_reverse_readiness():
     m = ViT(image_size=32, patch_size=8, num_classes=10, dim=32, depth=3, heads=2, mlp_dim=64)
     names = {id(p): n for n, p in m.named_parameters()}
-    params, n_early = _ordered_params(m)
+    params, n_early, layer_end = _ordered_params(m)
+    assert sorted(layer_end) == [0, 1, 2] and layer_end[2] < layer_end[1] < layer_end[0] == n_early
     order = [names[id(p)] for p in params]
     assert order[0].startswith("mlp_head") and order[2].startswith("transformer.norm")
     layer_of = [int(n.split(".")[2]) for n in order if n.startswith("transformer.layers.")]

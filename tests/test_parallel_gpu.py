@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
         cfg = dict(image_size=32, patch_size=8, num_classes=10, dim=64, depth=2, heads=2, mlp_dim=128)
         torch.manual_seed(100 + rank)                                   # different init: broadcast must align the ranks
         model = ViT(**cfg).to("cuda", dtype=torch.bfloat16)
-        dp = DataParallel(model)
+        dp = DataParallel(model, layers_per_chunk=1)                       # one chunk per layer: exercises the chunked path
         torch.manual_seed(200 + rank)
         x = torch.randn(4, 3, 32, 32, device="cuda").to(torch.bfloat16)
         # local gradients without the wrapper
@@ -37,7 +37,8 @@ def _worker(rank, world, port, q):
         model(x).float().square().mean().backward()
         local = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
         dp.backward(dp(x).float().square().mean())
-        assert dp.sink._early_launched and dp.sink._late_launched           # both collectives left from inside backward
+        assert dp.sink._early_launched and dp.sink._late_launched           # all collectives left from inside backward
+        assert dp.sink._cursor == dp.sink.boundary
         assert len(dp.sink._filled) == len([p for p in dp.sink.params if p.numel()])  # every gradient went straight to the sink
         worst = 0.0
         for i, (n, p) in enumerate(model.named_parameters()):

@@ -262,6 +262,10 @@ class TransformerFn(torch.autograd.Function):
             grads[base + 0], grads[base + 1] = dl1w, dl1b
             g, gb = g1, g1b
             del g2, g2b, da1
+            sk = _sink()
+            if sk is not None and sk.wants_layer(li):
+                fork.join()                      # this layer's weight gradients (side stream) are part of the chunk
+                sk.stage_done("layer", li)
         fork.join()
         s = _sink()
         if s is not None:

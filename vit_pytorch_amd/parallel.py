@@ -7,10 +7,11 @@ hooks per parameter).  This is the MI355X-first replacement for that step:
   * every parameter gradient is written by the backward kernels DIRECTLY into one flat buffer
     (engine.set_grad_sink), laid out in reverse-readiness order: head, final norm, layers
     depth-1 .. 0, then the patch-embedding stage (cls, pos, patch Linear, LayerNorms);
-  * when the transformer stage's backward has been enqueued, ONE all-reduce of the big
-    segment (everything but the patch-embedding stage: >99% of the bytes) is launched on a side
-    stream behind an event, so it overlaps the patch-embedding backward (north_star); the small
-    patch-embedding segment follows as a second collective when its gradients are enqueued;
+  * during the transformer backward, every `layers_per_chunk` layers the contiguous slice finished so
+    far is all-reduced on a side stream behind an event (3-4 large messages for ViT-B, overlapping
+    the backward of the layers below); the remainder of the big segment goes out when the transformer
+    stage is done and overlaps the patch-embedding backward (north_star); the small patch-embedding
+    segment follows as the last collective when its gradients are enqueued;
   * xGMI is point-to-point (7 links/GPU): a few large collectives beat many 25 MiB buckets, so
     there is no bucketing at all -- 173 MB (ViT-B bf16) / 609 MB (ViT-L) go out as one message
     and RCCL picks its algorithm for the fully connected 8-GPU node.
@@ -28,13 +29,14 @@ import torch.distributed as dist
 from . import engine as E
 
 
-def _ordered_params(model: torch.nn.Module) -> (List[torch.nn.Parameter], int):
-    """Parameters in reverse-readiness order and the index where the late (patch-embed) stage starts."""
+def _ordered_params(model: torch.nn.Module):
+    """Parameters in reverse-readiness order, the index where the late (patch-embed) stage starts, and for every
+    transformer layer the index one past its last parameter (layers are laid out depth-1 .. 0)."""
     params = [p for p in model.parameters() if p.requires_grad]
     late_names = ("to_patch_embedding", "cls_token", "pos_embedding")
     named = list(model.named_parameters())
     if not any(n.startswith(late_names) for n, _ in named):
-        return params, len(params)
+        return params, len(params), {}
     early, late = [], []
     for n, p in named:
         if not p.requires_grad:
@@ -52,17 +54,22 @@ def _ordered_params(model: torch.nn.Module) -> (List[torch.nn.Parameter], int):
         return (3, 0)
 
     early.sort(key=key)
-    return [p for _, p in early] + [p for _, p in late], len(early)
+    layer_end = {}
+    for i, (n, _) in enumerate(early):
+        if n.startswith("transformer.layers."):
+            layer_end[int(n.split(".")[2])] = i + 1
+    return [p for _, p in early] + [p for _, p in late], len(early), layer_end
 
 
 class FlatGradSink:
     """Owns the flat gradient buffer; handed to the engine as the gradient sink."""
 
-    def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True):
+    def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True, layers_per_chunk: int = 3):
         self.model = model
         self.group = process_group
         self.average = average
-        self.params, self.n_early = _ordered_params(model)
+        self.params, self.n_early, layer_end = _ordered_params(model)
+        self.layers_per_chunk = layers_per_chunk
         p0 = self.params[0]
         self.dtype, self.device = p0.dtype, p0.device
         assert all(p.dtype == self.dtype and p.device == self.device for p in self.params), \
@@ -74,6 +81,9 @@ class FlatGradSink:
         self.offsets = offs
         self.total = total
         self.boundary = offs[self.n_early] if self.n_early < len(self.params) else total
+        # flat offset one past layer li's gradients (layers are stored depth-1 .. 0)
+        self.layer_end_off = {li: (offs[i] if i < len(offs) else total) for li, i in layer_end.items()}
+        self._cursor = 0
         self.flat = torch.zeros(total, dtype=self.dtype, device=self.device)
         self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
         self._by_ptr: Dict[int, int] = {p.data_ptr(): i for i, p in enumerate(self.params) if p.numel()}
@@ -92,15 +102,31 @@ class FlatGradSink:
         self._filled.add(i)
         return self.views[i]
 
+    def wants_layer(self, layer: int) -> bool:
+        return self.world > 1 and self.layers_per_chunk > 0 and layer % self.layers_per_chunk == 0 and layer in self.layer_end_off
+
     def owns(self, t: torch.Tensor) -> bool:
         return t.data_ptr() in self._view_ptrs
 
-    def stage_done(self, stage: str):
-        """Called from inside backward (autograd thread) when a stage's gradients are enqueued."""
+    def stage_done(self, stage: str, layer: int = -1):
+        """Called from inside backward (autograd thread) when a stage's gradients are enqueued.
+
+        "layer" (every transformer layer, depth-1 .. 0): every `layers_per_chunk` layers the contiguous slice of the
+        flat buffer finished so far goes out as one all-reduce on the side stream, overlapping the backward of the
+        layers below it.  "transformer": whatever is left of the early segment.  "patch_embed": the late segment."""
         if self.world == 1:
             return
-        if stage == "transformer" and not self._early_launched and self.boundary > 0:
-            self._launch(self.flat[:self.boundary])
+        if stage == "layer":
+            end = self.layer_end_off.get(layer)
+            if end is None or self.layers_per_chunk <= 0:
+                return
+            if layer % self.layers_per_chunk == 0 and end > self._cursor:
+                self._launch(self.flat[self._cursor:end])
+                self._cursor = end
+        elif stage == "transformer" and not self._early_launched and self.boundary > 0:
+            if self.boundary > self._cursor:
+                self._launch(self.flat[self._cursor:self.boundary])
+                self._cursor = self.boundary
             self._early_launched = True
         elif stage == "patch_embed" and not self._late_launched and self.boundary < self.total:
             self._launch(self.flat[self.boundary:])
@@ -127,6 +153,7 @@ class FlatGradSink:
     # ---- step-facing ----------------------------------------------------------------------------
     def begin_step(self):
         self._filled.clear()
+        self._cursor = 0
         self._early_launched = self._late_launched = False
         for p in self.params:
             p.grad = None
@@ -147,11 +174,11 @@ class FlatGradSink:
             early_was, late_was = self._early_launched, self._late_launched
             if self.side is not None:
                 torch.cuda.current_stream(self.device).wait_stream(self.side)
-            if not early_was and not late_was:
+            if not early_was and not late_was and self._cursor == 0:
                 self._allreduce(self.flat)                       # nothing went out during backward: one collective
             else:
-                if not early_was and self.boundary > 0:
-                    self._allreduce(self.flat[:self.boundary])
+                if not early_was and self.boundary > self._cursor:
+                    self._allreduce(self.flat[self._cursor:self.boundary])
                 if not late_was and self.boundary < self.total:
                     self._allreduce(self.flat[self.boundary:])
                 for i in missing:                                # arrived after their segment had already gone out
@@ -170,10 +197,11 @@ class DataParallel(torch.nn.Module):
         optimizer.step()
     """
 
-    def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True, broadcast: bool = True):
+    def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True, broadcast: bool = True,
+                 layers_per_chunk: int = 3):
         super().__init__()
         self.module = model
-        self.sink = FlatGradSink(model, process_group, average)
+        self.sink = FlatGradSink(model, process_group, average, layers_per_chunk)
         if broadcast and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             for p in model.parameters():
                 dist.broadcast(p.data, src=0, group=process_group)
