@@ -398,3 +398,47 @@ def test_dropout_statistics_and_backward():
     dy = rnd(n, dtype=BF, seed=103); dx = torch.empty_like(dy)
     K.dropout_bwd(dy, mask, dx, p)
     assert rel(dx, dy.float() * mask.float() / (1 - p)) < 4e-3
+
+
+# ---- NaViT / ViT-H data movement -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [F32, BF])
+def test_patchify_cpp_order_and_row_offset(dtype):
+    C, H, W, p = 3, 24, 40, 8
+    img = rnd(C, H, W, dtype=dtype, seed=201)
+    n = (H // p) * (W // p)
+    out = torch.zeros(n + 5, C * p * p, dtype=dtype, device=DEV)
+    K.patchify_cpp(img, out, C, H, W, p, 3, C * p * p)
+    ref = img.reshape(C, H // p, p, W // p, p).permute(1, 3, 0, 2, 4).reshape(n, C * p * p)   # (h w) (c p1 p2)
+    assert torch.equal(out[3:3 + n], ref)
+    assert out[:3].abs().max().item() == 0 and out[3 + n:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", [F32, BF])
+def test_gather_add2_and_csr_rowsum(dtype):
+    T, D, nh, nw = 50, 64, 5, 7
+    x = rnd(T, D, dtype=dtype, seed=202); A = rnd(nh, D, dtype=dtype, seed=203); Bm = rnd(nw, D, dtype=dtype, seed=204)
+    g = torch.Generator().manual_seed(5)
+    ia = torch.randint(0, nh, (T,), generator=g).to(torch.int32).to(DEV); ib = torch.randint(0, nw, (T,), generator=g).to(torch.int32).to(DEV)
+    out = torch.empty_like(x)
+    K.gather_add2(x, A, ia, Bm, ib, out, T, D)
+    ref = x.double() + A.double()[ia.long()] + Bm.double()[ib.long()]
+    assert rel(out, ref) < (1e-6 if dtype == F32 else 4e-3)
+    # backward of the gather: dA[i] = sum of g over the tokens with ia == i (deterministic CSR form)
+    gr = rnd(T, D, dtype=dtype, seed=205)
+    order = torch.argsort(ia.long(), stable=True).to(torch.int32)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(ia.long().cpu(), minlength=nh).cumsum(0)]).to(torch.int32).to(DEV)
+    dA = torch.empty(nh, D, dtype=dtype, device=DEV)
+    K.csr_rowsum(gr, ptr, order, dA, nh, D)
+    refA = torch.zeros(nh, D, dtype=torch.float64, device=DEV).index_add_(0, ia.long(), gr.double())
+    assert rel(dA, refA) < (1e-6 if dtype == F32 else 6e-3)
+
+
+def test_copy_cols_pad_and_strip():
+    rows, cols, pad = 37, 588, 608
+    x = rnd(rows, cols, dtype=BF, seed=206)
+    y = torch.full((rows, pad), 7.0, dtype=BF, device=DEV)
+    K.copy_cols(x, cols, y, pad, rows, cols, pad)
+    assert torch.equal(y[:, :cols], x) and y[:, cols:].abs().max().item() == 0
+    z = torch.empty(rows, cols, dtype=BF, device=DEV)
+    K.copy_cols(y, pad, z, cols, rows, cols, cols)
+    assert torch.equal(z, x)

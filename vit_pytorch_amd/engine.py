@@ -23,7 +23,6 @@ buffer and to be told when the transformer's gradients are complete (data-parall
 """
 from __future__ import annotations
 
-import threading
 from typing import List, Optional
 
 import torch
@@ -35,7 +34,6 @@ from ._lib import RowMap, VitkError
 Tensor = torch.Tensor
 F32 = torch.float32
 
-_sink_local = threading.local()
 _sink_global = [None]
 
 
@@ -115,9 +113,6 @@ class _Fork:
 def _check_dims(D: int, what: str):
     if D % 4 != 0:
         raise VitkError(f"{what}: feature dimension {D} must be a multiple of 4 for the HIP kernels")
-
-
-LAYER_NPARAM = 10  # ln1_w, ln1_b, Wqkv, Wout, bout, ln2_w, ln2_b, W1, b1, W2, b2 -> see pack order below
 
 
 def pack_layer_params(attn, ff) -> List[Optional[Tensor]]:

@@ -42,11 +42,6 @@ def require_device(*ts: Tensor):
                 f"{t.device}. Move the module and its input to 'cuda'. There is no CPU path.")
 
 
-def _c(t: Tensor) -> Tensor:
-    assert t.is_contiguous(), "libvitk wrappers take contiguous tensors"
-    return t
-
-
 # ---- LayerNorm -------------------------------------------------------------------------------
 def layernorm_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], y: Tensor, mean: Tensor, rstd: Tensor,
                   rows: int, D: int, eps: float = 1e-5, imap: RowMap = IDENT, omap: RowMap = IDENT,
