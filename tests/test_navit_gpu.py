@@ -149,3 +149,33 @@ def test_navit_grouping_and_token_dropout_run():
     m.eval()
     a = m(imgs); b = m([imgs[:2], imgs[2:]])            # packing must not change the result
     assert torch.equal(a, b)
+
+
+def test_navit_fused_stack_vs_op_by_op():
+    """The fused packed-token engine (engine.PackedTransformerFn) against the op-by-op module path and an f32 run."""
+    cfg = dict(image_size=128, patch_size=8, num_classes=11, dim=256, depth=3, heads=4, mlp_dim=512)
+    sizes = [[(64, 64), (128, 40), (8, 8)], [(96, 120), (16, 72)]]
+    torch.manual_seed(3)
+    base = NaViT(**cfg)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    imgs = [[torch.randn(3, h, w, generator=g) for (h, w) in pack] for pack in sizes]
+
+    def run(dtype, fused):
+        m = NaViT(**cfg)
+        m.load_state_dict(sd)
+        m = m.to(DEV, dtype=dtype).eval()
+        if not fused:
+            m.transformer.norm.register_forward_hook(lambda *a: None)       # any hook turns the fused stack off
+        assert m.transformer._fusable(torch.empty(1, dtype=dtype)) == (fused and dtype == BF)
+        out = m([[im.to(DEV, dtype=dtype) for im in p] for p in imgs])
+        NO.O.loss_fn(out).backward()
+        return out, torch.cat([p.grad.detach().float().flatten() for p in m.parameters()])
+
+    o32, g32 = run(torch.float32, False)
+    of, gf = run(BF, True)
+    ou, gu = run(BF, False)
+    ef, eu = rel(of, o32), rel(ou, o32)
+    df, du = rel(gf, g32), rel(gu, g32)
+    print(f"fused: logits {ef:.2e} grads {df:.2e}; op-by-op: logits {eu:.2e} grads {du:.2e}")
+    assert ef <= 1.5 * eu + 1e-3 and df <= 1.5 * du + 1e-3

@@ -421,3 +421,150 @@ class HeadFn(torch.autograd.Function):
         if s is not None:
             s.stage_done("head")
         return dy, None, _ret(dw), _ret(db)
+
+
+# ==================================================================================================
+# NaViT transformer stack (na_vit.py:171-193) on packed tokens -- the same fusion plan as TransformerFn
+# (f32 residual stream, GEMM epilogues for bias+GELU / residual, LayerNorm backward producing the bias
+# column sums, weight gradients on the side stream) with NaViT's block: LayerNorms without bias, separate
+# to_q / to_kv weights (concatenated once per call so q|k|v is ONE GEMM into a merged buffer), RMSNorm on
+# q and k per head, variable-length attention over per-image token ranges (scale = 1), bias-free to_out.
+# ==================================================================================================
+NLP_NAVIT = 11  # ln1_g, wq, wkv, gq, gk, wout, ln2_g, w1, b1, w2, b2
+
+
+def pack_navit_layer_params(attn, ff) -> List[Tensor]:
+    return [attn.norm.gamma, attn.to_q.weight, attn.to_kv.weight, attn.q_norm.gamma, attn.k_norm.gamma,
+            attn.to_out[0].weight, ff[0].gamma, ff[1].weight, ff[1].bias, ff[4].weight, ff[4].bias]
+
+
+def _cat_rows(a: Tensor, b: Tensor) -> Tensor:
+    out = torch.empty((a.shape[0] + b.shape[0], a.shape[1]), dtype=a.dtype, device=a.device)
+    K.cast(a, out[:a.shape[0]])
+    K.cast(b, out[a.shape[0]:])
+    return out
+
+
+class PackedTransformerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, segs, heads: int, dim_head: int, norm_g, *lp):
+        K.require_device(x, norm_g)
+        depth = len(lp) // NLP_NAVIT
+        T = norm_g.dtype
+        Tn, D = x.shape
+        _check_dims(D, "NaViT Transformer")
+        I = heads * dim_head
+        d = dim_head
+        if T != torch.bfloat16 or d != 64:
+            raise VitkError("PackedTransformerFn: fused NaViT stack needs bfloat16 parameters and dim_head == 64")
+        x = x.contiguous()
+        if x.dtype == F32:
+            xs = x
+        else:
+            xs = ops.empty((Tn, D), F32, x)
+            K.cast(x, xs)
+        saved = []
+        for li in range(depth):
+            ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
+            a1 = ops.empty((Tn, D), T, xs)
+            st1 = ops.ln_fwd(xs, ln1g, None, Tn, D, a1)
+            wcat = _cat_rows(wq, wkv)                                   # (3I, D): q | k | v in one GEMM
+            qkv = ops.linear_fwd(a1, wcat, None, Tn)
+            gqf, gkf = gq.reshape(heads, d).contiguous(), gk.reshape(heads, d).contiguous()
+            qn = ops.empty((Tn, I), T, xs); kn = ops.empty((Tn, I), T, xs)
+            rq = ops.empty((Tn * heads,), F32, xs); rk = ops.empty((Tn * heads,), F32, xs)
+            K.rmsnorm_heads_fwd(qkv, 3 * I, gqf, qn, I, rq, Tn, heads, d)
+            K.rmsnorm_heads_fwd(qkv, 3 * I, gkf, kn, I, rk, Tn, heads, d, x_off=I)
+            o = ops.empty((Tn, I), T, xs)
+            lse = ops.empty((heads, Tn), F32, xs)
+            K.attn_varlen_fwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(qkv, d, 3 * I, offset=2 * I), K.hnd(o, d, I), lse,
+                                   segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, Tn, heads, d, 1.0)
+            x2 = ops.linear_fwd(o, wout, None, Tn, resid=xs)
+            a2 = ops.empty((Tn, D), T, xs)
+            st2 = ops.ln_fwd(x2, ln2g, None, Tn, D, a2)
+            act, pre = ops.linear_fwd(a2, w1, b1, Tn, gelu=True)
+            x3 = ops.linear_fwd(act, w2, b2, Tn, resid=x2)
+            saved.append((xs, a1, st1, wcat, qkv, gqf, gkf, qn, kn, rq, rk, o, lse, x2, a2, st2, pre, act))
+            xs = x3
+        y = ops.empty((Tn, D), T, xs)
+        stf = ops.ln_fwd(xs, norm_g, None, Tn, D, y)
+        ctx.saved = saved
+        ctx.x_last, ctx.stf = xs, stf
+        ctx.meta = (segs, heads, dim_head, depth, Tn, D, x.dtype)
+        ctx.save_for_backward(norm_g, *lp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        segs, heads, d, depth, Tn, D, in_dtype = ctx.meta
+        sv = list(ctx.saved_tensors)
+        norm_g, lp = sv[0], sv[1:]
+        T = norm_g.dtype
+        I = heads * d
+        dy = dy.contiguous()
+        grads: List[Optional[Tensor]] = [None] * len(lp)
+        fork = _Fork(dy.device)
+
+        def newg():
+            return ops.empty((Tn, D), F32, dy), ops.empty((Tn, D), T, dy)
+
+        g, gb = newg()
+        dng = _grad_buf(norm_g)
+        dcol = ops.empty((D,), F32, dy)
+        ops.ln_bwd(dy, ctx.x_last, norm_g, ctx.stf[0], ctx.stf[1], Tn, D, dx_f32=g, dx_t=gb, dw=dng, dcol=dcol)
+        ctx.x_last = None
+        for li in reversed(range(depth)):
+            ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
+            xs, a1, st1, wcat, qkv, gqf, gkf, qn, kn, rq, rk, o, lse, x2, a2, st2, pre, act = ctx.saved[li]
+            ctx.saved[li] = None
+            base = li * NLP_NAVIT
+            # ---- feed-forward ----
+            dw2 = _grad_buf(w2)
+            fork.run(lambda: ops.linear_dw(gb, act, Tn, dw2), gb, act, dw2)
+            db2 = _grad_buf(b2)
+            K.cast(dcol, db2)
+            grads[base + 9], grads[base + 10] = dw2, db2
+            dpre = ops.linear_dx(gb, w2, Tn, gelu_pre=pre)
+            dw1, db1 = _grad_buf(w1), _grad_buf(b1)
+            fork.run(lambda: ops.linear_dw(dpre, a2, Tn, dw1, db1), dpre, a2, dw1, db1)
+            grads[base + 7], grads[base + 8] = dw1, db1
+            da2 = ops.linear_dx(dpre, w1, Tn)
+            del dpre, pre, act
+            g2, g2b = newg()
+            dl2 = _grad_buf(ln2g)
+            ops.ln_bwd(da2, x2, ln2g, st2[0], st2[1], Tn, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2)
+            grads[base + 6] = dl2
+            del da2, g, gb
+            # ---- attention ----
+            dwo = _grad_buf(wout)
+            fork.run(lambda: ops.linear_dw(g2b, o, Tn, dwo), g2b, o, dwo)
+            grads[base + 5] = dwo
+            do = ops.linear_dx(g2b, wout, Tn)
+            dqn = ops.empty((Tn, I), T, dy); dkn = ops.empty((Tn, I), T, dy)
+            dqkv = ops.empty((Tn, 3 * I), T, dy)
+            delta = ops.empty((heads, Tn), F32, dy)
+            K.attn_varlen_bwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(qkv, d, 3 * I, offset=2 * I), K.hnd(o, d, I),
+                                   K.hnd(do, d, I), lse, delta, K.hnd(dqn, d, I), K.hnd(dkn, d, I),
+                                   K.hnd(dqkv, d, 3 * I, offset=2 * I), segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0,
+                                   segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, Tn, heads, d, 1.0)
+            dgq = torch.empty_like(gqf); dgk = torch.empty_like(gkf)
+            part = ops.empty((K.rmsnorm_heads_rows(Tn, heads) * 64,), F32, dy)
+            K.rmsnorm_heads_bwd(dqn, I, qkv, 3 * I, gqf, rq, dqkv, 3 * I, dgq, part, Tn, heads, d)
+            K.rmsnorm_heads_bwd(dkn, I, qkv, 3 * I, gkf, rk, dqkv, 3 * I, dgk, part, Tn, heads, d, x_off=I, dx_off=I)
+            grads[base + 3], grads[base + 4] = dgq.view(gq.shape), dgk.view(gk.shape)
+            dwq, dwkv = _grad_buf(wq), _grad_buf(wkv)
+            fork.run(lambda: (ops.linear_dw(dqkv, a1, Tn, dwq, ldy=3 * I), ops.linear_dw(dqkv[:, I:], a1, Tn, dwkv, ldy=3 * I)),
+                     dqkv, a1, dwq, dwkv)
+            grads[base + 1], grads[base + 2] = dwq, dwkv
+            da1 = ops.linear_dx(dqkv, wcat, Tn)
+            del dqkv, do, qkv, o, dqn, dkn
+            g1, g1b = newg()
+            dl1 = _grad_buf(ln1g)
+            dcol = ops.empty((D,), F32, dy)
+            ops.ln_bwd(da1, xs, ln1g, st1[0], st1[1], Tn, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1, dcol=dcol)
+            grads[base + 0] = dl1
+            g, gb = g1, g1b
+            del g2, g2b, da1
+        fork.join()
+        dx = g if in_dtype == F32 else gb
+        return (dx, None, None, None, _ret(dng), *[_ret(t) for t in grads])

@@ -276,7 +276,26 @@ class Transformer(nn.Module):
             ]))
         self.norm = LayerNorm(dim)
 
+    def _fusable(self, x) -> bool:
+        if x.dtype != torch.bfloat16 or self.norm.gamma.dtype != torch.bfloat16:
+            return False
+        for attn, ff in self.layers:
+            if attn.q_norm.gamma.shape[-1] != 64:
+                return False
+            if self.training and (attn.dropout_p > 0. or any(isinstance(m, nn.Dropout) and m.p > 0. for m in list(ff) + list(attn.to_out))):
+                return False
+            if any(bool(m._forward_hooks) or bool(m._forward_pre_hooks) for m in list(attn.modules()) + list(ff.modules())):
+                return False
+        return not (self.norm._forward_hooks or self.norm._forward_pre_hooks)
+
     def forward(self, x, segs: Segments):
+        if self._fusable(x):
+            from . import engine as E
+            params = []
+            for attn, ff in self.layers:
+                params += E.pack_navit_layer_params(attn, ff)
+            heads = self.layers[0][0].heads if len(self.layers) else 1
+            return E.PackedTransformerFn.apply(x, segs, heads, 64, self.norm.gamma, *params)
         for attn, ff in self.layers:
             x = Fn.AddFn.apply(attn(x, segs), x)
             x = Fn.AddFn.apply(ff(x), x)
