@@ -439,9 +439,22 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         const int ncol = ncol0 + rc * 4;
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (bias && ncol < N) b4 = load4<__bf16>(bias + ncol);
+        // the residual rows are fetched up front (16 x 16 B per lane and half) so their latency hides behind the
+        // LDS staging instead of being paid once per row group
+        constexpr int NF0 = 4, NF1 = FM - 4;
+        f32x4 rpre[2][16];
+        auto fetch_resid = [&](int hh) {
+            const int nf = hh ? NF1 : NF0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = mrow0 + hh * 64 + j * 4 + rr;
+                rpre[hh][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < nf * 4 && m < M && ncol < N) rpre[hh][j] = *reinterpret_cast<const f32x4*>(resid + (long long)m * ldc + ncol);
+            }
+        };
+        fetch_resid(0);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            constexpr int NF0 = 4, NF1 = FM - 4;
             const int nf = hh ? NF1 : NF0;
 #pragma unroll
             for (int f4 = 0; f4 < 4; ++f4) {
@@ -454,15 +467,18 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                     }
                 }
             }
-            for (int j = 0; j < nf * 4; ++j) {
-                const int row = j * 4 + rr;
-                f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 256 + ((rc ^ (row & 15)) * 16));
-                const int m = mrow0 + hh * 64 + row;
-                if (m < M && ncol < N) {
-                    const long long o = (long long)m * ldc + ncol;
-                    v += b4;
-                    v += *reinterpret_cast<const f32x4*>(resid + o);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + o) = v;
+            if (hh == 0) fetch_resid(1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < nf * 4) {
+                    const int row = j * 4 + rr;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 256 + ((rc ^ (row & 15)) * 16));
+                    const int m = mrow0 + hh * 64 + row;
+                    if (m < M && ncol < N) {
+                        v += b4;
+                        v += rpre[hh][j];
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + ncol) = v;
+                    }
                 }
             }
         }
@@ -476,6 +492,17 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                 if (n < N) b4[fn] = load4<__bf16>(bias + n);
             }
         }
+        const int rr = lane >> 3, rc = lane & 7;       // read-back: 8 rows x 8 chunks of 8 bf16
+        const int ncol = ncol0 + rc * 8;
+        bf16x8 hpre[2 * FM];                           // GELU_BWD: the saved pre-activations, fetched before the staging
+        if constexpr (EPI == VITK_EPI_GELU_BWD) {
+#pragma unroll
+            for (int j = 0; j < 2 * FM; ++j) {
+                const int m = mrow0 + j * 8 + rr;
+                hpre[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < M && ncol < N) hpre[j] = *reinterpret_cast<const bf16x8*>(aux + (long long)m * ldc + ncol);
+            }
+        }
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) {
             const int row = fm * 16 + fi;
@@ -487,9 +514,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                 *reinterpret_cast<bf16x4*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fg & 1) * 8) = pk;
             }
         }
-        const int rr = lane >> 3, rc = lane & 7;       // read-back: 8 rows x 8 chunks of 8 bf16
-        const int ncol = ncol0 + rc * 8;
-#pragma unroll 2
+#pragma unroll
         for (int j = 0; j < 2 * FM; ++j) {
             const int row = j * 8 + rr;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row * 128 + ((rc ^ (row & 7)) * 16));
@@ -502,13 +527,19 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                     *reinterpret_cast<bf16x8*>(aux + o) = v;
                     bf16x8 g8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) g8[e] = (__bf16)gelu_erf((float)v[e]);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 g2 = gelu_fast2(f32x2{(float)v[e], (float)v[e + 1]});
+                        g8[e] = (__bf16)g2[0]; g8[e + 1] = (__bf16)g2[1];
+                    }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
                 } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
-                    const bf16x8 h8 = *reinterpret_cast<const bf16x8*>(aux + o);
+                    const bf16x8 h8 = hpre[j];
                     bf16x8 g8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) g8[e] = (__bf16)((float)v[e] * gelu_erf_grad((float)h8[e]));
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 g2 = f32x2{(float)v[e], (float)v[e + 1]} * gelu_grad_fast2(f32x2{(float)h8[e], (float)h8[e + 1]});
+                        g8[e] = (__bf16)g2[0]; g8[e + 1] = (__bf16)g2[1];
+                    }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
                 }
             }
