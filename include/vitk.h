@@ -108,6 +108,16 @@ int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
                       void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                       int epilogue, const void* bias, const float* resid, void* aux, void* stream);
 
+/* The VITK_EPI_GELU_BWD product with the column sums of C as a by-product (C = dY.W2 * gelu'(pre) is the gradient at
+ * the first FeedForward Linear's output, so colsum(C) is that Linear's bias gradient -- autograd of vit.py:20).
+ * Writes R = vitk_gemm_nt_colsum_rows(M, N, K, ldc) rows of N float partial sums (row-major, ld = N) taken over the
+ * bf16-rounded C; fold them with vitk_colsum_partials(partials, R, N, N, ...).  R == 0: the shape is not served by
+ * the 256-row kernel and this entry point refuses it (use vitk_gemm_nt_bf16 + vitk_colsum).                       */
+int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc);
+int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, const void* W, int64_t ldw,
+                                      void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                      void* aux, float* colsum_partials, void* stream);
+
 /* dW[N,K] = sum_m dY[m,N]^T X[m,K]  ("TN": both operands are read with the reduction index as
  * the strided one).  Split over M into `splits` slabs of f32 partials (ws: splits*N*K floats),
  * then reduced into dW (dtype odt, ld = ldo; accumulate: dW += ...).  N % 8 == 0, K % 8 == 0.  */

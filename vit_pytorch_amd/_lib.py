@@ -50,6 +50,8 @@ SIGNATURES = {
     "vitk_colsum_ws_floats": (_i64, [_i64, _i64]),
     "vitk_colsum": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _vp, _vp]),
     "vitk_gemm_nt_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
+    "vitk_gemm_nt_colsum_rows": (_i64, [_i64, _i64, _i64, _i64]),
+    "vitk_gemm_nt_bf16_gelu_bwd_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_tn_splits": (_i64, [_i64, _i64, _i64]),
     "vitk_gemm_tn_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _i64, _i64, _i64, _vp, _i64, _vp]),
     "vitk_gemm_generic": (_i, [Mat, Mat, Mat, _vp, _i, _i64, _i64, _i64, _i64, _i64, _f, _f, _vp]),

@@ -43,6 +43,34 @@ __device__ __forceinline__ void fill_tile(char* tile, const __bf16* src, long lo
         *reinterpret_cast<bf16x8*>(tile + row * AT_LD + col8 * 16) = v;
     }
 }
+// Two tiles at once with every global load of a batch in flight before the first LDS store: a plain
+// load -> store loop is serialised by the compiler (s_waitcnt vmcnt(0) per 16 bytes), which at ~2 us of
+// HBM latency per trip was most of a (batch, head) workgroup's life.
+__device__ __forceinline__ void fill_tiles2(char* t0, const __bf16* s0, long long n0, char* t1, const __bf16* s1, long long n1,
+                                            int N, int rows_pad, int tid) {
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int lim = rows_pad * 8;
+    for (int c0 = tid; c0 < lim; c0 += 4 * AT_THREADS) {
+        bf16x8 va[4], vb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j * AT_THREADS, row = c >> 3, col8 = c & 7;
+            va[j] = zero8; vb[j] = zero8;
+            if (c < lim && row < N) {
+                va[j] = *reinterpret_cast<const bf16x8*>(s0 + (long long)row * n0 + col8 * 8);
+                vb[j] = *reinterpret_cast<const bf16x8*>(s1 + (long long)row * n1 + col8 * 8);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j * AT_THREADS, row = c >> 3, col8 = c & 7;
+            if (c < lim) {
+                *reinterpret_cast<bf16x8*>(t0 + row * AT_LD + col8 * 16) = va[j];
+                *reinterpret_cast<bf16x8*>(t1 + row * AT_LD + col8 * 16) = vb[j];
+            }
+        }
+    }
+}
 // 16 rows x (32 of the 64 columns) as an MFMA A/B operand: lane (i = lane&15, g = lane>>4) holds
 // tile[row0 + i][ks*32 + 8g .. +7]
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int ks, int fi, int fg) {
@@ -66,8 +94,31 @@ __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b) {
     for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)b[e];
     return s;
 }
+// Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48 hold the same query/key column):
+// v_permlane16_swap / v_permlane32_swap exchange the groups in the VALU -- no LDS round trip and no
+// s_waitcnt lgkmcnt(0) in the middle of the fragment reads, unlike ds_bpermute (__shfl_xor).
+__device__ __forceinline__ float groups_max(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    u = __builtin_bit_cast(unsigned, x);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float groups_sum(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    u = __builtin_bit_cast(unsigned, x);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// R = 16-row query tiles a wave carries at once: every K / V fragment read from LDS feeds R MFMAs, so R = 2 halves
+// the LDS traffic per flop and gives the scheduler two independent softmax chains; with 8 waves it also covers
+// N <= 256 (ViT-B/L: 13 tiles) in ONE pass instead of two unbalanced ones.
+template <int R>
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BHND v, BHND o, float* __restrict__ lse,
                                                         int H, int N, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -75,67 +126,115 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
     const int fi = lane & 15, fg = lane >> 4;
     const int rows_pad = ((N + 31) >> 5) << 5;
     char* Ks = smem;
-    char* Vs = smem + rows_pad * AT_LD;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    fill_tile(Ks, k.p + b * k.s_b + h * k.s_h, k.s_n, N, rows_pad, tid);
-    fill_tile(Vs, v.p + b * v.s_b + h * v.s_h, v.s_n, N, rows_pad, tid);
-    __syncthreads();
-
+    char* Vs = Ks + rows_pad * AT_LD;
     const int nqt = (N + 15) >> 4, nks = rows_pad >> 5;
+    int bh = 0, b = 0, h = 0, t0 = 0;
+    const __bf16* qbase = q.p;
+    bf16x8 qf[R][2];
+    auto load_q = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int qi = (t + r) * 16 + fi;
+            const __bf16* qp = qbase + (long long)(qi < N ? qi : N - 1) * q.s_n;
+            qf[r][0] = *reinterpret_cast<const bf16x8*>(qp + 8 * fg);
+            qf[r][1] = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * fg);
+        }
+    };
+    auto prepare = [&](int item) {
+        bh = item; b = bh / H; h = bh % H;
+        qbase = q.p + b * q.s_b + h * q.s_h;
+        t0 = wave * R;
+        if (t0 < nqt) load_q(t0);          // in flight while K / V are staged
+        fill_tiles2(Ks, k.p + b * k.s_b + h * k.s_h, k.s_n, Vs, v.p + b * v.s_b + h * v.s_h, v.s_n, N, rows_pad, tid);
+    };
+    auto compute = [&]() {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int qt = wave; qt < nqt; qt += AT_WAVES) {
-        const int qi = qt * 16 + fi;
-        const int qrow = qi < N ? qi : N - 1;
-        const __bf16* qp = q.p + b * q.s_b + h * q.s_h + (long long)qrow * q.s_n;
-        const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * fg);
-        const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * fg);
-        float m = -INFINITY, lsum = 0.f;
-        f32x4 acc[4] = {z4, z4, z4, z4};
+    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    const float c = scale_log2e;            // > 0 (checked on the host): max() commutes with the scaling
+    while (t0 < nqt) {
+        // Softmax bookkeeping is kept off the VALU, which is the busy pipe of this kernel (measured: 12 VALU
+        // instructions per MFMA before, VALU 55-60 % busy vs MFMA 16 %):
+        //  * the row sums come from one extra MFMA per step against an all-ones operand (l = 1^T P^T), not from adds;
+        //  * the reference maximum is LAZY: it is only raised (and the accumulators rescaled) when some score
+        //    exceeds it by more than 2^8 -- exp2(s - mref) <= 256 is harmless in f32 / bf16 -- so after the first
+        //    step the rescale and its cross-lane reduction almost never run (wave-uniform branch on a ballot);
+        //  * scale and -mref are folded into the exp2 argument as one FMA.
+        float mref[R];
+        f32x4 acc[R][4], accl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { mref[r] = -INFINITY; accl[r] = z4; acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = z4; }
         for (int s = 0; s < nks; ++s) {
-            f32x4 st[2];
-            float mx = -INFINITY;
+            bf16x8 kf[2][2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const int row0 = s * 32 + hh * 16;
-                st[hh] = MFMA(row_frag(Ks, row0, 0, fi, fg), qf0, z4);
-                st[hh] = MFMA(row_frag(Ks, row0, 1, fi, fg), qf1, st[hh]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = row0 + 4 * fg + r;
-                    st[hh][r] = key < N ? st[hh][r] * scale_log2e : -INFINITY;
-                    mx = fmaxf(mx, st[hh][r]);
-                }
+                kf[hh][0] = row_frag(Ks, s * 32 + hh * 16, 0, fi, fg);
+                kf[hh][1] = row_frag(Ks, s * 32 + hh * 16, 1, fi, fg);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-            float ps = 0.f;
+            bf16x8 pb[R];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int r = 0; r < R; ++r) {
+                f32x4 st[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { st[hh][r] = __builtin_amdgcn_exp2f(st[hh][r] - m_new); ps += st[hh][r]; }
-            lsum = lsum * alpha + ps;
-            m = m_new;
-            const bf16x8 pb = pack8(st[0], st[1]);
+                for (int hh = 0; hh < 2; ++hh) {
+                    st[hh] = MFMA(kf[hh][0], qf[r][0], z4);
+                    st[hh] = MFMA(kf[hh][1], qf[r][1], st[hh]);
+                }
+                if (s == nks - 1) {            // only the last 32-key step holds padding keys
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (s * 32 + hh * 16 + 4 * fg + e >= N) st[hh][e] = -INFINITY;
+                }
+                float mloc = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+                mloc = fmaxf(fmaxf(mloc, st[0][3]), st[1][0]);
+                mloc = fmaxf(fmaxf(mloc, st[1][1]), st[1][2]);
+                mloc = fmaxf(mloc, st[1][3]);
+                if (__builtin_amdgcn_ballot_w64(mloc * c > mref[r] + 8.0f) != 0) {
+                    const float m_new = fmaxf(mref[r], groups_max(mloc) * c);
+                    const float alpha = __builtin_amdgcn_exp2f(mref[r] - m_new);
+#pragma unroll
+                    for (int fd = 0; fd < 4; ++fd) acc[r][fd] *= alpha;
+                    accl[r] *= alpha;
+                    mref[r] = m_new;
+                }
+                const float nm = -mref[r];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
+                pb[r] = pack8(st[0], st[1]);
+                accl[r] = MFMA(ones, pb[r], accl[r]);
+            }
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) {
-                acc[fd] *= alpha;
-                acc[fd] = MFMA(tr_frag(Vs, s * 32, fd * 16, fi, fg), pb, acc[fd]);
+                const bf16x8 vf = tr_frag(Vs, s * 32, fd * 16, fi, fg);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][fd] = MFMA(vf, pb[r], acc[r][fd]);
             }
         }
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
-        const float inv = 1.0f / lsum;
-        if (qi < N) {
-            __bf16* op = o.p + b * o.s_b + h * o.s_h + (long long)qi * o.s_n + 4 * fg;
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) store4<__bf16>(op + fd * 16, acc[fd] * inv);
-            if (fg == 0) lse[(long long)bh * N + qi] = (m + log2f(lsum)) * LN2;
+        for (int r = 0; r < R; ++r) {
+            const int qi = (t0 + r) * 16 + fi;
+            const float ls = accl[r][0];        // every row of 1^T P^T is the same sum
+            const float inv = 1.0f / ls;
+            if (qi < N) {
+                __bf16* op = o.p + b * o.s_b + h * o.s_h + (long long)qi * o.s_n + 4 * fg;
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) store4<__bf16>(op + fd * 16, acc[r][fd] * inv);
+                if (fg == 0) lse[(long long)bh * N + qi] = (mref[r] + log2f(ls)) * LN2;
+            }
         }
+        t0 += AT_WAVES * R;
+        if (t0 < nqt) load_q(t0);
     }
+    };
+    prepare(blockIdx.x);
+    __syncthreads();
+    compute();
 }
 
+template <int R>
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k, BHND v, BHND o, BHND dout,
                                                            const float* __restrict__ lse, float* __restrict__ delta,
                                                            BHND dq, int H, int N, float scale) {
@@ -144,61 +243,96 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k,
     const int fi = lane & 15, fg = lane >> 4;
     const int rows_pad = ((N + 31) >> 5) << 5;
     char* Ks = smem;
-    char* Vs = smem + rows_pad * AT_LD;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    fill_tile(Ks, k.p + b * k.s_b + h * k.s_h, k.s_n, N, rows_pad, tid);
-    fill_tile(Vs, v.p + b * v.s_b + h * v.s_h, v.s_n, N, rows_pad, tid);
-    __syncthreads();
-
+    char* Vs = Ks + rows_pad * AT_LD;
     const int nqt = (N + 15) >> 4, nks = rows_pad >> 5;
     const float scale_log2e = scale * LOG2E;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int qt = wave; qt < nqt; qt += AT_WAVES) {
-        const int qi = qt * 16 + fi;
-        const int qrow = qi < N ? qi : N - 1;
-        const __bf16* qp = q.p + b * q.s_b + h * q.s_h + (long long)qrow * q.s_n;
-        const __bf16* dop = dout.p + b * dout.s_b + h * dout.s_h + (long long)qrow * dout.s_n;
-        const __bf16* op = o.p + b * o.s_b + h * o.s_h + (long long)qrow * o.s_n;
-        const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * fg);
-        const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * fg);
-        const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * fg);
-        const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * fg);
-        const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(op + 8 * fg);
-        const bf16x8 of1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * fg);
-        float dl = dot8(df0, of0) + dot8(df1, of1);
-        dl += __shfl_xor(dl, 16, 64);
-        dl += __shfl_xor(dl, 32, 64);
-        if (qi < N && fg == 0) delta[(long long)bh * N + qi] = dl;
-        const float l2 = lse[(long long)bh * N + qrow] * LOG2E;
-        f32x4 acc[4] = {z4, z4, z4, z4};
+    int bh = 0, b = 0, h = 0, t0 = 0;
+
+    bf16x8 qf[R][2], df[R][2];
+    float dl[R], l2[R];
+    auto load_rows = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int qi = (t + r) * 16 + fi;
+            const int qrow = qi < N ? qi : N - 1;
+            const __bf16* qp = q.p + b * q.s_b + h * q.s_h + (long long)qrow * q.s_n;
+            const __bf16* dop = dout.p + b * dout.s_b + h * dout.s_h + (long long)qrow * dout.s_n;
+            const __bf16* op = o.p + b * o.s_b + h * o.s_h + (long long)qrow * o.s_n;
+            qf[r][0] = *reinterpret_cast<const bf16x8*>(qp + 8 * fg);
+            qf[r][1] = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * fg);
+            df[r][0] = *reinterpret_cast<const bf16x8*>(dop + 8 * fg);
+            df[r][1] = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * fg);
+            const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(op + 8 * fg);
+            const bf16x8 of1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * fg);
+            l2[r] = -lse[(long long)bh * N + qrow] * LOG2E;      // negated: the exp2 argument is one FMA
+            dl[r] = groups_sum(dot8(df[r][0], of0) + dot8(df[r][1], of1));
+            if (qi < N && fg == 0) delta[(long long)bh * N + qi] = dl[r];
+        }
+    };
+    auto prepare = [&](int item) {
+        bh = item; b = bh / H; h = bh % H;
+        t0 = wave * R;
+        if (t0 < nqt) load_rows(t0);
+        fill_tiles2(Ks, k.p + b * k.s_b + h * k.s_h, k.s_n, Vs, v.p + b * v.s_b + h * v.s_h, v.s_n, N, rows_pad, tid);
+    };
+    auto compute = [&]() {
+    while (t0 < nqt) {
+        f32x4 acc[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = z4;
         for (int s = 0; s < nks; ++s) {
-            f32x4 ds[2];
+            bf16x8 dsb[R];
+            f32x4 ds[R][2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int row0 = s * 32 + hh * 16;
-                f32x4 st = MFMA(row_frag(Ks, row0, 0, fi, fg), qf0, z4);
-                st = MFMA(row_frag(Ks, row0, 1, fi, fg), qf1, st);
-                f32x4 dp = MFMA(row_frag(Vs, row0, 0, fi, fg), df0, z4);
-                dp = MFMA(row_frag(Vs, row0, 1, fi, fg), df1, dp);
+                const bf16x8 k0 = row_frag(Ks, row0, 0, fi, fg), k1 = row_frag(Ks, row0, 1, fi, fg);
+                const bf16x8 v0 = row_frag(Vs, row0, 0, fi, fg), v1 = row_frag(Vs, row0, 1, fi, fg);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = row0 + 4 * fg + r;
-                    const float p = key < N ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - l2) : 0.f;
-                    ds[hh][r] = p * (dp[r] - dl) * scale;
+                for (int r = 0; r < R; ++r) {
+                    f32x4 st = MFMA(k0, qf[r][0], z4);
+                    st = MFMA(k1, qf[r][1], st);
+                    f32x4 dp = MFMA(v0, df[r][0], z4);
+                    dp = MFMA(v1, df[r][1], dp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)       // the common factor `scale` of dS is applied once, to dQ
+                        ds[r][hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l2[r])) * (dp[e] - dl[r]);
+                    if (s == nks - 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (row0 + 4 * fg + e >= N) ds[r][hh][e] = 0.f;
+                    }
                 }
             }
-            const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) acc[fd] = MFMA(tr_frag(Ks, s * 32, fd * 16, fi, fg), dsb, acc[fd]);
-        }
-        if (qi < N) {
-            __bf16* dqp = dq.p + b * dq.s_b + h * dq.s_h + (long long)qi * dq.s_n + 4 * fg;
+            for (int r = 0; r < R; ++r) dsb[r] = pack8(ds[r][0], ds[r][1]);
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) store4<__bf16>(dqp + fd * 16, acc[fd]);
+            for (int fd = 0; fd < 4; ++fd) {
+                const bf16x8 kt = tr_frag(Ks, s * 32, fd * 16, fi, fg);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][fd] = MFMA(kt, dsb[r], acc[r][fd]);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int qi = (t0 + r) * 16 + fi;
+            if (qi < N) {
+                __bf16* dqp = dq.p + b * dq.s_b + h * dq.s_h + (long long)qi * dq.s_n + 4 * fg;
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) store4<__bf16>(dqp + fd * 16, acc[r][fd] * scale);
+            }
+        }
+        t0 += AT_WAVES * R;
+        if (t0 < nqt) load_rows(t0);
     }
+    };
+    prepare(blockIdx.x);
+    __syncthreads();
+    compute();
 }
 
+template <int R>
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k, BHND v, BHND dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             BHND dk, BHND dv, int H, int N, float scale) {
@@ -207,64 +341,102 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
     const int fi = lane & 15, fg = lane >> 4;
     const int rows_pad = ((N + 31) >> 5) << 5;
     char* Qs = smem;
-    char* Ds = smem + rows_pad * AT_LD;
-    float* lse_s = reinterpret_cast<float*>(smem + 2 * rows_pad * AT_LD);
+    char* Ds = Qs + rows_pad * AT_LD;
+    float* lse_s = reinterpret_cast<float*>(Qs + 2 * rows_pad * AT_LD);
     float* del_s = lse_s + rows_pad;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    fill_tile(Qs, q.p + b * q.s_b + h * q.s_h, q.s_n, N, rows_pad, tid);
-    fill_tile(Ds, dout.p + b * dout.s_b + h * dout.s_h, dout.s_n, N, rows_pad, tid);
-    for (int r = tid; r < rows_pad; r += AT_THREADS) {
-        lse_s[r] = r < N ? lse[(long long)bh * N + r] * LOG2E : 0.f;
-        del_s[r] = r < N ? delta[(long long)bh * N + r] : 0.f;
-    }
-    __syncthreads();
-
     const int nkt = (N + 15) >> 4, nqs = rows_pad >> 5;
     const float scale_log2e = scale * LOG2E;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int kt = wave; kt < nkt; kt += AT_WAVES) {
-        const int ki = kt * 16 + fi;
-        const int krow = ki < N ? ki : N - 1;
-        const __bf16* kp = k.p + b * k.s_b + h * k.s_h + (long long)krow * k.s_n;
-        const __bf16* vp = v.p + b * v.s_b + h * v.s_h + (long long)krow * v.s_n;
-        const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp + 8 * fg);
-        const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * fg);
-        const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + 8 * fg);
-        const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * fg);
-        f32x4 accK[4] = {z4, z4, z4, z4}, accV[4] = {z4, z4, z4, z4};
+    int bh = 0, b = 0, h = 0, t0 = 0;
+
+    bf16x8 kf[R][2], vf[R][2];
+    auto load_rows = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int ki = (t + r) * 16 + fi;
+            const int krow = ki < N ? ki : N - 1;
+            const __bf16* kp = k.p + b * k.s_b + h * k.s_h + (long long)krow * k.s_n;
+            const __bf16* vp = v.p + b * v.s_b + h * v.s_h + (long long)krow * v.s_n;
+            kf[r][0] = *reinterpret_cast<const bf16x8*>(kp + 8 * fg);
+            kf[r][1] = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * fg);
+            vf[r][0] = *reinterpret_cast<const bf16x8*>(vp + 8 * fg);
+            vf[r][1] = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * fg);
+        }
+    };
+    auto prepare = [&](int item) {
+        bh = item; b = bh / H; h = bh % H;
+        t0 = wave * R;
+        if (t0 < nkt) load_rows(t0);
+        float lv = 0.f, dv_ = 0.f;     // rows_pad <= 480 < AT_THREADS: one row of lse / delta per thread
+        if (tid < N) { lv = -lse[(long long)bh * N + tid] * LOG2E; dv_ = -delta[(long long)bh * N + tid]; }   // negated (FMA / add forms)
+        fill_tiles2(Qs, q.p + b * q.s_b + h * q.s_h, q.s_n, Ds, dout.p + b * dout.s_b + h * dout.s_h, dout.s_n, N, rows_pad, tid);
+        if (tid < rows_pad) { lse_s[tid] = lv; del_s[tid] = dv_; }
+    };
+    auto compute = [&]() {
+    while (t0 < nkt) {
+        f32x4 accK[R][4], accV[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) { accK[r][fd] = z4; accV[r][fd] = z4; }
         for (int s = 0; s < nqs; ++s) {
-            f32x4 p[2], ds[2];
+            f32x4 p[R][2], ds[R][2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int row0 = s * 32 + hh * 16;
-                f32x4 st = MFMA(row_frag(Qs, row0, 0, fi, fg), kf0, z4);   // S[q = row0+4g+r][key = ki]
-                st = MFMA(row_frag(Qs, row0, 1, fi, fg), kf1, st);
-                f32x4 dp = MFMA(row_frag(Ds, row0, 0, fi, fg), vf0, z4);   // dP[q][key]
-                dp = MFMA(row_frag(Ds, row0, 1, fi, fg), vf1, dp);
+                const bf16x8 q0 = row_frag(Qs, row0, 0, fi, fg), q1 = row_frag(Qs, row0, 1, fi, fg);
+                const bf16x8 d0 = row_frag(Ds, row0, 0, fi, fg), d1 = row_frag(Ds, row0, 1, fi, fg);
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qidx = row0 + 4 * fg + r;
-                    p[hh][r] = qidx < N ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - l4[r]) : 0.f;
-                    ds[hh][r] = p[hh][r] * (dp[r] - d4[r]) * scale;
+                for (int r = 0; r < R; ++r) {
+                    f32x4 st = MFMA(q0, kf[r][0], z4);     // S[q = row0+4g+e][key]
+                    st = MFMA(q1, kf[r][1], st);
+                    f32x4 dp = MFMA(d0, vf[r][0], z4);     // dP[q][key]
+                    dp = MFMA(d1, vf[r][1], dp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        p[r][hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l4[e]));
+                        ds[r][hh][e] = p[r][hh][e] * (dp[e] + d4[e]);      // `scale` is applied once, to dK
+                    }
+                    if (s == nqs - 1) {                    // padding query rows only exist in the last step
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (row0 + 4 * fg + e >= N) { p[r][hh][e] = 0.f; ds[r][hh][e] = 0.f; }
+                    }
                 }
             }
-            const bf16x8 pb = pack8(p[0], p[1]);
-            const bf16x8 dsb = pack8(ds[0], ds[1]);
+            bf16x8 pb[R], dsb[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { pb[r] = pack8(p[r][0], p[r][1]); dsb[r] = pack8(ds[r][0], ds[r][1]); }
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) {
-                accV[fd] = MFMA(tr_frag(Ds, s * 32, fd * 16, fi, fg), pb, accV[fd]);   // dV^T[d][key]
-                accK[fd] = MFMA(tr_frag(Qs, s * 32, fd * 16, fi, fg), dsb, accK[fd]);  // dK^T[d][key]
+                const bf16x8 dt = tr_frag(Ds, s * 32, fd * 16, fi, fg);
+                const bf16x8 qt = tr_frag(Qs, s * 32, fd * 16, fi, fg);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    accV[r][fd] = MFMA(dt, pb[r], accV[r][fd]);    // dV^T[d][key]
+                    accK[r][fd] = MFMA(qt, dsb[r], accK[r][fd]);   // dK^T[d][key]
+                }
             }
         }
-        if (ki < N) {
-            __bf16* dkp = dk.p + b * dk.s_b + h * dk.s_h + (long long)ki * dk.s_n + 4 * fg;
-            __bf16* dvp = dv.p + b * dv.s_b + h * dv.s_h + (long long)ki * dv.s_n + 4 * fg;
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd]); store4<__bf16>(dvp + fd * 16, accV[fd]); }
+        for (int r = 0; r < R; ++r) {
+            const int ki = (t0 + r) * 16 + fi;
+            if (ki < N) {
+                __bf16* dkp = dk.p + b * dk.s_b + h * dk.s_h + (long long)ki * dk.s_n + 4 * fg;
+                __bf16* dvp = dv.p + b * dv.s_b + h * dv.s_h + (long long)ki * dv.s_n + 4 * fg;
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[r][fd] * scale); store4<__bf16>(dvp + fd * 16, accV[r][fd]); }
+            }
         }
+        t0 += AT_WAVES * R;
+        if (t0 < nkt) load_rows(t0);
     }
+    };
+    prepare(blockIdx.x);
+    __syncthreads();
+    compute();
 }
 
 // ==========================================================================================
@@ -646,25 +818,38 @@ int set_lds_once(K kernel) {
 }
 #define SET_LDS(kernel, name) do { static const int rc__ = set_lds_once(kernel); \
     if (rc__ != 0) { vitk_set_error("%s: hipFuncSetAttribute(max dynamic LDS) failed: %d", name, rc__); return rc__; } } while (0)
-int attn_shape_check(const char* name, int64_t B, int64_t H, int64_t N, int64_t d) {
+int attn_shape_check(const char* name, int64_t B, int64_t H, int64_t N, int64_t d, float scale) {
+    if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "%s: scale must be positive (got %g)", name, (double)scale);
     if (d != 64) VITK_FAIL(VITK_E_SHAPE, "%s: fused path needs dim_head == 64 (got %lld)", name, (long long)d);
     if (B <= 0 || H <= 0 || N <= 0 || N > 480 || B * H > 0x7fffffffLL)
         VITK_FAIL(VITK_E_SHAPE, "%s: fused path needs 1 <= N <= 480 (got %lld)", name, (long long)N);
     return 0;
 }
 
+// Query / key tiles per wave (template parameter R).  Forward: two once a single pass of one tile per wave would not
+// cover the sequence (N > 128): every K / V fragment read then feeds two MFMAs and the wave has two independent softmax
+// chains in flight (112 VGPRs, two workgroups per CU still fit).  Backward: one -- two tiles need 158 / 218 VGPRs, which
+// halves the occupancy and measured slower (ViT-B shapes: 0.259 ms vs 0.276 / 0.283 ms).  VITK_ATTN_R_* override (tests).
+int tiles_per_wave(const char* env, bool prefer2, int64_t N) {
+    if (const char* e = getenv(env)) return atoi(e) == 2 ? 2 : 1;
+    return prefer2 && (N + 15) / 16 > AT_WAVES ? 2 : 1;
+}
+#define ATTN_LAUNCH(KERNEL, name, r, grid, lds, st, ...) do { \
+    if (r == 2) { SET_LDS(KERNEL<2>, name); hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(AT_THREADS), lds, st, __VA_ARGS__); } \
+    else        { SET_LDS(KERNEL<1>, name); hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(AT_THREADS), lds, st, __VA_ARGS__); } \
+    } while (0)
+
 }  // namespace
 
 extern "C" int vitk_attn_fwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, float* lse, int64_t B, int64_t H,
                                   int64_t N, int64_t d, float scale, void* stream) {
-    if (int rc = attn_shape_check("attn_fwd_bf16", B, H, N, d)) return rc;
+    if (int rc = attn_shape_check("attn_fwd_bf16", B, H, N, d, scale)) return rc;
     if (!bhnd_ok(q) || !bhnd_ok(k) || !bhnd_ok(v) || !bhnd_ok(o) || !lse)
         VITK_FAIL(VITK_E_ALIGN, "attn_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     const int rows_pad = (int)((N + 31) / 32 * 32);
-    const size_t lds = (size_t)2 * rows_pad * AT_LD;
-    SET_LDS(attn_fwd_kernel, "attn_fwd_bf16");
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(AT_THREADS), lds, (hipStream_t)stream, to_bhnd(q), to_bhnd(k),
-                       to_bhnd(v), to_bhnd(o), lse, (int)H, (int)N, scale * LOG2E);
+    const int r = tiles_per_wave("VITK_ATTN_R_FWD", true, N);
+    ATTN_LAUNCH(attn_fwd_kernel, "attn_fwd_bf16", r, (unsigned)(B * H), (size_t)2 * rows_pad * AT_LD, (hipStream_t)stream, to_bhnd(q),
+                to_bhnd(k), to_bhnd(v), to_bhnd(o), lse, (int)H, (int)N, scale * LOG2E);
     VITK_CHECK_LAUNCH("attn_fwd_bf16");
     return 0;
 }
@@ -672,21 +857,20 @@ extern "C" int vitk_attn_fwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bh
 extern "C" int vitk_attn_bwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_bhnd dout, const float* lse,
                                   float* delta, vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv, int64_t B, int64_t H, int64_t N,
                                   int64_t d, float scale, void* stream) {
-    if (int rc = attn_shape_check("attn_bwd_bf16", B, H, N, d)) return rc;
+    if (int rc = attn_shape_check("attn_bwd_bf16", B, H, N, d, scale)) return rc;
     if (!bhnd_ok(q) || !bhnd_ok(k) || !bhnd_ok(v) || !bhnd_ok(o) || !bhnd_ok(dout) || !bhnd_ok(dq) || !bhnd_ok(dk) || !bhnd_ok(dv) ||
         !lse || !delta)
         VITK_FAIL(VITK_E_ALIGN, "attn_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     const int rows_pad = (int)((N + 31) / 32 * 32);
     const size_t lds1 = (size_t)2 * rows_pad * AT_LD;
     const size_t lds2 = lds1 + (size_t)2 * rows_pad * sizeof(float);
-    SET_LDS(attn_bwd_dq_kernel, "attn_bwd_dq");
-    SET_LDS(attn_bwd_dkv_kernel, "attn_bwd_dkv");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(AT_THREADS), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v),
-                       to_bhnd(o), to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale);
+    const int r1 = tiles_per_wave("VITK_ATTN_R_DQ", false, N), r2 = tiles_per_wave("VITK_ATTN_R_DKV", false, N);
+    ATTN_LAUNCH(attn_bwd_dq_kernel, "attn_bwd_dq", r1, (unsigned)(B * H), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(o),
+                to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale);
     VITK_CHECK_LAUNCH("attn_bwd_dq");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(AT_THREADS), lds2, st, to_bhnd(q), to_bhnd(k), to_bhnd(v),
-                       to_bhnd(dout), lse, delta, to_bhnd(dk), to_bhnd(dv), (int)H, (int)N, scale);
+    ATTN_LAUNCH(attn_bwd_dkv_kernel, "attn_bwd_dkv", r2, (unsigned)(B * H), lds2, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(dout),
+                lse, delta, to_bhnd(dk), to_bhnd(dv), (int)H, (int)N, scale);
     VITK_CHECK_LAUNCH("attn_bwd_dkv");
     return 0;
 }

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ W, long long ldw,
     void* __restrict__ Cv, long long ldc, int M, int N, int K,
     const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
-    int tiles_n, int nwg, int group_n) {
+    int tiles_n, int nwg, int group_n, float* __restrict__ csum) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -514,6 +514,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                 *reinterpret_cast<bf16x4*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fg & 1) * 8) = pk;
             }
         }
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // GELU_BWD: column sums of this lane's rows (bias gradient)
 #pragma unroll
         for (int j = 0; j < 2 * FM; ++j) {
             const int row = j * 8 + rr;
@@ -539,9 +540,24 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                     for (int e = 0; e < 8; e += 2) {
                         const f32x2 g2 = f32x2{(float)v[e], (float)v[e + 1]} * gelu_grad_fast2(f32x2{(float)h8[e], (float)h8[e + 1]});
                         g8[e] = (__bf16)g2[0]; g8[e + 1] = (__bf16)g2[1];
+                        cs[e] += (float)g8[e]; cs[e + 1] += (float)g8[e + 1];      // of the ROUNDED values: what a later colsum(C) would read
                     }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
                 }
+            }
+        }
+        if constexpr (EPI == VITK_EPI_GELU_BWD) {
+            // db = colsum(C) comes for free: the 8 row-groups of a wave are combined through its (now idle) LDS slice and
+            // every wave writes one partial row of 64 sums; vitk_colsum_partials() folds the 2 * tiles_m rows.
+            if (csum) {
+                float* cp = reinterpret_cast<float*>(ep);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cp[rr * 64 + rc * 8 + e] = cs[e];
+                float t = 0.f;
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) t += cp[r8 * 64 + lane];
+                const int n = ncol0 + lane;
+                if (n < N) csum[(long long)(tm * 2 + wm) * N + n] = t;
             }
         }
     }
@@ -666,28 +682,62 @@ int set_max_lds(Kern kernel, int bytes) {
 
 }  // namespace
 
+namespace {
+struct NtPlan { bool large; int fm; };
+NtPlan nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
+    NtPlan pl;
+    pl.large = (K % L_BK == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux)) && !getenv("VITK_NO_256");
+    // Tile height: 256 rows (8 m-fragments per wave) or 224 (7).  One workgroup per CU, so the grid is
+    // quantised in rounds of 256 tiles: pick the height whose (rounds x height) is smaller -- e.g. M = 50,432,
+    // N = 768: 591 tiles of 256 rows need 3 rounds for 2.31 rounds of work, 678 tiles of 224 rows need 3
+    // rounds of 7/8-size tiles (-12.5 %).
+    pl.fm = 8;
+    if (pl.large) {
+        const long long tn_ = (N + L_BN - 1) / L_BN;
+        const long long t8 = ((M + 255) / 256) * tn_, t7 = ((M + 223) / 224) * tn_;
+        const long long cost8 = ((t8 + 255) / 256) * 8, cost7 = ((t7 + 255) / 256) * 7;
+        if (cost7 * 10 <= cost8 * 9) pl.fm = 7;   // only when it buys >= 10 %: the shorter tile re-uses each W fragment 7x instead of 8x
+        if (getenv("VITK_NT_FM")) pl.fm = atoi(getenv("VITK_NT_FM")) == 7 ? 7 : 8;
+    }
+    return pl;
+}
+int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                 int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream);
+}  // namespace
+
 extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                                  int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux,
                                  void* stream) {
+    return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, nullptr, stream);
+}
+
+extern "C" int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const NtPlan pl = nt_plan(M, N, K, ldc, nullptr);
+    if (!pl.large) return 0;
+    return 2 * ((M + 32 * pl.fm - 1) / (32 * pl.fm));
+}
+
+extern "C" int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                                 int64_t M, int64_t N, int64_t K, void* aux, float* colsum_partials, void* stream) {
+    if (!colsum_partials) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16_gelu_bwd_colsum: null partials");
+    if (vitk_gemm_nt_colsum_rows(M, N, K, ldc) == 0 || (aux && !aligned16(aux)))
+        VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16_gelu_bwd_colsum: shape not served by the 256-row kernel (vitk_gemm_nt_colsum_rows() == 0)");
+    return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, VITK_EPI_GELU_BWD, nullptr, nullptr, aux, colsum_partials, stream);
+}
+
+namespace {
+int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                 int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream) {
     if (!A || !W || !C) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: null pointer");
     if (M <= 0 || N <= 0 || K <= 0 || (K % NT_BK) || (N & 3) || M > (1 << 30) || N > (1 << 30))
         VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: need K %% 32 == 0 and N %% 4 == 0 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
     if ((lda & 7) || (ldw & 7) || (ldc & 3) || !aligned16(A) || !aligned16(W) || !aligned16(C) || (bias && !aligned8(bias)) ||
         (resid && !aligned16(resid)) || (aux && !aligned8(aux)))
         VITK_FAIL(VITK_E_ALIGN, "gemm_nt_bf16: lda/ldw %% 8, ldc %% 4 and 16-byte aligned pointers required");
-    const bool large = (K % L_BK == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux)) && !getenv("VITK_NO_256");
-    // Tile height: 256 rows (8 m-fragments per wave) or 224 (7).  One workgroup per CU, so the grid is
-    // quantised in rounds of 256 tiles: pick the height whose (rounds x height) is smaller -- e.g. M = 50,432,
-    // N = 768: 591 tiles of 256 rows need 3 rounds for 2.31 rounds of work, 678 tiles of 224 rows need 3
-    // rounds of 7/8-size tiles (-12.5 %).
-    int fm = 8;
-    if (large) {
-        const long long tn_ = (N + L_BN - 1) / L_BN;
-        const long long t8 = ((M + 255) / 256) * tn_, t7 = ((M + 223) / 224) * tn_;
-        const long long cost8 = ((t8 + 255) / 256) * 8, cost7 = ((t7 + 255) / 256) * 7;
-        if (cost7 * 10 <= cost8 * 9) fm = 7;   // only when it buys >= 10 %: the shorter tile re-uses each W fragment 7x instead of 8x
-        if (getenv("VITK_NT_FM")) fm = atoi(getenv("VITK_NT_FM")) == 7 ? 7 : 8;
-    }
+    const NtPlan pl = nt_plan(M, N, K, ldc, aux);
+    const bool large = pl.large;
+    const int fm = pl.fm;
     const int tbm = large ? 32 * fm : BM, tbn = large ? L_BN : BN;
     const int tiles_m = (int)((M + tbm - 1) / tbm), tiles_n = (int)((N + tbn - 1) / tbn);
     const long long nwg = (long long)tiles_m * tiles_n;
@@ -701,7 +751,7 @@ extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
         static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E, F>, P_LDS_BYTES); \
         if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", P_LDS_BYTES); \
         hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, (const __bf16*)A, (long long)lda, \
-            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n); \
+            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum); \
     } while (0)
 #define NT_LAUNCH(E) do { \
     if (large && fm == 7) NT_LAUNCH_PP(E, 7); \
@@ -731,6 +781,7 @@ extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int6
     VITK_CHECK_LAUNCH("gemm_nt_bf16");
     return 0;
 }
+}  // namespace
 
 static bool tn_large(int64_t M, int64_t N, int64_t K) { return M >= 4096 && N >= 256 && K >= 256 && !getenv("VITK_NO_256"); }
 

@@ -218,10 +218,14 @@ class TransformerFn(torch.autograd.Function):
                 db2 = _grad_buf(b2)
                 K.cast(dcol, db2)
                 grads[base + 10] = db2
-            dpre = ops.linear_dx(gT, w2, M, gelu_pre=pre)
             dw1 = _grad_buf(w1)
             db1 = _grad_buf(b1) if b1 is not None else None
-            fork.run(lambda: ops.linear_dw(dpre, a2, M, dw1, db1), dpre, a2, dw1, db1)
+            if db1 is not None:
+                dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, db=db1)   # b1's gradient out of the GEMM epilogue
+            else:
+                dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre), True
+            db_todo = None if db_done else db1
+            fork.run(lambda: ops.linear_dw(dpre, a2, M, dw1, db_todo), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
             da2 = ops.linear_dx(dpre, w1, M)
             del dpre, pre, act
@@ -524,9 +528,10 @@ class PackedTransformerFn(torch.autograd.Function):
             db2 = _grad_buf(b2)
             K.cast(dcol, db2)
             grads[base + 9], grads[base + 10] = dw2, db2
-            dpre = ops.linear_dx(gb, w2, Tn, gelu_pre=pre)
             dw1, db1 = _grad_buf(w1), _grad_buf(b1)
-            fork.run(lambda: ops.linear_dw(dpre, a2, Tn, dw1, db1), dpre, a2, dw1, db1)
+            dpre, db_done = ops.linear_dx(gb, w2, Tn, gelu_pre=pre, db=db1)
+            db_todo = None if db_done else db1
+            fork.run(lambda: ops.linear_dw(dpre, a2, Tn, dw1, db_todo), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
             da2 = ops.linear_dx(dpre, w1, Tn)
             del dpre, pre, act

@@ -94,6 +94,16 @@ def gemm_nt_bf16(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, 
                                      _p(aux), _stream()), "gemm_nt_bf16")
 
 
+def gemm_nt_colsum_rows(M: int, N: int, K: int, ldc: int) -> int:
+    return int(L.load().vitk_gemm_nt_colsum_rows(M, N, K, ldc))
+
+
+def gemm_nt_bf16_gelu_bwd_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
+                                 aux: Tensor, partials: Tensor):
+    check(L.load().vitk_gemm_nt_bf16_gelu_bwd_colsum(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, _p(aux), _p(partials),
+                                                     _stream()), "gemm_nt_bf16_gelu_bwd_colsum")
+
+
 def gemm_tn_splits(M: int, N: int, K: int) -> int:
     return int(L.load().vitk_gemm_tn_splits(M, N, K))
 

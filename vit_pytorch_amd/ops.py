@@ -108,13 +108,23 @@ def transpose_weight(W: Tensor) -> Tensor:
     return Wt
 
 
-def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = None) -> Tensor:
-    """dX = dY @ W  (optionally * gelu'(pre): the GELU backward fused as an epilogue)."""
+def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = None, db: Optional[Tensor] = None):
+    """dX = dY @ W  (optionally * gelu'(pre): the GELU backward fused as an epilogue).
+
+    With gelu_pre and db: returns (dX, done) -- done is True when colsum(dX), the bias gradient of the Linear that
+    produced `pre`, was written to db as a by-product of the GEMM epilogue (otherwise the caller still owes it)."""
     N, Kd = W.shape
     T = dy.dtype
     dx = empty((M, Kd), T, dy)
     if T == BF16 and N % 32 == 0 and Kd % 4 == 0:
         Wt = transpose_weight(W)  # (K, N): makes dX an NT GEMM with reduction dim N contiguous
+        if gelu_pre is not None and db is not None:
+            R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
+            if R > 0:
+                part = empty((R * Kd,), F32, dy)
+                K.gemm_nt_bf16_gelu_bwd_colsum(dy, N, Wt, N, dx, Kd, M, Kd, N, gelu_pre, part)
+                K.colsum_partials(part, R, Kd, Kd, db)
+                return dx, True
         if gelu_pre is not None:
             K.gemm_nt_bf16(dy, N, Wt, N, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, aux=gelu_pre)
         else:
@@ -123,7 +133,7 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
         K.gemm_generic(K.mat(dy, N, 1), K.mat(W, Kd, 1), K.mat(dx, Kd, 1), M, Kd, N)
         if gelu_pre is not None:
             K.gelu_bwd(dx, gelu_pre, dx)
-    return dx
+    return (dx, False) if db is not None else dx
 
 
 def linear_dw(dy: Tensor, x: Tensor, M: int, dW: Tensor, db: Optional[Tensor] = None,
