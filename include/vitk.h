@@ -225,6 +225,14 @@ int vitk_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dt, int6
  * extent is not a multiple of 32, e.g. patch_dim = 588 of ViT-H/14, so that the MFMA GEMMs can take it)          */
 int vitk_copy_cols(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int dt, int64_t rows, int64_t cols_copy,
                    int64_t cols_dst, void* stream);
+/* One Adam (decoupled = 0; torch.optim.Adam as used by train_vit_decorr.py:68-70,110) or AdamW (decoupled = 1) step over a
+ * flat range of n elements: param, grad of dtype dt; exp_avg, exp_avg_sq (and the optional f32 master copy of bf16
+ * parameters) f32.  step counts from 1 (bias corrections 1 - beta^step are formed on the host in double).  grad is read as
+ * grad * grad_scale (loss-scale / gradient-averaging factor).  With the flat gradient buffer of the data-parallel sink
+ * and parameters re-homed into one flat buffer this is ONE launch for the whole model.                              */
+int vitk_adam_step(void* param, const void* grad, int dt, float* exp_avg, float* exp_avg_sq, float* master, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled, int64_t step,
+                   float grad_scale, void* stream);
 /* 2-D transpose out[c][r] = in[r][c] (weights: W^T for the dX GEMMs) */
 int vitk_transpose(const void* in, void* out, int dt, int64_t rows, int64_t cols, void* stream);
 

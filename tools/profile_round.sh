@@ -1,0 +1,20 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one GPU call:  bash tools/profile_round.sh [tag]
+#   gpurun_out/<tag>_bench.json.log         default `python bench.py` line (with cpu_baseline)
+#   gpurun_out/<tag>_stats_{two_streams,serialized}/  rocprofv3 --kernel-trace --stats of a short bench run
+#   gpurun_out/<tag>_pmc_{fetch,write}/     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/kprof.py
+set -u
+tag=${1:-r01}
+root=$PWD
+export PYTHONPATH=$root
+out=$root/gpurun_out
+mkdir -p $out
+python bench.py > $out/${tag}_bench.json.log 2> $out/${tag}_bench.err
+tail -1 $out/${tag}_bench.json.log | cut -c1-400
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_two_streams -o run --output-format csv -- python $root/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline > $out/${tag}_stats_two_streams.log 2>&1
+VITK_DW_STREAM=0 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_serialized -o run --output-format csv -- python $root/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline > $out/${tag}_stats_serialized.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o run --output-format csv -- python $root/tools/kprof.py > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write -o run --output-format csv -- python $root/tools/kprof.py > $out/${tag}_pmc_write.log 2>&1
+cd $root
+ls $out/${tag}_stats_serialized $out/${tag}_pmc_fetch | head

@@ -52,15 +52,36 @@ template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, f32x4 v) {
 }
 
 // ---- wave reductions (wave = 64) --------------------------------------------------------
+// All 64 lanes receive the result.  Rotations inside each row of 16 lanes are DPP modifiers and the two cross-row
+// levels are v_permlane16_swap / v_permlane32_swap: pure VALU, no ds_bpermute round trips through the LDS crossbar
+// (6 dependent ~100-cycle hops per reduction with __shfl_xor) and no s_waitcnt lgkmcnt in the middle of a row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0x128>(v);   // row_ror:8
+    v += dpp_f32<0x124>(v);   // row_ror:4
+    v += dpp_f32<0x122>(v);   // row_ror:2
+    v += dpp_f32<0x121>(v);   // row_ror:1
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    u = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<0x128>(v));
+    v = fmaxf(v, dpp_f32<0x124>(v));
+    v = fmaxf(v, dpp_f32<0x122>(v));
+    v = fmaxf(v, dpp_f32<0x121>(v));
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    u = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
 }
 
 // ---- math ------------------------------------------------------------------------------

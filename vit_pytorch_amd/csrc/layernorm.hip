@@ -104,8 +104,17 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
         const DYT* dyr = dy + map_row(dymap, row) * (long long)D;
         const XT* xr = x + map_row(xmap, row) * (long long)D;
         const float mean = mean_in[row], rstd = rstd_in[row];
-        f32x4 g[MAXC], xh[MAXC];
+        const long long orow = map_row(dxmap, row);
+        f32x4 g[MAXC], xh[MAXC], gi[MAXC];
         float s1 = 0.f, s2 = 0.f;
+        // every load of the row -- incoming stream gradient included -- is issued before the first reduction, so a row
+        // costs one memory round trip, not two
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            gi[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gin && want_dx && c < nchunk) gi[t] = *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
+        }
 #pragma unroll
         for (int t = 0; t < MAXC; ++t) {
             const int c = lane + 64 * t;
@@ -126,15 +135,13 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
         if (want_dx) {
             const float c1 = wave_sum(s1) * invD;
             const float c2 = wave_sum(s2) * invD;
-            const long long orow = map_row(dxmap, row);
 #pragma unroll
             for (int t = 0; t < MAXC; ++t) {
                 const int c = lane + 64 * t;
                 if (c < nchunk) {
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2);
-                    if (gin) { const f32x4 gi = *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c); o += gi; }
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2) + gi[t][e];
                     if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow * D + 4 * c) = o;
                     if (dx_t) store4<DXT>(dx_t + orow * D + 4 * c, o);
                     if (colsum_dx) acc_x[t] += o;
@@ -169,17 +176,21 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
 
 // out[c] = (acc ? out[c] : 0) + sum_p partials[p*ld + c]
 template <typename OT>
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partials, long long nparts,
-                                                               long long ld, long long cols, OT* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ partials, long long nparts,
+                                                                long long ld, long long cols, OT* __restrict__ out, int accumulate) {
+    // 64 columns x 16 partial phases per block: the lists are a few hundred rows long (394 for the FF1 bias gradient
+    // of ViT-B), so the walk over them is what takes the time -- 16 rows in flight per column instead of 4
+    __shared__ float red[16][64];
     const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const long long c = (long long)blockIdx.x * 64 + cx;
     float s = 0.f;
-    if (c < cols) for (long long p = ph; p < nparts; p += 4) s += partials[p * ld + c];
+    if (c < cols) for (long long p = ph; p < nparts; p += 16) s += partials[p * ld + c];
     red[ph][cx] = s;
     __syncthreads();
     if (ph == 0 && c < cols) {
-        float t = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
         if (accumulate) t += to_f32<OT>(out[c]);
         out[c] = from_f32<OT>(t);
     }
@@ -359,7 +370,7 @@ extern "C" int vitk_colsum_partials(const float* partials, int64_t nparts, int64
     if (!partials || !out) VITK_FAIL(VITK_E_ARG, "colsum_partials: null pointer");
     if (cols <= 0 || nparts <= 0) VITK_FAIL(VITK_E_SHAPE, "colsum_partials: empty");
     const unsigned blocks = (unsigned)((cols + 63) / 64);
-    VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((colsum_partials_kernel<OT>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((colsum_partials_kernel<OT>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream,
                                                   partials, (long long)nparts, (long long)ld, (long long)cols, (OT*)out, accumulate));
     VITK_CHECK_LAUNCH("colsum_partials");
     return 0;

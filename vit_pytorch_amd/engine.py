@@ -29,6 +29,7 @@ import torch
 
 from . import kernels as K
 from . import ops
+from . import _lib as L
 from ._lib import RowMap, VitkError
 
 Tensor = torch.Tensor
@@ -389,14 +390,19 @@ class HeadFn(torch.autograd.Function):
         C = w.shape[0]
         y = y.contiguous()
         logits = ops.empty((B, C), T, y)
+        fast = T == torch.bfloat16 and D % 32 == 0 and C % 8 == 0          # MFMA kernels (row strides are arguments)
         if pool_mean:
             pooled = ops.empty((B, D), T, y)
             K.mean_pool_fwd(y, pooled, B, N, D)
-            K.gemm_generic(K.mat(pooled, D, 1), K.mat(w, 1, D), K.mat(logits, C, 1), B, C, D, bias=b)
+            src, ld = pooled, D
             ctx.pooled = pooled
         else:  # row 0 of every image read in place through the row stride N*D
-            K.gemm_generic(K.mat(y, N * D, 1), K.mat(w, 1, D), K.mat(logits, C, 1), B, C, D, bias=b)
+            src, ld = y, N * D
             ctx.pooled = None
+        if fast:
+            K.gemm_nt_bf16(src, ld, w, D, logits, C, B, C, D, L.EPI_BIAS if b is not None else L.EPI_NONE, bias=b)
+        else:
+            K.gemm_generic(K.mat(src, ld, 1), K.mat(w, 1, D), K.mat(logits, C, 1), B, C, D, bias=b)
         ctx.save_for_backward(y, w, *([b] if b is not None else []))
         ctx.meta = (B, N, D, C, pool_mean, b is not None)
         return logits
@@ -410,17 +416,14 @@ class HeadFn(torch.autograd.Function):
         dw = _grad_buf(w)
         db = _grad_buf(ctx.saved_tensors[2]) if has_b else None
         dy = torch.zeros((B, N, D), dtype=T, device=dl.device) if not pool_mean else ops.empty((B, N, D), T, dl)
+        src, ld = (ctx.pooled, D) if pool_mean else (y, N * D)
+        ops.linear_dw(dl, src, B, dw, db if has_b else None, ldx=ld)       # dW = dl^T . pooled rows (+ db = colsum(dl))
         if pool_mean:
-            pooled = ctx.pooled
-            K.gemm_generic(K.mat(dl, 1, C), K.mat(pooled, D, 1), K.mat(dw, D, 1), C, D, B)
             dpooled = ops.empty((B, D), T, dl)
             K.gemm_generic(K.mat(dl, C, 1), K.mat(w, D, 1), K.mat(dpooled, D, 1), B, D, C)
             K.mean_pool_bwd(dpooled, dy, B, N, D)
         else:
-            K.gemm_generic(K.mat(dl, 1, C), K.mat(y, N * D, 1), K.mat(dw, D, 1), C, D, B)
             K.gemm_generic(K.mat(dl, C, 1), K.mat(w, D, 1), K.mat(dy, N * D, 1), B, D, C)  # writes row 0 of each image
-        if has_b:
-            ops.colsum(dl, B, C, db)
         s = _sink()
         if s is not None:
             s.stage_done("head")

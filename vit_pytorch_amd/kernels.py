@@ -244,3 +244,9 @@ def csr_rowsum(g: Tensor, ptr: Tensor, rows: Tensor, out: Tensor, nseg: int, D: 
 
 def copy_cols(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, cols_copy: int, cols_dst: int):
     check(L.load().vitk_copy_cols(_p(src), ld_src, _p(dst), ld_dst, dt(src), rows, cols_copy, cols_dst, _stream()), "copy_cols")
+
+
+def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, master: Optional[Tensor], n: int, lr: float,
+              beta1: float, beta2: float, eps: float, weight_decay: float, decoupled: bool, step: int, grad_scale: float = 1.0):
+    check(L.load().vitk_adam_step(_p(param), _p(grad), dt(param), _p(exp_avg), _p(exp_avg_sq), _p(master), n, lr, beta1, beta2,
+                                  eps, weight_decay, int(decoupled), step, grad_scale, _stream()), "adam_step")

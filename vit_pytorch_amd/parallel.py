@@ -94,6 +94,10 @@ class FlatGradSink:
         self._late_launched = False
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def refresh_param_ptrs(self):
+        """Re-index the parameters after their storage moved (optim.Adam re-homes them into one flat buffer)."""
+        self._by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params) if p.numel()}
+
     # ---- engine-facing ------------------------------------------------------------------------
     def buffer_for(self, param: torch.Tensor) -> Optional[torch.Tensor]:
         i = self._by_ptr.get(param.data_ptr())
