@@ -16,7 +16,10 @@
  *     thread-local human readable string for the last non-zero return on this thread.
  *   - thread safety: re-entrant; no global mutable state (error string is thread-local).
  *     Callable from the autograd worker thread.
- *   - dtype tags: VITK_F32 = 0, VITK_BF16 = 1.  "T" below means the model dtype.
+ *   - dtype tags: VITK_F32 = 0, VITK_BF16 = 1.  "T" below means the model dtype.  The same ABI ships twice:
+ *     libvitk.so, where the 16-bit type is bfloat16, and libvitk_f16.so (same sources, -DVITK_HALF_IS_F16),
+ *     where every "bf16" of this header is IEEE binary16 (model.half()): tag 1 then denotes half, the `_bf16` entry
+ *     points run v_mfma_f32_16x16x32_f16, accumulation stays f32.  vitk_half_type() tells the two apart.
  *   - all matrices are row-major with explicit leading dimensions (in elements).
  */
 #ifndef VITK_H
@@ -32,7 +35,8 @@ extern "C" {
 #define VITK_VERSION 100
 
 #define VITK_F32 0
-#define VITK_BF16 1
+#define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
+#define VITK_F16 2           /* only as the return value of vitk_half_type() */
 
 #define VITK_E_ARG (-1)      /* null pointer / bad enum */
 #define VITK_E_SHAPE (-2)    /* unsupported extent */
@@ -40,6 +44,7 @@ extern "C" {
 #define VITK_E_DTYPE (-4)    /* unsupported dtype combination */
 
 int vitk_version(void);
+int vitk_half_type(void);    /* VITK_BF16 or VITK_F16: what dtype tag 1 means in this library */
 const char* vitk_last_error(void);
 
 /* A row map sends logical row r to physical row (r / group) * gstride + (r % group) + offset.

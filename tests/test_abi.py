@@ -40,6 +40,17 @@ def test_header_binding_and_exports_agree(lib):
         assert len(L.SIGNATURES[name][1]) == nargs, (name, nargs, len(L.SIGNATURES[name][1]))
 
 
+def test_f16_flavour_exports_the_same_abi():
+    """libvitk_f16.so: the same sources with the 16-bit type switched to IEEE half; same symbols, told apart by vitk_half_type()."""
+    if not os.path.exists(L.LIB_PATH_F16):
+        import __graft_entry__ as g
+        g.build()
+    lib16 = L.load_f16()
+    assert lib16.vitk_half_type() == L.HALF_TYPE_F16 and L.load().vitk_half_type() == L.BF16
+    for name in header_functions():
+        assert hasattr(lib16, name), f"{name} not exported by libvitk_f16.so"
+
+
 def test_version_and_no_torch_symbols(lib):
     assert lib.vitk_version() == L.VITK_VERSION
     # the boundary is plain C: the library must not depend on libtorch / libc10

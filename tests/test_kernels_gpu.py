@@ -464,3 +464,51 @@ def test_copy_cols_pad_and_strip():
     z = torch.empty(rows, cols, dtype=BF, device=DEV)
     K.copy_cols(y, pad, z, cols, rows, cols, cols)
     assert torch.equal(z, x)
+
+
+# ---------------------------------------------------------------------------------------------
+# IEEE-half flavour (libvitk_f16.so): the same kernels, operands float16
+F16 = torch.float16
+
+
+@pytest.mark.parametrize("M,N,Kd", [(2500, 768, 768), (6304, 3072, 768), (130, 132, 96)])
+def test_f16_gemms(M, N, Kd):
+    A = rnd(M, Kd, seed=141).to(F16); W = (rnd(N, Kd, seed=142) * (Kd ** -0.5)).to(F16)
+    bias = rnd(N, seed=143).to(F16)
+    ref = A.double() @ W.double().t()
+    C = torch.empty(M, N, dtype=F16, device=DEV); aux = torch.empty(M, N, dtype=F16, device=DEV)
+    K.gemm_nt_bf16(A, Kd, W, Kd, C, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    pre = ref + bias.double()
+    assert rel(aux, pre) < 6e-4 and rel(C, torch.nn.functional.gelu(pre)) < 8e-4
+    resid = rnd(M, N, seed=147); out = torch.empty(M, N, device=DEV)
+    K.gemm_nt_bf16(A, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid)
+    assert rel(out, resid.double() + pre) < 1e-5
+    if N % 8 == 0 and Kd % 8 == 0:
+        dY = rnd(M, N, seed=148).to(F16)
+        splits = K.gemm_tn_splits(M, N, Kd)
+        ws = torch.empty(splits * N * Kd, device=DEV); dW = torch.empty(N, Kd, dtype=F16, device=DEV)
+        K.gemm_tn_bf16(dY, N, A, Kd, dW, Kd, M, N, Kd, ws, splits)
+        assert rel(dW, dY.double().t() @ A.double()) < 6e-4
+    with pytest.raises(L.VitkError):                       # one 16-bit type per call
+        K.gemm_nt_bf16(A, Kd, W.to(BF), Kd, C, N, M, N, Kd)
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 64), (2, 2, 256)])
+def test_f16_attention_fwd_bwd(B, H, N):
+    d = 64
+    I = H * d
+    scale = d ** -0.5
+    qkv = (rnd(B, N, 3 * I, seed=171) * 1.5).to(F16)
+    do = rnd(B, N, I, seed=172).to(F16)
+    o = torch.empty(B, N, I, dtype=F16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV); delta = torch.empty(B, H, N, device=DEV)
+    sb, sh, sn = N * 3 * I, d, 3 * I
+    q_ = K.bhnd(qkv, sb, sh, sn); k_ = K.bhnd(qkv, sb, sh, sn, offset=I); v_ = K.bhnd(qkv, sb, sh, sn, offset=2 * I)
+    o_ = K.bhnd(o, N * I, d, I)
+    K.attn_fwd_bf16(q_, k_, v_, o_, lse, B, H, N, d, scale)
+    oref, lref, gref = _attn_ref(qkv, B, N, H, d, scale, do)
+    assert rel(o, oref) < 1e-3 and maxabs(lse, lref) < 1e-3
+    dqkv = torch.empty_like(qkv)
+    K.attn_bwd_bf16(q_, k_, v_, o_, K.bhnd(do, N * I, d, I), lse, delta, K.bhnd(dqkv, sb, sh, sn),
+                    K.bhnd(dqkv, sb, sh, sn, offset=I), K.bhnd(dqkv, sb, sh, sn, offset=2 * I), B, H, N, d, scale)
+    assert rel(dqkv, gref) < 2e-3

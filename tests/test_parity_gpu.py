@@ -40,11 +40,13 @@ def build(kind, cfg, params, dtype):
     return m.to(DEV, dtype=dtype)
 
 
-def run_mine(kind, cfg, params, img, dtype):
+def run_mine(kind, cfg, params, img, dtype, loss_scale=1.0):
+    """loss_scale: IEEE half has 5 exponent bits -- the 1e-6-sized gradients of a mean-of-squares loss behind a mean
+    pool fall into its subnormals -- so fp16 runs scale the loss (as any fp16 training does) and unscale the gradients."""
     m = build(kind, cfg, params, dtype)
     out = m(img.to(DEV, dtype=dtype))
-    O.loss_fn(out).backward()
-    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+    (O.loss_fn(out) * loss_scale).backward()
+    grads = {k: ((p.grad.float() / loss_scale) if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
     return out, grads
 
 
@@ -69,6 +71,25 @@ def test_f32_mode_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", list(CASES))
+def test_fp16_mode_vs_golden(name):
+    """model.half() (libvitk_f16.so: the same kernels with IEEE-half operands, v_mfma_..._f16, f32 accumulation).
+    Half carries 11 significant bits against bfloat16's 8, so the gate is an absolute one: 3e-3 relative L2 of the
+    reference's golden logits / gradients (measured ~5e-4)."""
+    case = CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000, case.get("image"))
+    out, grads = run_mine(case["kind"], case["cfg"], params, img, torch.float16, loss_scale=256.0)
+    assert out.dtype == torch.float16
+    keys = [k for k in params if params[k].numel() > 0]
+    cat = lambda get: torch.cat([get(k).detach().float().flatten().cpu() for k in keys])
+    e = rel(out, torch.from_numpy(gold["logits"]))
+    g = rel(cat(lambda k: grads[k]), cat(lambda k: torch.from_numpy(gold["grad::" + k])))
+    print(f"{name} fp16: logits {e:.2e} grads {g:.2e}")
+    assert e <= 3e-3 and g <= 3e-3
+
+
+@pytest.mark.parametrize("name", list(CASES))
 def test_bf16_mode_vs_oracle(name):
     case = CASES[name]
     params = make_params(case["kind"], case["cfg"], case["seed"])
@@ -89,7 +110,7 @@ VITB_SMALL = dict(image_size=224, patch_size=16, num_classes=1000, dim=768, dept
 
 
 @pytest.mark.parametrize("kind", ["vit", "simple_vit"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_vit_b16_width_depth2_vs_oracle(kind, dtype):
     """BASELINE config 2's layer shapes (N=197, D=768, h=12, F=3072: the MFMA fast path in bf16)
     at depth 2 / batch 4 so the CPU oracle finishes in seconds."""
@@ -97,7 +118,7 @@ def test_vit_b16_width_depth2_vs_oracle(kind, dtype):
     params = make_params(kind, cfg, 7)
     img = make_images(cfg, 4, 1007)
     ref_out, ref_g = O.run_fwd_bwd(kind, cfg, params, img, torch.float32)
-    out, grads = run_mine(kind, cfg, params, img, dtype)
+    out, grads = run_mine(kind, cfg, params, img, dtype, loss_scale=4096.0 if dtype == torch.float16 else 1.0)
     keys = list(params)
     cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
     e, g = rel(out, ref_out), rel(cat(grads), cat(ref_g))
@@ -105,6 +126,9 @@ def test_vit_b16_width_depth2_vs_oracle(kind, dtype):
         assert e <= 1e-3 and g <= 1e-3, (e, g)
         worst = max(rel(grads[k], ref_g[k]) for k in keys)
         assert worst <= 1e-3, worst
+    elif dtype == torch.float16:                      # 11-bit significand: an absolute gate (see test_fp16_mode_vs_golden)
+        print(f"{kind} fp16 depth2: logits {e:.2e} grads {g:.2e}")
+        assert e <= 3e-3 and g <= 3e-3, (e, g)
     else:
         bf_out, bf_g = O.run_fwd_bwd(kind, cfg, params, img, torch.bfloat16)
         e_ref, g_ref = rel(bf_out, ref_out), rel(cat(bf_g), cat(ref_g))

@@ -15,6 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitk.so")
+LIB_F16 = os.path.join(HERE, "libvitk_f16.so")
 SOURCES = ["elementwise.hip", "layernorm.hip", "gemm_bf16.hip", "gemm_generic.hip", "attention.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "vitk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -34,9 +35,8 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = True) -> str:
+def _build_one(lib: str, bdir: str, extra, force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
-    bdir = os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
     jobs = []
     objs = []
@@ -45,7 +45,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *extra, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -57,9 +57,15 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
+
+
+def build_lib(force: bool = False, verbose: bool = True) -> str:
+    """libvitk.so (16-bit type = bfloat16) and libvitk_f16.so (same sources, 16-bit type = IEEE half)."""
+    _build_one(LIB_F16, os.path.join(CSRC, "build", "f16"), ["-DVITK_HALF_IS_F16=1"], force, verbose)
+    return _build_one(LIB, os.path.join(CSRC, "build"), [], force, verbose)
 
 
 if __name__ == "__main__":

@@ -7,11 +7,14 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvitk.so")
+LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit type is IEEE half (model.half())
 
-F32, BF16 = 0, 1
+F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
+HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3, 4
 VITK_VERSION = 100
 
@@ -50,6 +53,7 @@ SIGNATURES = {
     "vitk_colsum_ws_floats": (_i64, [_i64, _i64]),
     "vitk_colsum": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _vp, _vp]),
     "vitk_gemm_nt_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
+    "vitk_half_type": (_i, []),
     "vitk_adam_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i64, _f, _vp]),
     "vitk_gemm_nt_colsum_rows": (_i64, [_i64, _i64, _i64, _i64]),
     "vitk_gemm_nt_bf16_gelu_bwd_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
@@ -83,36 +87,57 @@ SIGNATURES = {
 }
 
 _lib = None
+_lib_f16 = None
 
 
 class VitkError(RuntimeError):
     pass
 
 
-def load():
-    """Load libvitk.so once.  Raises VitkError (never falls back) if it is absent or stale."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path: str, half_type: int):
+    if not os.path.exists(path):
         raise VitkError(
-            f"{LIB_PATH} not found: the HIP kernel library is not built. "
+            f"{path} not found: the HIP kernel library is not built. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `python -m vit_pytorch_amd._build`). There is no CPU/eager fallback.")
     import torch  # noqa: F401  -- torch must load ITS HIP runtime first; a second runtime copy cannot see the device
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     v = lib.vitk_version()
     if v != VITK_VERSION:
-        raise VitkError(f"libvitk.so version {v} != binding version {VITK_VERSION}; rebuild")
-    _lib = lib
+        raise VitkError(f"{os.path.basename(path)} version {v} != binding version {VITK_VERSION}; rebuild")
+    if lib.vitk_half_type() != half_type:
+        raise VitkError(f"{os.path.basename(path)} was built for the wrong 16-bit type; rebuild")
     return lib
+
+
+def load():
+    """Load libvitk.so (16-bit type: bfloat16) once.  Raises VitkError (never falls back) if it is absent or stale."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH, BF16)
+    return _lib
+
+
+def load_f16():
+    """Load libvitk_f16.so (the same kernels instantiated for IEEE half) once."""
+    global _lib_f16
+    if _lib_f16 is None:
+        _lib_f16 = _open(LIB_PATH_F16, HALF_TYPE_F16)
+    return _lib_f16
+
+
+_tls = threading.local()
+
+
+def note_last_lib(lib):
+    _tls.lib = lib
 
 
 def check(rc: int, what: str = ""):
     if rc != 0:
-        msg = load().vitk_last_error().decode("utf-8", "replace")
+        msg = (getattr(_tls, "lib", None) or load()).vitk_last_error().decode("utf-8", "replace")
         raise VitkError(f"{what}: vitk error {rc}: {msg}")

@@ -6,6 +6,15 @@
 #include <stdarg.h>
 #include "../../include/vitk.h"
 
+// libvitk_f16.so is built from these same sources with -DVITK_HALF_IS_F16: every "bf16" below then IS IEEE binary16
+// (_Float16) -- 16-bit storage, the same 8-element fragments, v_mfma_f32_16x16x32_f16 instead of ..._bf16, f32
+// accumulation everywhere -- and dtype tag 1 means "this library's 16-bit type" (vitk_half_type() says which).
+// The switch sits after the HIP headers so that their own bf16 helpers are left alone.
+#ifdef VITK_HALF_IS_F16
+#define __bf16 _Float16
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

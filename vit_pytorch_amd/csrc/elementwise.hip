@@ -11,6 +11,14 @@ void vitk_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+extern "C" int vitk_half_type(void) {
+#ifdef VITK_HALF_IS_F16
+    return VITK_F16;
+#else
+    return VITK_BF16;
+#endif
+}
+
 extern "C" int vitk_version(void) { return VITK_VERSION; }
 extern "C" const char* vitk_last_error(void) { return g_err; }
 

@@ -390,7 +390,7 @@ class HeadFn(torch.autograd.Function):
         C = w.shape[0]
         y = y.contiguous()
         logits = ops.empty((B, C), T, y)
-        fast = T == torch.bfloat16 and D % 32 == 0 and C % 8 == 0          # MFMA kernels (row strides are arguments)
+        fast = T in ops.HALF and D % 32 == 0 and C % 8 == 0          # MFMA kernels (row strides are arguments)
         if pool_mean:
             pooled = ops.empty((B, D), T, y)
             K.mean_pool_fwd(y, pooled, B, N, D)
@@ -462,8 +462,8 @@ class PackedTransformerFn(torch.autograd.Function):
         _check_dims(D, "NaViT Transformer")
         I = heads * dim_head
         d = dim_head
-        if T != torch.bfloat16 or d != 64:
-            raise VitkError("PackedTransformerFn: fused NaViT stack needs bfloat16 parameters and dim_head == 64")
+        if T not in ops.HALF or d != 64:
+            raise VitkError("PackedTransformerFn: fused NaViT stack needs 16-bit parameters and dim_head == 64")
         x = x.contiguous()
         if x.dtype == F32:
             xs = x

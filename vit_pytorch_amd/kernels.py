@@ -17,13 +17,33 @@ from ._lib import BF16, F32, IDENT, BHND, Mat, RowMap, check
 Tensor = torch.Tensor
 
 
+HALF_DTYPES = (torch.bfloat16, torch.float16)
+
+
 def dt(t_or_dtype) -> int:
     d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
     if d == torch.float32:
         return F32
-    if d == torch.bfloat16:
-        return BF16
-    raise L.VitkError(f"unsupported dtype {d}: libvitk computes in float32 or bfloat16")
+    if d in HALF_DTYPES:
+        return BF16          # "the library's 16-bit type": _lib_for() routes float16 tensors to libvitk_f16.so
+    raise L.VitkError(f"unsupported dtype {d}: libvitk computes in float32, bfloat16 or float16")
+
+
+def _lib_for(*objs):
+    """The library instance that serves these operands: libvitk_f16.so as soon as one of them is float16.
+
+    Operands are tensors or the pointer structs built by mat() / bhnd() / hnd() (which remember their tensor's dtype).
+    bfloat16 and float16 operands must not meet in one call -- each library knows a single 16-bit type."""
+    f16 = b16 = False
+    for o in objs:
+        d = o.dtype if isinstance(o, torch.Tensor) else getattr(o, "_dtype", None)
+        f16 = f16 or d == torch.float16
+        b16 = b16 or d == torch.bfloat16
+    if f16 and b16:
+        raise L.VitkError("float16 and bfloat16 operands in one call: a model must use ONE 16-bit dtype")
+    lib = L.load_f16() if f16 else L.load()
+    L.note_last_lib(lib)        # check() reads the (thread-local, per-library) error string from the right instance
+    return lib
 
 
 def _p(t: Optional[Tensor]):
@@ -46,7 +66,7 @@ def require_device(*ts: Tensor):
 def layernorm_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], y: Tensor, mean: Tensor, rstd: Tensor,
                   rows: int, D: int, eps: float = 1e-5, imap: RowMap = IDENT, omap: RowMap = IDENT,
                   add: Optional[Tensor] = None, add_group: int = 0, add_off: int = 0):
-    lib = L.load()
+    lib = _lib_for(x, w, y, mean, rstd)
     check(lib.vitk_layernorm_fwd(_p(x), dt(x), _p(w), _p(b), dt(w), _p(y), dt(y), _p(mean), _p(rstd),
                                  rows, D, eps, imap, omap, _p(add), add_group, add_off, _stream()),
           "layernorm_fwd")
@@ -59,7 +79,7 @@ def layernorm_bwd_blocks(rows: int) -> int:
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, gin: Optional[Tensor],
                   dx_f32: Optional[Tensor], dx_t: Optional[Tensor], partials: Tensor, colsum_dx: bool,
                   rows: int, D: int, dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT):
-    lib = L.load()
+    lib = _lib_for(dy, x, w, mean, rstd, partials)
     check(lib.vitk_layernorm_bwd(_p(dy), dt(dy), _p(x), dt(x), _p(w), dt(w), _p(mean), _p(rstd), _p(gin),
                                  _p(dx_f32), _p(dx_t), dt(dx_t) if dx_t is not None else F32, _p(partials),
                                  1 if colsum_dx else 0, rows, D, dymap, xmap, dxmap, _stream()),
@@ -68,12 +88,12 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
 
 def layernorm_bwd_finalize(partials: Tensor, nblk: int, D: int, dw: Optional[Tensor], db: Optional[Tensor],
                            dcol: Optional[Tensor], odt: int):
-    check(L.load().vitk_layernorm_bwd_finalize(_p(partials), nblk, D, _p(dw), _p(db), odt, _p(dcol), _stream()),
+    check(_lib_for(partials, dw, db).vitk_layernorm_bwd_finalize(_p(partials), nblk, D, _p(dw), _p(db), odt, _p(dcol), _stream()),
           "layernorm_bwd_finalize")
 
 
 def colsum_partials(partials: Tensor, nparts: int, ld: int, cols: int, out: Tensor, accumulate: bool = False):
-    check(L.load().vitk_colsum_partials(_p(partials), nparts, ld, cols, _p(out), dt(out), int(accumulate), _stream()),
+    check(_lib_for(partials, out).vitk_colsum_partials(_p(partials), nparts, ld, cols, _p(out), dt(out), int(accumulate), _stream()),
           "colsum_partials")
 
 
@@ -82,7 +102,7 @@ def colsum_ws_floats(rows: int, cols: int) -> int:
 
 
 def colsum(x: Tensor, rows: int, cols: int, ld: int, out: Tensor, ws: Tensor, accumulate: bool = False):
-    check(L.load().vitk_colsum(_p(x), dt(x), rows, cols, ld, _p(out), dt(out), int(accumulate), _p(ws), _stream()),
+    check(_lib_for(x, out, ws).vitk_colsum(_p(x), dt(x), rows, cols, ld, _p(out), dt(out), int(accumulate), _p(ws), _stream()),
           "colsum")
 
 
@@ -90,7 +110,7 @@ def colsum(x: Tensor, rows: int, cols: int, ld: int, out: Tensor, ws: Tensor, ac
 def gemm_nt_bf16(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
                  epilogue: int = L.EPI_NONE, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
                  aux: Optional[Tensor] = None):
-    check(L.load().vitk_gemm_nt_bf16(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, epilogue, _p(bias), _p(resid),
+    check(_lib_for(A, W, C).vitk_gemm_nt_bf16(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, epilogue, _p(bias), _p(resid),
                                      _p(aux), _stream()), "gemm_nt_bf16")
 
 
@@ -100,7 +120,7 @@ def gemm_nt_colsum_rows(M: int, N: int, K: int, ldc: int) -> int:
 
 def gemm_nt_bf16_gelu_bwd_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
                                  aux: Tensor, partials: Tensor):
-    check(L.load().vitk_gemm_nt_bf16_gelu_bwd_colsum(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, _p(aux), _p(partials),
+    check(_lib_for(A, W, C, aux, partials).vitk_gemm_nt_bf16_gelu_bwd_colsum(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, _p(aux), _p(partials),
                                                      _stream()), "gemm_nt_bf16_gelu_bwd_colsum")
 
 
@@ -110,105 +130,111 @@ def gemm_tn_splits(M: int, N: int, K: int) -> int:
 
 def gemm_tn_bf16(dY: Tensor, ldy: int, X: Tensor, ldx: int, dW: Tensor, ldo: int, M: int, N: int, K: int,
                  ws: Tensor, splits: int, accumulate: bool = False):
-    check(L.load().vitk_gemm_tn_bf16(_p(dY), ldy, _p(X), ldx, _p(dW), dt(dW), ldo, int(accumulate), M, N, K,
+    check(_lib_for(dY, X, dW, ws).vitk_gemm_tn_bf16(_p(dY), ldy, _p(X), ldx, _p(dW), dt(dW), ldo, int(accumulate), M, N, K,
                                      _p(ws), splits, _stream()), "gemm_tn_bf16")
 
 
 def mat(t: Tensor, s_row: int, s_col: int, s_b1: int = 0, s_b2: int = 0, offset: int = 0) -> Mat:
-    return Mat(t.data_ptr() + offset * t.element_size(), dt(t), s_b1, s_b2, s_row, s_col)
+    m = Mat(t.data_ptr() + offset * t.element_size(), dt(t), s_b1, s_b2, s_row, s_col)
+    m._dtype = t.dtype
+    return m
 
 
 def gemm_generic(A: Mat, B: Mat, Cm: Mat, M: int, N: int, K: int, nb1: int = 1, nb2: int = 1,
                  bias: Optional[Tensor] = None, alpha: float = 1.0, beta: float = 0.0):
-    check(L.load().vitk_gemm_generic(A, B, Cm, _p(bias), dt(bias) if bias is not None else F32, nb1, nb2, M, N, K,
+    check(_lib_for(A, B, Cm).vitk_gemm_generic(A, B, Cm, _p(bias), dt(bias) if bias is not None else F32, nb1, nb2, M, N, K,
                                      alpha, beta, _stream()), "gemm_generic")
 
 
 # ---- attention -------------------------------------------------------------------------------
 def bhnd(t: Tensor, s_b: int, s_h: int, s_n: int, offset: int = 0) -> BHND:
-    return BHND(t.data_ptr() + offset * t.element_size(), s_b, s_h, s_n)
+    r = BHND(t.data_ptr() + offset * t.element_size(), s_b, s_h, s_n)
+    r._dtype = t.dtype
+    return r
 
 
 def attn_fwd_bf16(q: BHND, k: BHND, v: BHND, o: BHND, lse: Tensor, B: int, H: int, N: int, d: int, scale: float):
-    check(L.load().vitk_attn_fwd_bf16(q, k, v, o, _p(lse), B, H, N, d, scale, _stream()), "attn_fwd_bf16")
+    check(_lib_for(q, k, v, o, lse).vitk_attn_fwd_bf16(q, k, v, o, _p(lse), B, H, N, d, scale, _stream()), "attn_fwd_bf16")
 
 
 def attn_bwd_bf16(q: BHND, k: BHND, v: BHND, o: BHND, dout: BHND, lse: Tensor, delta: Tensor, dq: BHND, dk: BHND,
                   dv: BHND, B: int, H: int, N: int, d: int, scale: float):
-    check(L.load().vitk_attn_bwd_bf16(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, B, H, N, d, scale, _stream()),
+    check(_lib_for(q, k, v, o, dout, lse, delta, dq, dk, dv).vitk_attn_bwd_bf16(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, B, H, N, d, scale, _stream()),
           "attn_bwd_bf16")
 
 
 def softmax_fwd(s: Tensor, p: Tensor, rows: int, cols: int, scale: float):
-    check(L.load().vitk_softmax_fwd(_p(s), _p(p), dt(s), rows, cols, scale, _stream()), "softmax_fwd")
+    check(_lib_for(s, p).vitk_softmax_fwd(_p(s), _p(p), dt(s), rows, cols, scale, _stream()), "softmax_fwd")
 
 
 def softmax_bwd(p: Tensor, dp: Tensor, ds: Tensor, rows: int, cols: int, scale: float):
-    check(L.load().vitk_softmax_bwd(_p(p), _p(dp), _p(ds), dt(p), rows, cols, scale, _stream()), "softmax_bwd")
+    check(_lib_for(p, dp, ds).vitk_softmax_bwd(_p(p), _p(dp), _p(ds), dt(p), rows, cols, scale, _stream()), "softmax_bwd")
 
 
 # ---- element-wise ------------------------------------------------------------------------------
 def patchify(img: Tensor, out: Tensor, B: int, C: int, H: int, W: int, p1: int, p2: int):
-    check(L.load().vitk_patchify(_p(img), _p(out), dt(img), B, C, H, W, p1, p2, _stream()), "patchify")
+    check(_lib_for(img, out).vitk_patchify(_p(img), _p(out), dt(img), B, C, H, W, p1, p2, _stream()), "patchify")
 
 
 def gelu_fwd(x: Tensor, y: Tensor):
-    check(L.load().vitk_gelu_fwd(_p(x), _p(y), dt(x), x.numel(), _stream()), "gelu_fwd")
+    check(_lib_for(x, y).vitk_gelu_fwd(_p(x), _p(y), dt(x), x.numel(), _stream()), "gelu_fwd")
 
 
 def gelu_bwd(dy: Tensor, x: Tensor, dx: Tensor):
-    check(L.load().vitk_gelu_bwd(_p(dy), _p(x), _p(dx), dt(x), x.numel(), _stream()), "gelu_bwd")
+    check(_lib_for(dy, x, dx).vitk_gelu_bwd(_p(dy), _p(x), _p(dx), dt(x), x.numel(), _stream()), "gelu_bwd")
 
 
 def add_rows(a: Tensor, b: Tensor, bias: Optional[Tensor], out: Tensor, rows: int, cols: int):
-    check(L.load().vitk_add_rows(_p(a), dt(a), _p(b), dt(b), _p(bias), dt(bias) if bias is not None else dt(b),
+    check(_lib_for(a, b, out).vitk_add_rows(_p(a), dt(a), _p(b), dt(b), _p(bias), dt(bias) if bias is not None else dt(b),
                                  _p(out), dt(out), rows, cols, _stream()), "add_rows")
 
 
 def cast(x: Tensor, y: Tensor):
-    check(L.load().vitk_cast(_p(x), dt(x), _p(y), dt(y), x.numel(), _stream()), "cast")
+    check(_lib_for(x, y).vitk_cast(_p(x), dt(x), _p(y), dt(y), x.numel(), _stream()), "cast")
 
 
 def write_cls_rows(x: Tensor, cls: Tensor, pos: Tensor, B: int, N: int, D: int, ncls: int):
-    check(L.load().vitk_write_cls_rows(_p(x), dt(x), _p(cls), _p(pos), dt(pos), B, N, D, ncls, _stream()),
+    check(_lib_for(x, cls, pos).vitk_write_cls_rows(_p(x), dt(x), _p(cls), _p(pos), dt(pos), B, N, D, ncls, _stream()),
           "write_cls_rows")
 
 
 def mean_pool_fwd(x: Tensor, out: Tensor, B: int, N: int, D: int):
-    check(L.load().vitk_mean_pool_fwd(_p(x), dt(x), _p(out), dt(out), B, N, D, _stream()), "mean_pool_fwd")
+    check(_lib_for(x, out).vitk_mean_pool_fwd(_p(x), dt(x), _p(out), dt(out), B, N, D, _stream()), "mean_pool_fwd")
 
 
 def mean_pool_bwd(dout: Tensor, dx: Tensor, B: int, N: int, D: int):
-    check(L.load().vitk_mean_pool_bwd(_p(dout), dt(dout), _p(dx), dt(dx), B, N, D, _stream()), "mean_pool_bwd")
+    check(_lib_for(dout, dx).vitk_mean_pool_bwd(_p(dout), dt(dout), _p(dx), dt(dx), B, N, D, _stream()), "mean_pool_bwd")
 
 
 def dropout_fwd(x: Tensor, y: Tensor, mask: Tensor, p: float, seed: int, offset: int):
-    check(L.load().vitk_dropout_fwd(_p(x), _p(y), _p(mask), dt(x), x.numel(), p, seed, offset, _stream()), "dropout_fwd")
+    check(_lib_for(x, y, mask).vitk_dropout_fwd(_p(x), _p(y), _p(mask), dt(x), x.numel(), p, seed, offset, _stream()), "dropout_fwd")
 
 
 def dropout_bwd(dy: Tensor, mask: Tensor, dx: Tensor, p: float):
-    check(L.load().vitk_dropout_bwd(_p(dy), _p(mask), _p(dx), dt(dy), dy.numel(), p, _stream()), "dropout_bwd")
+    check(_lib_for(dy, mask, dx).vitk_dropout_bwd(_p(dy), _p(mask), _p(dx), dt(dy), dy.numel(), p, _stream()), "dropout_bwd")
 
 
 def transpose(x: Tensor, out: Tensor, rows: int, cols: int):
-    check(L.load().vitk_transpose(_p(x), _p(out), dt(x), rows, cols, _stream()), "transpose")
+    check(_lib_for(x, out).vitk_transpose(_p(x), _p(out), dt(x), rows, cols, _stream()), "transpose")
 
 
 # ---- NaViT: packed / variable-length path ----------------------------------------------------------
 def hnd(t: Tensor, s_h: int, s_n: int, offset: int = 0) -> L.HND:
-    return L.HND(t.data_ptr() + offset * t.element_size(), s_h, s_n)
+    r = L.HND(t.data_ptr() + offset * t.element_size(), s_h, s_n)
+    r._dtype = t.dtype
+    return r
 
 
 def attn_varlen_fwd_bf16(q: L.HND, k: L.HND, v: L.HND, o: L.HND, lse: Tensor, cu_q: Tensor, cu_k: Tensor, blk_seg: Tensor,
                          blk_r0: Tensor, nblk: int, tq_total: int, H: int, d: int, scale: float):
-    check(L.load().vitk_attn_varlen_fwd_bf16(q, k, v, o, _p(lse), _p(cu_q), _p(cu_k), _p(blk_seg), _p(blk_r0), nblk,
+    check(_lib_for(q, k, v, o, lse, cu_q, cu_k, blk_seg, blk_r0).vitk_attn_varlen_fwd_bf16(q, k, v, o, _p(lse), _p(cu_q), _p(cu_k), _p(blk_seg), _p(blk_r0), nblk,
                                              tq_total, H, d, scale, _stream()), "attn_varlen_fwd_bf16")
 
 
 def attn_varlen_bwd_bf16(q: L.HND, k: L.HND, v: L.HND, o: L.HND, dout: L.HND, lse: Tensor, delta: Tensor, dq: L.HND,
                          dk: L.HND, dv: L.HND, cu_q: Tensor, cu_k: Tensor, qblk_seg: Tensor, qblk_r0: Tensor, nqblk: int,
                          kblk_seg: Tensor, kblk_r0: Tensor, nkblk: int, tq_total: int, H: int, d: int, scale: float):
-    check(L.load().vitk_attn_varlen_bwd_bf16(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, _p(cu_q), _p(cu_k),
+    check(_lib_for(q, k, v, o, dout, lse, delta, dq, dk, dv, cu_q, cu_k, qblk_seg, qblk_r0, kblk_seg, kblk_r0).vitk_attn_varlen_bwd_bf16(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, _p(cu_q), _p(cu_k),
                                              _p(qblk_seg), _p(qblk_r0), nqblk, _p(kblk_seg), _p(kblk_r0), nkblk,
                                              tq_total, H, d, scale, _stream()), "attn_varlen_bwd_bf16")
 
@@ -219,34 +245,34 @@ def rmsnorm_heads_rows(T: int, H: int) -> int:
 
 def rmsnorm_heads_fwd(x: Tensor, ldx: int, gamma: Tensor, y: Tensor, ldy: int, rnorm: Tensor, T: int, H: int, d: int,
                       x_off: int = 0):
-    check(L.load().vitk_rmsnorm_heads_fwd(x.data_ptr() + x_off * x.element_size(), ldx, _p(gamma), _p(y), ldy, _p(rnorm),
+    check(_lib_for(x, gamma, y, rnorm).vitk_rmsnorm_heads_fwd(x.data_ptr() + x_off * x.element_size(), ldx, _p(gamma), _p(y), ldy, _p(rnorm),
                                           dt(x), T, H, d, _stream()), "rmsnorm_heads_fwd")
 
 
 def rmsnorm_heads_bwd(dy: Tensor, lddy: int, x: Tensor, ldx: int, gamma: Tensor, rnorm: Tensor, dx: Tensor, lddx: int,
                       dgamma: Tensor, partials: Tensor, T: int, H: int, d: int, x_off: int = 0, dx_off: int = 0):
-    check(L.load().vitk_rmsnorm_heads_bwd(_p(dy), lddy, x.data_ptr() + x_off * x.element_size(), ldx, _p(gamma), _p(rnorm),
+    check(_lib_for(dy, x, gamma, rnorm, dx, dgamma, partials).vitk_rmsnorm_heads_bwd(_p(dy), lddy, x.data_ptr() + x_off * x.element_size(), ldx, _p(gamma), _p(rnorm),
                                           dx.data_ptr() + dx_off * dx.element_size(), lddx, _p(dgamma), _p(partials),
                                           dt(x), T, H, d, _stream()), "rmsnorm_heads_bwd")
 
 
 def patchify_cpp(img: Tensor, out: Tensor, C: int, H: int, W: int, p: int, row0: int, ld: int):
-    check(L.load().vitk_patchify_cpp(_p(img), _p(out), dt(img), C, H, W, p, row0, ld, _stream()), "patchify_cpp")
+    check(_lib_for(img, out).vitk_patchify_cpp(_p(img), _p(out), dt(img), C, H, W, p, row0, ld, _stream()), "patchify_cpp")
 
 
 def gather_add2(x: Tensor, A: Tensor, ia: Tensor, B: Tensor, ib: Tensor, out: Tensor, T: int, D: int):
-    check(L.load().vitk_gather_add2(_p(x), _p(A), _p(ia), _p(B), _p(ib), _p(out), dt(x), T, D, _stream()), "gather_add2")
+    check(_lib_for(x, A, ia, B, ib, out).vitk_gather_add2(_p(x), _p(A), _p(ia), _p(B), _p(ib), _p(out), dt(x), T, D, _stream()), "gather_add2")
 
 
 def csr_rowsum(g: Tensor, ptr: Tensor, rows: Tensor, out: Tensor, nseg: int, D: int):
-    check(L.load().vitk_csr_rowsum(_p(g), dt(g), _p(ptr), _p(rows), _p(out), dt(out), nseg, D, _stream()), "csr_rowsum")
+    check(_lib_for(g, ptr, rows, out).vitk_csr_rowsum(_p(g), dt(g), _p(ptr), _p(rows), _p(out), dt(out), nseg, D, _stream()), "csr_rowsum")
 
 
 def copy_cols(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, cols_copy: int, cols_dst: int):
-    check(L.load().vitk_copy_cols(_p(src), ld_src, _p(dst), ld_dst, dt(src), rows, cols_copy, cols_dst, _stream()), "copy_cols")
+    check(_lib_for(src, dst).vitk_copy_cols(_p(src), ld_src, _p(dst), ld_dst, dt(src), rows, cols_copy, cols_dst, _stream()), "copy_cols")
 
 
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, master: Optional[Tensor], n: int, lr: float,
               beta1: float, beta2: float, eps: float, weight_decay: float, decoupled: bool, step: int, grad_scale: float = 1.0):
-    check(L.load().vitk_adam_step(_p(param), _p(grad), dt(param), _p(exp_avg), _p(exp_avg_sq), _p(master), n, lr, beta1, beta2,
+    check(_lib_for(param, grad, exp_avg, exp_avg_sq).vitk_adam_step(_p(param), _p(grad), dt(param), _p(exp_avg), _p(exp_avg_sq), _p(master), n, lr, beta1, beta2,
                                   eps, weight_decay, int(decoupled), step, grad_scale, _stream()), "adam_step")

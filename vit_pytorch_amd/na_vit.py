@@ -97,7 +97,7 @@ class _QKNormAttnFn(torch.autograd.Function):
         K.rmsnorm_heads_fwd(q, I, gqf, qn, I, rq, Tq, heads, d)
         K.rmsnorm_heads_fwd(kv, 2 * I, gkf, kn, I, rk, Tk, heads, d)
         o = torch.empty((Tq, I), dtype=T, device=q.device)
-        if T == torch.bfloat16:
+        if T in (torch.bfloat16, torch.float16):
             lse = torch.empty((heads, Tq), dtype=F32, device=q.device)
             K.attn_varlen_fwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), lse,
                                    segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, Tq, heads, d, 1.0)
@@ -130,7 +130,7 @@ class _QKNormAttnFn(torch.autograd.Function):
         do = Fn._to(do, T)
         dqn = torch.empty_like(qn); dkn = torch.empty_like(kn)
         dkv = torch.empty_like(kv)
-        if T == torch.bfloat16:
+        if T in (torch.bfloat16, torch.float16):
             delta = torch.empty((heads, Tq), dtype=F32, device=q.device)
             K.attn_varlen_bwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I),
                                    K.hnd(do, d, I), ctx.att, delta, K.hnd(dqn, d, I), K.hnd(dkn, d, I),
@@ -277,7 +277,7 @@ class Transformer(nn.Module):
         self.norm = LayerNorm(dim)
 
     def _fusable(self, x) -> bool:
-        if x.dtype != torch.bfloat16 or self.norm.gamma.dtype != torch.bfloat16:
+        if x.dtype not in (torch.bfloat16, torch.float16) or self.norm.gamma.dtype != x.dtype:
             return False
         for attn, ff in self.layers:
             if attn.q_norm.gamma.shape[-1] != 64:

@@ -23,6 +23,7 @@ from .segments import uniform_segments
 
 Tensor = torch.Tensor
 BF16 = torch.bfloat16
+HALF = (torch.bfloat16, torch.float16)      # the two 16-bit model dtypes (libvitk.so / libvitk_f16.so)
 F32 = torch.float32
 LN_EPS = 1e-5
 
@@ -63,7 +64,7 @@ def colsum(x: Tensor, rows: int, cols: int, out: Tensor, accumulate: bool = Fals
 
 # ---- Linear --------------------------------------------------------------------------------------
 def _fast_nt(x: Tensor, N: int, Kd: int) -> bool:
-    return x.dtype == BF16 and Kd % 32 == 0 and N % 4 == 0
+    return x.dtype in HALF and Kd % 32 == 0 and N % 4 == 0
 
 
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bool = False,
@@ -94,7 +95,7 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
             K.gelu_fwd(pre, act)
         return act, pre
     y = empty((M, N), out_dtype or T, x)
-    if _fast_nt(x, N, Kd) and y.dtype == BF16:
+    if _fast_nt(x, N, Kd) and y.dtype in HALF:
         K.gemm_nt_bf16(x, Kd, W, Kd, y, N, M, N, Kd, L.EPI_BIAS if bias is not None else L.EPI_NONE, bias=bias)
     else:
         K.gemm_generic(K.mat(x, Kd, 1), K.mat(W, 1, Kd), K.mat(y, N, 1), M, N, Kd, bias=bias)
@@ -116,7 +117,7 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
     N, Kd = W.shape
     T = dy.dtype
     dx = empty((M, Kd), T, dy)
-    if T == BF16 and N % 32 == 0 and Kd % 4 == 0:
+    if T in HALF and N % 32 == 0 and Kd % 4 == 0:
         Wt = transpose_weight(W)  # (K, N): makes dX an NT GEMM with reduction dim N contiguous
         if gelu_pre is not None and db is not None:
             R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
@@ -142,7 +143,7 @@ def linear_dw(dy: Tensor, x: Tensor, M: int, dW: Tensor, db: Optional[Tensor] = 
     N, Kd = dW.shape
     ldy = ldy or N
     ldx = ldx or Kd
-    if dy.dtype == BF16 and N % 8 == 0 and Kd % 8 == 0 and ldy % 8 == 0 and ldx % 8 == 0:
+    if dy.dtype in HALF and N % 8 == 0 and Kd % 8 == 0 and ldy % 8 == 0 and ldx % 8 == 0:
         splits = K.gemm_tn_splits(M, N, Kd)
         ws = empty((splits * N * Kd,), F32, dy)
         K.gemm_tn_bf16(dy, ldy, x, ldx, dW, Kd, M, N, Kd, ws, splits)
@@ -169,12 +170,12 @@ def unpad_cols(x: Tensor, rows: int, cols_pad: int, cols: int, out: Optional[Ten
 # ---- attention core --------------------------------------------------------------------------------
 def attn_fast_ok(T, N: int, d: int) -> bool:
     """whole-head-in-LDS kernels: bf16, dim_head 64, N <= 480"""
-    return T == BF16 and d == 64 and 1 <= N <= 480
+    return T in HALF and d == 64 and 1 <= N <= 480
 
 
 def attn_varlen_ok(T, d: int) -> bool:
     """chunked kernels (any N): bf16, dim_head 64 or 80 (ViT-H/14: dim_head 80, N = 577)"""
-    return T == BF16 and d in (64, 80)
+    return T in HALF and d in (64, 80)
 
 
 def attn_fwd(qkv: Tensor, B: int, N: int, H: int, d: int, scale: float):
