@@ -69,12 +69,12 @@ int vitk_layernorm_fwd(const void* x, int xdt, const void* w, const void* b, int
  *   g   = dy[dymap(r)] * w ; xhat = (x[xmap(r)] - mean_r) * rstd_r
  *   dx  = rstd_r * (g - mean(g) - xhat * mean(g * xhat))            (+ gin[dxmap(r)] if gin)
  *   written to dx_f32[dxmap(r)] and/or dx_T[dxmap(r)] (either may be null; both null = only dw/db)
- *   dw/db partial column sums go to `partials` (f32, 2 * nblk * D, nblk = vitk_layernorm_bwd_blocks());
+ *   dw/db partial column sums go to `partials` (f32, 2 * nblk * D, nblk = vitk_layernorm_bwd_blocks(rows, D));
  *   finish with vitk_colsum_partials.  If colsum_dx != 0 a third slab (column sums of the value
  *   written to dx, i.e. the bias gradient of the Linear that produced the residual branch) is
  *   also accumulated: partials has 3 * nblk * D floats.
  */
-int64_t vitk_layernorm_bwd_blocks(int64_t rows);
+int64_t vitk_layernorm_bwd_blocks(int64_t rows, int64_t D);
 int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int xdt, const void* w, int wdt,
                        const float* mean, const float* rstd,
                        const float* gin, float* dx_f32, void* dx_t, int dxtdt,
@@ -83,7 +83,7 @@ int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int xdt, const v
                        vitk_rowmap dymap, vitk_rowmap xmap, vitk_rowmap dxmap, void* stream);
 
 /* One-launch finish of vitk_layernorm_bwd: dw, db (dtype odt, either may be null) and, if non-null, the f32
- * column sums dcol of dx, from the `partials` buffer of that call (nblk = vitk_layernorm_bwd_blocks(rows)). */
+ * column sums dcol of dx, from the `partials` buffer of that call (nblk = vitk_layernorm_bwd_blocks(rows, D)). */
 int vitk_layernorm_bwd_finalize(const float* partials, int64_t nblk, int64_t D, void* dw, void* db, int odt,
                                 float* dcol, void* stream);
 

@@ -75,7 +75,7 @@ def test_host_side_validation_without_gpu(lib):
     rc = lib.vitk_attn_fwd_bf16(q, q, q, q, p, 1, 1, 16, 80, 0.1, None)  # dim_head != 64 on the fused path
     assert rc == -2 and b"dim_head" in lib.vitk_last_error()
     assert lib.vitk_gemm_tn_splits(50432, 2304, 768) >= 1
-    assert lib.vitk_layernorm_bwd_blocks(50432) == 1024
+    assert lib.vitk_layernorm_bwd_blocks(50432, 768) == 1024 and lib.vitk_layernorm_bwd_blocks(50432, 1024) == 768
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -71,7 +71,7 @@ def test_layernorm_fwd_rowmaps_and_posadd():
 
 
 @pytest.mark.parametrize("dydt,xdt,wdt", [(F32, F32, F32), (BF, F32, BF), (BF, BF, BF), (F32, F32, BF)])
-@pytest.mark.parametrize("rows,D", [(333, 768), (40, 64), (7, 1280), (2100, 256)])
+@pytest.mark.parametrize("rows,D", [(333, 768), (40, 64), (7, 1280), (2100, 256), (3100, 1024), (2600, 1280)])
 def test_layernorm_bwd(dydt, xdt, wdt, rows, D):
     x = rnd(rows, D, dtype=xdt, seed=11) * 1.5 + 0.3
     dy = rnd(rows, D, dtype=dydt, seed=12)
@@ -81,7 +81,7 @@ def test_layernorm_bwd(dydt, xdt, wdt, rows, D):
     yref = torch.nn.functional.layer_norm(xd, (D,), wd, bd, 1e-5)
     yref.backward(dy.double())
     mean = x.double().mean(-1).float(); rstd = (1 / torch.sqrt(x.double().var(-1, unbiased=False) + 1e-5)).float()
-    nblk = K.layernorm_bwd_blocks(rows)
+    nblk = K.layernorm_bwd_blocks(rows, D)
     partials = torch.empty(3 * nblk * D, device=DEV)
     dxf = torch.empty(rows, D, device=DEV)
     dxt = torch.empty(rows, D, dtype=wdt, device=DEV)
@@ -105,7 +105,7 @@ def test_layernorm_bwd_maps():
     dy = rnd(B, D, dtype=BF, seed=22)
     w = rnd(D, dtype=BF, seed=23)
     mean = xs[:, 0].mean(-1).contiguous(); rstd = (1 / torch.sqrt(xs[:, 0].var(-1, unbiased=False) + 1e-5)).contiguous()
-    nblk = K.layernorm_bwd_blocks(B)
+    nblk = K.layernorm_bwd_blocks(B, D)
     partials = torch.empty(2 * nblk * D, device=DEV)
     dx = torch.zeros(B, N, D, device=DEV)
     m = L.RowMap(1, N, 0)

@@ -21,7 +21,7 @@ def timeit(fn, iters=20, warm=3):
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 256
     N, D, F, H, d = 197, 768, 3072, 12, 64
     M = B * N
     print(f"device={torch.cuda.get_device_name(0)} B={B} M={M}")
@@ -72,7 +72,7 @@ def main():
     y = torch.empty(M, D, dtype=BF, device=dev); mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
     t = timeit(lambda: K.layernorm_fwd(x, w, b, y, mean, rstd, M, D))
     print(f"layernorm_fwd f32->bf16: {t:.3f} ms  {M * D * 6 / t / 1e6:.0f} GB/s")
-    nblk = K.layernorm_bwd_blocks(M); partials = torch.empty(3 * nblk * D, device=dev)
+    nblk = K.layernorm_bwd_blocks(M, D); partials = torch.empty(3 * nblk * D, device=dev)
     dxf = torch.empty(M, D, device=dev); dxt = torch.empty(M, D, dtype=BF, device=dev); gin = torch.randn(M, D, device=dev)
     t = timeit(lambda: K.layernorm_bwd(y, x, w, mean, rstd, gin, dxf, dxt, partials, True, M, D))
     print(f"layernorm_bwd: {t:.3f} ms  {M * D * (2 + 4 + 4 + 4 + 2) / t / 1e6:.0f} GB/s")
@@ -83,3 +83,18 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def ln_wide():
+    """LayerNorm backward at the ViT-L / NaViT row width (D = 1024: the 4-wave block variant)."""
+    M, D = 25216, 1024
+    x = torch.randn(M, D, device=dev); w = torch.ones(D, dtype=BF, device=dev); y = torch.randn(M, D, device=dev).to(BF)
+    mean = torch.zeros(M, device=dev); rstd = torch.ones(M, device=dev); gin = torch.randn(M, D, device=dev)
+    nblk = K.layernorm_bwd_blocks(M, D); partials = torch.empty(3 * nblk * D, device=dev)
+    dxf = torch.empty(M, D, device=dev); dxt = torch.empty(M, D, dtype=BF, device=dev)
+    t = timeit(lambda: K.layernorm_bwd(y, x, w, mean, rstd, gin, dxf, dxt, partials, True, M, D))
+    print(f"layernorm_bwd D=1024 M={M}: {t:.3f} ms  {M * D * 16 / t / 1e6:.0f} GB/s")
+
+
+if __name__ == "__main__" and "--ln-wide" in sys.argv:
+    ln_wide()

@@ -14,7 +14,7 @@ for _ in range(3):
 M,D=B*N,768
 x=torch.randn(M,D,device=dev); w=torch.ones(D,dtype=BF,device=dev); y=torch.randn(M,D,device=dev).to(BF)
 mean=torch.zeros(M,device=dev); rstd=torch.ones(M,device=dev); gin=torch.randn(M,D,device=dev)
-nblk=K.layernorm_bwd_blocks(M); partials=torch.empty(3*nblk*D,device=dev); dxf=torch.empty(M,D,device=dev); dxt=torch.empty(M,D,dtype=BF,device=dev)
+nblk=K.layernorm_bwd_blocks(M,D); partials=torch.empty(3*nblk*D,device=dev); dxf=torch.empty(M,D,device=dev); dxt=torch.empty(M,D,dtype=BF,device=dev)
 for _ in range(3):
     K.layernorm_bwd(y,x,w,mean,rstd,gin,dxf,dxt,partials,True,M,D)
 torch.cuda.synchronize()

@@ -46,7 +46,7 @@ SIGNATURES = {
     "vitk_version": (_i, []),
     "vitk_last_error": (C.c_char_p, []),
     "vitk_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i64, _f, RowMap, RowMap, _vp, _i64, _i64, _vp]),
-    "vitk_layernorm_bwd_blocks": (_i64, [_i64]),
+    "vitk_layernorm_bwd_blocks": (_i64, [_i64, _i64]),
     "vitk_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i64, RowMap, RowMap, RowMap, _vp]),
     "vitk_layernorm_bwd_finalize": (_i, [_vp, _i64, _i64, _vp, _vp, _i, _vp, _vp]),
     "vitk_colsum_partials": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _i, _vp]),

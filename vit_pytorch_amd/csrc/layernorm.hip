@@ -78,8 +78,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 }
 
 // Backward.  DXT is the dtype of the optional second dx output (dx_t).
-template <typename DYT, typename XT, typename WT, typename DXT, int MAXC>
-__global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
+// NW waves per block: 8 for rows up to 768 columns (<= 128 VGPRs: two blocks per CU), 4 for wider rows, whose three
+// column accumulators push the kernel to ~155-170 VGPRs -- three 4-wave blocks then fit a CU (12 waves) where a single
+// 8-wave block would (8 waves).
+template <typename DYT, typename XT, typename WT, typename DXT, int MAXC, int NW>
+__global__ __launch_bounds__(NW * WAVE) void ln_bwd_kernel(
     const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
         acc_b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc_x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (long long row = (long long)blockIdx.x * LNB_WAVES + wave; row < rows; row += (long long)gridDim.x * LNB_WAVES) {
+    for (long long row = (long long)blockIdx.x * NW + wave; row < rows; row += (long long)gridDim.x * NW) {
         const DYT* dyr = dy + map_row(dymap, row) * (long long)D;
         const XT* xr = x + map_row(xmap, row) * (long long)D;
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -109,11 +112,12 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
         float s1 = 0.f, s2 = 0.f;
         // every load of the row -- incoming stream gradient included -- is issued before the first reduction, so a row
         // costs one memory round trip, not two
+        constexpr bool EARLY_GIN = MAXC <= 3;     // wider rows: the 4*MAXC extra registers would cost a wave per SIMD
 #pragma unroll
         for (int t = 0; t < MAXC; ++t) {
             const int c = lane + 64 * t;
             gi[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gin && want_dx && c < nchunk) gi[t] = *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
+            if (EARLY_GIN && gin && want_dx && c < nchunk) gi[t] = *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
         }
 #pragma unroll
         for (int t = 0; t < MAXC; ++t) {
@@ -141,7 +145,9 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
                 if (c < nchunk) {
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2) + gi[t][e];
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2);
+                    if (EARLY_GIN) o += gi[t];
+                    else if (gin) o += *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
                     if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow * D + 4 * c) = o;
                     if (dx_t) store4<DXT>(dx_t + orow * D + 4 * c, o);
                     if (colsum_dx) acc_x[t] += o;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
         }
     }
     // block reduce the per-wave column accumulators through LDS, one slab at a time
-    __shared__ f32x4 red[LNB_WAVES][64];
+    __shared__ f32x4 red[NW][64];
     const int nslab = colsum_dx ? 3 : 2;
     for (int slab = 0; slab < nslab; ++slab) {
 #pragma unroll
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
                     if (c < nchunk) {
                         f32x4 sum = red[0][lane];
 #pragma unroll
-                        for (int wv_ = 1; wv_ < LNB_WAVES; ++wv_) sum += red[wv_][lane];
+                        for (int wv_ = 1; wv_ < NW; ++wv_) sum += red[wv_][lane];
                         *reinterpret_cast<f32x4*>(partials + ((long long)slab * gridDim.x + blockIdx.x) * D + 4 * c) = sum;
                     }
                 }
@@ -286,8 +292,8 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
                   RowMap om, hipStream_t st) {
     const int nchunk = D / 4;
     const int maxc = (nchunk + 63) / 64;
-    const long long blocks = vitk_layernorm_bwd_blocks(rows);
-#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC>), dim3((unsigned)blocks), dim3(LNB_THREADS), 0, st, \
+    const long long blocks = vitk_layernorm_bwd_blocks(rows, D);
+#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC, (MC >= 4 ? 4 : 8)>), dim3((unsigned)blocks), dim3((MC >= 4 ? 4 : 8) * WAVE), 0, st, \
         (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om)
     if (maxc <= 1) LN_BWD_CASE(1);
     else if (maxc <= 3) LN_BWD_CASE(3);
@@ -324,9 +330,13 @@ extern "C" int vitk_layernorm_fwd(const void* x, int xdt, const void* w, const v
     VITK_FAIL(VITK_E_DTYPE, "layernorm_fwd: bad dtype combination");
 }
 
-extern "C" int64_t vitk_layernorm_bwd_blocks(int64_t rows) {
-    int64_t blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
-    if (blocks > LNB_MAX_BLOCKS) blocks = LNB_MAX_BLOCKS;
+extern "C" int64_t vitk_layernorm_bwd_blocks(int64_t rows, int64_t D) {
+    // one partial row per block; the block shape follows the row width (see ln_bwd_kernel): 8 waves and up to 1024
+    // blocks (4 per CU) up to 768 columns, 4 waves and up to 768 blocks (3 per CU, all resident at once) beyond
+    const bool wide = (D / 4 + 63) / 64 >= 4;
+    const int64_t nw = wide ? 4 : LNB_WAVES, cap = wide ? 768 : LNB_MAX_BLOCKS;
+    int64_t blocks = (rows + nw - 1) / nw;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return blocks;
 }

@@ -72,8 +72,8 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], y: Tensor, mean: Te
           "layernorm_fwd")
 
 
-def layernorm_bwd_blocks(rows: int) -> int:
-    return int(L.load().vitk_layernorm_bwd_blocks(rows))
+def layernorm_bwd_blocks(rows: int, D: int) -> int:
+    return int(L.load().vitk_layernorm_bwd_blocks(rows, D))
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, gin: Optional[Tensor],

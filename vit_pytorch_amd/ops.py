@@ -48,7 +48,7 @@ def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, rows: i
            dw: Optional[Tensor] = None, db: Optional[Tensor] = None, dcol: Optional[Tensor] = None,
            dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT):
     """LayerNorm backward; dw/db are (D,) outputs of dtype T, dcol (D,) float32 = column sums of dx."""
-    nblk = K.layernorm_bwd_blocks(rows)
+    nblk = K.layernorm_bwd_blocks(rows, D)
     nslab = 3 if dcol is not None else 2
     partials = empty((nslab * nblk * D,), F32, x)
     K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap)
