@@ -511,7 +511,9 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                 const int c16 = fn * 2 + (fg >> 1);
                 const f32x4 v = acc[fn][fm] + b4[fn];
                 const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fg & 1) * 8) = pk;
+                // rows r and r + 8 share a 16-byte slot column after the XOR: they take opposite 8-byte halves of it, so the 16
+                // lanes of a ds_write_b64 group cover 32 distinct banks (was a 2-way conflict, ~2 % of the kernel by PMC)
+                *reinterpret_cast<bf16x4*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (((fg & 1) ^ ((row >> 3) & 1)) * 8)) = pk;
             }
         }
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // GELU_BWD: column sums of this lane's rows (bias gradient)
@@ -519,6 +521,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         for (int j = 0; j < 2 * FM; ++j) {
             const int row = j * 8 + rr;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row * 128 + ((rc ^ (row & 7)) * 16));
+            if (j & 1) v = bf16x8{v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};     // rows 8..15 of a 16-row group: halves swapped
             const int m = mrow0 + row;
             if (m < M && ncol < N) {
                 const long long o = (long long)m * ldc + ncol;
