@@ -67,3 +67,46 @@ def test_engine_data_parallel_two_ranks_one_gpu():
         assert p.exitcode == 0
     res = [q.get(timeout=5) for _ in range(2)]
     assert all(w < 2e-2 for _, w in res), res   # bf16 average of two bf16 gradients
+
+
+def _nccl_worker(port, q):
+    """One rank, backend nccl (= RCCL): the collectives the 8-GPU run issues -- AVG all-reduce of bf16 slices of the flat
+    buffer, launched from inside backward on the side stream -- run for real on the device.  With one rank the average
+    is the identity, so the gradients must equal the unwrapped model's bit for bit; `world` is forced to 2 on the sink
+    so that the chunked in-backward launches (a no-op at world 1) are taken."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from vit_pytorch_amd import ViT
+        from vit_pytorch_amd.parallel import DataParallel
+        cfg = dict(image_size=64, patch_size=8, num_classes=10, dim=128, depth=6, heads=2, mlp_dim=256)
+        torch.manual_seed(1)
+        model = ViT(**cfg).to("cuda", dtype=torch.bfloat16)
+        x = torch.randn(8, 3, 64, 64, device="cuda").to(torch.bfloat16)
+        model.zero_grad(set_to_none=True)
+        model(x).float().square().mean().backward()
+        local = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        dp = DataParallel(model)                     # default: one all-reduce per 3 layers
+        dp.sink.world = 2                            # take the multi-rank code path on the 1-rank communicator
+        for _ in range(2):                           # twice: the second step reuses streams / events / buffers
+            dp.backward(dp(x).float().square().mean())
+            torch.cuda.synchronize()
+            assert dp.sink._early_launched and dp.sink._late_launched and dp.sink._cursor == dp.sink.boundary
+            for n, p in model.named_parameters():
+                if p.numel():
+                    assert torch.equal(p.grad, local[n]), n
+        q.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_in_backward_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"
