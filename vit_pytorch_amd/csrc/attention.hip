@@ -465,14 +465,38 @@ template <int DH> struct HD {
     static constexpr int NCH = NKS * 4;             // 16-byte chunks per LDS row that are read by fragments
 };
 
+// One 128-row chunk of TWO (n, h, d) tensors, global -> registers -> LDS in two separate steps, so that the loads of
+// chunk c+1 are in flight while chunk c is being multiplied (a plain load/store loop is serialised by the compiler and
+// left the whole workgroup waiting on HBM once per chunk).  NP 16-byte pieces per thread and tensor: 2 (d = 64) or 3.
+template <int DH> struct ChunkRegs {
+    static constexpr int NP = VL_CH * HD<DH>::NCH / AT_THREADS;
+    bf16x8 a[NP], b[NP];
+};
 template <int DH>
-__device__ __forceinline__ void fill_chunk_t(char* tile, const __bf16* src, long long s_n, int rows, int rows_pad, int tid) {
-    constexpr int NCH = HD<DH>::NCH, LD = HD<DH>::LD;
+__device__ __forceinline__ void chunk_load(ChunkRegs<DH>& r, const __bf16* srca, long long sna, const __bf16* srcb, long long snb,
+                                           int rows, int rows_pad, int tid) {
+    constexpr int NCH = HD<DH>::NCH;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int c = tid; c < rows_pad * NCH; c += AT_THREADS) {
-        const int row = c / NCH, col8 = c % NCH;
-        const bf16x8 v = (row < rows && col8 * 8 < DH) ? *reinterpret_cast<const bf16x8*>(src + (long long)row * s_n + col8 * 8) : zero8;
-        *reinterpret_cast<bf16x8*>(tile + row * LD + col8 * 16) = v;
+#pragma unroll
+    for (int j = 0; j < ChunkRegs<DH>::NP; ++j) {
+        const int c = tid + j * AT_THREADS, row = c / NCH, col8 = c % NCH;
+        r.a[j] = zero8; r.b[j] = zero8;
+        if (c < rows_pad * NCH && row < rows && col8 * 8 < DH) {
+            r.a[j] = *reinterpret_cast<const bf16x8*>(srca + (long long)row * sna + col8 * 8);
+            r.b[j] = *reinterpret_cast<const bf16x8*>(srcb + (long long)row * snb + col8 * 8);
+        }
+    }
+}
+template <int DH>
+__device__ __forceinline__ void chunk_store(const ChunkRegs<DH>& r, char* tilea, char* tileb, int rows_pad, int tid) {
+    constexpr int NCH = HD<DH>::NCH, LD = HD<DH>::LD;
+#pragma unroll
+    for (int j = 0; j < ChunkRegs<DH>::NP; ++j) {
+        const int c = tid + j * AT_THREADS, row = c / NCH, col8 = c % NCH;
+        if (c < rows_pad * NCH) {
+            *reinterpret_cast<bf16x8*>(tilea + row * LD + col8 * 16) = r.a[j];
+            *reinterpret_cast<bf16x8*>(tileb + row * LD + col8 * 16) = r.b[j];
+        }
     }
 }
 template <int DH>
@@ -521,60 +545,73 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
     const int qrow = qs + (qi < nq ? qi : nq - 1);
     bf16x8 qf[NKS];
     load_row_frags<DH>(qf, q.p + (long long)qrow * q.s_n + h * q.s_h, fg);
+    const __bf16* kbase = k.p + (long long)ks0 * k.s_n + h * k.s_h;
+    const __bf16* vbase = v.p + (long long)ks0 * v.s_n + h * v.s_h;
+    ChunkRegs<DH> cr;
+    {
+        const int rows = nk < VL_CH ? nk : VL_CH;
+        chunk_load<DH>(cr, kbase, k.s_n, vbase, v.s_n, rows, ((rows + 31) >> 5) << 5, tid);
+    }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, lsum = 0.f;
-    f32x4 acc[NFD];
+    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    const float c = scale_log2e;                      // > 0 (host check)
+    float mref = -INFINITY;                           // lazy reference maximum, row sums by MFMA: see attn_fwd_kernel
+    f32x4 acc[NFD], accl = z4;
 #pragma unroll
     for (int fd = 0; fd < NFD; ++fd) acc[fd] = z4;
     for (int c0 = 0; c0 < nk; c0 += VL_CH) {
         const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
         __syncthreads();
-        fill_chunk_t<DH>(Ks, k.p + (long long)(ks0 + c0) * k.s_n + h * k.s_h, k.s_n, rows, rows_pad, tid);
-        fill_chunk_t<DH>(Vs, v.p + (long long)(ks0 + c0) * v.s_n + h * v.s_h, v.s_n, rows, rows_pad, tid);
+        chunk_store<DH>(cr, Ks, Vs, rows_pad, tid);
         __syncthreads();
+        if (c0 + VL_CH < nk) {                        // next chunk: in flight while this one is multiplied
+            const int nrows = nk - c0 - VL_CH < VL_CH ? nk - c0 - VL_CH : VL_CH;
+            chunk_load<DH>(cr, kbase + (long long)(c0 + VL_CH) * k.s_n, k.s_n, vbase + (long long)(c0 + VL_CH) * v.s_n, v.s_n, nrows,
+                           ((nrows + 31) >> 5) << 5, tid);
+        }
         if (!wave_active) continue;
         for (int s = 0; s < (rows_pad >> 5); ++s) {
             f32x4 st[2];
-            float mx = -INFINITY;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int row0 = s * 32 + hh * 16;
-                st[hh] = mfma_over_d<DH>(Ks, row0, qf, fi, fg);
+            for (int hh = 0; hh < 2; ++hh) st[hh] = mfma_over_d<DH>(Ks, s * 32 + hh * 16, qf, fi, fg);
+            if (s * 32 + 32 > rows) {                 // padding keys: only in the last step of the last chunk
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = row0 + 4 * fg + r;
-                    st[hh][r] = key < rows ? st[hh][r] * scale_log2e : -INFINITY;
-                    mx = fmaxf(mx, st[hh][r]);
-                }
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (s * 32 + hh * 16 + 4 * fg + e >= rows) st[hh][e] = -INFINITY;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-            float ps = 0.f;
+            float mloc = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+            mloc = fmaxf(fmaxf(mloc, st[0][3]), st[1][0]);
+            mloc = fmaxf(fmaxf(mloc, st[1][1]), st[1][2]);
+            mloc = fmaxf(mloc, st[1][3]);
+            if (__builtin_amdgcn_ballot_w64(mloc * c > mref + 8.0f) != 0) {
+                const float m_new = fmaxf(mref, groups_max(mloc) * c);
+                const float alpha = __builtin_amdgcn_exp2f(mref - m_new);
+#pragma unroll
+                for (int fd = 0; fd < NFD; ++fd) acc[fd] *= alpha;
+                accl *= alpha;
+                mref = m_new;
+            }
+            const float nm = -mref;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { st[hh][r] = __builtin_amdgcn_exp2f(st[hh][r] - m_new); ps += st[hh][r]; }
-            lsum = lsum * alpha + ps;
-            m = m_new;
+                for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
             const bf16x8 pb = pack8(st[0], st[1]);
+            accl = MFMA(ones, pb, accl);
 #pragma unroll
-            for (int fd = 0; fd < NFD; ++fd) {
-                acc[fd] *= alpha;
-                acc[fd] = MFMA(tr_frag_t<DH>(Vs, s * 32, fd * 16, fi, fg), pb, acc[fd]);
-            }
+            for (int fd = 0; fd < NFD; ++fd) acc[fd] = MFMA(tr_frag_t<DH>(Vs, s * 32, fd * 16, fi, fg), pb, acc[fd]);
         }
     }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
     if (wave_active && qi < nq) {
-        const float inv = 1.0f / lsum;
+        const float ls = accl[0];
+        const float inv = 1.0f / ls;
         __bf16* op = o.p + (long long)(qs + qi) * o.s_n + h * o.s_h + 4 * fg;
 #pragma unroll
         for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(op + fd * 16, acc[fd] * inv);
-        if (fg == 0) lse[(long long)h * tq_total + qs + qi] = (m + log2f(lsum)) * LN2;
+        if (fg == 0) lse[(long long)h * tq_total + qs + qi] = (mref + log2f(ls)) * LN2;
     }
 }
 
@@ -595,6 +632,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
     const int qi = blk_r0[blockIdx.x] + wave * 16 + fi;
     const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nq;
     const int qrow = qs + (qi < nq ? qi : nq - 1);
+    const __bf16* kbase = k.p + (long long)ks0 * k.s_n + h * k.s_h;
+    const __bf16* vbase = v.p + (long long)ks0 * v.s_n + h * v.s_h;
+    ChunkRegs<DH> cr;
+    {
+        const int rows = nk < VL_CH ? nk : VL_CH;
+        chunk_load<DH>(cr, kbase, k.s_n, vbase, v.s_n, rows, ((rows + 31) >> 5) << 5, tid);
+    }
     bf16x8 qf[NKS], df[NKS], of[NKS];
     load_row_frags<DH>(qf, q.p + (long long)qrow * q.s_n + h * q.s_h, fg);
     load_row_frags<DH>(df, dout.p + (long long)qrow * dout.s_n + h * dout.s_h, fg);
@@ -602,10 +646,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
     float dl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) dl += dot8(df[ks], of[ks]);
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);
+    dl = groups_sum(dl);
     if (wave_active && qi < nq && fg == 0) delta[(long long)h * tq_total + qs + qi] = dl;
-    const float l2 = lse[(long long)h * tq_total + qrow] * LOG2E;
+    const float nl2 = -lse[(long long)h * tq_total + qrow] * LOG2E;
     const float scale_log2e = scale * LOG2E;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[NFD];
@@ -615,9 +658,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
         const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
         __syncthreads();
-        fill_chunk_t<DH>(Ks, k.p + (long long)(ks0 + c0) * k.s_n + h * k.s_h, k.s_n, rows, rows_pad, tid);
-        fill_chunk_t<DH>(Vs, v.p + (long long)(ks0 + c0) * v.s_n + h * v.s_h, v.s_n, rows, rows_pad, tid);
+        chunk_store<DH>(cr, Ks, Vs, rows_pad, tid);
         __syncthreads();
+        if (c0 + VL_CH < nk) {
+            const int nrows = nk - c0 - VL_CH < VL_CH ? nk - c0 - VL_CH : VL_CH;
+            chunk_load<DH>(cr, kbase + (long long)(c0 + VL_CH) * k.s_n, k.s_n, vbase + (long long)(c0 + VL_CH) * v.s_n, v.s_n, nrows,
+                           ((nrows + 31) >> 5) << 5, tid);
+        }
         if (!wave_active) continue;
         for (int s = 0; s < (rows_pad >> 5); ++s) {
             f32x4 ds[2];
@@ -627,10 +674,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
                 const f32x4 st = mfma_over_d<DH>(Ks, row0, qf, fi, fg);
                 const f32x4 dp = mfma_over_d<DH>(Vs, row0, df, fi, fg);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = row0 + 4 * fg + r;
-                    const float p = key < rows ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - l2) : 0.f;
-                    ds[hh][r] = p * (dp[r] - dl) * scale;
+                for (int e = 0; e < 4; ++e)          // `scale` of dS is applied once, to dQ
+                    ds[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, nl2)) * (dp[e] - dl);
+                if (row0 + 16 > rows) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row0 + 4 * fg + e >= rows) ds[hh][e] = 0.f;
                 }
             }
             const bf16x8 dsb = pack8(ds[0], ds[1]);
@@ -641,12 +690,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
     if (wave_active && qi < nq) {
         __bf16* dqp = dq.p + (long long)(qs + qi) * dq.s_n + h * dq.s_h + 4 * fg;
 #pragma unroll
-        for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(dqp + fd * 16, acc[fd]);
+        for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(dqp + fd * 16, acc[fd] * scale);
     }
 }
 
 template <int DH>
-__global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
+__global__ __launch_bounds__(AT_THREADS, 4) void attn_varlen_bwd_dkv_kernel(
     HND q, HND k, HND v, HND dout, const float* __restrict__ lse, const float* __restrict__ delta, HND dk, HND dv,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
     const int* __restrict__ blk_r0, int tq_total, float scale) {
@@ -664,6 +713,19 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
     const int ki = blk_r0[blockIdx.x] + wave * 16 + fi;        // key row inside the segment
     const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nk;
     const int krow = ks0 + (ki < nk ? ki : nk - 1);
+    const __bf16* qbase = q.p + (long long)qs * q.s_n + h * q.s_h;
+    const __bf16* dbase = dout.p + (long long)qs * dout.s_n + h * dout.s_h;
+    const float* lbase = lse + (long long)h * tq_total + qs;
+    const float* dlbase = delta + (long long)h * tq_total + qs;
+    ChunkRegs<DH> cr;
+    float lv = 0.f, dv_ = 0.f;                                  // one row of -lse*log2e / -delta per thread (tid < 128)
+    auto prefetch = [&](int c0) {
+        const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
+        chunk_load<DH>(cr, qbase + (long long)c0 * q.s_n, q.s_n, dbase + (long long)c0 * dout.s_n, dout.s_n, rows, ((rows + 31) >> 5) << 5, tid);
+        lv = 0.f; dv_ = 0.f;
+        if (tid < rows) { lv = -lbase[c0 + tid] * LOG2E; dv_ = -dlbase[c0 + tid]; }
+    };
+    prefetch(0);
     bf16x8 kf[NKS], vf[NKS];
     load_row_frags<DH>(kf, k.p + (long long)krow * k.s_n + h * k.s_h, fg);
     load_row_frags<DH>(vf, v.p + (long long)krow * v.s_n + h * v.s_h, fg);
@@ -676,13 +738,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
         const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
         __syncthreads();
-        fill_chunk_t<DH>(Qs, q.p + (long long)(qs + c0) * q.s_n + h * q.s_h, q.s_n, rows, rows_pad, tid);
-        fill_chunk_t<DH>(Ds, dout.p + (long long)(qs + c0) * dout.s_n + h * dout.s_h, dout.s_n, rows, rows_pad, tid);
-        for (int r = tid; r < rows_pad; r += AT_THREADS) {
-            lse_s[r] = r < rows ? lse[(long long)h * tq_total + qs + c0 + r] * LOG2E : 0.f;
-            del_s[r] = r < rows ? delta[(long long)h * tq_total + qs + c0 + r] : 0.f;
-        }
+        chunk_store<DH>(cr, Qs, Ds, rows_pad, tid);
+        if (tid < VL_CH) { lse_s[tid] = lv; del_s[tid] = dv_; }
         __syncthreads();
+        if (c0 + VL_CH < nq) prefetch(c0 + VL_CH);
         if (!wave_active) continue;
         for (int s = 0; s < (rows_pad >> 5); ++s) {
             f32x4 p[2], ds[2];
@@ -694,10 +753,14 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qidx = row0 + 4 * fg + r;
-                    p[hh][r] = qidx < rows ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - l4[r]) : 0.f;
-                    ds[hh][r] = p[hh][r] * (dp[r] - d4[r]) * scale;
+                for (int e = 0; e < 4; ++e) {
+                    p[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l4[e]));
+                    ds[hh][e] = p[hh][e] * (dp[e] + d4[e]);                    // `scale` is applied once, to dK
+                }
+                if (row0 + 16 > rows) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row0 + 4 * fg + e >= rows) { p[hh][e] = 0.f; ds[hh][e] = 0.f; }
                 }
             }
             const bf16x8 pb = pack8(p[0], p[1]);
@@ -713,7 +776,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dkv_kernel(
         __bf16* dkp = dk.p + (long long)(ks0 + ki) * dk.s_n + h * dk.s_h + 4 * fg;
         __bf16* dvp = dv.p + (long long)(ks0 + ki) * dv.s_n + h * dv.s_h + 4 * fg;
 #pragma unroll
-        for (int fd = 0; fd < NFD; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd]); store4<__bf16>(dvp + fd * 16, accV[fd]); }
+        for (int fd = 0; fd < NFD; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd] * scale); store4<__bf16>(dvp + fd * 16, accV[fd]); }
     }
 }
 
@@ -915,6 +978,7 @@ extern "C" int vitk_attn_varlen_fwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vit
                                          const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0, int64_t nblk,
                                          int64_t tq_total, int64_t H, int64_t d, float scale, void* stream) {
     if (d != 64 && d != 80) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: needs dim_head 64 or 80 (got %lld)", (long long)d);
+    if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_fwd_bf16: scale must be positive (got %g)", (double)scale);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !lse || !cu_q || !cu_k || !blk_seg || !blk_r0)
         VITK_FAIL(VITK_E_ALIGN, "attn_varlen_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     if (nblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: empty problem");
@@ -932,6 +996,7 @@ extern "C" int vitk_attn_varlen_bwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vit
                                          const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk, int64_t tq_total,
                                          int64_t H, int64_t d, float scale, void* stream) {
     if (d != 64 && d != 80) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: needs dim_head 64 or 80 (got %lld)", (long long)d);
+    if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_bwd_bf16: scale must be positive (got %g)", (double)scale);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !hnd_ok(dout) || !hnd_ok(dq) || !hnd_ok(dk) || !hnd_ok(dv) || !lse ||
         !delta || !cu_q || !cu_k || !qblk_seg || !qblk_r0 || !kblk_seg || !kblk_r0)
         VITK_FAIL(VITK_E_ALIGN, "attn_varlen_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
