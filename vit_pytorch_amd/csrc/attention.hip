@@ -5,9 +5,9 @@
 // matrix is never materialised; q/k/v are read in place from the merged (B, N, 3*h*d) to_qkv output
 // and O / dQ,dK,dV are written in merged layouts, so no contiguity copies exist.
 //
-// ViT sequences are short (N = 197 for ViT-B/L at 224^2), so ONE workgroup owns one (batch, head):
-// the whole K and V of that head (2 x N x 128 B) are staged once into LDS and each of the 4 waves
-// walks 16-row query tiles against them.
+// ViT sequences are short (N = 197 for ViT-B/L at 224^2), so ONE 8-wave workgroup owns one (batch, head):
+// the whole K and V of that head (2 x N x 128 B) are staged once into LDS and every wave carries R (1 or 2)
+// 16-row query tiles against them (backward: query tiles in the dQ kernel, key tiles in the dK/dV kernel).
 //
 // Fragment algebra (v_mfma_f32_16x16x32_bf16; D[i][j] = sum_k A[i][k] B[k][j]; a lane holds
 // D[4*(lane>>4)+r][lane&15], r = 0..3):
@@ -20,8 +20,8 @@
 //   bwd dQ    S^T, dP^T = V dO^T, dS^T = P^T*(dP^T - delta)*scale,  dQ^T = K^T dS^T   (query-tile outer)
 //   bwd dK/dV S = Q K^T, dP = dO V^T (A from LDS rows of Q / dO, B = K / V rows in registers),
 //             dV^T = dO^T P, dK^T = Q^T dS (A via transpose reads of dO / Q)          (key-tile outer)
-// Softmax is online (running max / sum per query row, exp2 domain); backward recomputes P from
-// the saved row log-sum-exp.  LDS rows are padded to 160 B: conflict-free for both the b128 row
+// Softmax is online in the exp2 domain with a LAZY reference maximum and MFMA row sums (see attn_fwd_kernel);
+// backward recomputes P from the saved row log-sum-exp.  LDS rows are padded to 160 B: conflict-free for both the b128 row
 // reads and the b64 transpose reads.
 #include "common.h"
 

@@ -5,22 +5,24 @@
 //   NT  C[M,N]  = A[M,K] . W[N,K]^T   (+ fused epilogue)      forward Linear, and dX with W^T
 //   TN  dW[N,K] = dY[M,N]^T . X[M,K]  (split over M)          weight gradients
 //
-// Design (MFMA-bound, f32 accumulation, v_mfma_f32_16x16x32_bf16):
-//  * 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 MFMA fragments.
-//  * NT: K-step 32, operands go HBM -> LDS with global_load_lds dwordx4 (no VGPR round trip),
-//    two LDS stages, one barrier per K-step.  The LDS image is lane-linear (DMA constraint), so
-//    the bank swizzle is applied to the per-lane SOURCE address and to the ds_read_b128 address
-//    (same involution on both sides).
-//  * The MFMA "A" operand is the W fragment and "B" the activation fragment, so a lane ends up
-//    holding 4 CONSECUTIVE output columns of one output row: every epilogue store is an 8-byte
-//    (bf16) or 16-byte (f32) vector store and bias / GELU / residual / GELU' are applied in
-//    registers -- the activation tensor is written exactly once.
-//  * TN: the reduction index (token row m) is the strided one in both operands; tiles are staged
-//    row-major through registers into padded LDS rows and read with ds_read_b64_tr_b16 (hardware
-//    transpose read) to form MFMA fragments.  Split-M slabs of f32 partials + a deterministic
-//    reduce (no atomics), which also converts to the gradient dtype / accumulates.
-//  * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs walks a contiguous run of tiles
-//    (n fastest), so the activation panel a tile row shares is fetched into one L2, not eight.
+// Kernels (all f32 accumulation on v_mfma_f32_16x16x32_bf16; the f16 library flavour uses ..._f16, see common.h):
+//  * gemm_nt256pp_kernel<EPI, FM>: the production NT kernel -- 256(224) x 256 tile, 8 waves, four LDS-DMA stages,
+//    ping-pong wave groups (described at the kernel).  Used when M >= 1024, N >= 256, K % 64 == 0.
+//  * gemm_nt_kernel<EPI>: 128 x 128 tile, 4 waves (2x2, 64x64 per wave), K-step 32, two LDS-DMA stages, one barrier per
+//    K-step: small and odd shapes (the classifier head, tiny models).
+//  * gemm_tn256_kernel / gemm_tn_kernel + tn_reduce_kernel: weight gradients.  The reduction index (token row m) is the
+//    strided one in both operands; tiles are staged row-major through registers into padded LDS rows and read with
+//    ds_read_b64_tr_b16 (hardware transpose read).  Split-M slabs of f32 partials + a deterministic reduce (no atomics),
+//    which also converts to the gradient dtype / accumulates.
+// Common to the NT kernels:
+//  * operands go HBM -> LDS with global_load_lds dwordx4 (no VGPR round trip).  The LDS image is lane-linear (DMA
+//    constraint), so the bank swizzle is applied to the per-lane SOURCE address and to the ds_read_b128 address (the same
+//    involution on both sides): SQ_LDS_BANK_CONFLICT = 0.
+//  * the MFMA "A" operand is the W fragment and "B" the activation fragment, so a lane ends up holding 4 CONSECUTIVE output
+//    columns of one output row; bias / GELU / residual / GELU' are applied in the epilogue and the activation tensor is
+//    written exactly once.
+//  * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs walks a contiguous run of tiles, so the activation panel
+//    a tile row shares is fetched into one L2, not eight.
 #include "common.h"
 #include <stdlib.h>
 
