@@ -123,6 +123,17 @@ int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, const void* W,
                                       void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                       void* aux, float* colsum_partials, void* stream);
 
+/* fp8 operands (BASELINE config 5): C = alpha * A8[M,K] . W8[N,K]^T with the epilogues of
+ * vitk_gemm_nt_bf16; A8, W8 are OCP e4m3 bytes (K contiguous, K %% 64 == 0, lda / ldw %% 16 == 0), C / bias / aux the
+ * library's 16-bit type, accumulation f32 on v_mfma_f32_16x16x32_fp8_fp8.  alpha = 1 / (scale_a * scale_w) undoes the
+ * per-tensor scales.  Served by the 256-row kernel only (M >= 1024, N >= 256).
+ * vitk_fp8_amax_scale: scale2[0] = 448 / max|x|, scale2[1] = max|x| / 448, computed on the device (no host sync).
+ * vitk_quantize_fp8: out[i] = e4m3(clamp(x[i] * scale, +-448)), round to nearest even; scale from scale_dev[0] if given. */
+int vitk_gemm_nt_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                     int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float alpha, void* stream);
+int vitk_fp8_amax_scale(const void* x, int dt, int64_t n, float* scale2, void* stream);
+int vitk_quantize_fp8(const void* x, int dt, void* out, int64_t n, const float* scale_dev, float scale_host, void* stream);
+
 /* dW[N,K] = sum_m dY[m,N]^T X[m,K]  ("TN": both operands are read with the reduction index as
  * the strided one).  Split over M into `splits` slabs of f32 partials (ws: splits*N*K floats),
  * then reduced into dW (dtype odt, ld = ldo; accumulate: dW += ...).  N % 8 == 0, K % 8 == 0.  */

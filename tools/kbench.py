@@ -81,7 +81,7 @@ def main():
     print(f"colsum M x 3072 bf16: {t:.3f} ms  {M * F * 2 / t / 1e6:.0f} GB/s")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not any(a.startswith("--") for a in sys.argv[1:]):
     main()
 
 
@@ -98,3 +98,24 @@ def ln_wide():
 
 if __name__ == "__main__" and "--ln-wide" in sys.argv:
     ln_wide()
+
+
+def fp8():
+    """fp8 (e4m3) operand NT GEMM against the bf16 one at the config-2 and config-5 FeedForward shapes."""
+    for name, (M, n, k) in {"vit-b ff1": (50432, 3072, 768), "vit-b ff2": (50432, 768, 3072), "vit-b qkv": (50432, 2304, 768),
+                            "vit-h ff1 (b64)": (36928, 5120, 1280), "vit-h ff2 (b64)": (36928, 1280, 5120)}.items():
+        A = torch.randn(M, k, device=dev).to(BF); W = (torch.randn(n, k, device=dev) * k ** -0.5).to(BF)
+        C = torch.empty(M, n, dtype=BF, device=dev)
+        A8 = torch.empty(M, k, dtype=torch.uint8, device=dev); W8 = torch.empty(n, k, dtype=torch.uint8, device=dev)
+        sa = torch.empty(2, device=dev); sw = torch.empty(2, device=dev)
+        K.fp8_amax_scale(A, sa); K.fp8_amax_scale(W, sw); K.quantize_fp8(A, A8, scale_dev=sa); K.quantize_fp8(W, W8, scale_dev=sw)
+        t16 = timeit(lambda: K.gemm_nt_bf16(A, k, W, k, C, n, M, n, k))
+        t8 = timeit(lambda: K.gemm_nt_fp8(A8, k, W8, k, C, n, M, n, k, 1.0))
+        tq = timeit(lambda: (K.fp8_amax_scale(A, sa), K.quantize_fp8(A, A8, scale_dev=sa)))
+        fl = 2 * M * n * k
+        print(f"{name:16s} M={M} N={n} K={k}: bf16 {t16:.3f} ms {fl / t16 / 1e9:6.0f} TF/s | fp8 {t8:.3f} ms {fl / t8 / 1e9:6.0f} TF/s"
+              f" (x{t16 / t8:.2f}) | amax+quantise A {tq:.3f} ms")
+
+
+if __name__ == "__main__" and "--fp8" in sys.argv:
+    fp8()

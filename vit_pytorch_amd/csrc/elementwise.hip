@@ -138,6 +138,45 @@ __global__ __launch_bounds__(256) void adam_kernel(PT* __restrict__ p, const PT*
     }
 }
 
+// ---- fp8 (OCP e4m3) quantisation for vitk_gemm_nt_fp8 -----------------------------------------------------------------
+// absmax: one atomicMax on the float's bit pattern per block (non-negative floats order like unsigned ints).
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = load4<T>(x + 4 * i);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(to_f32<T>(x[n4 * 4 + threadIdx.x])));
+    m = wave_max(m);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __builtin_bit_cast(unsigned, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+// out = e4m3(clamp(x * scale, -448, 448)), round to nearest even (v_cvt_pk_fp8_f32), 4 elements -> one dword
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ x, unsigned* __restrict__ out, long long n4,
+                                                            const float* __restrict__ scale_dev, float scale_host) {
+    const float sc = scale_dev ? *scale_dev : scale_host;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 v = load4<T>(x + 4 * i) * sc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -448.f, 448.f);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+        out[i] = (unsigned)w;
+    }
+}
+// scale[0] = 448 / max(amax, tiny);  scale[1] = 1 / scale[0]   (device-side, so the step never syncs with the host)
+__global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale) {
+    const float a = fmaxf(__builtin_bit_cast(float, *amax_bits), 1e-12f);
+    scale[0] = 448.f / a;
+    scale[1] = a / 448.f;
+}
+
 template <typename XT, typename PT>
 __global__ __launch_bounds__(256) void write_cls_kernel(XT* __restrict__ x, const PT* __restrict__ cls, const PT* __restrict__ pos,
                                                          long long B, long long N, int D, int ncls) {
@@ -362,6 +401,31 @@ extern "C" int vitk_adam_step(void* param, const void* grad, int dt, float* exp_
                                                 exp_avg_sq, master, (long long)n, lr, beta1, beta2, eps, weight_decay, decoupled, inv_c1,
                                                 inv_sqrt_c2, grad_scale));
     VITK_CHECK_LAUNCH("adam_step");
+    return 0;
+}
+
+extern "C" int vitk_fp8_amax_scale(const void* x, int dt, int64_t n, float* scale2, void* stream) {
+    if (!x || !scale2) VITK_FAIL(VITK_E_ARG, "fp8_amax_scale: null pointer");
+    if (n <= 0) VITK_FAIL(VITK_E_SHAPE, "fp8_amax_scale: empty tensor");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* bits = reinterpret_cast<unsigned*>(scale2) + 1;          // scale2[1] doubles as the amax scratch word
+    if (hipMemsetAsync(bits, 0, sizeof(unsigned), st) != hipSuccess) VITK_FAIL(1, "fp8_amax_scale: memset failed");
+    unsigned blocks = ew_blocks((n + 3) / 4); if (blocks > 1024) blocks = 1024;
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((absmax_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (long long)n, bits));
+    hipLaunchKernelGGL(fp8_scale_kernel, dim3(1), dim3(1), 0, st, bits, scale2);
+    VITK_CHECK_LAUNCH("fp8_amax_scale");
+    return 0;
+}
+
+extern "C" int vitk_quantize_fp8(const void* x, int dt, void* out, int64_t n, const float* scale_dev, float scale_host, void* stream) {
+    if (!x || !out) VITK_FAIL(VITK_E_ARG, "quantize_fp8: null pointer");
+    if (n <= 0 || (n & 3)) VITK_FAIL(VITK_E_SHAPE, "quantize_fp8: n must be a positive multiple of 4");
+    if (!aligned16(x) || !aligned16(out)) VITK_FAIL(VITK_E_ALIGN, "quantize_fp8: 16-byte aligned pointers required");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = ew_blocks(n / 4);
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((quantize_fp8_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (unsigned*)out,
+                                                (long long)(n / 4), scale_dev, scale_host));
+    VITK_CHECK_LAUNCH("quantize_fp8");
     return 0;
 }
 

@@ -319,12 +319,18 @@ constexpr int P_LDS_BYTES = P_STAGES * P_STAGE_BYTES; // 128 KiB
 
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int EPI, int FM>
+// EB = bytes per operand element: 2 (bf16 / f16) or 1 (fp8 e4m3, OCP): the 64-byte LDS rows then hold 64 k-values, every
+// 16-byte fragment read feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes: any split of the k index is legal
+// as long as both operands use the same one), so a K-step covers 64 k with the same DMA / LDS traffic and barrier count as
+// 32 k of bf16 -- the main loop is paced by exactly those.  `alpha` (fp8: 1 / (scale_a * scale_w)) multiplies the sums.
+template <int EPI, int FM, int EB = 2>
 __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
-    const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ W, long long ldw,
+    const void* __restrict__ Av, long long lda, const void* __restrict__ Wv, long long ldw,
     void* __restrict__ Cv, long long ldc, int M, int N, int K,
     const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
-    int tiles_n, int nwg, int group_n, float* __restrict__ csum) {
+    int tiles_n, int nwg, int group_n, float* __restrict__ csum, float alpha) {
+    const char* A = reinterpret_cast<const char*>(Av);
+    const char* W = reinterpret_cast<const char*>(Wv);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -340,28 +346,38 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     // staging: 64-byte rows, a wave-instruction fills 16 rows; wave w owns row groups 2w, 2w+1 of each operand
     const int srow = lane >> 2, spos = lane & 3;
     const int schunk = spos ^ swz_f(lane >> 4);
-    const __bf16* a_src[2];
-    const __bf16* w_src[2];
+    const char* a_src[2];     // byte addresses: a K-step is 64 bytes of every row whatever the element size
+    const char* w_src[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int ar = m0 + (wave * 2 + j) * 16 + srow; ar = ar < M ? ar : M - 1;
         int wr = n0 + (wave * 2 + j) * 16 + srow; wr = wr < N ? wr : N - 1;
-        a_src[j] = A + (long long)ar * lda + schunk * 8;
-        w_src[j] = W + (long long)wr * ldw + schunk * 8;
+        a_src[j] = A + (long long)ar * lda * EB + schunk * 16;
+        w_src[j] = W + (long long)wr * ldw * EB + schunk * 16;
     }
     auto stage_a = [&](int kt) {
         char* base = lds + (kt & 3) * P_STAGE_BYTES + wave * 2048;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + kt * P_BK),
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + kt * 64),
                                              (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
     };
     auto stage_w = [&](int kt) {
         char* base = lds + (kt & 3) * P_STAGE_BYTES + P_TILE_BYTES + wave * 2048;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + kt * P_BK),
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + kt * 64),
                                              (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
+    };
+    auto mma = [&](const bf16x8& wfr, const bf16x8& xfr, f32x4 c) -> f32x4 {
+        if constexpr (EB == 2) {
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xfr, c, 0, 0, 0);
+        } else {
+            typedef long l2 __attribute__((ext_vector_type(2)));
+            const l2 w2 = __builtin_bit_cast(l2, wfr), x2 = __builtin_bit_cast(l2, xfr);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], x2[0], c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], x2[1], c, 0, 0, 0);
+        }
     };
 
     const int fi = lane & 15, fg = lane >> 4;
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = K / P_BK;
+    const int nt = K * EB / 64;
     // prologue: K-steps 0..2 in flight, K-step 0 landed
     stage_a(0); stage_w(0);
     if (nt > 1) { stage_a(1); stage_w(1); }
@@ -404,7 +420,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
             for (int f = 0; f < 4; ++f)
-                acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][f], 0, 0, 0);
+                acc[fn][f] = mma(wf[fn], xf[f], acc[fn][f]);
         __builtin_amdgcn_s_setprio(0);
         PP_BARRIER();
         // ---- R1 ----
@@ -423,11 +439,17 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
             for (int f = 0; f < FM - 4; ++f)
-                acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], xf[f], acc[fn][4 + f], 0, 0, 0);
+                acc[fn][4 + f] = mma(wf[fn], xf[f], acc[fn][4 + f]);
         __builtin_amdgcn_s_setprio(0);
         PP_BARRIER();
     }
     if (!grp_b) PP_BARRIER();  // pairs with group B's extra barrier
+    if constexpr (EB == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < FM; ++jj) acc[i][jj] *= alpha;
+    }
 
     // ---- epilogue: accumulators -> (wave-private 16 KiB of the now idle LDS) -> full-line global I/O ----
     // A lane holds 4 consecutive columns of 4*FM scattered (row, 16-col block) pairs; stored directly that is
@@ -707,13 +729,19 @@ NtPlan nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
     return pl;
 }
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                 int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream);
+                 int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8 = false,
+                 float alpha = 1.0f);
 }  // namespace
 
 extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                                  int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux,
                                  void* stream) {
     return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, nullptr, stream);
+}
+
+extern "C" int vitk_gemm_nt_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                               int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float alpha, void* stream) {
+    return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, nullptr, stream, true, alpha);
 }
 
 extern "C" int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc) {
@@ -733,8 +761,10 @@ extern "C" int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, con
 
 namespace {
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                 int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream) {
+                 int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8, float alpha) {
     if (!A || !W || !C) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: null pointer");
+    if (fp8 && ((lda & 15) || (ldw & 15) || (K % 64)))
+        VITK_FAIL(VITK_E_ALIGN, "gemm_nt_fp8: K %% 64 == 0 and lda, ldw %% 16 == 0 required");
     if (M <= 0 || N <= 0 || K <= 0 || (K % NT_BK) || (N & 3) || M > (1 << 30) || N > (1 << 30))
         VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: need K %% 32 == 0 and N %% 4 == 0 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
     if ((lda & 7) || (ldw & 7) || (ldc & 3) || !aligned16(A) || !aligned16(W) || !aligned16(C) || (bias && !aligned8(bias)) ||
@@ -743,6 +773,7 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     const NtPlan pl = nt_plan(M, N, K, ldc, aux);
     const bool large = pl.large;
     const int fm = pl.fm;
+    if (fp8 && !large) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_fp8: served by the 256-row kernel only (M >= 1024, N >= 256, N %% 8 == 0)");
     const int tbm = large ? 32 * fm : BM, tbn = large ? L_BN : BN;
     const int tiles_m = (int)((M + tbm - 1) / tbm), tiles_n = (int)((N + tbn - 1) / tbn);
     const long long nwg = (long long)tiles_m * tiles_n;
@@ -753,10 +784,17 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     if (getenv("VITK_GROUP_N")) group_n = atoi(getenv("VITK_GROUP_N")) > 0 ? atoi(getenv("VITK_GROUP_N")) : tiles_n;
     if (group_n > tiles_n) group_n = tiles_n;
 #define NT_LAUNCH_PP(E, F) do { \
-        static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E, F>, P_LDS_BYTES); \
-        if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", P_LDS_BYTES); \
-        hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, (const __bf16*)A, (long long)lda, \
-            (const __bf16*)W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum); \
+        if (fp8) { \
+            static const int rc8__ = set_max_lds(gemm_nt256pp_kernel<E, F, 1>, P_LDS_BYTES); \
+            if (rc8__ != 0) VITK_FAIL(rc8__, "gemm_nt_fp8: cannot enable %d B of LDS", P_LDS_BYTES); \
+            hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F, 1>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, A, (long long)lda, \
+                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, alpha); \
+        } else { \
+            static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E, F, 2>, P_LDS_BYTES); \
+            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", P_LDS_BYTES); \
+            hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F, 2>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, A, (long long)lda, \
+                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, 1.0f); \
+        } \
     } while (0)
 #define NT_LAUNCH(E) do { \
     if (large && fm == 7) NT_LAUNCH_PP(E, 7); \

@@ -276,3 +276,20 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
               beta1: float, beta2: float, eps: float, weight_decay: float, decoupled: bool, step: int, grad_scale: float = 1.0):
     check(_lib_for(param, grad, exp_avg, exp_avg_sq).vitk_adam_step(_p(param), _p(grad), dt(param), _p(exp_avg), _p(exp_avg_sq), _p(master), n, lr, beta1, beta2,
                                   eps, weight_decay, int(decoupled), step, grad_scale, _stream()), "adam_step")
+
+
+# ---- fp8 (e4m3) operands ---------------------------------------------------------------------------------------------
+def gemm_nt_fp8(A8: Tensor, lda: int, W8: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int, alpha: float,
+                epilogue: int = L.EPI_NONE, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
+                aux: Optional[Tensor] = None):
+    """A8, W8: uint8 / float8_e4m3fn storage of e4m3 values; C, bias, aux: the 16-bit model dtype (selects the library)."""
+    check(_lib_for(C, bias, aux).vitk_gemm_nt_fp8(_p(A8), lda, _p(W8), ldw, _p(C), ldc, M, N, K, epilogue, _p(bias), _p(resid),
+                                                 _p(aux), alpha, _stream()), "gemm_nt_fp8")
+
+
+def fp8_amax_scale(x: Tensor, scale2: Tensor):
+    check(_lib_for(x).vitk_fp8_amax_scale(_p(x), dt(x), x.numel(), _p(scale2), _stream()), "fp8_amax_scale")
+
+
+def quantize_fp8(x: Tensor, out: Tensor, scale_dev: Optional[Tensor] = None, scale: float = 1.0):
+    check(_lib_for(x).vitk_quantize_fp8(_p(x), dt(x), _p(out), x.numel(), _p(scale_dev), scale, _stream()), "quantize_fp8")
