@@ -227,6 +227,22 @@ def test_batch_of_one_and_odd_batch():
         assert max(rel(grads[k], ref_g[k]) for k in params) <= 1e-3
 
 
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+@pytest.mark.parametrize("channels,patch", [(1, 4), (4, 8), (2, (4, 6))])
+def test_channel_counts_and_small_patch_dims(kind, channels, patch):
+    """`channels` other than 3 (vit.py:86, :94): patch_dim = 16 (below one MFMA K-step: zero-padded to 32), 256 and 48."""
+    cfg = dict(image_size=(24, 24), patch_size=patch, num_classes=6, dim=64, depth=1, heads=2, dim_head=32, mlp_dim=96, channels=channels)
+    params = make_params(kind, cfg, 21)
+    img = make_images(cfg, 3, 2100)
+    ref_out, ref_g = O.run_fwd_bwd(kind, cfg, params, img, torch.float32)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+        out, grads = run_mine(kind, cfg, params, img, dtype)
+        assert rel(out, ref_out) <= tol, (dtype, rel(out, ref_out))
+        keys = [k for k in params if params[k].numel()]
+        cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
+        assert rel(cat(grads), cat(ref_g)) <= (tol if dtype == torch.float32 else 8e-2), dtype
+
+
 def test_vit_l16_width_bf16_runs_fast_path():
     """BASELINE config 3's layer shapes (D=1024, h=16, F=4096) at depth 2 / batch 8, bf16, vs the f32 oracle."""
     cfg = dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=2, heads=16, mlp_dim=4096)
