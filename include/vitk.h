@@ -168,6 +168,17 @@ int vitk_attn_bwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_
                        const float* lse, float* delta,
                        vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv,
                        int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream);
+/* The same with nn.Dropout(p) on the attention matrix (vit.py:42,60; training mode): kept probabilities are scaled by
+ * 1 / (1 - p) for P.V while the softmax denominators stay those of the full row.  The keep decision of entry
+ * (b, h, query, key) is hash(hash((b*H + h)*N + query ^ seed) + key) >= p * 2^32 -- recomputed by the backward kernels from
+ * the same (p, seed), no mask tensor exists; vitk_dropout_keep() materialises the decisions for tests.              */
+int vitk_attn_fwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, float* lse, int64_t B, int64_t H,
+                            int64_t N, int64_t d, float scale, float drop_p, uint32_t drop_seed, void* stream);
+int vitk_attn_bwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_bhnd dout, const float* lse,
+                            float* delta, vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv, int64_t B, int64_t H, int64_t N,
+                            int64_t d, float scale, float drop_p, uint32_t drop_seed, void* stream);
+/* keep[r * cols + c] = 1 if element (r, c) survives dropout(p) under `seed` in the fused kernels, else 0. */
+int vitk_dropout_keep(uint8_t* keep, int64_t rows, int64_t cols, float p, uint32_t seed, void* stream);
 
 /* Variable-length (packed) attention -- the NaViT path (na_vit.py:115-169: F.scaled_dot_product_attention with a dense
  * boolean "same image & key not padding" mask, :335-337; and the attention pool :371-387).  Tokens of all images are

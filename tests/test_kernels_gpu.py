@@ -512,3 +512,52 @@ def test_f16_attention_fwd_bwd(B, H, N):
     K.attn_bwd_bf16(q_, k_, v_, o_, K.bhnd(do, N * I, d, I), lse, delta, K.bhnd(dqkv, sb, sh, sn),
                     K.bhnd(dqkv, sb, sh, sn, offset=I), K.bhnd(dqkv, sb, sh, sn, offset=2 * I), B, H, N, d, scale)
     assert rel(dqkv, gref) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# fused dropout: decisions are a counter hash of (seed, row, col); vitk_dropout_keep materialises them for the reference
+def test_dropout_keep_hash_statistics():
+    keep = torch.empty(4096, 1000, dtype=torch.uint8, device=DEV)
+    for p in (0.1, 0.5):
+        K.dropout_keep(keep, 4096, 1000, p, 1234)
+        f = keep.float()
+        assert abs(f.mean().item() - (1 - p)) < 2e-3
+        assert (f.mean(0) - (1 - p)).abs().max().item() < 0.04 and (f.mean(1) - (1 - p)).abs().max().item() < 0.07   # no dead rows / columns
+        k2 = torch.empty_like(keep)
+        K.dropout_keep(k2, 4096, 1000, p, 1235)
+        assert abs((keep == k2).float().mean().item() - (p * p + (1 - p) ** 2)) < 3e-3                                # seeds are independent
+    K.dropout_keep(keep, 4096, 1000, 0.0, 7)
+    assert keep.min().item() == 1
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 64), (2, 2, 256)])
+@pytest.mark.parametrize("r", ["1", "2"])
+def test_attention_with_probability_dropout(B, H, N, r, monkeypatch):
+    """nn.Dropout on the attention matrix inside the flash kernels (vit.py:60), forward and backward, against a float64
+    reference that uses the very same keep decisions."""
+    for v in ("VITK_ATTN_R_FWD", "VITK_ATTN_R_DQ", "VITK_ATTN_R_DKV"):
+        monkeypatch.setenv(v, r)
+    d, p, seed = 64, 0.2, 4321
+    I = H * d
+    scale = d ** -0.5
+    qkv = rnd(B, N, 3 * I, dtype=BF, seed=271) * 1.5
+    do = rnd(B, N, I, dtype=BF, seed=272)
+    keep = torch.empty(B * H * N, N, dtype=torch.uint8, device=DEV)
+    K.dropout_keep(keep, B * H * N, N, p, seed)
+    mask = keep.view(B, H, N, N).double() / (1 - p)
+    q, k, v = (qkv[..., i * I:(i + 1) * I].reshape(B, N, H, d).permute(0, 2, 1, 3).double().requires_grad_(True) for i in range(3))
+    pm = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) * mask
+    oref = (pm @ v).permute(0, 2, 1, 3).reshape(B, N, I)
+    oref.backward(do.double())
+    gref = torch.cat([t.grad.permute(0, 2, 1, 3).reshape(B, N, I) for t in (q, k, v)], -1)
+    o = torch.empty(B, N, I, dtype=BF, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV); delta = torch.empty(B, H, N, device=DEV)
+    sb, sh, sn = N * 3 * I, d, 3 * I
+    q_ = K.bhnd(qkv, sb, sh, sn); k_ = K.bhnd(qkv, sb, sh, sn, offset=I); v_ = K.bhnd(qkv, sb, sh, sn, offset=2 * I)
+    o_ = K.bhnd(o, N * I, d, I)
+    K.attn_fwd_bf16(q_, k_, v_, o_, lse, B, H, N, d, scale, p, seed)
+    assert rel(o, oref) < 8e-3, rel(o, oref)
+    dqkv = torch.empty_like(qkv)
+    K.attn_bwd_bf16(q_, k_, v_, o_, K.bhnd(do, N * I, d, I), lse, delta, K.bhnd(dqkv, sb, sh, sn),
+                    K.bhnd(dqkv, sb, sh, sn, offset=I), K.bhnd(dqkv, sb, sh, sn, offset=2 * I), B, H, N, d, scale, p, seed)
+    assert rel(dqkv, gref) < 1.5e-2, rel(dqkv, gref)

@@ -65,6 +65,9 @@ SIGNATURES = {
     "vitk_gemm_generic": (_i, [Mat, Mat, Mat, _vp, _i, _i64, _i64, _i64, _i64, _i64, _f, _f, _vp]),
     "vitk_attn_fwd_bf16": (_i, [BHND, BHND, BHND, BHND, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_attn_bwd_bf16": (_i, [BHND, BHND, BHND, BHND, BHND, _vp, _vp, BHND, BHND, BHND, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_attn_fwd_bf16_drop": (_i, [BHND, BHND, BHND, BHND, _vp, _i64, _i64, _i64, _i64, _f, _f, C.c_uint32, _vp]),
+    "vitk_attn_bwd_bf16_drop": (_i, [BHND, BHND, BHND, BHND, BHND, _vp, _vp, BHND, BHND, BHND, _i64, _i64, _i64, _i64, _f, _f, C.c_uint32, _vp]),
+    "vitk_dropout_keep": (_i, [_vp, _i64, _i64, _f, C.c_uint32, _vp]),
     "vitk_attn_varlen_fwd_bf16": (_i, [HND, HND, HND, HND, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_attn_varlen_bwd_bf16": (_i, [HND, HND, HND, HND, HND, _vp, _vp, HND, HND, HND, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_rmsnorm_heads_rows": (_i64, [_i64, _i64]),

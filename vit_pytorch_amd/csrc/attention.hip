@@ -120,7 +120,8 @@ __device__ __forceinline__ float groups_sum(float x) {
 // N <= 256 (ViT-B/L: 13 tiles) in ONE pass instead of two unbalanced ones.
 template <int R>
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BHND v, BHND o, float* __restrict__ lse,
-                                                        int H, int N, float scale_log2e) {
+                                                        int H, int N, float scale_log2e, unsigned drop_t, unsigned drop_seed,
+                                                        float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
@@ -204,7 +205,16 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
 #pragma unroll
                     for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
                 pb[r] = pack8(st[0], st[1]);
-                accl[r] = MFMA(ones, pb[r], accl[r]);
+                accl[r] = MFMA(ones, pb[r], accl[r]);          // softmax denominators: of the UNDROPPED probabilities
+                if (drop_t) {                                  // nn.Dropout on the attention matrix (vit.py:60): zero P entries for P.V
+                    const unsigned hrow = drop_row((unsigned)(bh * N + (t0 + r) * 16 + fi), drop_seed);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!drop_keep(hrow, (unsigned)(s * 32 + hh * 16 + 4 * fg + e), drop_t)) st[hh][e] = 0.f;
+                    pb[r] = pack8(st[0], st[1]);
+                }
             }
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) {
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
         for (int r = 0; r < R; ++r) {
             const int qi = (t0 + r) * 16 + fi;
             const float ls = accl[r][0];        // every row of 1^T P^T is the same sum
-            const float inv = 1.0f / ls;
+            const float inv = inv_keep / ls;    // kept entries are scaled by 1 / (1 - p)
             if (qi < N) {
                 __bf16* op = o.p + b * o.s_b + h * o.s_h + (long long)qi * o.s_n + 4 * fg;
 #pragma unroll
@@ -237,7 +247,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
 template <int R>
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k, BHND v, BHND o, BHND dout,
                                                            const float* __restrict__ lse, float* __restrict__ delta,
-                                                           BHND dq, int H, int N, float scale) {
+                                                           BHND dq, int H, int N, float scale, unsigned drop_t,
+                                                           unsigned drop_seed, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
@@ -295,6 +306,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k,
                     st = MFMA(k1, qf[r][1], st);
                     f32x4 dp = MFMA(v0, df[r][0], z4);
                     dp = MFMA(v1, df[r][1], dp);
+                    if (drop_t) {                     // dP = dP_dropped * keep / (1 - p)
+                        const unsigned hrow = drop_row((unsigned)(bh * N + (t0 + r) * 16 + fi), drop_seed);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            dp[e] = drop_keep(hrow, (unsigned)(row0 + 4 * fg + e), drop_t) ? dp[e] * inv_keep : 0.f;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)       // the common factor `scale` of dS is applied once, to dQ
                         ds[r][hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l2[r])) * (dp[e] - dl[r]);
@@ -335,7 +352,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k,
 template <int R>
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k, BHND v, BHND dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            BHND dk, BHND dv, int H, int N, float scale) {
+                                                            BHND dk, BHND dv, int H, int N, float scale, unsigned drop_t,
+                                                            unsigned drop_seed, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
@@ -344,6 +362,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
     char* Ds = Qs + rows_pad * AT_LD;
     float* lse_s = reinterpret_cast<float*>(Qs + 2 * rows_pad * AT_LD);
     float* del_s = lse_s + rows_pad;
+    unsigned* hq_s = reinterpret_cast<unsigned*>(del_s + rows_pad);     // dropout row hashes of the query rows
     const int nkt = (N + 15) >> 4, nqs = rows_pad >> 5;
     const float scale_log2e = scale * LOG2E;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
         float lv = 0.f, dv_ = 0.f;     // rows_pad <= 480 < AT_THREADS: one row of lse / delta per thread
         if (tid < N) { lv = -lse[(long long)bh * N + tid] * LOG2E; dv_ = -delta[(long long)bh * N + tid]; }   // negated (FMA / add forms)
         fill_tiles2(Qs, q.p + b * q.s_b + h * q.s_h, q.s_n, Ds, dout.p + b * dout.s_b + h * dout.s_h, dout.s_n, N, rows_pad, tid);
-        if (tid < rows_pad) { lse_s[tid] = lv; del_s[tid] = dv_; }
+        if (tid < rows_pad) { lse_s[tid] = lv; del_s[tid] = dv_; hq_s[tid] = drop_row((unsigned)(bh * N + tid), drop_seed); }
     };
     auto compute = [&]() {
     while (t0 < nkt) {
@@ -397,7 +416,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         p[r][hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l4[e]));
-                        ds[r][hh][e] = p[r][hh][e] * (dp[e] + d4[e]);      // `scale` is applied once, to dK
+                        if (drop_t) {               // dV takes P * keep / (1 - p); dP = dP_dropped * keep / (1 - p)
+                            const float km = drop_keep(hq_s[row0 + 4 * fg + e], (unsigned)((t0 + r) * 16 + fi), drop_t) ? inv_keep : 0.f;
+                            ds[r][hh][e] = p[r][hh][e] * (dp[e] * km + d4[e]);
+                            p[r][hh][e] *= km;
+                        } else {
+                            ds[r][hh][e] = p[r][hh][e] * (dp[e] + d4[e]);  // `scale` is applied once, to dK
+                        }
                     }
                     if (s == nqs - 1) {                    // padding query rows only exist in the last step
 #pragma unroll
@@ -884,7 +909,7 @@ bool bhnd_ok(vitk_bhnd t) { return t.p && aligned16(t.p) && (t.s_b % 8 == 0) && 
 
 // Dynamic LDS above the 64 KiB default needs an opt-in; done once per kernel (thread-safe static
 // initialisation) with the largest size the shape check admits (N <= 480).
-constexpr size_t AT_MAX_LDS = (size_t)2 * 480 * AT_LD + (size_t)2 * 480 * sizeof(float);
+constexpr size_t AT_MAX_LDS = (size_t)2 * 480 * AT_LD + (size_t)3 * 480 * sizeof(float);
 template <typename K>
 int set_lds_once(K kernel) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AT_MAX_LDS);
@@ -916,13 +941,20 @@ int tiles_per_wave(const char* env, bool prefer2, int64_t N) {
 
 extern "C" int vitk_attn_fwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, float* lse, int64_t B, int64_t H,
                                   int64_t N, int64_t d, float scale, void* stream) {
+    return vitk_attn_fwd_bf16_drop(q, k, v, o, lse, B, H, N, d, scale, 0.f, 0u, stream);
+}
+
+extern "C" int vitk_attn_fwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, float* lse, int64_t B, int64_t H,
+                                       int64_t N, int64_t d, float scale, float drop_p, uint32_t drop_seed, void* stream) {
     if (int rc = attn_shape_check("attn_fwd_bf16", B, H, N, d, scale)) return rc;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "attn_fwd_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
     if (!bhnd_ok(q) || !bhnd_ok(k) || !bhnd_ok(v) || !bhnd_ok(o) || !lse)
         VITK_FAIL(VITK_E_ALIGN, "attn_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     const int rows_pad = (int)((N + 31) / 32 * 32);
     const int r = tiles_per_wave("VITK_ATTN_R_FWD", true, N);
     ATTN_LAUNCH(attn_fwd_kernel, "attn_fwd_bf16", r, (unsigned)(B * H), (size_t)2 * rows_pad * AT_LD, (hipStream_t)stream, to_bhnd(q),
-                to_bhnd(k), to_bhnd(v), to_bhnd(o), lse, (int)H, (int)N, scale * LOG2E);
+                to_bhnd(k), to_bhnd(v), to_bhnd(o), lse, (int)H, (int)N, scale * LOG2E, drop_thresh(drop_p), drop_seed,
+                1.0f / (1.0f - drop_p));
     VITK_CHECK_LAUNCH("attn_fwd_bf16");
     return 0;
 }
@@ -930,20 +962,27 @@ extern "C" int vitk_attn_fwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bh
 extern "C" int vitk_attn_bwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_bhnd dout, const float* lse,
                                   float* delta, vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv, int64_t B, int64_t H, int64_t N,
                                   int64_t d, float scale, void* stream) {
+    return vitk_attn_bwd_bf16_drop(q, k, v, o, dout, lse, delta, dq, dk, dv, B, H, N, d, scale, 0.f, 0u, stream);
+}
+
+extern "C" int vitk_attn_bwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_bhnd dout, const float* lse,
+                                       float* delta, vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv, int64_t B, int64_t H, int64_t N,
+                                       int64_t d, float scale, float drop_p, uint32_t drop_seed, void* stream) {
     if (int rc = attn_shape_check("attn_bwd_bf16", B, H, N, d, scale)) return rc;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "attn_bwd_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
     if (!bhnd_ok(q) || !bhnd_ok(k) || !bhnd_ok(v) || !bhnd_ok(o) || !bhnd_ok(dout) || !bhnd_ok(dq) || !bhnd_ok(dk) || !bhnd_ok(dv) ||
         !lse || !delta)
         VITK_FAIL(VITK_E_ALIGN, "attn_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     const int rows_pad = (int)((N + 31) / 32 * 32);
     const size_t lds1 = (size_t)2 * rows_pad * AT_LD;
-    const size_t lds2 = lds1 + (size_t)2 * rows_pad * sizeof(float);
+    const size_t lds2 = lds1 + (size_t)3 * rows_pad * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int r1 = tiles_per_wave("VITK_ATTN_R_DQ", false, N), r2 = tiles_per_wave("VITK_ATTN_R_DKV", false, N);
     ATTN_LAUNCH(attn_bwd_dq_kernel, "attn_bwd_dq", r1, (unsigned)(B * H), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(o),
-                to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale);
+                to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
     VITK_CHECK_LAUNCH("attn_bwd_dq");
     ATTN_LAUNCH(attn_bwd_dkv_kernel, "attn_bwd_dkv", r2, (unsigned)(B * H), lds2, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(dout),
-                lse, delta, to_bhnd(dk), to_bhnd(dv), (int)H, (int)N, scale);
+                lse, delta, to_bhnd(dk), to_bhnd(dv), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
     VITK_CHECK_LAUNCH("attn_bwd_dkv");
     return 0;
 }

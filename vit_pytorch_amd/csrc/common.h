@@ -141,6 +141,23 @@ __device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
     return __builtin_elementwise_fma(x * splat2(0.39894228040143267794f), e, phi_poly2(x));
 }
 
+// ---- counter-based dropout decisions for the fused paths ------------------------------------------------------------
+// keep(row, col) = hash32(hash32(row ^ seed) + col) >= thresh, thresh = p * 2^32.  Stateless: the forward kernel, the
+// backward kernels and vitk_dropout_keep() (the test hook) regenerate the same decision from (seed, row, col), so no
+// mask tensor is stored or read.  hash32 = the "lowbias32" integer finaliser (2 multiplies, full avalanche).
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ unsigned drop_row(unsigned row, unsigned seed) { return hash32(row ^ seed); }
+__device__ __forceinline__ bool drop_keep(unsigned hrow, unsigned col, unsigned thresh) { return hash32(hrow + col) >= thresh; }
+static inline unsigned drop_thresh(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+}
+
 // ---- row map (see vitk.h) ---------------------------------------------------------------
 struct RowMap { long long group, gstride, offset; };
 __device__ __forceinline__ long long map_row(const RowMap& m, long long r) {

@@ -177,6 +177,15 @@ __global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* 
     scale[1] = a / 448.f;
 }
 
+__global__ __launch_bounds__(256) void dropout_keep_kernel(uint8_t* __restrict__ keep, long long rows, long long cols, unsigned thresh,
+                                                            unsigned seed) {
+    const long long n = rows * cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned r = (unsigned)(i / cols), c = (unsigned)(i % cols);
+        keep[i] = drop_keep(drop_row(r, seed), c, thresh) ? 1 : 0;
+    }
+}
+
 template <typename XT, typename PT>
 __global__ __launch_bounds__(256) void write_cls_kernel(XT* __restrict__ x, const PT* __restrict__ cls, const PT* __restrict__ pos,
                                                          long long B, long long N, int D, int ncls) {
@@ -426,6 +435,15 @@ extern "C" int vitk_quantize_fp8(const void* x, int dt, void* out, int64_t n, co
     VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((quantize_fp8_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (unsigned*)out,
                                                 (long long)(n / 4), scale_dev, scale_host));
     VITK_CHECK_LAUNCH("quantize_fp8");
+    return 0;
+}
+
+extern "C" int vitk_dropout_keep(uint8_t* keep, int64_t rows, int64_t cols, float p, uint32_t seed, void* stream) {
+    if (!keep) VITK_FAIL(VITK_E_ARG, "dropout_keep: null pointer");
+    if (rows <= 0 || cols <= 0 || rows > 0xffffffffLL || cols > 0x7fffffffLL) VITK_FAIL(VITK_E_SHAPE, "dropout_keep: bad extents");
+    hipLaunchKernelGGL(dropout_keep_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, (hipStream_t)stream, keep, (long long)rows,
+                       (long long)cols, drop_thresh(p), (unsigned)seed);
+    VITK_CHECK_LAUNCH("dropout_keep");
     return 0;
 }
 

@@ -153,13 +153,16 @@ def bhnd(t: Tensor, s_b: int, s_h: int, s_n: int, offset: int = 0) -> BHND:
     return r
 
 
-def attn_fwd_bf16(q: BHND, k: BHND, v: BHND, o: BHND, lse: Tensor, B: int, H: int, N: int, d: int, scale: float):
-    check(_lib_for(q, k, v, o, lse).vitk_attn_fwd_bf16(q, k, v, o, _p(lse), B, H, N, d, scale, _stream()), "attn_fwd_bf16")
+def attn_fwd_bf16(q: BHND, k: BHND, v: BHND, o: BHND, lse: Tensor, B: int, H: int, N: int, d: int, scale: float,
+                  drop_p: float = 0.0, drop_seed: int = 0):
+    check(_lib_for(q, k, v, o, lse).vitk_attn_fwd_bf16_drop(q, k, v, o, _p(lse), B, H, N, d, scale, drop_p, drop_seed & 0xffffffff,
+                                                           _stream()), "attn_fwd_bf16")
 
 
 def attn_bwd_bf16(q: BHND, k: BHND, v: BHND, o: BHND, dout: BHND, lse: Tensor, delta: Tensor, dq: BHND, dk: BHND,
-                  dv: BHND, B: int, H: int, N: int, d: int, scale: float):
-    check(_lib_for(q, k, v, o, dout, lse, delta, dq, dk, dv).vitk_attn_bwd_bf16(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, B, H, N, d, scale, _stream()),
+                  dv: BHND, B: int, H: int, N: int, d: int, scale: float, drop_p: float = 0.0, drop_seed: int = 0):
+    check(_lib_for(q, k, v, o, dout, lse, delta, dq, dk, dv).vitk_attn_bwd_bf16_drop(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, B, H, N, d, scale,
+                                                                                    drop_p, drop_seed & 0xffffffff, _stream()),
           "attn_bwd_bf16")
 
 
@@ -293,3 +296,8 @@ def fp8_amax_scale(x: Tensor, scale2: Tensor):
 
 def quantize_fp8(x: Tensor, out: Tensor, scale_dev: Optional[Tensor] = None, scale: float = 1.0):
     check(_lib_for(x).vitk_quantize_fp8(_p(x), dt(x), _p(out), x.numel(), _p(scale_dev), scale, _stream()), "quantize_fp8")
+
+
+def dropout_keep(keep: Tensor, rows: int, cols: int, p: float, seed: int):
+    """uint8 (rows, cols): the keep decisions the fused dropout kernels take for (p, seed) -- a test hook."""
+    check(L.load().vitk_dropout_keep(_p(keep), rows, cols, p, seed & 0xffffffff, _stream()), "dropout_keep")
