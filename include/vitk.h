@@ -81,6 +81,13 @@ int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int xdt, const v
                        float* partials, int colsum_dx,
                        int64_t rows, int64_t D,
                        vitk_rowmap dymap, vitk_rowmap xmap, vitk_rowmap dxmap, void* stream);
+/* The same when the Linear that produced the residual branch ended in nn.Dropout(p) (vit.py:24,48): dx_t and the column
+ * sums (= the gradient at that Linear's output and its bias gradient) carry the keep decisions / 1/(1-p) of (p, seed) at
+ * (row, column); dx_f32, the residual stream gradient, is not masked.                                               */
+int vitk_layernorm_bwd_drop(const void* dy, int dydt, const void* x, int xdt, const void* w, int wdt,
+                            const float* mean, const float* rstd, const float* gin, float* dx_f32, void* dx_t, int dxtdt,
+                            float* partials, int colsum_dx, int64_t rows, int64_t D, vitk_rowmap dymap, vitk_rowmap xmap,
+                            vitk_rowmap dxmap, float drop_p, uint32_t drop_seed, void* stream);
 
 /* One-launch finish of vitk_layernorm_bwd: dw, db (dtype odt, either may be null) and, if non-null, the f32
  * column sums dcol of dx, from the `partials` buffer of that call (nblk = vitk_layernorm_bwd_blocks(rows, D)). */
@@ -122,6 +129,13 @@ int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc);
 int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, const void* W, int64_t ldw,
                                       void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                       void* aux, float* colsum_partials, void* stream);
+/* General form with fused nn.Dropout(p) (training mode; 256-row kernel only): RESID -- the Linear output is dropped before
+ * the residual add (vit.py:24,48 with :80-81); BIAS_GELU -- C = dropout(gelu(aux)), aux stays undropped (vit.py:21-22);
+ * GELU_BWD -- the matching backward factor; colsum_partials as in vitk_gemm_nt_bf16_gelu_bwd_colsum or null.  Keep decision
+ * of element (m, n): hash(hash(m ^ seed) + n) >= p * 2^32 (vitk_dropout_keep).                                       */
+int vitk_gemm_nt_bf16_drop(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                           int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* colsum_partials,
+                           float drop_p, uint32_t drop_seed, void* stream);
 
 /* fp8 operands (BASELINE config 5): C = alpha * A8[M,K] . W8[N,K]^T with the epilogues of
  * vitk_gemm_nt_bf16; A8, W8 are OCP e4m3 bytes (K contiguous, K %% 64 == 0, lda / ldw %% 16 == 0), C / bias / aux the

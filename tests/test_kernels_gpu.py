@@ -561,3 +561,52 @@ def test_attention_with_probability_dropout(B, H, N, r, monkeypatch):
     K.attn_bwd_bf16(q_, k_, v_, o_, K.bhnd(do, N * I, d, I), lse, delta, K.bhnd(dqkv, sb, sh, sn),
                     K.bhnd(dqkv, sb, sh, sn, offset=I), K.bhnd(dqkv, sb, sh, sn, offset=2 * I), B, H, N, d, scale, p, seed)
     assert rel(dqkv, gref) < 1.5e-2, rel(dqkv, gref)
+
+
+def _keep(rows, cols, p, seed):
+    k = torch.empty(rows, cols, dtype=torch.uint8, device=DEV)
+    K.dropout_keep(k, rows, cols, p, seed)
+    return k.double() / (1 - p)
+
+
+def test_gemm_epilogues_with_fused_dropout():
+    M, N, Kd, p = 1300, 768, 768, 0.25
+    A = rnd(M, Kd, dtype=BF, seed=344); W = rnd(N, Kd, dtype=BF, seed=345) * (Kd ** -0.5)
+    bias = rnd(N, dtype=BF, seed=346)
+    pre = A.double() @ W.double().t() + bias.double()
+    mk = _keep(M, N, p, 99)
+    resid = rnd(M, N, seed=347); out = torch.empty(M, N, device=DEV)
+    K.gemm_nt_bf16_drop(A, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, p, 99, bias=bias, resid=resid)
+    assert rel(out, resid.double() + pre * mk) < 1e-5
+    C = torch.empty(M, N, dtype=BF, device=DEV); aux = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt_bf16_drop(A, Kd, W, Kd, C, N, M, N, Kd, L.EPI_BIAS_GELU, p, 99, bias=bias, aux=aux)
+    assert rel(aux, pre) < 4e-3 and rel(C, torch.nn.functional.gelu(pre) * mk) < 5e-3
+    h = rnd(M, N, dtype=BF, seed=348)
+    R = K.gemm_nt_colsum_rows(M, N, Kd, N)
+    part = torch.empty(R * N, device=DEV)
+    K.gemm_nt_bf16_drop(A, Kd, W, Kd, C, N, M, N, Kd, L.EPI_GELU_BWD, p, 99, aux=h, partials=part)
+    hd = h.double().requires_grad_(True)
+    (torch.nn.functional.gelu(hd) * mk).backward(A.double() @ W.double().t())
+    assert rel(C, hd.grad) < 5e-3
+    assert rel(part.view(R, N).double().sum(0), C.double().sum(0)) < 1e-5
+    with pytest.raises(L.VitkError):                      # small shapes run on the 128-row kernel: no fused dropout there
+        K.gemm_nt_bf16_drop(A[:256], Kd, W, Kd, out, N, 256, N, Kd, L.EPI_RESID, p, 99, bias=bias, resid=resid)
+
+
+def test_layernorm_bwd_with_output_dropout():
+    rows, D, p = 700, 768, 0.3
+    x = rnd(rows, D, seed=411); dy = rnd(rows, D, dtype=BF, seed=412); w = (1 + 0.2 * rnd(D, seed=413)).to(BF); gin = rnd(rows, D, seed=415)
+    mean = x.double().mean(-1).float(); rstd = (1 / torch.sqrt(x.double().var(-1, unbiased=False) + 1e-5)).float()
+    nblk = K.layernorm_bwd_blocks(rows, D)
+    partials = torch.empty(3 * nblk * D, device=DEV)
+    dxf = torch.empty(rows, D, device=DEV); dxt = torch.empty(rows, D, dtype=BF, device=DEV)
+    K.layernorm_bwd(dy, x, w, mean, rstd, gin, dxf, dxt, partials, True, rows, D, drop_p=p, drop_seed=77)
+    xd = x.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (D,), w.double(), None, 1e-5).backward(dy.double())
+    dx_ref = xd.grad + gin.double()
+    mk = _keep(rows, D, p, 77)
+    assert rel(dxf, dx_ref) < 3e-6                                         # the stream gradient is not masked
+    assert rel(dxt, dx_ref * mk) < 4e-3                                    # the 16-bit copy (GEMM operand) is
+    dc = torch.empty(D, device=DEV)
+    K.colsum_partials(partials[2 * nblk * D:], nblk, D, D, dc)
+    assert rel(dc, (dx_ref * mk).sum(0)) < 1e-4                            # and so is the bias gradient it yields

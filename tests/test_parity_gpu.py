@@ -312,3 +312,52 @@ def test_long_sequence_dim_head_64_uses_chunked_attention():
     cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
     assert rel(out, ref_out) <= 1.5 * rel(bf_out, ref_out) + 1e-3
     assert rel(cat(grads), cat(ref_g)) <= 1.5 * rel(cat(bf_g), cat(ref_g)) + 1e-3
+
+
+def test_fused_dropout_layer_matches_masked_reference():
+    """Active dropout (vit.py:22,24,48,60 at p = 0.1, training mode) runs inside the fused engine; its keep decisions are
+    a counter hash, so a float64 reference that applies the very same masks (vitk_dropout_keep) must agree."""
+    from vit_pytorch_amd import engine as E, kernels as K
+    from vit_pytorch_amd.vit import Transformer
+    B, N, D, H, d, Fh, p = 8, 197, 768, 12, 64, 3072, 0.1
+    torch.manual_seed(5)
+    blk = Transformer(D, 1, H, d, Fh, dropout=p).to(DEV, dtype=torch.bfloat16).train()
+    for q in blk.parameters():                                   # non-trivial affine / bias values
+        if q.ndim == 1:
+            q.data.add_(0.1 * torch.randn_like(q))
+    x = torch.randn(B, N, D, device=DEV).to(torch.bfloat16)
+    assert blk._fusable(x) and blk._dropout_p() == p
+    Transformer._drop_calls[0] = 3
+    seed = (int(torch.initial_seed()) + 0x9E3779B1 * 3) & 0xffffffff
+    y = blk(x)
+    assert Transformer._drop_calls[0] == 4                      # the fused path drew its seeds
+    O.loss_fn(y).backward()
+
+    def keep(rows, cols, k):
+        m = torch.empty(rows, cols, dtype=torch.uint8, device=DEV)
+        K.dropout_keep(m, rows, cols, p, E._hash32(seed + k))
+        return m.double() / (1 - p)
+
+    attn, ff = blk.layers[0]
+    P = {k_: v.detach().double().requires_grad_(True) for k_, v in blk.named_parameters()}
+    xd = x.double()
+    ln = torch.nn.functional.layer_norm
+    a1 = ln(xd, (D,), P["layers.0.0.norm.weight"], P["layers.0.0.norm.bias"], 1e-5)
+    qkv = a1 @ P["layers.0.0.to_qkv.weight"].t()
+    q, k, v = (qkv[..., i * H * d:(i + 1) * H * d].reshape(B, N, H, d).permute(0, 2, 1, 3) for i in range(3))
+    pm = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) * keep(B * H * N, N, 0).view(B, H, N, N)
+    o = (pm @ v).permute(0, 2, 1, 3).reshape(B, N, H * d)
+    x2 = xd + (o @ P["layers.0.0.to_out.0.weight"].t() + P["layers.0.0.to_out.0.bias"]) * keep(B * N, D, 1).view(B, N, D)
+    a2 = ln(x2, (D,), P["layers.0.1.net.0.weight"], P["layers.0.1.net.0.bias"], 1e-5)
+    act = torch.nn.functional.gelu(a2 @ P["layers.0.1.net.1.weight"].t() + P["layers.0.1.net.1.bias"]) * keep(B * N, Fh, 2).view(B, N, Fh)
+    x3 = x2 + (act @ P["layers.0.1.net.4.weight"].t() + P["layers.0.1.net.4.bias"]) * keep(B * N, D, 3).view(B, N, D)
+    yref = ln(x3, (D,), P["norm.weight"], P["norm.bias"], 1e-5)
+    O.loss_fn(yref).backward()
+    e = rel(y, yref)
+    keys = list(P)
+    g = rel(torch.cat([blk.get_parameter(k_).grad.float().flatten() for k_ in keys]), torch.cat([P[k_].grad.flatten() for k_ in keys]))
+    worst = max(rel(blk.get_parameter(k_).grad, P[k_].grad) for k_ in keys)
+    print(f"fused dropout layer: out {e:.2e}, grads {g:.2e}, worst tensor {worst:.2e}")
+    assert e < 1e-2 and g < 2e-2 and worst < 6e-2
+    blk.eval()
+    assert blk._dropout_p() == 0.0

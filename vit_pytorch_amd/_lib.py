@@ -55,6 +55,8 @@ SIGNATURES = {
     "vitk_gemm_nt_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
     "vitk_half_type": (_i, []),
     "vitk_adam_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i64, _f, _vp]),
+    "vitk_gemm_nt_bf16_drop": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, C.c_uint32, _vp]),
+    "vitk_layernorm_bwd_drop": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i64, RowMap, RowMap, RowMap, _f, C.c_uint32, _vp]),
     "vitk_gemm_nt_fp8": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _f, _vp]),
     "vitk_fp8_amax_scale": (_i, [_vp, _i, _i64, _vp, _vp]),
     "vitk_quantize_fp8": (_i, [_vp, _i, _vp, _i64, _vp, _f, _vp]),

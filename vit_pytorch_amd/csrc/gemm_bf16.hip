@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     const void* __restrict__ Av, long long lda, const void* __restrict__ Wv, long long ldw,
     void* __restrict__ Cv, long long ldc, int M, int N, int K,
     const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
-    int tiles_n, int nwg, int group_n, float* __restrict__ csum, float alpha) {
+    int tiles_n, int nwg, int group_n, float* __restrict__ csum, float alpha, unsigned drop_t, unsigned drop_seed, float inv_keep) {
     const char* A = reinterpret_cast<const char*>(Av);
     const char* W = reinterpret_cast<const char*>(Wv);
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -500,6 +500,11 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                     const int m = mrow0 + hh * 64 + row;
                     if (m < M && ncol < N) {
                         v += b4;
+                        if (drop_t) {       // nn.Dropout on the Linear output, before the residual add (vit.py:24,48 + :80-81)
+                            const unsigned hrow = drop_row((unsigned)m, drop_seed);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = drop_keep(hrow, (unsigned)(ncol + e), drop_t) ? v[e] * inv_keep : 0.f;
+                        }
                         v += rpre[hh][j];
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + ncol) = v;
                     }
@@ -559,13 +564,24 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                         const f32x2 g2 = gelu_fast2(f32x2{(float)v[e], (float)v[e + 1]});
                         g8[e] = (__bf16)g2[0]; g8[e + 1] = (__bf16)g2[1];
                     }
+                    if (drop_t) {           // nn.Dropout after the GELU (vit.py:22): the saved pre-activation stays undropped
+                        const unsigned hrow = drop_row((unsigned)m, drop_seed);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            g8[e] = drop_keep(hrow, (unsigned)(ncol + e), drop_t) ? (__bf16)((float)g8[e] * inv_keep) : (__bf16)0.f;
+                    }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
                 } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
                     const bf16x8 h8 = hpre[j];
                     bf16x8 g8;
+                    const unsigned hrow = drop_t ? drop_row((unsigned)m, drop_seed) : 0u;
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        const f32x2 g2 = f32x2{(float)v[e], (float)v[e + 1]} * gelu_grad_fast2(f32x2{(float)h8[e], (float)h8[e + 1]});
+                        f32x2 g2 = f32x2{(float)v[e], (float)v[e + 1]} * gelu_grad_fast2(f32x2{(float)h8[e], (float)h8[e + 1]});
+                        if (drop_t) {       // the forward dropped gelu(pre) at (m, n): same decision, same 1 / (1 - p)
+                            g2[0] = drop_keep(hrow, (unsigned)(ncol + e), drop_t) ? g2[0] * inv_keep : 0.f;
+                            g2[1] = drop_keep(hrow, (unsigned)(ncol + e + 1), drop_t) ? g2[1] * inv_keep : 0.f;
+                        }
                         g8[e] = (__bf16)g2[0]; g8[e + 1] = (__bf16)g2[1];
                         cs[e] += (float)g8[e]; cs[e + 1] += (float)g8[e + 1];      // of the ROUNDED values: what a later colsum(C) would read
                     }
@@ -730,13 +746,21 @@ NtPlan nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
 }
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                  int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8 = false,
-                 float alpha = 1.0f);
+                 float alpha = 1.0f, float drop_p = 0.f, unsigned drop_seed = 0u);
 }  // namespace
 
 extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                                  int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux,
                                  void* stream) {
     return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, nullptr, stream);
+}
+
+extern "C" int vitk_gemm_nt_bf16_drop(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                                      int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* colsum_partials,
+                                      float drop_p, uint32_t drop_seed, void* stream) {
+    if (colsum_partials && (epilogue != VITK_EPI_GELU_BWD || vitk_gemm_nt_colsum_rows(M, N, K, ldc) == 0))
+        VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16_drop: column sums come with the GELU_BWD epilogue of the 256-row kernel only");
+    return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, colsum_partials, stream, false, 1.0f, drop_p, drop_seed);
 }
 
 extern "C" int vitk_gemm_nt_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
@@ -761,8 +785,12 @@ extern "C" int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, con
 
 namespace {
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                 int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8, float alpha) {
+                 int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8, float alpha,
+                 float drop_p, unsigned drop_seed) {
     if (!A || !W || !C) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: null pointer");
+    if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
+    const unsigned drop_t = drop_thresh(drop_p);
+    const float inv_keep = 1.0f / (1.0f - drop_p);
     if (fp8 && ((lda & 15) || (ldw & 15) || (K % 64)))
         VITK_FAIL(VITK_E_ALIGN, "gemm_nt_fp8: K %% 64 == 0 and lda, ldw %% 16 == 0 required");
     if (M <= 0 || N <= 0 || K <= 0 || (K % NT_BK) || (N & 3) || M > (1 << 30) || N > (1 << 30))
@@ -774,6 +802,8 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     const bool large = pl.large;
     const int fm = pl.fm;
     if (fp8 && !large) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_fp8: served by the 256-row kernel only (M >= 1024, N >= 256, N %% 8 == 0)");
+    if (drop_t && (!large || (epilogue != VITK_EPI_RESID && epilogue != VITK_EPI_BIAS_GELU && epilogue != VITK_EPI_GELU_BWD)))
+        VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: fused dropout exists in the 256-row kernel for the RESID / BIAS_GELU / GELU_BWD epilogues only");
     const int tbm = large ? 32 * fm : BM, tbn = large ? L_BN : BN;
     const int tiles_m = (int)((M + tbm - 1) / tbm), tiles_n = (int)((N + tbn - 1) / tbn);
     const long long nwg = (long long)tiles_m * tiles_n;
@@ -788,12 +818,12 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
             static const int rc8__ = set_max_lds(gemm_nt256pp_kernel<E, F, 1>, P_LDS_BYTES); \
             if (rc8__ != 0) VITK_FAIL(rc8__, "gemm_nt_fp8: cannot enable %d B of LDS", P_LDS_BYTES); \
             hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F, 1>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, A, (long long)lda, \
-                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, alpha); \
+                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, alpha, drop_t, drop_seed, inv_keep); \
         } else { \
             static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E, F, 2>, P_LDS_BYTES); \
             if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", P_LDS_BYTES); \
             hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F, 2>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, A, (long long)lda, \
-                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, 1.0f); \
+                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, 1.0f, drop_t, drop_seed, inv_keep); \
         } \
     } while (0)
 #define NT_LAUNCH(E) do { \

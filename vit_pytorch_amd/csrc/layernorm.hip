@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NW * WAVE) void ln_bwd_kernel(
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
     float* __restrict__ partials, int colsum_dx,
-    long long rows, int D, RowMap dymap, RowMap xmap, RowMap dxmap) {
+    long long rows, int D, RowMap dymap, RowMap xmap, RowMap dxmap, unsigned drop_t, unsigned drop_seed, float inv_keep) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nchunk = D >> 2;
@@ -149,6 +149,12 @@ __global__ __launch_bounds__(NW * WAVE) void ln_bwd_kernel(
                     if (EARLY_GIN) o += gi[t];
                     else if (gin) o += *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
                     if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow * D + 4 * c) = o;
+                    if (drop_t) {           // dx_t / its column sums are the gradient at the OUTPUT of the preceding Linear, whose
+                                            // dropout (vit.py:24,48) kept element (row, col) by the same hash; the f32 stream is not masked
+                        const unsigned hrow = drop_row((unsigned)orow, drop_seed);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = drop_keep(hrow, (unsigned)(4 * c + e), drop_t) ? o[e] * inv_keep : 0.f;
+                    }
                     if (dx_t) store4<DXT>(dx_t + orow * D + 4 * c, o);
                     if (colsum_dx) acc_x[t] += o;
                 }
@@ -289,12 +295,12 @@ int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* m
 template <typename DYT, typename XT, typename WT, typename DXT>
 int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const float* gin,
                   float* dxf, void* dxt, float* partials, int colsum_dx, long long rows, int D, RowMap dm, RowMap xm,
-                  RowMap om, hipStream_t st) {
+                  RowMap om, hipStream_t st, unsigned drop_t, unsigned drop_seed, float inv_keep) {
     const int nchunk = D / 4;
     const int maxc = (nchunk + 63) / 64;
     const long long blocks = vitk_layernorm_bwd_blocks(rows, D);
 #define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC, (MC >= 4 ? 4 : 8)>), dim3((unsigned)blocks), dim3((MC >= 4 ? 4 : 8) * WAVE), 0, st, \
-        (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om)
+        (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om, drop_t, drop_seed, inv_keep)
     if (maxc <= 1) LN_BWD_CASE(1);
     else if (maxc <= 3) LN_BWD_CASE(3);
     else if (maxc <= 4) LN_BWD_CASE(4);
@@ -345,7 +351,18 @@ extern "C" int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int x
                                   const float* mean, const float* rstd, const float* gin, float* dx_f32, void* dx_t,
                                   int dxtdt, float* partials, int colsum_dx, int64_t rows, int64_t D, vitk_rowmap dymap,
                                   vitk_rowmap xmap, vitk_rowmap dxmap, void* stream) {
+    return vitk_layernorm_bwd_drop(dy, dydt, x, xdt, w, wdt, mean, rstd, gin, dx_f32, dx_t, dxtdt, partials, colsum_dx, rows, D, dymap,
+                                   xmap, dxmap, 0.f, 0u, stream);
+}
+
+extern "C" int vitk_layernorm_bwd_drop(const void* dy, int dydt, const void* x, int xdt, const void* w, int wdt,
+                                       const float* mean, const float* rstd, const float* gin, float* dx_f32, void* dx_t,
+                                       int dxtdt, float* partials, int colsum_dx, int64_t rows, int64_t D, vitk_rowmap dymap,
+                                       vitk_rowmap xmap, vitk_rowmap dxmap, float drop_p, uint32_t drop_seed, void* stream) {
     if (!dy || !x || !w || !mean || !rstd || !partials) VITK_FAIL(VITK_E_ARG, "layernorm_bwd: null pointer");
+    if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "layernorm_bwd: dropout p must be in [0, 1) (got %g)", (double)drop_p);
+    const unsigned drop_t = drop_thresh(drop_p);
+    const float inv_keep = 1.0f / (1.0f - drop_p);
     if (rows <= 0 || D <= 0 || (D & 3) || D > 4096) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd: need rows > 0, D %% 4 == 0, D <= 4096");
     if (!aligned16(dy) || !aligned16(x) || (gin && !aligned16(gin)) || (dx_f32 && !aligned16(dx_f32)) || (dx_t && !aligned16(dx_t)))
         VITK_FAIL(VITK_E_ALIGN, "layernorm_bwd: pointers must be 16-byte aligned");
@@ -353,14 +370,14 @@ extern "C" int vitk_layernorm_bwd(const void* dy, int dydt, const void* x, int x
     const RowMap dm = to_map(dymap), xm = to_map(xmap), om = to_map(dxmap);
     if (wdt == VITK_F32) {
         if (dydt != VITK_F32 || xdt != VITK_F32 || (dx_t && dxtdt != VITK_F32)) VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: f32 params need f32 tensors");
-        return launch_ln_bwd<float, float, float, float>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
+        return launch_ln_bwd<float, float, float, float>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, drop_t, drop_seed, inv_keep);
     }
     if (wdt != VITK_BF16) VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: bad wdt");
     if (dx_t && dxtdt != VITK_BF16) VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: dx_t must be bf16 with bf16 params");
-    if (dydt == VITK_BF16 && xdt == VITK_F32) return launch_ln_bwd<__bf16, float, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
-    if (dydt == VITK_BF16 && xdt == VITK_BF16) return launch_ln_bwd<__bf16, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
-    if (dydt == VITK_F32 && xdt == VITK_F32) return launch_ln_bwd<float, float, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
-    if (dydt == VITK_F32 && xdt == VITK_BF16) return launch_ln_bwd<float, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st);
+    if (dydt == VITK_BF16 && xdt == VITK_F32) return launch_ln_bwd<__bf16, float, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, drop_t, drop_seed, inv_keep);
+    if (dydt == VITK_BF16 && xdt == VITK_BF16) return launch_ln_bwd<__bf16, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, drop_t, drop_seed, inv_keep);
+    if (dydt == VITK_F32 && xdt == VITK_F32) return launch_ln_bwd<float, float, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, drop_t, drop_seed, inv_keep);
+    if (dydt == VITK_F32 && xdt == VITK_BF16) return launch_ln_bwd<float, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, drop_t, drop_seed, inv_keep);
     VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: bad dtype combination");
 }
 

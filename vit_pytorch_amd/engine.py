@@ -133,11 +133,31 @@ def pack_layer_params(attn, ff) -> List[Optional[Tensor]]:
 NLP = 11  # tensors per layer in pack_layer_params
 
 
+def _hash32(x: int) -> int:
+    """The device's hash32 (common.h): decorrelates the per-site dropout seeds derived from one base seed."""
+    x &= 0xffffffff
+    x ^= x >> 16; x = (x * 0x21f0aaad) & 0xffffffff
+    x ^= x >> 15; x = (x * 0x735a2d97) & 0xffffffff
+    x ^= x >> 15
+    return x
+
+
+def dropout_fusable(T, B: int, N: int, D: int, heads: int, dim_head: int, F: int) -> bool:
+    """Active dropout (vit.py:22,24,42,48) runs inside the fused engine when the four Linear layers are served by the
+    256-row GEMM kernel (their epilogues carry the fused dropout) and attention by the fixed-length flash kernel."""
+    M, I = B * N, heads * dim_head
+    return (T in ops.HALF and ops.attn_fast_ok(T, N, dim_head) and ops.fused_dropout_ok(T, M, D, I)
+            and ops.fused_dropout_ok(T, M, F, D) and ops.fused_dropout_ok(T, M, D, F))
+
+
 class TransformerFn(torch.autograd.Function):
-    """Transformer.forward (vit.py:78-83 / simple_vit.py:74-78), dropout = 0."""
+    """Transformer.forward (vit.py:78-83 / simple_vit.py:74-78).  drop_p > 0 (training): the four dropouts of a layer --
+    attention matrix (vit.py:60), after to_out (:48), after the GELU (:22), after the second FeedForward Linear (:24) --
+    are taken inside the attention kernel and the GEMM epilogues with counter-hash keep decisions under per-site seeds
+    derived from drop_seed; the backward kernels regenerate them, no mask tensor exists."""
 
     @staticmethod
-    def forward(ctx, x, heads: int, dim_head: int, norm_w, norm_b, *lp):
+    def forward(ctx, x, heads: int, dim_head: int, drop_p: float, drop_seed: int, norm_w, norm_b, *lp):
         K.require_device(x, norm_w)
         depth = len(lp) // NLP
         T = norm_w.dtype
@@ -153,21 +173,24 @@ class TransformerFn(torch.autograd.Function):
             xs = ops.empty((B, N, D), F32, x)
             K.cast(x, xs)
         saved = []
+        if drop_p > 0.0 and (lp[3] is None or lp[8] is None or not dropout_fusable(T, B, N, D, heads, dim_head, lp[7].shape[0])):
+            raise VitkError("TransformerFn: this shape does not take the fused dropout path (caller must check dropout_fusable)")
+        site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
         for li in range(depth):
             ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
             a1 = ops.empty((M, D), T, xs)
             st1 = ops.ln_fwd(xs, ln1w, ln1b, M, D, a1)
             qkv = ops.linear_fwd(a1, wqkv, None, M)
-            o, att_saved = ops.attn_fwd(qkv, B, N, heads, dim_head, scale)
+            o, att_saved = ops.attn_fwd(qkv, B, N, heads, dim_head, scale, drop=site(li, 0))
             if wout is not None:
-                x2 = ops.linear_fwd(o, wout, bout, M, resid=xs)
+                x2 = ops.linear_fwd(o, wout, bout, M, resid=xs, drop=site(li, 1))
             else:  # to_out = Identity (heads == 1 and dim_head == dim, vit.py:34,49)
                 x2 = ops.empty((M, D), F32, xs)
                 K.add_rows(xs, o, None, x2, M, D)
             a2 = ops.empty((M, D), T, xs)
             st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2)
-            act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True)
-            x3 = ops.linear_fwd(act, w2, b2, M, resid=x2)
+            act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True, drop=site(li, 2))
+            x3 = ops.linear_fwd(act, w2, b2, M, resid=x2, drop=site(li, 3))
             saved.append((xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act))
             xs = x3
         y = ops.empty((B, N, D), T, xs)
@@ -176,6 +199,7 @@ class TransformerFn(torch.autograd.Function):
         ctx.x_last = xs
         ctx.stf = stf
         ctx.meta = (heads, dim_head, depth, B, N, D, x.dtype)
+        ctx.drop = (drop_p, drop_seed)
         ctx.save_for_backward(norm_w, norm_b, *[t for t in lp if t is not None])
         ctx.lp_mask = [t is not None for t in lp]
         return y
@@ -183,6 +207,8 @@ class TransformerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         heads, dim_head, depth, B, N, D, in_dtype = ctx.meta
+        drop_p, drop_seed = ctx.drop
+        site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
         sv = list(ctx.saved_tensors)
         norm_w, norm_b = sv[0], sv[1]
         it = iter(sv[2:])
@@ -203,7 +229,9 @@ class TransformerFn(torch.autograd.Function):
         g, gb = newg()
         dnw, dnb = _grad_buf(norm_w), _grad_buf(norm_b)
         dcol = ops.empty((D,), F32, dy)  # colsum of g == bias gradient of the last layer's second FF Linear
-        ops.ln_bwd(dy, ctx.x_last, norm_w, ctx.stf[0], ctx.stf[1], M, D, dx_f32=g, dx_t=gb, dw=dnw, db=dnb, dcol=dcol)
+        # (with dropout: gb and dcol carry the keep decisions of the LAST layer's post-FF2 dropout; g, the stream gradient, does not)
+        ops.ln_bwd(dy, ctx.x_last, norm_w, ctx.stf[0], ctx.stf[1], M, D, dx_f32=g, dx_t=gb, dw=dnw, db=dnb, dcol=dcol,
+                   drop=site(depth - 1, 3) if depth else None)
         ctx.x_last = None
         for li in reversed(range(depth)):
             ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
@@ -222,9 +250,9 @@ class TransformerFn(torch.autograd.Function):
             dw1 = _grad_buf(w1)
             db1 = _grad_buf(b1) if b1 is not None else None
             if db1 is not None:
-                dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, db=db1)   # b1's gradient out of the GEMM epilogue
+                dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, db=db1, drop=site(li, 2))   # b1's gradient out of the GEMM epilogue
             else:
-                dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre), True
+                dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, drop=site(li, 2)), True
             db_todo = None if db_done else db1
             fork.run(lambda: ops.linear_dw(dpre, a2, M, dw1, db_todo), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
@@ -233,7 +261,8 @@ class TransformerFn(torch.autograd.Function):
             g2, g2b = newg()
             dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
             dcol2 = ops.empty((D,), F32, dy)
-            ops.ln_bwd(da2, x2, ln2w, st2[0], st2[1], M, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2w, db=dl2b, dcol=dcol2)
+            ops.ln_bwd(da2, x2, ln2w, st2[0], st2[1], M, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2w, db=dl2b, dcol=dcol2,
+                       drop=site(li, 1))      # g2b / dcol2: gradient at to_out's output, behind its dropout
             grads[base + 5], grads[base + 6] = dl2w, dl2b
             del da2, g, gb
             g2T = g2b if bf else g2
@@ -249,7 +278,7 @@ class TransformerFn(torch.autograd.Function):
                 do = ops.linear_dx(g2T, wout, M)
             else:
                 do = g2T
-            dqkv = ops.attn_bwd(qkv, o, do, att_saved, B, N, heads, dim_head, scale)
+            dqkv = ops.attn_bwd(qkv, o, do, att_saved, B, N, heads, dim_head, scale, drop=site(li, 0))
             dwq = _grad_buf(wqkv)
             fork.run(lambda: ops.linear_dw(dqkv, a1, M, dwq), dqkv, a1, dwq)
             grads[base + 2] = dwq
@@ -258,7 +287,8 @@ class TransformerFn(torch.autograd.Function):
             g1, g1b = newg()
             dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
             dcol = ops.empty((D,), F32, dy)
-            ops.ln_bwd(da1, xs, ln1w, st1[0], st1[1], M, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1w, db=dl1b, dcol=dcol)
+            ops.ln_bwd(da1, xs, ln1w, st1[0], st1[1], M, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1w, db=dl1b, dcol=dcol,
+                       drop=site(li - 1, 3) if li > 0 else None)   # feeds the layer below: behind ITS post-FF2 dropout
             grads[base + 0], grads[base + 1] = dl1w, dl1b
             g, gb = g1, g1b
             del g2, g2b, da1
@@ -274,7 +304,7 @@ class TransformerFn(torch.autograd.Function):
             dx = g.view(B, N, D)
         else:
             dx = (gb if gb is not None else g).view(B, N, D)
-        return (dx, None, None, _ret(dnw), _ret(dnb), *[_ret(t) for t in grads])
+        return (dx, None, None, None, None, _ret(dnw), _ret(dnb), *[_ret(t) for t in grads])
 
 
 class PatchEmbedFn(torch.autograd.Function):

@@ -78,11 +78,12 @@ def layernorm_bwd_blocks(rows: int, D: int) -> int:
 
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, gin: Optional[Tensor],
                   dx_f32: Optional[Tensor], dx_t: Optional[Tensor], partials: Tensor, colsum_dx: bool,
-                  rows: int, D: int, dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT):
+                  rows: int, D: int, dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT,
+                  drop_p: float = 0.0, drop_seed: int = 0):
     lib = _lib_for(dy, x, w, mean, rstd, partials)
-    check(lib.vitk_layernorm_bwd(_p(dy), dt(dy), _p(x), dt(x), _p(w), dt(w), _p(mean), _p(rstd), _p(gin),
-                                 _p(dx_f32), _p(dx_t), dt(dx_t) if dx_t is not None else F32, _p(partials),
-                                 1 if colsum_dx else 0, rows, D, dymap, xmap, dxmap, _stream()),
+    check(lib.vitk_layernorm_bwd_drop(_p(dy), dt(dy), _p(x), dt(x), _p(w), dt(w), _p(mean), _p(rstd), _p(gin),
+                                      _p(dx_f32), _p(dx_t), dt(dx_t) if dx_t is not None else F32, _p(partials),
+                                      1 if colsum_dx else 0, rows, D, dymap, xmap, dxmap, drop_p, drop_seed & 0xffffffff, _stream()),
           "layernorm_bwd")
 
 
@@ -112,6 +113,14 @@ def gemm_nt_bf16(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, 
                  aux: Optional[Tensor] = None):
     check(_lib_for(A, W, C).vitk_gemm_nt_bf16(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, epilogue, _p(bias), _p(resid),
                                      _p(aux), _stream()), "gemm_nt_bf16")
+
+
+def gemm_nt_bf16_drop(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int, epilogue: int,
+                      drop_p: float, drop_seed: int, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
+                      aux: Optional[Tensor] = None, partials: Optional[Tensor] = None):
+    """vitk_gemm_nt_bf16 with nn.Dropout(p) fused into the RESID / BIAS_GELU / GELU_BWD epilogue (256-row kernel only)."""
+    check(_lib_for(A, W, C).vitk_gemm_nt_bf16_drop(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, epilogue, _p(bias), _p(resid), _p(aux),
+                                                   _p(partials), drop_p, drop_seed & 0xffffffff, _stream()), "gemm_nt_bf16_drop")
 
 
 def gemm_nt_colsum_rows(M: int, N: int, K: int, ldc: int) -> int:

@@ -46,12 +46,13 @@ def ln_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], rows: int, D: int, out: Te
 def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, rows: int, D: int, *,
            gin: Optional[Tensor] = None, dx_f32: Optional[Tensor] = None, dx_t: Optional[Tensor] = None,
            dw: Optional[Tensor] = None, db: Optional[Tensor] = None, dcol: Optional[Tensor] = None,
-           dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT):
+           dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT, drop: Optional[Tuple[float, int]] = None):
     """LayerNorm backward; dw/db are (D,) outputs of dtype T, dcol (D,) float32 = column sums of dx."""
     nblk = K.layernorm_bwd_blocks(rows, D)
     nslab = 3 if dcol is not None else 2
     partials = empty((nslab * nblk * D,), F32, x)
-    K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap)
+    K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap,
+                    *(drop if drop else (0.0, 0)))
     assert dcol is None or dcol.dtype == F32
     K.layernorm_bwd_finalize(partials, nblk, D, dw, db, dcol, K.dt(w))
 
@@ -67,8 +68,13 @@ def _fast_nt(x: Tensor, N: int, Kd: int) -> bool:
     return x.dtype in HALF and Kd % 32 == 0 and N % 4 == 0
 
 
+def fused_dropout_ok(x_dtype, M: int, N: int, Kd: int) -> bool:
+    """nn.Dropout fused into a GEMM epilogue exists in the 256-row kernel only."""
+    return x_dtype in HALF and Kd % 64 == 0 and K.gemm_nt_colsum_rows(M, N, Kd, N) > 0
+
+
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bool = False,
-               resid: Optional[Tensor] = None, out_dtype=None):
+               resid: Optional[Tensor] = None, out_dtype=None, drop: Optional[Tuple[float, int]] = None):
     """y = x @ W^T + b  (vit.py:20,23,44,47,102).  x: (M,K) T contiguous; W: (N,K) T.
 
     gelu=True  -> returns (gelu(y), y)         (vit.py:20-21 fused)
@@ -76,9 +82,13 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
     """
     N, Kd = W.shape
     T = x.dtype
+    if drop is not None and not fused_dropout_ok(T, M, N, Kd):
+        raise L.VitkError("linear_fwd: fused dropout needs a shape served by the 256-row kernel (caller must check fused_dropout_ok)")
     if resid is not None:
         out = empty((M, N), F32, x)
-        if _fast_nt(x, N, Kd):
+        if drop is not None:
+            K.gemm_nt_bf16_drop(x, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, drop[0], drop[1], bias=bias, resid=resid)
+        elif _fast_nt(x, N, Kd):
             K.gemm_nt_bf16(x, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid)
         else:
             y = empty((M, N), T, x)
@@ -88,7 +98,11 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
     if gelu:
         act = empty((M, N), T, x)
         pre = empty((M, N), T, x)
-        if _fast_nt(x, N, Kd) and bias is not None:
+        if drop is not None:
+            if bias is None:
+                raise L.VitkError("linear_fwd: the fused GELU + dropout epilogue needs a bias")
+            K.gemm_nt_bf16_drop(x, Kd, W, Kd, act, N, M, N, Kd, L.EPI_BIAS_GELU, drop[0], drop[1], bias=bias, aux=pre)
+        elif _fast_nt(x, N, Kd) and bias is not None:
             K.gemm_nt_bf16(x, Kd, W, Kd, act, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=pre)
         else:
             K.gemm_generic(K.mat(x, Kd, 1), K.mat(W, 1, Kd), K.mat(pre, N, 1), M, N, Kd, bias=bias)
@@ -109,7 +123,8 @@ def transpose_weight(W: Tensor) -> Tensor:
     return Wt
 
 
-def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = None, db: Optional[Tensor] = None):
+def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = None, db: Optional[Tensor] = None,
+              drop: Optional[Tuple[float, int]] = None):
     """dX = dY @ W  (optionally * gelu'(pre): the GELU backward fused as an epilogue).
 
     With gelu_pre and db: returns (dX, done) -- done is True when colsum(dX), the bias gradient of the Linear that
@@ -119,6 +134,16 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
     dx = empty((M, Kd), T, dy)
     if T in HALF and N % 32 == 0 and Kd % 4 == 0:
         Wt = transpose_weight(W)  # (K, N): makes dX an NT GEMM with reduction dim N contiguous
+        if drop is not None:        # backward of dropout(gelu(pre)): same keep decisions, fused with GELU' (and db)
+            R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
+            if gelu_pre is None or R == 0:
+                raise L.VitkError("linear_dx: fused dropout backward needs gelu_pre and a shape served by the 256-row kernel")
+            part = empty((R * Kd,), F32, dy) if db is not None else None
+            K.gemm_nt_bf16_drop(dy, N, Wt, N, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, drop[0], drop[1], aux=gelu_pre, partials=part)
+            if db is not None:
+                K.colsum_partials(part, R, Kd, Kd, db)
+                return dx, True
+            return dx
         if gelu_pre is not None and db is not None:
             R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
             if R > 0:
@@ -178,17 +203,19 @@ def attn_varlen_ok(T, d: int) -> bool:
     return T in HALF and d in (64, 80)
 
 
-def attn_fwd(qkv: Tensor, B: int, N: int, H: int, d: int, scale: float):
+def attn_fwd(qkv: Tensor, B: int, N: int, H: int, d: int, scale: float, drop: Optional[Tuple[float, int]] = None):
     """softmax(scale * q k^T) v on the merged (B*N, 3*H*d) to_qkv output (vit.py:54-63).
     Returns (o (B*N, H*d), saved) where saved is lse (fused) or the attention matrix P."""
     I = H * d
     T = qkv.dtype
     o = empty((B * N, I), T, qkv)
     sb, sh, sn = N * 3 * I, d, 3 * I
+    if drop is not None and not attn_fast_ok(T, N, d):
+        raise L.VitkError("attn_fwd: attention-matrix dropout is fused in the fixed-length kernel only (caller must check attn_fast_ok)")
     if attn_fast_ok(T, N, d):
         lse = empty((B, H, N), F32, qkv)
         K.attn_fwd_bf16(K.bhnd(qkv, sb, sh, sn), K.bhnd(qkv, sb, sh, sn, offset=I), K.bhnd(qkv, sb, sh, sn, offset=2 * I),
-                        K.bhnd(o, N * I, d, I), lse, B, H, N, d, scale)
+                        K.bhnd(o, N * I, d, I), lse, B, H, N, d, scale, *(drop if drop else (0.0, 0)))
         return o, lse
     if attn_varlen_ok(T, d):
         sg = uniform_segments(B, N, qkv.device)
@@ -207,7 +234,8 @@ def attn_fwd(qkv: Tensor, B: int, N: int, H: int, d: int, scale: float):
     return o, P
 
 
-def attn_bwd(qkv: Tensor, o: Tensor, do: Tensor, saved: Tensor, B: int, N: int, H: int, d: int, scale: float) -> Tensor:
+def attn_bwd(qkv: Tensor, o: Tensor, do: Tensor, saved: Tensor, B: int, N: int, H: int, d: int, scale: float,
+             drop: Optional[Tuple[float, int]] = None) -> Tensor:
     """Returns dqkv (B*N, 3*H*d) in the merged layout (it is the dY of the to_qkv GEMM)."""
     I = H * d
     T = qkv.dtype
@@ -218,7 +246,7 @@ def attn_bwd(qkv: Tensor, o: Tensor, do: Tensor, saved: Tensor, B: int, N: int, 
         K.attn_bwd_bf16(K.bhnd(qkv, sb, sh, sn), K.bhnd(qkv, sb, sh, sn, offset=I), K.bhnd(qkv, sb, sh, sn, offset=2 * I),
                         K.bhnd(o, N * I, d, I), K.bhnd(do, N * I, d, I), saved, delta,
                         K.bhnd(dqkv, sb, sh, sn), K.bhnd(dqkv, sb, sh, sn, offset=I), K.bhnd(dqkv, sb, sh, sn, offset=2 * I),
-                        B, H, N, d, scale)
+                        B, H, N, d, scale, *(drop if drop else (0.0, 0)))
         return dqkv
     if attn_varlen_ok(T, d):
         sg = uniform_segments(B, N, qkv.device)

@@ -89,23 +89,46 @@ class Transformer(Module):
                 FeedForward(dim, mlp_dim, dropout=dropout),
             ]))
 
-    def _fusable(self) -> bool:
-        """The fused engine covers the block when nothing needs to observe or perturb its inside."""
+    _drop_calls = [0]      # every training call draws fresh dropout seeds (with torch.initial_seed(): reproducible runs)
+
+    def _dropout_p(self):
+        """The common p of the block's active dropouts (0.0 if inactive); None if the modules disagree (a user edited them)."""
+        if not self.training:
+            return 0.0
+        ps = set()
         for attn, ff in self.layers:
-            if attn._needs_attention_matrix() or _has_fwd_hooks(attn) or _has_fwd_hooks(ff):
+            ps.update(m.p for m in list(ff.net) + list(attn.modules()) if isinstance(m, nn.Dropout))
+        return ps.pop() if len(ps) == 1 else (0.0 if not ps else None)
+
+    def _fusable(self, x) -> bool:
+        """The fused engine covers the block when nothing needs to observe its inside; active dropout is fused too when
+        the shapes are those the fused-dropout kernels serve (engine.dropout_fusable), else the block runs op by op."""
+        for attn, ff in self.layers:
+            if _has_fwd_hooks(attn.attend) or any(_has_fwd_hooks(m) for m in list(attn.modules()) + list(ff.modules())):
                 return False
-            if self.training and any(isinstance(m, nn.Dropout) and m.p > 0. for m in list(ff.net) + list(attn.modules())):
+        if _has_fwd_hooks(self.norm):
+            return False
+        p = self._dropout_p()
+        if p is None:
+            return False
+        if p > 0.:
+            if not len(self.layers) or isinstance(self.layers[0][0].to_out, nn.Identity):
                 return False
-            if any(_has_fwd_hooks(m) for m in list(attn.modules()) + list(ff.modules())):
-                return False
-        return not _has_fwd_hooks(self.norm)
+            B, N, D = x.shape
+            return E.dropout_fusable(self.norm.weight.dtype, B, N, D, self._heads, self._dim_head, self.layers[0][1].net[1].weight.shape[0])
+        return True
 
     def forward(self, x):
-        if self._fusable():
+        if self._fusable(x):
             params = []
             for attn, ff in self.layers:
                 params += E.pack_layer_params(attn, ff)
-            return E.TransformerFn.apply(x, self._heads, self._dim_head, self.norm.weight, self.norm.bias, *params)
+            p = self._dropout_p()
+            seed = 0
+            if p > 0.:
+                seed = (int(torch.initial_seed()) + 0x9E3779B1 * Transformer._drop_calls[0]) & 0xffffffff
+                Transformer._drop_calls[0] += 1
+            return E.TransformerFn.apply(x, self._heads, self._dim_head, float(p), seed, self.norm.weight, self.norm.bias, *params)
         x = Fn._to(x, self.norm.weight.dtype)
         for attn, ff in self.layers:
             x = Fn.AddFn.apply(attn(x), x)
