@@ -209,6 +209,18 @@ int vitk_attn_varlen_bwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, vi
                               const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
                               const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk,
                               int64_t tq_total, int64_t H, int64_t d, float scale, void* stream);
+/* The same with dropout on the attention matrix (na_vit.py:163 `dropout_p`): keep decision of (head h, packed query row r,
+ * key j of the image) = hash(hash(h * tq_total + r ^ seed) + j) >= p * 2^32, as in vitk_attn_fwd_bf16_drop.          */
+int vitk_attn_varlen_fwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse,
+                                   const int32_t* cu_q, const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0,
+                                   int64_t nblk, int64_t tq_total, int64_t H, int64_t d, float scale, float drop_p,
+                                   uint32_t drop_seed, void* stream);
+int vitk_attn_varlen_bwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, vitk_hnd dout, const float* lse, float* delta,
+                                   vitk_hnd dq, vitk_hnd dk, vitk_hnd dv, const int32_t* cu_q, const int32_t* cu_k,
+                                   const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
+                                   const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk,
+                                   int64_t tq_total, int64_t H, int64_t d, float scale, float drop_p, uint32_t drop_seed,
+                                   void* stream);
 
 /* NaViT q/k normalisation (RMSNorm, na_vit.py:93-101): y = x / max(||x||, 1e-12) * sqrt(d) * gamma[h, :] for every
  * (token, head); x, y viewed (T, H, 64) with token strides ldx / ldy.  rnorm: f32 (T*H) saved for backward.

@@ -179,3 +179,54 @@ def test_navit_fused_stack_vs_op_by_op():
     df, du = rel(gf, g32), rel(gu, g32)
     print(f"fused: logits {ef:.2e} grads {df:.2e}; op-by-op: logits {eu:.2e} grads {du:.2e}")
     assert ef <= 1.5 * eu + 1e-3 and df <= 1.5 * du + 1e-3
+
+
+@pytest.mark.parametrize("lens", [[197], [16, 300, 1, 129, 64]])
+@pytest.mark.parametrize("H,d", [(3, 64), (2, 80)])
+def test_varlen_attention_with_dropout(lens, H, d):
+    """Attention dropout (na_vit.py:163 dropout_p) inside the packed kernels against a float64 reference with the same keep
+    decisions: row = (head, packed query row), column = key index inside the image."""
+    I = H * d
+    T = sum(lens)
+    p, seed, scale = 0.25, 9876, 0.2
+    g = torch.Generator().manual_seed(len(lens) * 11 + H)
+    q = torch.randn(T, I, generator=g).to(BF).to(DEV)
+    kv = torch.randn(T, 2 * I, generator=g).to(BF).to(DEV)
+    do = torch.randn(T, I, generator=g).to(BF).to(DEV)
+    segs = Segments(lens, lens, torch.device(DEV))
+    o = torch.empty(T, I, dtype=BF, device=DEV); lse = torch.empty(H, T, device=DEV)
+    K.attn_varlen_fwd_bf16(K.hnd(q, d, I), K.hnd(kv, d, 2 * I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), lse, segs.cu_q,
+                           segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, T, H, d, scale, p, seed)
+    dq = torch.zeros_like(q); dkv = torch.zeros_like(kv); delta = torch.empty(H, T, device=DEV)
+    K.attn_varlen_bwd_bf16(K.hnd(q, d, I), K.hnd(kv, d, 2 * I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), K.hnd(do, d, I), lse, delta,
+                           K.hnd(dq, d, I), K.hnd(dkv, d, 2 * I), K.hnd(dkv, d, 2 * I, offset=I), segs.cu_q, segs.cu_k, segs.qblk_seg,
+                           segs.qblk_r0, segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, T, H, d, scale, p, seed)
+    keep = torch.empty(H * T, max(lens), dtype=torch.uint8, device=DEV)
+    K.dropout_keep(keep, H * T, max(lens), p, seed)
+    keep = keep.view(H, T, max(lens)).double() / (1 - p)
+    qd = q.double().requires_grad_(True); kvd = kv.double().requires_grad_(True)
+    outs, start = [], 0
+    for n in lens:
+        qs = qd[start:start + n].view(n, H, d).transpose(0, 1)
+        ks = kvd[start:start + n, :I].view(n, H, d).transpose(0, 1)
+        vs = kvd[start:start + n, I:].view(n, H, d).transpose(0, 1)
+        pm = torch.softmax(qs @ ks.transpose(-1, -2) * scale, -1) * keep[:, start:start + n, :n]
+        outs.append((pm @ vs).transpose(0, 1).reshape(n, I))
+        start += n
+    oref = torch.cat(outs)
+    oref.backward(do.double())
+    assert rel(o, oref) < 8e-3
+    assert rel(dq, qd.grad) < 1.5e-2 and rel(dkv, kvd.grad) < 1.5e-2
+
+
+def test_navit_trains_with_dropout():
+    cfg = dict(NAVIT_CASES["navit_two_packs"]["cfg"], dropout=0.1, emb_dropout=0.1)
+    torch.manual_seed(0)
+    m = NaViT(**cfg).to(DEV, dtype=BF).train()
+    imgs = [torch.randn(3, h, w, device=DEV).to(BF) for (h, w) in [(32, 32), (64, 16), (8, 8), (48, 64)]]
+    out1 = m(imgs); out2 = m(imgs)
+    assert torch.isfinite(out1.float()).all() and not torch.equal(out1, out2)       # fresh masks per call
+    out1.float().square().mean().backward()
+    assert all(torch.isfinite(q.grad.float()).all() for q in m.parameters())
+    m.eval()
+    assert torch.equal(m(imgs), m(imgs))

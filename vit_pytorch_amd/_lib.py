@@ -72,6 +72,8 @@ SIGNATURES = {
     "vitk_dropout_keep": (_i, [_vp, _i64, _i64, _f, C.c_uint32, _vp]),
     "vitk_attn_varlen_fwd_bf16": (_i, [HND, HND, HND, HND, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_attn_varlen_bwd_bf16": (_i, [HND, HND, HND, HND, HND, _vp, _vp, HND, HND, HND, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_attn_varlen_fwd_bf16_drop": (_i, [HND, HND, HND, HND, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f, _f, C.c_uint32, _vp]),
+    "vitk_attn_varlen_bwd_bf16_drop": (_i, [HND, HND, HND, HND, HND, _vp, _vp, HND, HND, HND, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _f, _f, C.c_uint32, _vp]),
     "vitk_rmsnorm_heads_rows": (_i64, [_i64, _i64]),
     "vitk_rmsnorm_heads_fwd": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i64, _i64, _i64, _vp]),
     "vitk_rmsnorm_heads_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i64, _i64, _i64, _vp]),

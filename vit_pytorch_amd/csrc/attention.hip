@@ -555,7 +555,8 @@ __device__ __forceinline__ f32x4 mfma_over_d(const char* tile, int row0, const b
 template <int DH>
 __global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
     HND q, HND k, HND v, HND o, float* __restrict__ lse, const int* __restrict__ cu_q, const int* __restrict__ cu_k,
-    const int* __restrict__ blk_seg, const int* __restrict__ blk_r0, int tq_total, float scale_log2e) {
+    const int* __restrict__ blk_seg, const int* __restrict__ blk_r0, int tq_total, float scale_log2e, unsigned drop_t,
+    unsigned drop_seed, float inv_keep) {
     constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
     __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -624,15 +625,24 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
-            const bf16x8 pb = pack8(st[0], st[1]);
+            bf16x8 pb = pack8(st[0], st[1]);
             accl = MFMA(ones, pb, accl);
+            if (drop_t) {     // attention dropout (na_vit.py:163 dropout_p): row = (head, global query row), column = key inside the image
+                const unsigned hrow = drop_row((unsigned)(h * tq_total + qrow), drop_seed);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!drop_keep(hrow, (unsigned)(c0 + s * 32 + hh * 16 + 4 * fg + e), drop_t)) st[hh][e] = 0.f;
+                pb = pack8(st[0], st[1]);
+            }
 #pragma unroll
             for (int fd = 0; fd < NFD; ++fd) acc[fd] = MFMA(tr_frag_t<DH>(Vs, s * 32, fd * 16, fi, fg), pb, acc[fd]);
         }
     }
     if (wave_active && qi < nq) {
         const float ls = accl[0];
-        const float inv = 1.0f / ls;
+        const float inv = inv_keep / ls;
         __bf16* op = o.p + (long long)(qs + qi) * o.s_n + h * o.s_h + 4 * fg;
 #pragma unroll
         for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(op + fd * 16, acc[fd] * inv);
@@ -644,7 +654,7 @@ template <int DH>
 __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
     HND q, HND k, HND v, HND o, HND dout, const float* __restrict__ lse, float* __restrict__ delta, HND dq,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
-    const int* __restrict__ blk_r0, int tq_total, float scale) {
+    const int* __restrict__ blk_r0, int tq_total, float scale, unsigned drop_t, unsigned drop_seed, float inv_keep) {
     constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
     __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -697,7 +707,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
             for (int hh = 0; hh < 2; ++hh) {
                 const int row0 = s * 32 + hh * 16;
                 const f32x4 st = mfma_over_d<DH>(Ks, row0, qf, fi, fg);
-                const f32x4 dp = mfma_over_d<DH>(Vs, row0, df, fi, fg);
+                f32x4 dp = mfma_over_d<DH>(Vs, row0, df, fi, fg);
+                if (drop_t) {
+                    const unsigned hrow = drop_row((unsigned)(h * tq_total + qrow), drop_seed);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dp[e] = drop_keep(hrow, (unsigned)(c0 + row0 + 4 * fg + e), drop_t) ? dp[e] * inv_keep : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)          // `scale` of dS is applied once, to dQ
                     ds[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, nl2)) * (dp[e] - dl);
@@ -723,15 +739,16 @@ template <int DH>
 __global__ __launch_bounds__(AT_THREADS, 4) void attn_varlen_bwd_dkv_kernel(
     HND q, HND k, HND v, HND dout, const float* __restrict__ lse, const float* __restrict__ delta, HND dk, HND dv,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
-    const int* __restrict__ blk_r0, int tq_total, float scale) {
+    const int* __restrict__ blk_r0, int tq_total, float scale, unsigned drop_t, unsigned drop_seed, float inv_keep) {
     constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
-    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD + 2 * VL_CH * sizeof(float)];
+    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD + 3 * VL_CH * sizeof(float)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     char* Qs = smem;
     char* Ds = smem + VL_CH * LD;
     float* lse_s = reinterpret_cast<float*>(smem + 2 * VL_CH * LD);
     float* del_s = lse_s + VL_CH;
+    unsigned* hq_s = reinterpret_cast<unsigned*>(del_s + VL_CH);       // dropout row hashes of the chunk's query rows
     const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
     const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
     const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
@@ -744,11 +761,13 @@ __global__ __launch_bounds__(AT_THREADS, 4) void attn_varlen_bwd_dkv_kernel(
     const float* dlbase = delta + (long long)h * tq_total + qs;
     ChunkRegs<DH> cr;
     float lv = 0.f, dv_ = 0.f;                                  // one row of -lse*log2e / -delta per thread (tid < 128)
+    unsigned hv = 0u;
     auto prefetch = [&](int c0) {
         const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
         chunk_load<DH>(cr, qbase + (long long)c0 * q.s_n, q.s_n, dbase + (long long)c0 * dout.s_n, dout.s_n, rows, ((rows + 31) >> 5) << 5, tid);
         lv = 0.f; dv_ = 0.f;
         if (tid < rows) { lv = -lbase[c0 + tid] * LOG2E; dv_ = -dlbase[c0 + tid]; }
+        hv = drop_row((unsigned)(h * tq_total + qs + c0 + tid), drop_seed);
     };
     prefetch(0);
     bf16x8 kf[NKS], vf[NKS];
@@ -764,7 +783,7 @@ __global__ __launch_bounds__(AT_THREADS, 4) void attn_varlen_bwd_dkv_kernel(
         const int rows_pad = ((rows + 31) >> 5) << 5;
         __syncthreads();
         chunk_store<DH>(cr, Qs, Ds, rows_pad, tid);
-        if (tid < VL_CH) { lse_s[tid] = lv; del_s[tid] = dv_; }
+        if (tid < VL_CH) { lse_s[tid] = lv; del_s[tid] = dv_; hq_s[tid] = hv; }
         __syncthreads();
         if (c0 + VL_CH < nq) prefetch(c0 + VL_CH);
         if (!wave_active) continue;
@@ -780,7 +799,13 @@ __global__ __launch_bounds__(AT_THREADS, 4) void attn_varlen_bwd_dkv_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     p[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l4[e]));
-                    ds[hh][e] = p[hh][e] * (dp[e] + d4[e]);                    // `scale` is applied once, to dK
+                    if (drop_t) {
+                        const float km = drop_keep(hq_s[row0 + 4 * fg + e], (unsigned)ki, drop_t) ? inv_keep : 0.f;
+                        ds[hh][e] = p[hh][e] * (dp[e] * km + d4[e]);
+                        p[hh][e] *= km;
+                    } else {
+                        ds[hh][e] = p[hh][e] * (dp[e] + d4[e]);                // `scale` is applied once, to dK
+                    }
                 }
                 if (row0 + 16 > rows) {
 #pragma unroll
@@ -1016,15 +1041,26 @@ bool hnd_ok(vitk_hnd t) { return t.p && aligned16(t.p) && (t.s_h % 8 == 0) && (t
 extern "C" int vitk_attn_varlen_fwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse, const int32_t* cu_q,
                                          const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0, int64_t nblk,
                                          int64_t tq_total, int64_t H, int64_t d, float scale, void* stream) {
+    return vitk_attn_varlen_fwd_bf16_drop(q, k, v, o, lse, cu_q, cu_k, blk_seg, blk_r0, nblk, tq_total, H, d, scale, 0.f, 0u, stream);
+}
+
+extern "C" int vitk_attn_varlen_fwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse, const int32_t* cu_q,
+                                              const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0, int64_t nblk,
+                                              int64_t tq_total, int64_t H, int64_t d, float scale, float drop_p, uint32_t drop_seed,
+                                              void* stream) {
+    if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_fwd_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
+    if (H * tq_total > 0xffffffffLL) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: H * tokens exceeds the 32-bit dropout row index");
     if (d != 64 && d != 80) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: needs dim_head 64 or 80 (got %lld)", (long long)d);
     if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_fwd_bf16: scale must be positive (got %g)", (double)scale);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !lse || !cu_q || !cu_k || !blk_seg || !blk_r0)
         VITK_FAIL(VITK_E_ALIGN, "attn_varlen_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     if (nblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: empty problem");
     if (d == 64) hipLaunchKernelGGL(attn_varlen_fwd_kernel<64>, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q),
-                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E);
+                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E, drop_thresh(drop_p), drop_seed,
+                       1.0f / (1.0f - drop_p));
     else hipLaunchKernelGGL(attn_varlen_fwd_kernel<80>, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q),
-                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E);
+                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E, drop_thresh(drop_p), drop_seed,
+                       1.0f / (1.0f - drop_p));
     VITK_CHECK_LAUNCH("attn_varlen_fwd_bf16");
     return 0;
 }
@@ -1034,6 +1070,19 @@ extern "C" int vitk_attn_varlen_bwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vit
                                          const int32_t* cu_k, const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
                                          const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk, int64_t tq_total,
                                          int64_t H, int64_t d, float scale, void* stream) {
+    return vitk_attn_varlen_bwd_bf16_drop(q, k, v, o, dout, lse, delta, dq, dk, dv, cu_q, cu_k, qblk_seg, qblk_r0, nqblk, kblk_seg, kblk_r0,
+                                          nkblk, tq_total, H, d, scale, 0.f, 0u, stream);
+}
+
+extern "C" int vitk_attn_varlen_bwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, vitk_hnd dout, const float* lse,
+                                              float* delta, vitk_hnd dq, vitk_hnd dk, vitk_hnd dv, const int32_t* cu_q,
+                                              const int32_t* cu_k, const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
+                                              const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk, int64_t tq_total,
+                                              int64_t H, int64_t d, float scale, float drop_p, uint32_t drop_seed, void* stream) {
+    if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_bwd_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
+    if (H * tq_total > 0xffffffffLL) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: H * tokens exceeds the 32-bit dropout row index");
+    const unsigned drop_t = drop_thresh(drop_p);
+    const float inv_keep = 1.0f / (1.0f - drop_p);
     if (d != 64 && d != 80) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: needs dim_head 64 or 80 (got %lld)", (long long)d);
     if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_bwd_bf16: scale must be positive (got %g)", (double)scale);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !hnd_ok(dout) || !hnd_ok(dq) || !hnd_ok(dk) || !hnd_ok(dv) || !lse ||
@@ -1043,9 +1092,9 @@ extern "C" int vitk_attn_varlen_bwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vit
     hipStream_t st = (hipStream_t)stream;
 #define VL_BWD(DHV) do { \
     hipLaunchKernelGGL(attn_varlen_bwd_dq_kernel<DHV>, dim3((unsigned)nqblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k), \
-                       to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale); \
+                       to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep); \
     hipLaunchKernelGGL(attn_varlen_bwd_dkv_kernel<DHV>, dim3((unsigned)nkblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k), \
-                       to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale); } while (0)
+                       to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep); } while (0)
     if (d == 64) VL_BWD(64); else VL_BWD(80);
 #undef VL_BWD
     VITK_CHECK_LAUNCH("attn_varlen_bwd_dkv");

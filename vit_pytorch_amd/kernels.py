@@ -238,17 +238,18 @@ def hnd(t: Tensor, s_h: int, s_n: int, offset: int = 0) -> L.HND:
 
 
 def attn_varlen_fwd_bf16(q: L.HND, k: L.HND, v: L.HND, o: L.HND, lse: Tensor, cu_q: Tensor, cu_k: Tensor, blk_seg: Tensor,
-                         blk_r0: Tensor, nblk: int, tq_total: int, H: int, d: int, scale: float):
-    check(_lib_for(q, k, v, o, lse, cu_q, cu_k, blk_seg, blk_r0).vitk_attn_varlen_fwd_bf16(q, k, v, o, _p(lse), _p(cu_q), _p(cu_k), _p(blk_seg), _p(blk_r0), nblk,
-                                             tq_total, H, d, scale, _stream()), "attn_varlen_fwd_bf16")
+                         blk_r0: Tensor, nblk: int, tq_total: int, H: int, d: int, scale: float, drop_p: float = 0.0, drop_seed: int = 0):
+    check(_lib_for(q, k, v, o, lse, cu_q, cu_k, blk_seg, blk_r0).vitk_attn_varlen_fwd_bf16_drop(q, k, v, o, _p(lse), _p(cu_q), _p(cu_k), _p(blk_seg), _p(blk_r0), nblk,
+                                             tq_total, H, d, scale, drop_p, drop_seed & 0xffffffff, _stream()), "attn_varlen_fwd_bf16")
 
 
 def attn_varlen_bwd_bf16(q: L.HND, k: L.HND, v: L.HND, o: L.HND, dout: L.HND, lse: Tensor, delta: Tensor, dq: L.HND,
                          dk: L.HND, dv: L.HND, cu_q: Tensor, cu_k: Tensor, qblk_seg: Tensor, qblk_r0: Tensor, nqblk: int,
-                         kblk_seg: Tensor, kblk_r0: Tensor, nkblk: int, tq_total: int, H: int, d: int, scale: float):
-    check(_lib_for(q, k, v, o, dout, lse, delta, dq, dk, dv, cu_q, cu_k, qblk_seg, qblk_r0, kblk_seg, kblk_r0).vitk_attn_varlen_bwd_bf16(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, _p(cu_q), _p(cu_k),
+                         kblk_seg: Tensor, kblk_r0: Tensor, nkblk: int, tq_total: int, H: int, d: int, scale: float,
+                         drop_p: float = 0.0, drop_seed: int = 0):
+    check(_lib_for(q, k, v, o, dout, lse, delta, dq, dk, dv, cu_q, cu_k, qblk_seg, qblk_r0, kblk_seg, kblk_r0).vitk_attn_varlen_bwd_bf16_drop(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, _p(cu_q), _p(cu_k),
                                              _p(qblk_seg), _p(qblk_r0), nqblk, _p(kblk_seg), _p(kblk_r0), nkblk,
-                                             tq_total, H, d, scale, _stream()), "attn_varlen_bwd_bf16")
+                                             tq_total, H, d, scale, drop_p, drop_seed & 0xffffffff, _stream()), "attn_varlen_bwd_bf16")
 
 
 def rmsnorm_heads_rows(T: int, H: int) -> int:

@@ -82,7 +82,7 @@ class _QKNormAttnFn(torch.autograd.Function):
     (na_vit.py:147-168).  q: (Tq, I); kv: (Tk, 2I) = k | v, consumed in place; returns (Tq, I)."""
 
     @staticmethod
-    def forward(ctx, q, kv, gq, gk, segs: Segments, heads: int):
+    def forward(ctx, q, kv, gq, gk, segs: Segments, heads: int, drop_p: float = 0.0, drop_seed: int = 0):
         K.require_device(q, kv)
         q = q.contiguous(); kv = kv.contiguous()
         Tq, I = q.shape
@@ -100,9 +100,11 @@ class _QKNormAttnFn(torch.autograd.Function):
         if T in (torch.bfloat16, torch.float16):
             lse = torch.empty((heads, Tq), dtype=F32, device=q.device)
             K.attn_varlen_fwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), lse,
-                                   segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, Tq, heads, d, 1.0)
+                                   segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, Tq, heads, d, 1.0, drop_p, drop_seed)
             saved = lse
         else:  # f32 validation mode: per-segment materialising path on the coverage kernels
+            if drop_p > 0.0:
+                raise VitkError("attention dropout of NaViT is fused into the 16-bit attention kernels only (use bfloat16 / float16, or eval())")
             saved = []
             for s in range(segs.nseg):
                 q0, nq = int(segs.cu_q_host[s]), segs.q_lens[s]
@@ -118,6 +120,7 @@ class _QKNormAttnFn(torch.autograd.Function):
         ctx.save_for_backward(q, kv, gqf, gkf, qn, kn, o, rq, rk)
         ctx.att = saved
         ctx.meta = (segs, heads, d, gq.shape, gk.shape)
+        ctx.drop = (drop_p, drop_seed)
         return o
 
     @staticmethod
@@ -135,7 +138,7 @@ class _QKNormAttnFn(torch.autograd.Function):
             K.attn_varlen_bwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I),
                                    K.hnd(do, d, I), ctx.att, delta, K.hnd(dqn, d, I), K.hnd(dkn, d, I),
                                    K.hnd(dkv, d, 2 * I, offset=I), segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0,
-                                   segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, Tq, heads, d, 1.0)
+                                   segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, Tq, heads, d, 1.0, *ctx.drop)
         else:
             for s in range(segs.nseg):
                 q0, nq = int(segs.cu_q_host[s]), segs.q_lens[s]
@@ -155,7 +158,7 @@ class _QKNormAttnFn(torch.autograd.Function):
         pk = torch.empty(K.rmsnorm_heads_rows(Tk, heads) * 64, dtype=F32, device=q.device)
         K.rmsnorm_heads_bwd(dqn, I, q, I, gqf, rq, dq, I, dgq, pq, Tq, heads, d)
         K.rmsnorm_heads_bwd(dkn, I, kv, 2 * I, gkf, rk, dkv, 2 * I, dgk, pk, Tk, heads, d)
-        return dq, dkv, dgq.view(gq_shape), dgk.view(gk_shape), None, None
+        return dq, dkv, dgq.view(gq_shape), dgk.view(gk_shape), None, None, None, None
 
 
 class _PosEmbedFn(torch.autograd.Function):
@@ -238,6 +241,8 @@ def FeedForward(dim, hidden_dim, dropout=0.):
 
 
 class Attention(nn.Module):
+    _drop_calls = [0]
+
     def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
         super().__init__()
         inner_dim = dim_head * heads
@@ -255,13 +260,16 @@ class Attention(nn.Module):
 
     def forward(self, x, segs: Segments, context=None):
         """x: (Tq, dim) packed query-side tokens; context: (Tk, dim) packed key-side tokens (default: x)."""
-        if self.training and self.dropout_p > 0.:
-            raise VitkError("attention-probability dropout inside the fused NaViT attention is not implemented")
         x = self.norm(x)
         kv_input = default(context, x)
         q = self.to_q(x)
         kv = self.to_kv(kv_input)
-        out = _QKNormAttnFn.apply(q, kv, self.q_norm.gamma, self.k_norm.gamma, segs, self.heads)
+        p, seed = 0.0, 0
+        if self.training and self.dropout_p > 0.:       # F.scaled_dot_product_attention(dropout_p=...) of na_vit.py:163, in-kernel
+            p = float(self.dropout_p)
+            seed = (int(torch.initial_seed()) + 0x9E3779B1 * Attention._drop_calls[0]) & 0xffffffff
+            Attention._drop_calls[0] += 1
+        out = _QKNormAttnFn.apply(q, kv, self.q_norm.gamma, self.k_norm.gamma, segs, self.heads, p, seed)
         return self.to_out(out)
 
 
