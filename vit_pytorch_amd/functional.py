@@ -27,6 +27,12 @@ def _rows(x: Tensor):
     return x.numel() // D, D
 
 
+def dist_rank() -> int:
+    """Rank of this process (0 outside torch.distributed): data-parallel ranks draw different dropout masks."""
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def _to(x: Tensor, dtype) -> Tensor:
     """dtype conversion on the device through vitk_cast (no torch compute)."""
     x = x.contiguous()
@@ -165,7 +171,7 @@ class DropoutFn(torch.autograd.Function):
         x = x.contiguous()
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-        seed = int(torch.initial_seed()) & 0x7fffffffffffffff
+        seed = (int(torch.initial_seed()) + 0x632BE5AB * dist_rank()) & 0x7fffffffffffffff
         off = DropoutFn._offset[0]
         DropoutFn._offset[0] += x.numel()
         K.dropout_fwd(x, y, mask, p, seed, off)

@@ -267,7 +267,7 @@ class Attention(nn.Module):
         p, seed = 0.0, 0
         if self.training and self.dropout_p > 0.:       # F.scaled_dot_product_attention(dropout_p=...) of na_vit.py:163, in-kernel
             p = float(self.dropout_p)
-            seed = (int(torch.initial_seed()) + 0x9E3779B1 * Attention._drop_calls[0]) & 0xffffffff
+            seed = (int(torch.initial_seed()) + 0x9E3779B1 * Attention._drop_calls[0] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
             Attention._drop_calls[0] += 1
         out = _QKNormAttnFn.apply(q, kv, self.q_norm.gamma, self.k_norm.gamma, segs, self.heads, p, seed)
         return self.to_out(out)

@@ -126,7 +126,7 @@ class Transformer(Module):
             p = self._dropout_p()
             seed = 0
             if p > 0.:
-                seed = (int(torch.initial_seed()) + 0x9E3779B1 * Transformer._drop_calls[0]) & 0xffffffff
+                seed = (int(torch.initial_seed()) + 0x9E3779B1 * Transformer._drop_calls[0] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
                 Transformer._drop_calls[0] += 1
             return E.TransformerFn.apply(x, self._heads, self._dim_head, float(p), seed, self.norm.weight, self.norm.bias, *params)
         x = Fn._to(x, self.norm.weight.dtype)
