@@ -1,7 +1,8 @@
 """vit_pytorch_amd: MI355X-native drop-in for vit_pytorch.ViT / vit_pytorch.SimpleViT.
 
 Mirrors the export surface of the reference package (vit_pytorch/__init__.py:1-5 exports
-ViT and SimpleViT; MAE and Dino are out of scope).
+ViT and SimpleViT; MAE and Dino are out of scope).  Sub-modules: `na_vit` (NaViT on packed tokens),
+`parallel` (flat-buffer data parallelism over RCCL), `optim` (fused Adam / AdamW), `graphs` (HIP-graph capture).
 """
 __version__ = "0.1.0"
 

@@ -18,6 +18,10 @@ Data flow per transformer layer (T = model dtype, residual stream x in f32):
     pre = a2 W1^T + b1 ; act = gelu     T   (M, F) x2   fused bias+GELU epilogue
     x3  = x2 + act W2^T + b2            f32             fused residual epilogue
 
+With active dropout (training, p > 0) the same kernels take the four dropouts of a layer in place: o uses the dropped
+attention matrix, the two residual epilogues drop the Linear output before the add, act = dropout(gelu(pre)); the keep
+decisions are a counter hash that the backward kernels regenerate (see TransformerFn).
+
 A GradSink (see parallel.py) may be installed to place parameter gradients into one flat
 buffer and to be told when the transformer's gradients are complete (data-parallel overlap).
 """

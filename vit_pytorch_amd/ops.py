@@ -1,14 +1,15 @@
 """Host-side op layer: shape logic + kernel selection on top of the C-ABI wrappers.
 
-Every function here ends in libvitk kernels (fast bf16 MFMA kernels when the extents allow,
+Every function here ends in libvitk kernels (the 16-bit MFMA kernels when the extents allow,
 otherwise the generic coverage kernels).  No torch compute ops are used on the data path;
 torch only allocates buffers (``torch.empty``) and carries the stream.
 
 dtype policy
-  * model dtype T = dtype of the parameters: torch.bfloat16 (production) or torch.float32
-    (validation mode: same host logic, f32 kernels).
-  * the residual stream and its gradient are always float32 (also in bf16 mode); everything
+  * model dtype T = dtype of the parameters: torch.bfloat16 (production), torch.float16 (model.half(): the same
+    kernels from libvitk_f16.so) or torch.float32 (validation mode: same host logic, f32 kernels).
+  * the residual stream and its gradient are always float32 (also in the 16-bit modes); everything
     that feeds a GEMM is T.
+  * `drop=(p, seed)` arguments: nn.Dropout fused into the kernel that produces the tensor (engine.TransformerFn).
 """
 from __future__ import annotations
 
