@@ -147,6 +147,23 @@ int vitk_gemm_nt_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, v
                      int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float alpha, void* stream);
 int vitk_fp8_amax_scale(const void* x, int dt, int64_t n, float* scale2, void* stream);
 int vitk_quantize_fp8(const void* x, int dt, void* out, int64_t n, const float* scale_dev, float scale_host, void* stream);
+/* Delayed-scaling variants: producers emit the e4m3 copy themselves.
+ * vitk_layernorm_fwd_fp8: vitk_layernorm_fwd that also writes y8 = e4m3(y * scale8[0]) (row-major like y; null = no copy)
+ *   and records max|y| of this call into amax64 (64 words, float bit patterns, atomicMax; null = do not record).
+ * vitk_gemm_nt_fp8_ex: A is e4m3 (a_is_fp8 != 0; W then too) or 16-bit; alpha_a / alpha_w are device pointers to inverse
+ *   scales multiplied into alpha (null = 1); with the BIAS_GELU epilogue c8 / c8_scale / c8_amax64 give the activation an
+ *   e4m3 copy and an amax record the same way.
+ * vitk_fp8_update_scales: for every slot s < nslots: m = max over amax64[64 s .. 64 s + 63]; if m > 0:
+ *   scales2[2 s] = 448 / m, scales2[2 s + 1] = m / 448; the words are reset to 0.                                     */
+int vitk_layernorm_fwd_fp8(const void* x, int xdt, const void* w, const void* b, int wdt, void* y, int ydt,
+                           float* mean, float* rstd, int64_t rows, int64_t D, float eps, vitk_rowmap imap, vitk_rowmap omap,
+                           const void* add, int64_t add_group, int64_t add_off, void* y8, const float* scale8,
+                           uint32_t* amax64, void* stream);
+int vitk_gemm_nt_fp8_ex(const void* A, int64_t lda, int a_is_fp8, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                        int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float alpha,
+                        const float* alpha_a, const float* alpha_w, void* c8, const float* c8_scale, uint32_t* c8_amax64,
+                        void* stream);
+int vitk_fp8_update_scales(uint32_t* amax64, float* scales2, int64_t nslots, void* stream);
 
 /* dW[N,K] = sum_m dY[m,N]^T X[m,K]  ("TN": both operands are read with the reduction index as
  * the strided one).  Split over M into `splits` slabs of f32 partials (ws: splits*N*K floats),

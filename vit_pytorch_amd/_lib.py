@@ -60,6 +60,9 @@ SIGNATURES = {
     "vitk_gemm_nt_fp8": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _f, _vp]),
     "vitk_fp8_amax_scale": (_i, [_vp, _i, _i64, _vp, _vp]),
     "vitk_quantize_fp8": (_i, [_vp, _i, _vp, _i64, _vp, _f, _vp]),
+    "vitk_layernorm_fwd_fp8": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i64, _f, RowMap, RowMap, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "vitk_gemm_nt_fp8_ex": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vitk_fp8_update_scales": (_i, [_vp, _vp, _i64, _vp]),
     "vitk_gemm_nt_colsum_rows": (_i64, [_i64, _i64, _i64, _i64]),
     "vitk_gemm_nt_bf16_gelu_bwd_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_tn_splits": (_i64, [_i64, _i64, _i64]),

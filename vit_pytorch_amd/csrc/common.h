@@ -141,6 +141,23 @@ __device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
     return __builtin_elementwise_fma(x * splat2(0.39894228040143267794f), e, phi_poly2(x));
 }
 
+// ---- fp8 (e4m3) side output of a producer kernel (delayed scaling) ---------------------------------------------------
+// A producer that already holds the values in registers (LayerNorm forward, the GELU epilogue) can emit an e4m3 copy for the
+// next GEMM: p = destination (1 byte / element, same row-major layout; null = no copy), scale = device pointer to the
+// quantisation scale decided BEFORE this step (448 / amax of the previous step), amax = 64 device words that collect
+// max|value| of THIS step as float bit patterns (null = do not record); vitk_fp8_update_scales() turns them into the next
+// step's scales.  No pass over the tensor is added and the step never waits for its own statistics.
+struct F8Out { unsigned char* p; const float* scale; unsigned* amax; };
+__device__ __forceinline__ unsigned pack_fp8x4(f32x4 v, float sc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * sc, -448.f, 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    return (unsigned)w;
+}
+__device__ __forceinline__ float absmax4(f32x4 v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
+
 // ---- counter-based dropout decisions for the fused paths ------------------------------------------------------------
 // keep(row, col) = hash32(hash32(row ^ seed) + col) >= thresh, thresh = p * 2^32.  Stateless: the forward kernel, the
 // backward kernels and vitk_dropout_keep() (the test hook) regenerate the same decision from (seed, row, col), so no

@@ -186,6 +186,17 @@ __global__ __launch_bounds__(256) void dropout_keep_kernel(uint8_t* __restrict__
     }
 }
 
+// Delayed scaling bookkeeping: slot s owns 64 amax words (bit patterns) and 2 floats {scale, 1/scale}.  After a step:
+// scale = 448 / max(amax words) for every slot that recorded something, words reset to 0.
+__global__ __launch_bounds__(64) void fp8_update_scales_kernel(unsigned* __restrict__ amax, float* __restrict__ scales, int nslots) {
+    const int s = blockIdx.x;
+    if (s >= nslots) return;
+    float m = __builtin_bit_cast(float, amax[s * 64 + threadIdx.x]);
+    amax[s * 64 + threadIdx.x] = 0u;
+    m = wave_max(m);
+    if (threadIdx.x == 0 && m > 0.f) { scales[2 * s] = 448.f / m; scales[2 * s + 1] = m / 448.f; }
+}
+
 template <typename XT, typename PT>
 __global__ __launch_bounds__(256) void write_cls_kernel(XT* __restrict__ x, const PT* __restrict__ cls, const PT* __restrict__ pos,
                                                          long long B, long long N, int D, int ncls) {
@@ -444,6 +455,14 @@ extern "C" int vitk_dropout_keep(uint8_t* keep, int64_t rows, int64_t cols, floa
     hipLaunchKernelGGL(dropout_keep_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, (hipStream_t)stream, keep, (long long)rows,
                        (long long)cols, drop_thresh(p), (unsigned)seed);
     VITK_CHECK_LAUNCH("dropout_keep");
+    return 0;
+}
+
+extern "C" int vitk_fp8_update_scales(uint32_t* amax64, float* scales2, int64_t nslots, void* stream) {
+    if (!amax64 || !scales2) VITK_FAIL(VITK_E_ARG, "fp8_update_scales: null pointer");
+    if (nslots <= 0) return 0;
+    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((unsigned)nslots), dim3(64), 0, (hipStream_t)stream, (unsigned*)amax64, scales2, (int)nslots);
+    VITK_CHECK_LAUNCH("fp8_update_scales");
     return 0;
 }
 

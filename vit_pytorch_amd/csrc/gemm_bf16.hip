@@ -328,7 +328,8 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     const void* __restrict__ Av, long long lda, const void* __restrict__ Wv, long long ldw,
     void* __restrict__ Cv, long long ldc, int M, int N, int K,
     const __bf16* __restrict__ bias, const float* __restrict__ resid, __bf16* __restrict__ aux,
-    int tiles_n, int nwg, int group_n, float* __restrict__ csum, float alpha, unsigned drop_t, unsigned drop_seed, float inv_keep) {
+    int tiles_n, int nwg, int group_n, float* __restrict__ csum, float alpha, unsigned drop_t, unsigned drop_seed, float inv_keep,
+    const float* __restrict__ alpha_a, const float* __restrict__ alpha_w, F8Out f8) {
     const char* A = reinterpret_cast<const char*>(Av);
     const char* W = reinterpret_cast<const char*>(Wv);
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -445,10 +446,12 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     }
     if (!grp_b) PP_BARRIER();  // pairs with group B's extra barrier
     if constexpr (EB == 1) {
+        // per-tensor scales are undone here: alpha (host) x the two device-resident inverse scales (delayed scaling)
+        const float al = alpha * (alpha_a ? *alpha_a : 1.0f) * (alpha_w ? *alpha_w : 1.0f);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jj = 0; jj < FM; ++jj) acc[i][jj] *= alpha;
+            for (int jj = 0; jj < FM; ++jj) acc[i][jj] *= al;
     }
 
     // ---- epilogue: accumulators -> (wave-private 16 KiB of the now idle LDS) -> full-line global I/O ----
@@ -546,6 +549,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
             }
         }
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // GELU_BWD: column sums of this lane's rows (bias gradient)
+        float f8max = 0.f;                                        // BIAS_GELU with an fp8 side output: max |activation|
 #pragma unroll
         for (int j = 0; j < 2 * FM; ++j) {
             const int row = j * 8 + rr;
@@ -571,6 +575,16 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                             g8[e] = drop_keep(hrow, (unsigned)(ncol + e), drop_t) ? (__bf16)((float)g8[e] * inv_keep) : (__bf16)0.f;
                     }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
+                    if (f8.p || f8.amax) {        // e4m3 copy of the activation for the next GEMM (+ this step's amax)
+                        const f32x4 lo = {(float)g8[0], (float)g8[1], (float)g8[2], (float)g8[3]};
+                        const f32x4 hi = {(float)g8[4], (float)g8[5], (float)g8[6], (float)g8[7]};
+                        if (f8.p) {
+                            const float sc8 = *f8.scale;
+                            unsigned* d8 = reinterpret_cast<unsigned*>(f8.p + o);
+                            d8[0] = pack_fp8x4(lo, sc8); d8[1] = pack_fp8x4(hi, sc8);
+                        }
+                        if (f8.amax) f8max = fmaxf(f8max, fmaxf(absmax4(lo), absmax4(hi)));
+                    }
                 } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
                     const bf16x8 h8 = hpre[j];
                     bf16x8 g8;
@@ -586,6 +600,21 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                         cs[e] += (float)g8[e]; cs[e + 1] += (float)g8[e + 1];      // of the ROUNDED values: what a later colsum(C) would read
                     }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
+                }
+            }
+        }
+        if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+            if (f8.amax) {     // one atomic per workgroup, through the first words of its (idle) LDS
+                f8max = wave_max(f8max);
+                __syncthreads();
+                float* red = reinterpret_cast<float*>(lds);
+                if (lane == 0) red[wave] = f8max;
+                __syncthreads();
+                if (tid == 0) {
+                    float m = red[0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) m = fmaxf(m, red[k]);
+                    atomicMax(f8.amax + (blockIdx.x & 63), __builtin_bit_cast(unsigned, m));
                 }
             }
         }
@@ -746,7 +775,8 @@ NtPlan nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
 }
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                  int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8 = false,
-                 float alpha = 1.0f, float drop_p = 0.f, unsigned drop_seed = 0u);
+                 float alpha = 1.0f, float drop_p = 0.f, unsigned drop_seed = 0u, const float* alpha_a = nullptr,
+                 const float* alpha_w = nullptr, F8Out f8 = F8Out{nullptr, nullptr, nullptr});
 }  // namespace
 
 extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
@@ -761,6 +791,15 @@ extern "C" int vitk_gemm_nt_bf16_drop(const void* A, int64_t lda, const void* W,
     if (colsum_partials && (epilogue != VITK_EPI_GELU_BWD || vitk_gemm_nt_colsum_rows(M, N, K, ldc) == 0))
         VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16_drop: column sums come with the GELU_BWD epilogue of the 256-row kernel only");
     return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, colsum_partials, stream, false, 1.0f, drop_p, drop_seed);
+}
+
+extern "C" int vitk_gemm_nt_fp8_ex(const void* A, int64_t lda, int a_is_fp8, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                   int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float alpha,
+                                   const float* alpha_a, const float* alpha_w, void* c8, const float* c8_scale, uint32_t* c8_amax64,
+                                   void* stream) {
+    const F8Out f8{(unsigned char*)c8, c8_scale, (unsigned*)c8_amax64};
+    return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, nullptr, stream, a_is_fp8 != 0, alpha, 0.f, 0u,
+                        alpha_a, alpha_w, f8);
 }
 
 extern "C" int vitk_gemm_nt_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
@@ -786,7 +825,9 @@ extern "C" int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, con
 namespace {
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                  int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8, float alpha,
-                 float drop_p, unsigned drop_seed) {
+                 float drop_p, unsigned drop_seed, const float* alpha_a, const float* alpha_w, F8Out f8) {
+    if ((f8.p || f8.amax) && epilogue != VITK_EPI_BIAS_GELU) VITK_FAIL(VITK_E_ARG, "gemm_nt: the fp8 side output exists in the BIAS_GELU epilogue only");
+    if (f8.p && (!f8.scale || (ldc & 7))) VITK_FAIL(VITK_E_ARG, "gemm_nt: fp8 side output needs a scale and ldc %% 8 == 0");
     if (!A || !W || !C) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: null pointer");
     if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
     const unsigned drop_t = drop_thresh(drop_p);
@@ -802,6 +843,7 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     const bool large = pl.large;
     const int fm = pl.fm;
     if (fp8 && !large) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_fp8: served by the 256-row kernel only (M >= 1024, N >= 256, N %% 8 == 0)");
+    if ((f8.p || f8.amax) && !large) VITK_FAIL(VITK_E_SHAPE, "gemm_nt: the fp8 side output is served by the 256-row kernel only");
     if (drop_t && (!large || (epilogue != VITK_EPI_RESID && epilogue != VITK_EPI_BIAS_GELU && epilogue != VITK_EPI_GELU_BWD)))
         VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: fused dropout exists in the 256-row kernel for the RESID / BIAS_GELU / GELU_BWD epilogues only");
     const int tbm = large ? 32 * fm : BM, tbn = large ? L_BN : BN;
@@ -818,12 +860,12 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
             static const int rc8__ = set_max_lds(gemm_nt256pp_kernel<E, F, 1>, P_LDS_BYTES); \
             if (rc8__ != 0) VITK_FAIL(rc8__, "gemm_nt_fp8: cannot enable %d B of LDS", P_LDS_BYTES); \
             hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F, 1>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, A, (long long)lda, \
-                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, alpha, drop_t, drop_seed, inv_keep); \
+                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, alpha, drop_t, drop_seed, inv_keep, alpha_a, alpha_w, f8); \
         } else { \
             static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E, F, 2>, P_LDS_BYTES); \
             if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", P_LDS_BYTES); \
             hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F, 2>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, A, (long long)lda, \
-                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, 1.0f, drop_t, drop_seed, inv_keep); \
+                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, 1.0f, drop_t, drop_seed, inv_keep, nullptr, nullptr, f8); \
         } \
     } while (0)
 #define NT_LAUNCH(E) do { \

@@ -21,11 +21,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     const XT* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b,
     YT* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
     long long rows, int D, float eps, RowMap imap, RowMap omap,
-    const WT* __restrict__ add, long long add_group, long long add_off) {
+    const WT* __restrict__ add, long long add_group, long long add_off, F8Out f8) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nchunk = D >> 2;
     const float invD = 1.0f / (float)D;
+    const float sc8 = f8.p ? *f8.scale : 0.f;
+    float amax = 0.f;
 
     f32x4 wv[MAXC], bv[MAXC];
 #pragma unroll
@@ -71,9 +73,24 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
                 for (int e = 0; e < 4; ++e) o[e] = (v[t][e] - mean) * rstd * wv[t][e] + bv[t][e];
                 if (ar) { const f32x4 a = load4<WT>(ar + 4 * c); o += a; }
                 store4<YT>(yr + 4 * c, o);
+                if (f8.p) reinterpret_cast<unsigned*>(f8.p + map_row(omap, row) * (long long)D)[c] = pack_fp8x4(o, sc8);
+                if (f8.amax) amax = fmaxf(amax, absmax4(o));
             }
         }
         if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+    if (f8.amax) {     // one atomic per BLOCK (the launcher also caps the grid at 1024 blocks): same-address atomics retire at
+                       // ~4 ns each in L2 -- one per wave of an 8192-block grid quadrupled the kernel's duration
+        __shared__ float red[LN_WAVES];
+        amax = wave_max(amax);
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = red[0];
+#pragma unroll
+            for (int k = 1; k < LN_WAVES; ++k) m = fmaxf(m, red[k]);
+            atomicMax(f8.amax + (blockIdx.x & 63), __builtin_bit_cast(unsigned, m));
+        }
     }
 }
 
@@ -273,14 +290,15 @@ __global__ __launch_bounds__(256) void colsum_stage1_scalar_kernel(const XT* __r
 
 template <typename XT, typename YT, typename WT>
 int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, long long rows, int D,
-                  float eps, RowMap im, RowMap om, const void* add, long long ag, long long ao, hipStream_t st) {
+                  float eps, RowMap im, RowMap om, const void* add, long long ag, long long ao, hipStream_t st, F8Out f8) {
     const int nchunk = D / 4;
     const int maxc = (nchunk + 63) / 64;
     long long blocks = (rows + LN_WAVES - 1) / LN_WAVES;
     if (blocks > 8192) blocks = 8192;
+    if (f8.amax && blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
 #define LN_FWD_CASE(MC) hipLaunchKernelGGL((ln_fwd_kernel<XT, YT, WT, MC>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, \
-        (const XT*)x, (const WT*)w, (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao)
+        (const XT*)x, (const WT*)w, (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao, f8)
     if (maxc <= 1) LN_FWD_CASE(1);
     else if (maxc <= 3) LN_FWD_CASE(3);
     else if (maxc <= 4) LN_FWD_CASE(4);
@@ -317,6 +335,16 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
 extern "C" int vitk_layernorm_fwd(const void* x, int xdt, const void* w, const void* b, int wdt, void* y, int ydt,
                                   float* mean, float* rstd, int64_t rows, int64_t D, float eps, vitk_rowmap imap,
                                   vitk_rowmap omap, const void* add, int64_t add_group, int64_t add_off, void* stream) {
+    return vitk_layernorm_fwd_fp8(x, xdt, w, b, wdt, y, ydt, mean, rstd, rows, D, eps, imap, omap, add, add_group, add_off, nullptr,
+                                  nullptr, nullptr, stream);
+}
+
+extern "C" int vitk_layernorm_fwd_fp8(const void* x, int xdt, const void* w, const void* b, int wdt, void* y, int ydt,
+                                      float* mean, float* rstd, int64_t rows, int64_t D, float eps, vitk_rowmap imap,
+                                      vitk_rowmap omap, const void* add, int64_t add_group, int64_t add_off, void* y8,
+                                      const float* scale8, uint32_t* amax64, void* stream) {
+    if (y8 && !scale8) VITK_FAIL(VITK_E_ARG, "layernorm_fwd_fp8: an fp8 output needs its scale");
+    const F8Out f8{(unsigned char*)y8, scale8, (unsigned*)amax64};
     if (!x || !w || !y || !mean || !rstd) VITK_FAIL(VITK_E_ARG, "layernorm_fwd: null pointer");
     if (rows < 0 || D <= 0 || (D & 3) || D > 4096) VITK_FAIL(VITK_E_SHAPE, "layernorm_fwd: need D %% 4 == 0 and D <= 4096, got D=%lld", (long long)D);
     if (rows == 0) return 0;
@@ -326,13 +354,13 @@ extern "C" int vitk_layernorm_fwd(const void* x, int xdt, const void* w, const v
     const RowMap im = to_map(imap), om = to_map(omap);
     if (wdt == VITK_F32) {
         if (xdt != VITK_F32 || ydt != VITK_F32) VITK_FAIL(VITK_E_DTYPE, "layernorm_fwd: f32 params need f32 x/y");
-        return launch_ln_fwd<float, float, float>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
+        return launch_ln_fwd<float, float, float>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st, f8);
     }
     if (wdt != VITK_BF16) VITK_FAIL(VITK_E_DTYPE, "layernorm_fwd: bad wdt");
-    if (xdt == VITK_F32 && ydt == VITK_BF16) return launch_ln_fwd<float, __bf16, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
-    if (xdt == VITK_F32 && ydt == VITK_F32) return launch_ln_fwd<float, float, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
-    if (xdt == VITK_BF16 && ydt == VITK_BF16) return launch_ln_fwd<__bf16, __bf16, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
-    if (xdt == VITK_BF16 && ydt == VITK_F32) return launch_ln_fwd<__bf16, float, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st);
+    if (xdt == VITK_F32 && ydt == VITK_BF16) return launch_ln_fwd<float, __bf16, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st, f8);
+    if (xdt == VITK_F32 && ydt == VITK_F32) return launch_ln_fwd<float, float, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st, f8);
+    if (xdt == VITK_BF16 && ydt == VITK_BF16) return launch_ln_fwd<__bf16, __bf16, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st, f8);
+    if (xdt == VITK_BF16 && ydt == VITK_F32) return launch_ln_fwd<__bf16, float, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st, f8);
     VITK_FAIL(VITK_E_DTYPE, "layernorm_fwd: bad dtype combination");
 }
 

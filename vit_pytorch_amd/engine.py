@@ -161,7 +161,7 @@ class TransformerFn(torch.autograd.Function):
     derived from drop_seed; the backward kernels regenerate them, no mask tensor exists."""
 
     @staticmethod
-    def forward(ctx, x, heads: int, dim_head: int, drop_p: float, drop_seed: int, norm_w, norm_b, *lp):
+    def forward(ctx, x, heads: int, dim_head: int, drop_p: float, drop_seed: int, fp8, norm_w, norm_b, *lp):
         K.require_device(x, norm_w)
         depth = len(lp) // NLP
         T = norm_w.dtype
@@ -180,11 +180,25 @@ class TransformerFn(torch.autograd.Function):
         if drop_p > 0.0 and (lp[3] is None or lp[8] is None or not dropout_fusable(T, B, N, D, heads, dim_head, lp[7].shape[0])):
             raise VitkError("TransformerFn: this shape does not take the fused dropout path (caller must check dropout_fusable)")
         site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
+        # fp8 forward (fp8.py): e4m3 operands for QKV / FF1 / FF2 once the delayed scales exist; the first call only records amax
+        use8 = fp8 is not None and T in ops.HALF and drop_p == 0.0 and depth > 0 and lp[8] is not None and ops.fp8_gemm_ok(M, D, I, lp[7].shape[0])
+        go8 = use8 and fp8.ready
         for li in range(depth):
             ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
             a1 = ops.empty((M, D), T, xs)
-            st1 = ops.ln_fwd(xs, ln1w, ln1b, M, D, a1)
-            qkv = ops.linear_fwd(a1, wqkv, None, M)
+            if use8:
+                sc1, am1 = fp8.slot(li, 0)
+                a1_8 = torch.empty((M, D), dtype=torch.uint8, device=xs.device) if go8 else None
+                st1 = ops.ln_fwd(xs, ln1w, ln1b, M, D, a1, f8=(a1_8, sc1, am1))
+            else:
+                st1 = ops.ln_fwd(xs, ln1w, ln1b, M, D, a1)
+            if go8:
+                w8, wsc = fp8.weight(wqkv)
+                qkv = ops.empty((M, 3 * I), T, xs)
+                K.gemm_nt_fp8_ex(a1_8, D, w8, D, qkv, 3 * I, M, 3 * I, D, L.EPI_NONE, a_is_fp8=True, alpha_a=sc1[1:], alpha_w=wsc[1:])
+                del a1_8
+            else:
+                qkv = ops.linear_fwd(a1, wqkv, None, M)
             o, att_saved = ops.attn_fwd(qkv, B, N, heads, dim_head, scale, drop=site(li, 0))
             if wout is not None:
                 x2 = ops.linear_fwd(o, wout, bout, M, resid=xs, drop=site(li, 1))
@@ -192,11 +206,35 @@ class TransformerFn(torch.autograd.Function):
                 x2 = ops.empty((M, D), F32, xs)
                 K.add_rows(xs, o, None, x2, M, D)
             a2 = ops.empty((M, D), T, xs)
-            st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2)
-            act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True, drop=site(li, 2))
-            x3 = ops.linear_fwd(act, w2, b2, M, resid=x2, drop=site(li, 3))
+            if use8:
+                sc2, am2 = fp8.slot(li, 1)
+                sc3, am3 = fp8.slot(li, 2)
+                Fh = w1.shape[0]
+                a2_8 = torch.empty((M, D), dtype=torch.uint8, device=xs.device) if go8 else None
+                st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2, f8=(a2_8, sc2, am2))
+                act = ops.empty((M, Fh), T, xs); pre = ops.empty((M, Fh), T, xs)
+                if go8:
+                    w8, wsc = fp8.weight(w1)
+                    act_8 = torch.empty((M, Fh), dtype=torch.uint8, device=xs.device)
+                    K.gemm_nt_fp8_ex(a2_8, D, w8, D, act, Fh, M, Fh, D, L.EPI_BIAS_GELU, a_is_fp8=True, bias=b1, aux=pre,
+                                     alpha_a=sc2[1:], alpha_w=wsc[1:], c8=act_8, c8_scale=sc3, c8_amax64=am3)
+                    del a2_8
+                    w8, wsc = fp8.weight(w2)
+                    x3 = ops.empty((M, D), F32, xs)
+                    K.gemm_nt_fp8_ex(act_8, Fh, w8, Fh, x3, D, M, D, Fh, L.EPI_RESID, a_is_fp8=True, bias=b2, resid=x2,
+                                     alpha_a=sc3[1:], alpha_w=wsc[1:])
+                    del act_8
+                else:       # recording pass: 16-bit operands, amax of the GELU output collected by the same epilogue
+                    K.gemm_nt_fp8_ex(a2, D, w1, D, act, Fh, M, Fh, D, L.EPI_BIAS_GELU, a_is_fp8=False, bias=b1, aux=pre, c8_amax64=am3)
+                    x3 = ops.linear_fwd(act, w2, b2, M, resid=x2)
+            else:
+                st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2)
+                act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True, drop=site(li, 2))
+                x3 = ops.linear_fwd(act, w2, b2, M, resid=x2, drop=site(li, 3))
             saved.append((xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act))
             xs = x3
+        if use8:
+            fp8.end_of_forward()
         y = ops.empty((B, N, D), T, xs)
         stf = ops.ln_fwd(xs, norm_w, norm_b, M, D, y)
         ctx.saved = saved
@@ -308,7 +346,7 @@ class TransformerFn(torch.autograd.Function):
             dx = g.view(B, N, D)
         else:
             dx = (gb if gb is not None else g).view(B, N, D)
-        return (dx, None, None, None, None, _ret(dnw), _ret(dnb), *[_ret(t) for t in grads])
+        return (dx, None, None, None, None, None, _ret(dnw), _ret(dnb), *[_ret(t) for t in grads])
 
 
 class PatchEmbedFn(torch.autograd.Function):

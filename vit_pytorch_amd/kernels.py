@@ -65,10 +65,12 @@ def require_device(*ts: Tensor):
 # ---- LayerNorm -------------------------------------------------------------------------------
 def layernorm_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], y: Tensor, mean: Tensor, rstd: Tensor,
                   rows: int, D: int, eps: float = 1e-5, imap: RowMap = IDENT, omap: RowMap = IDENT,
-                  add: Optional[Tensor] = None, add_group: int = 0, add_off: int = 0):
+                  add: Optional[Tensor] = None, add_group: int = 0, add_off: int = 0, y8: Optional[Tensor] = None,
+                  scale8: Optional[Tensor] = None, amax64: Optional[Tensor] = None):
+    """y8 / scale8 / amax64: optional e4m3 copy of y under the (device) scale, and this call's amax record (fp8.py)."""
     lib = _lib_for(x, w, y, mean, rstd)
-    check(lib.vitk_layernorm_fwd(_p(x), dt(x), _p(w), _p(b), dt(w), _p(y), dt(y), _p(mean), _p(rstd),
-                                 rows, D, eps, imap, omap, _p(add), add_group, add_off, _stream()),
+    check(lib.vitk_layernorm_fwd_fp8(_p(x), dt(x), _p(w), _p(b), dt(w), _p(y), dt(y), _p(mean), _p(rstd),
+                                     rows, D, eps, imap, omap, _p(add), add_group, add_off, _p(y8), _p(scale8), _p(amax64), _stream()),
           "layernorm_fwd")
 
 
@@ -311,3 +313,17 @@ def quantize_fp8(x: Tensor, out: Tensor, scale_dev: Optional[Tensor] = None, sca
 def dropout_keep(keep: Tensor, rows: int, cols: int, p: float, seed: int):
     """uint8 (rows, cols): the keep decisions the fused dropout kernels take for (p, seed) -- a test hook."""
     check(L.load().vitk_dropout_keep(_p(keep), rows, cols, p, seed & 0xffffffff, _stream()), "dropout_keep")
+
+
+def gemm_nt_fp8_ex(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int, epilogue: int, *,
+                   a_is_fp8: bool, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, aux: Optional[Tensor] = None,
+                   alpha: float = 1.0, alpha_a: Optional[Tensor] = None, alpha_w: Optional[Tensor] = None,
+                   c8: Optional[Tensor] = None, c8_scale: Optional[Tensor] = None, c8_amax64: Optional[Tensor] = None):
+    """The NT GEMM with e4m3 or 16-bit operands, device-resident inverse scales and (BIAS_GELU) an e4m3 copy of the output."""
+    check(_lib_for(C, bias, aux, None if a_is_fp8 else A).vitk_gemm_nt_fp8_ex(
+        _p(A), lda, int(a_is_fp8), _p(W), ldw, _p(C), ldc, M, N, K, epilogue, _p(bias), _p(resid), _p(aux), alpha, _p(alpha_a),
+        _p(alpha_w), _p(c8), _p(c8_scale), _p(c8_amax64), _stream()), "gemm_nt_fp8_ex")
+
+
+def fp8_update_scales(amax64: Tensor, scales2: Tensor, nslots: int):
+    check(L.load().vitk_fp8_update_scales(_p(amax64), _p(scales2), nslots, _stream()), "fp8_update_scales")

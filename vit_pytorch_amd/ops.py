@@ -36,11 +36,13 @@ def empty(shape, dtype, like: Tensor) -> Tensor:
 # ---- LayerNorm ---------------------------------------------------------------------------------
 def ln_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], rows: int, D: int, out: Tensor,
            imap: RowMap = IDENT, omap: RowMap = IDENT, add: Optional[Tensor] = None,
-           add_group: int = 0, add_off: int = 0) -> Tuple[Tensor, Tensor]:
-    """nn.LayerNorm(D) over `rows` logical rows (vit.py:19,39,69,101,103). Returns (mean, rstd)."""
+           add_group: int = 0, add_off: int = 0, f8=None) -> Tuple[Tensor, Tensor]:
+    """nn.LayerNorm(D) over `rows` logical rows (vit.py:19,39,69,101,103). Returns (mean, rstd).
+    f8 = (y8 or None, scale tensor, amax words): e4m3 copy of the output / amax record for the fp8 forward (fp8.py)."""
     mean = empty((rows,), F32, x)
     rstd = empty((rows,), F32, x)
-    K.layernorm_fwd(x, w, b, out, mean, rstd, rows, D, LN_EPS, imap, omap, add, add_group, add_off)
+    y8, sc, am = f8 if f8 is not None else (None, None, None)
+    K.layernorm_fwd(x, w, b, out, mean, rstd, rows, D, LN_EPS, imap, omap, add, add_group, add_off, y8, sc, am)
     return mean, rstd
 
 
@@ -72,6 +74,12 @@ def _fast_nt(x: Tensor, N: int, Kd: int) -> bool:
 def fused_dropout_ok(x_dtype, M: int, N: int, Kd: int) -> bool:
     """nn.Dropout fused into a GEMM epilogue exists in the 256-row kernel only."""
     return x_dtype in HALF and Kd % 64 == 0 and K.gemm_nt_colsum_rows(M, N, Kd, N) > 0
+
+
+def fp8_gemm_ok(M: int, D: int, I: int, Fh: int) -> bool:
+    """The e4m3-operand GEMM (256-row kernel only; K % 64 == 0, leading dimensions % 16 == 0) serves QKV, FF1 and FF2."""
+    return (D % 64 == 0 and Fh % 64 == 0 and K.gemm_nt_colsum_rows(M, 3 * I, D, 3 * I) > 0 and K.gemm_nt_colsum_rows(M, Fh, D, Fh) > 0
+            and K.gemm_nt_colsum_rows(M, D, Fh, D) > 0)
 
 
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bool = False,

@@ -88,7 +88,7 @@ class Transformer(nn.Module):
             params = []
             for attn, ff in self.layers:
                 params += E.pack_layer_params(attn, ff)
-            return E.TransformerFn.apply(x, self._heads, self._dim_head, 0.0, 0, self.norm.weight, self.norm.bias, *params)
+            return E.TransformerFn.apply(x, self._heads, self._dim_head, 0.0, 0, getattr(self, "_fp8", None), self.norm.weight, self.norm.bias, *params)
         x = Fn._to(x, self.norm.weight.dtype)
         for attn, ff in self.layers:
             x = Fn.AddFn.apply(attn(x), x)
