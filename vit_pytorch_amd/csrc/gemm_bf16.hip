@@ -588,14 +588,18 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                 } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
                     const bf16x8 h8 = hpre[j];
                     bf16x8 g8;
-                    const unsigned hrow = drop_t ? drop_row((unsigned)m, drop_seed) : 0u;
+                    float km[8];            // dropout factor of the forward's dropout(gelu(pre)) at (m, n): same decision, same 1 / (1 - p)
+                    if (drop_t) {
+                        const unsigned hrow = drop_row((unsigned)m, drop_seed);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) km[e] = drop_keep(hrow, (unsigned)(ncol + e), drop_t) ? inv_keep : 0.f;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) km[e] = 1.f;
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        f32x2 g2 = f32x2{(float)v[e], (float)v[e + 1]} * gelu_grad_fast2(f32x2{(float)h8[e], (float)h8[e + 1]});
-                        if (drop_t) {       // the forward dropped gelu(pre) at (m, n): same decision, same 1 / (1 - p)
-                            g2[0] = drop_keep(hrow, (unsigned)(ncol + e), drop_t) ? g2[0] * inv_keep : 0.f;
-                            g2[1] = drop_keep(hrow, (unsigned)(ncol + e + 1), drop_t) ? g2[1] * inv_keep : 0.f;
-                        }
+                        const f32x2 g2 = f32x2{(float)v[e], (float)v[e + 1]} * gelu_grad_fast2(f32x2{(float)h8[e], (float)h8[e + 1]}) * f32x2{km[e], km[e + 1]};
                         g8[e] = (__bf16)g2[0]; g8[e + 1] = (__bf16)g2[1];
                         cs[e] += (float)g8[e]; cs[e + 1] += (float)g8[e + 1];      // of the ROUNDED values: what a later colsum(C) would read
                     }
