@@ -46,7 +46,7 @@ class Fp8State:
     def weight(self, w: torch.Tensor):
         """e4m3 copy of a (N, K) weight and its scale pair; re-quantised when the parameter changed."""
         ent = self._w.get(id(w))
-        if ent is None or ent[0] != w._version or ent[1].device != w.device:
+        if ent is None or ent[0] != w._version or ent[1].device != w.device or ent[1].shape != w.shape:
             sc = torch.empty(2, dtype=torch.float32, device=w.device)
             w8 = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
             K.fp8_amax_scale(w, sc)
