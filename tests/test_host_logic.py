@@ -119,3 +119,48 @@ def test_navit_state_dict_and_packing_contract():
     assert s.qblk_seg.tolist() == [0, 0, 1, 2, 2] and s.qblk_r0.tolist() == [0, 128, 0, 0, 128]
     with pytest.raises(VitkError, match="HIP"):
         m([torch.randn(3, 16, 16)])
+
+
+def test_dropout_routing_decisions_are_host_side():
+    """Which path active dropout takes is decided from shapes and module state on the host (no GPU needed): the fused
+    engine when the 256-row GEMM kernel and the fixed-length attention kernel serve the block, op by op otherwise."""
+    from vit_pytorch_amd import engine as E
+    from vit_pytorch_amd.vit import Transformer
+    blk = Transformer(768, 2, 12, 64, 3072, dropout=0.1).to(torch.bfloat16)
+    blk.train()
+    assert blk._dropout_p() == 0.1
+    big = torch.empty(8, 197, 768, dtype=torch.bfloat16)            # M = 1576 rows: served
+    small = torch.empty(2, 197, 768, dtype=torch.bfloat16)          # M = 394 rows: 128-row kernels, no fused dropout
+    long_seq = torch.empty(4, 577, 768, dtype=torch.bfloat16)       # N > 480: chunked attention kernels, no fused dropout
+    assert blk._fusable(big) and not blk._fusable(small) and not blk._fusable(long_seq)
+    assert E.dropout_fusable(torch.bfloat16, 8, 197, 768, 12, 64, 3072) and E.dropout_fusable(torch.float16, 8, 197, 768, 12, 64, 3072)
+    assert not E.dropout_fusable(torch.float32, 8, 197, 768, 12, 64, 3072)
+    blk.layers[1][1].net[3].p = 0.2                                  # a user edited one Dropout: no common p -> op by op
+    assert blk._dropout_p() is None and not blk._fusable(big)
+    blk.layers[1][1].net[3].p = 0.1
+    blk.eval()
+    assert blk._dropout_p() == 0.0 and blk._fusable(small)           # inactive dropout: every shape is fusable
+    # the host's copy of the device hash that derives per-site seeds (lowbias32)
+    def ref(x):
+        x &= 0xffffffff; x ^= x >> 16; x = (x * 0x21f0aaad) & 0xffffffff; x ^= x >> 15; x = (x * 0x735a2d97) & 0xffffffff; x ^= x >> 15
+        return x
+    assert all(E._hash32(v) == ref(v) for v in (0, 1, 12345, 0xffffffff, 0x9E3779B1 * 7))
+    assert len({E._hash32(1000 + k) for k in range(48)}) == 48       # 12 layers x 4 sites: distinct seeds
+
+
+def test_gpu_only_helpers_refuse_cpu_models():
+    from vit_pytorch_amd import ViT
+    from vit_pytorch_amd._lib import VitkError
+    from vit_pytorch_amd.fp8 import enable_fp8_forward
+    from vit_pytorch_amd.graphs import GraphedForward
+    from vit_pytorch_amd.optim import Adam
+    from vit_pytorch_amd.parallel import DataParallel
+    m = ViT(image_size=32, patch_size=8, num_classes=10, dim=64, depth=1, heads=2, mlp_dim=128)
+    with pytest.raises(VitkError):
+        enable_fp8_forward(m)                                        # float32 model: fp8 replaces 16-bit operands only
+    with pytest.raises(VitkError):
+        Adam(DataParallel(m))                                        # parameters on the CPU
+    with pytest.raises(VitkError):
+        GraphedForward(m, torch.zeros(1, 3, 32, 32))
+    with pytest.raises(TypeError):
+        Adam(m)
