@@ -23,41 +23,32 @@ def _has_fwd_hooks(m: Module) -> bool:
 
 
 class FeedForward(Module):
+    """LayerNorm -> Linear -> GELU -> Dropout -> Linear -> Dropout (vit.py:15-28); `net` indices 0, 1, 4 carry parameters."""
+
     def __init__(self, dim, hidden_dim, dropout=0.):
         super().__init__()
-        self.net = nn.Sequential(
-            Fn.LayerNorm(dim),
-            Fn.Linear(dim, hidden_dim),
-            Fn.GELU(),
-            Fn.Dropout(dropout),
-            Fn.Linear(hidden_dim, dim),
-            Fn.Dropout(dropout),
-        )
+        stages = [Fn.LayerNorm(dim), Fn.Linear(dim, hidden_dim), Fn.GELU(), Fn.Dropout(dropout),
+                  Fn.Linear(hidden_dim, dim), Fn.Dropout(dropout)]
+        self.net = nn.Sequential(*stages)
 
     def forward(self, x):
         return self.net(x)
 
 
 class Attention(Module):
+    """Pre-norm multi-head attention (vit.py:30-64).  `to_out` is Linear + Dropout, or Identity when a single head already
+    spans the model width; `attend` / `dropout` exist as modules so that hooks and `.p` edits keep working."""
+
     def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
         super().__init__()
-        inner_dim = dim_head * heads
-        project_out = not (heads == 1 and dim_head == dim)
-
-        self.heads = heads
-        self.scale = dim_head ** -0.5
-
+        width = heads * dim_head
+        self.heads, self.scale = heads, dim_head ** -0.5
         self.norm = Fn.LayerNorm(dim)
-
         self.attend = Fn.Softmax(dim=-1)
         self.dropout = Fn.Dropout(dropout)
-
-        self.to_qkv = Fn.Linear(dim, inner_dim * 3, bias=False)
-
-        self.to_out = nn.Sequential(
-            Fn.Linear(inner_dim, dim),
-            Fn.Dropout(dropout),
-        ) if project_out else nn.Identity()
+        self.to_qkv = Fn.Linear(dim, 3 * width, bias=False)
+        single_full_head = heads == 1 and dim_head == dim
+        self.to_out = nn.Identity() if single_full_head else nn.Sequential(Fn.Linear(width, dim), Fn.Dropout(dropout))
 
     def _needs_attention_matrix(self) -> bool:
         # forward hooks on `attend` (recorder.py:26-29) or active attention dropout need the N x N matrix
@@ -140,34 +131,23 @@ class ViT(Module):
     def __init__(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool='cls', channels=3,
                  dim_head=64, dropout=0., emb_dropout=0.):
         super().__init__()
-        image_height, image_width = pair(image_size)
-        self.patch_size = patch_height, patch_width = pair(patch_size)
-
-        assert image_height % patch_height == 0 and image_width % patch_width == 0, 'Image dimensions must be divisible by the patch size.'
-
-        num_patches = (image_height // patch_height) * (image_width // patch_width)
-        patch_dim = channels * patch_height * patch_width
-
+        (ih, iw), (ph, pw) = pair(image_size), pair(patch_size)
+        assert ih % ph == 0 and iw % pw == 0, 'Image dimensions must be divisible by the patch size.'
         assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
-        num_cls_tokens = 1 if pool == 'cls' else 0
-
-        self.to_patch_embedding = nn.Sequential(
-            Fn.Patchify(patch_height, patch_width),
-            Fn.LayerNorm(patch_dim),
-            Fn.Linear(patch_dim, dim),
-            Fn.LayerNorm(dim),
-        )
-
-        self.cls_token = nn.Parameter(torch.randn(num_cls_tokens, dim))
-        self.pos_embedding = nn.Parameter(torch.randn(num_patches + num_cls_tokens, dim))
-
-        self.dropout = Fn.Dropout(emb_dropout)
-
-        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
-
+        self.patch_size = (ph, pw)
         self.pool = pool
-        self.to_latent = nn.Identity()
+        n_cls = int(pool == 'cls')                      # a (0, dim) cls_token parameter exists with mean pooling (vit.py:97)
+        n_patches = (ih // ph) * (iw // pw)
+        patch_dim = channels * ph * pw
 
+        # children in the reference's order: to_patch_embedding, dropout, transformer, to_latent, mlp_head
+        self.to_patch_embedding = nn.Sequential(
+            Fn.Patchify(ph, pw), Fn.LayerNorm(patch_dim), Fn.Linear(patch_dim, dim), Fn.LayerNorm(dim))
+        self.cls_token = nn.Parameter(torch.randn(n_cls, dim))
+        self.pos_embedding = nn.Parameter(torch.randn(n_patches + n_cls, dim))
+        self.dropout = Fn.Dropout(emb_dropout)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+        self.to_latent = nn.Identity()
         self.mlp_head = Fn.Linear(dim, num_classes) if num_classes > 0 else None
 
     def _embed_fusable(self) -> bool:
