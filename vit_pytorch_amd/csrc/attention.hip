@@ -35,14 +35,6 @@ constexpr float LN2 = 0.6931471805599453f;
 
 struct BHND { __bf16* p; long long s_b, s_h, s_n; };
 
-__device__ __forceinline__ void fill_tile(char* tile, const __bf16* src, long long s_n, int N, int rows_pad, int tid) {
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int c = tid; c < rows_pad * 8; c += AT_THREADS) {
-        const int row = c >> 3, col8 = c & 7;
-        const bf16x8 v = row < N ? *reinterpret_cast<const bf16x8*>(src + (long long)row * s_n + col8 * 8) : zero8;
-        *reinterpret_cast<bf16x8*>(tile + row * AT_LD + col8 * 16) = v;
-    }
-}
 // Two tiles at once with every global load of a batch in flight before the first LDS store: a plain
 // load -> store loop is serialised by the compiler (s_waitcnt vmcnt(0) per 16 bytes), which at ~2 us of
 // HBM latency per trip was most of a (batch, head) workgroup's life.
@@ -475,7 +467,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
 // One workgroup = (segment, 128-query block, head); K/V are streamed through LDS in 128-key chunks with the
 // same online-softmax inner step as the fixed-length kernels.
 // ==========================================================================================
-constexpr int VL_QB = 16 * AT_WAVES;   // 128 queries (or keys, in the dK/dV kernel) per workgroup
+// a workgroup handles 16 * AT_WAVES = 128 queries (or keys, in the dK/dV kernel)
 constexpr int VL_CH = 128;             // rows per LDS chunk
 
 struct HND { __bf16* p; long long s_h, s_n; };   // element (n, h, d) at p + n*s_n + h*s_h + d

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // Per MFMA the 128^2 tile moves ~2x the LDS bytes (both DMA writes and fragment reads) and is
 // LDS-bound on gfx950; a 128x64 wave tile needs 12 ds_read_b128 per 32 MFMAs instead of 8 per 16.
 // ==========================================================================================
-constexpr int L_BM = 256, L_BN = 256, L_BK = 64;
+constexpr int L_BN = 256, L_BK = 64;
 
 // ==========================================================================================
 // Ping-pong variant of the 256 x 256 NT kernel.
