@@ -18,7 +18,7 @@ Values beyond the delayed scale's range saturate at +-448 * 1/scale; accumulatio
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 

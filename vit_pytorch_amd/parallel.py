@@ -21,7 +21,7 @@ Models that are not vit_pytorch_amd modules work too (no overlap: flatten after 
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist
