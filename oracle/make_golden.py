@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY.  Runs only where /root/reference exists (it does not
 travel to the GPU box); the fixtures it writes are committed.
 
-    python oracle/make_golden.py
+    python oracle/make_golden.py [case ...]
 
 For every case in oracle/params.py::CASES it loads the unmodified reference
 module by file path (vit.py / simple_vit.py import only torch + einops;
@@ -35,6 +35,7 @@ from oracle.params import CASES, NAVIT_CASES, make_images, make_navit_images, ma
 from oracle.vit_oracle import loss_fn  # noqa: E402
 
 REF = "/root/reference/vit_pytorch"
+ONLY = set(sys.argv[1:])      # optional case names: regenerate just those (the others keep their committed bytes)
 
 
 def load_ref(name: str):
@@ -64,6 +65,8 @@ def main():
     outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     for name, case in CASES.items():
+        if ONLY and name not in ONLY:
+            continue
         params = make_params(case["kind"], case["cfg"], case["seed"])
         img = make_images(case["cfg"], case["batch"], case["seed"] + 1000, case.get("image"))
         out, loss, grads = run_reference(case["kind"], case["cfg"], params, img)
@@ -80,6 +83,8 @@ def main_navit():
     outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
     mod = load_ref("na_vit")
     for name, case in NAVIT_CASES.items():
+        if ONLY and name not in ONLY:
+            continue
         params = make_navit_params(case["cfg"], case["seed"])
         images = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
         model = mod.NaViT(**case["cfg"])
