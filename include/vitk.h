@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 110
+#define VITK_VERSION 120
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -126,6 +126,9 @@ int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
  * bf16-rounded C; fold them with vitk_colsum_partials(partials, R, N, N, ...).  R == 0: the shape is not served by
  * the 256-row kernel and this entry point refuses it (use vitk_gemm_nt_bf16 + vitk_colsum).                       */
 int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc);
+/* Tile schedule of the persistent NT kernel for (M, N, K) (tests, tuning): out[0] = 1 when the shape is served by it,
+ * out[1] = 256-row m-tiles, out[2] = 128-row m-tiles of the tail region, out[3] = resident workgroups, out[4] = n-tiles. */
+int vitk_gemm_nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, int32_t* out5);
 int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, const void* W, int64_t ldw,
                                       void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                       void* aux, float* colsum_partials, void* stream);

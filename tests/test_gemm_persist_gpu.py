@@ -1,0 +1,103 @@
+"""GPU: the persistent NT GEMM (csrc/gemm_nt_persist.hip) against float64 products of the same operands.
+
+Covers what the kernel adds over the per-tile one: the continuous K-step stream across tiles (several tiles per
+workgroup), both tile heights in one launch, partial last rows / columns, very short K (one and two K-steps per tile, so
+the DMA prologue spans tiles), every epilogue, the in-register bias-gradient sums, and run-to-run bit identity (a race in
+the LDS ring or in the counted waits shows up as a changing result)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+os.environ["VITK_NTP_EPIS"] = "31"      # every epilogue on the persistent kernel (the default leaves plain stores on the per-tile one)
+
+from vit_pytorch_amd import kernels as K  # noqa: E402
+from vit_pytorch_amd import _lib as L  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    n = b.norm().item()
+    return (a - b).norm().item() / (n if n > 0 else 1.0)
+
+
+def rnd(*shape, dtype=torch.float32, seed=0):
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(dtype).to(DEV)
+
+
+# (M, N, K): many tiles per workgroup + tail (ViT-B quarter batch), partial rows and columns, K of one / two / three K-steps
+SHAPES = [(12608, 768, 768), (12608, 3072, 768), (12608, 768, 3072), (70001, 520, 96), (9000, 1000, 32), (33000, 264, 64), (1024, 256, 64),
+          (4100, 2304, 128)]
+
+
+def _all_epilogues(M, N, Kd, A, W, bias, resid, h):
+    out = {}
+    C = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt_bf16(A, Kd, W, Kd, C, N, M, N, Kd)
+    out["none"] = C.clone()
+    K.gemm_nt_bf16(A, Kd, W, Kd, C, N, M, N, Kd, L.EPI_BIAS, bias=bias)
+    out["bias"] = C.clone()
+    aux = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt_bf16(A, Kd, W, Kd, C, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=aux)
+    out["gelu"] = C.clone(); out["pre"] = aux
+    o32 = torch.empty(M, N, device=DEV)
+    K.gemm_nt_bf16(A, Kd, W, Kd, o32, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid)
+    out["resid"] = o32
+    R = K.gemm_nt_colsum_rows(M, N, Kd, N)
+    part = torch.full((R * N,), float("nan"), device=DEV)
+    C2 = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt_bf16_gelu_bwd_colsum(A, Kd, W, Kd, C2, N, M, N, Kd, h, part)
+    out["gbwd"] = C2; out["part"] = part.view(R, N)
+    return out
+
+
+@pytest.mark.parametrize("M,N,Kd", SHAPES)
+def test_persistent_nt_against_float64(M, N, Kd):
+    plan = K.gemm_nt_plan(M, N, Kd, N)
+    assert plan["persistent"]
+    A = rnd(M, Kd, dtype=BF, seed=1); W = (rnd(N, Kd, seed=2) * Kd ** -0.5).to(BF)
+    bias = rnd(N, dtype=BF, seed=3); resid = rnd(M, N, seed=4); h = rnd(M, N, dtype=BF, seed=5)
+    ref = A.double() @ W.double().t()
+    got = _all_epilogues(M, N, Kd, A, W, bias, resid, h)
+    assert rel(got["none"], ref) < 4e-3
+    # exact up to the output rounding: equal to the bf16 rounding of the f32-accumulated product within 2 ulp of the largest value
+    assert (got["none"].double() - ref.float().to(BF).double()).abs().max().item() <= 2 * 2 ** -8 * ref.abs().max().item()
+    pre = ref + bias.double()
+    assert rel(got["bias"], pre) < 4e-3
+    assert rel(got["pre"], pre) < 4e-3 and rel(got["gelu"], torch.nn.functional.gelu(pre)) < 4e-3
+    assert rel(got["resid"], resid.double() + pre) < 1e-5
+    hd = h.double().requires_grad_(True)
+    torch.nn.functional.gelu(hd).backward(ref)
+    assert rel(got["gbwd"], hd.grad) < 4e-3
+    assert not torch.isnan(got["part"]).any()
+    assert rel(got["part"].double().sum(0), got["gbwd"].double().sum(0)) < 1e-5
+    # run-to-run bit identity
+    for _ in range(2):
+        again = _all_epilogues(M, N, Kd, A, W, bias, resid, h)
+        for k in got:
+            assert torch.equal(got[k], again[k]), k
+
+
+def test_plan_uses_both_tile_heights_at_vit_b_sizes():
+    p = K.gemm_nt_plan(50432, 768, 3072, 768)
+    assert p["persistent"] and p["tiles_m256"] > 0 and p["tiles_m128"] > 0
+    assert 256 * p["tiles_m256"] + 128 * p["tiles_m128"] >= 50432
+    assert K.gemm_nt_colsum_rows(50432, 768, 3072, 768) == 2 * (p["tiles_m256"] + p["tiles_m128"])
+    assert not K.gemm_nt_plan(512, 768, 768, 768)["persistent"]          # small M stays on the 128-row kernel
+
+
+def test_persistent_nt_in_place_residual_and_strided_operands():
+    """The engine adds into the residual stream in place and reads q|k|v slices of the merged projection by leading dimension."""
+    M, N, Kd, ld = 5000, 768, 256, 1024
+    Abig = rnd(M, ld, dtype=BF, seed=11); W = (rnd(N, Kd, seed=12) * Kd ** -0.5).to(BF)
+    A = Abig[:, 256:512]
+    ref = A.double() @ W.double().t()
+    x = rnd(M, N, seed=13); x0 = x.clone()
+    L.check(L.load().vitk_gemm_nt_bf16(A.data_ptr(), ld, W.data_ptr(), Kd, x.data_ptr(), N, M, N, Kd, L.EPI_RESID, None, x.data_ptr(), None,
+                                       torch.cuda.current_stream().cuda_stream), "gemm_nt_bf16")
+    assert rel(x, x0.double() + ref) < 1e-5

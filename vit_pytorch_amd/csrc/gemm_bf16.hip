@@ -24,6 +24,7 @@
 //  * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs walks a contiguous run of tiles, so the activation panel
 //    a tile row shares is fetched into one L2, not eight.
 #include "common.h"
+#include "gemm_nt_plan.h"
 #include <stdlib.h>
 
 namespace {
@@ -813,9 +814,20 @@ extern "C" int vitk_gemm_nt_fp8(const void* A, int64_t lda, const void* W, int64
 
 extern "C" int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const NtpPlan q = ntp_plan(M, N, K, ldc, nullptr);      // the persistent kernel serves every 16-bit call it accepts
+    if (q.ok) return ntp_colsum_rows(q);
     const NtPlan pl = nt_plan(M, N, K, ldc, nullptr);
     if (!pl.large) return 0;
     return 2 * ((M + 32 * pl.fm - 1) / (32 * pl.fm));
+}
+
+extern "C" int vitk_gemm_nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, int32_t* out5) {
+    if (!out5) VITK_FAIL(VITK_E_ARG, "gemm_nt_plan: null output");
+    for (int i = 0; i < 5; ++i) out5[i] = 0;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const NtpPlan q = ntp_plan(M, N, K, ldc, nullptr);
+    if (q.ok) { out5[0] = 1; out5[1] = q.tm_main; out5[2] = q.tail_tm; out5[3] = q.grid; out5[4] = q.tiles_n; }
+    return 0;
 }
 
 extern "C" int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -843,6 +855,27 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     if ((lda & 7) || (ldw & 7) || (ldc & 3) || !aligned16(A) || !aligned16(W) || !aligned16(C) || (bias && !aligned8(bias)) ||
         (resid && !aligned16(resid)) || (aux && !aligned8(aux)))
         VITK_FAIL(VITK_E_ALIGN, "gemm_nt_bf16: lda/ldw %% 8, ldc %% 4 and 16-byte aligned pointers required");
+    if (!fp8 && !f8.p && !f8.amax) {
+        // 16-bit operands at M >= 1024: the persistent kernel (gemm_nt_persist.hip)
+        // Per-epilogue dispatch [measured, tools/nt_ab.py]: the persistent kernel wins where the epilogue is heavy (f32 residual
+        // 1.04-1.12x, bias+GELU 1.07x, GELU'+column sums 1.02x) and is level or slightly behind on plain 16-bit stores
+        // (0.94-1.0x), which therefore stay on the per-tile kernel.  VITK_NTP_EPIS = bit mask over VITK_EPI_* overrides.
+        const NtpPlan q = ntp_plan(M, N, K, ldc, aux);
+        const unsigned epis = getenv("VITK_NTP_EPIS") ? (unsigned)atoi(getenv("VITK_NTP_EPIS")) : 0x1cu;
+        if (q.ok && epilogue >= 0 && epilogue <= 4 && (((epis >> epilogue) & 1u) || epilogue == VITK_EPI_GELU_BWD)) {
+            switch (epilogue) {
+                case VITK_EPI_NONE: break;
+                case VITK_EPI_BIAS: if (!bias) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS needs bias"); break;
+                case VITK_EPI_BIAS_GELU: if (!bias || !aux) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS_GELU needs bias and aux"); break;
+                case VITK_EPI_RESID: if (!resid) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_RESID needs resid"); break;
+                case VITK_EPI_GELU_BWD: if (!aux) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_GELU_BWD needs aux"); break;
+                default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: bad epilogue %d", epilogue);
+            }
+            if (drop_t && epilogue != VITK_EPI_RESID && epilogue != VITK_EPI_BIAS_GELU && epilogue != VITK_EPI_GELU_BWD)
+                VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: fused dropout exists for the RESID / BIAS_GELU / GELU_BWD epilogues only");
+            return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);
+        }
+    }
     const NtPlan pl = nt_plan(M, N, K, ldc, aux);
     const bool large = pl.large;
     const int fm = pl.fm;

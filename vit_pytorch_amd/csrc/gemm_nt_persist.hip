@@ -1,0 +1,626 @@
+// gemm_nt_persist.hip -- persistent NT GEMM for gfx950:  C[M,N] = A[M,K] . W[N,K]^T (+ fused epilogue)
+//
+// Replaces nn.Linear forward (vit.py:20,23,44,47) and the dX GEMMs of its autograd at the sizes that dominate the step
+// (M >= 1024 token rows).  Same arithmetic as gemm_nt256pp_kernel (gemm_bf16.hip): 256-column tiles, 8 waves (2 x 4), wave
+// tile 128 x 64 on v_mfma_f32_16x16x32, K-step 32, operands HBM -> LDS by global_load_lds into four 32 KiB stages with
+// counted vmcnt, the two waves of a SIMD running one barrier slot apart (ping-pong).  What is different:
+//
+//  * ONE RESIDENT WORKGROUP PER CU walks a static list of tiles.  The K-step stream (tile, k) is continuous: the LDS-DMA of the
+//    next tile's first three K-steps is issued during the last three K-steps of the current tile and stays in flight across
+//    the epilogue, so a tile has no pipeline fill.  At K = 768 (24 K-steps) fill + drain used to be ~20 % of a tile.
+//  * THE EPILOGUE NEVER TOUCHES THE DMA RING (so the ring keeps running under it) and its global stores are not waited
+//    for: the counted vmcnt of the following K-steps allows for them (vmcnt retires in order), they drain under the next
+//    tile's MFMAs.  Every store instruction still covers FULL 128-byte lines (a first version with 64-byte pieces of 16 rows
+//    per instruction measured 0.82-0.95x the per-tile kernel: the epilogue is store-ISSUE bound, cost ~ lines touched):
+//    the MFMA "A" operand is the activation fragment and "B" the W fragment, so a lane holds output rows 4g..4g+3 of ONE
+//    column; the LDS-DMA places W row  4c + fn  of the wave's 64 columns at LDS row  16 fn + c  (a per-lane SOURCE address,
+//    free), so lane c's four fragments are 4 CONSECUTIVE columns 4c..4c+3 of each of its rows.  f32 outputs (residual
+//    epilogue): 16 bytes per lane, 16 lanes = 256 contiguous bytes of a row, 4 rows per instruction.  16-bit outputs: lane
+//    pairs (c, c^1) trade the halves of two rows through a DPP quad permute, after which even lanes own 8 consecutive
+//    columns of row r and odd lanes of row r + 1: 8 lanes = one 128-byte line, 8 lines per dwordx4 instruction.
+//  * the bias vector is staged ONCE per workgroup in the 32 KiB of LDS above the ring: a vector load in the epilogue would
+//    queue behind the LDS-DMA stream on vmcnt (hipcc waits vmcnt(0) for it -- an exposed memory round trip per tile).
+//  * TILE HEIGHTS 256 AND 128 in one launch (gemm_nt_plan.h): the rows that would form a mostly idle last round of 256-row
+//    tiles are cut into 128-row tiles (wave tile 64 x 64, two barrier slots per K-step instead of four).
+//  * the bias-gradient column sums of the GELU' epilogue are reduced in registers (DPP + v_permlane swaps).
+//
+// Scheduling of slots per K-step (group A = waves 0-3, group B = waves 4-7 one slot behind):
+//   256-row tile:  R0 (read W + X[0..3] fragments, DMA A of K-step +3)  M0 (16 MFMA)  R1 (read X[4..7], DMA W of +3, counted
+//                  wait for K-step +1)  M1 (16 MFMA)
+//   128-row tile:  R0 (read W + X[0..3], DMA A and W of +3, counted wait)  M0 (16 MFMA)
+// LDS hazards are those of gemm_nt256pp_kernel: a stage is re-filled only after the barrier that follows the last read of it
+// by BOTH groups, and read only after every wave's counted vmcnt plus a barrier.
+#include "common.h"
+#include "gemm_nt_plan.h"
+#include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
+#include <type_traits>
+
+namespace {
+
+constexpr int Q_TILE_BYTES = 256 * 64;              // one operand, one K-step: 256 rows of 64 bytes
+constexpr int Q_STAGE_BYTES = 2 * Q_TILE_BYTES;     // 32 KiB
+constexpr int Q_LDS_BYTES = 4 * Q_STAGE_BYTES;      // 128 KiB ring
+constexpr int Q_LDS_MAX = Q_LDS_BYTES + 32768;      // + bias image
+
+#define QQ_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+__device__ __forceinline__ int q_swz(int x) { return (0x1320 >> (4 * (x & 3))) & 3; }   // permutation [0,2,3,1]
+
+__device__ __forceinline__ void q_grouped_tile(int t, int tiles_m, int tiles_n, int gn, int& tm, int& tn) {
+    const int per_group = gn * tiles_m;
+    const int g = t / per_group;
+    const int r = t - g * per_group;
+    const int rem = tiles_n - g * gn;
+    const int w = rem < gn ? rem : gn;
+    tm = r / w;
+    tn = g * gn + (r - tm * w);
+}
+
+struct NtpArgs {
+    const char* A; long long lda;      // element strides; operands are 2-byte elements
+    const char* W; long long ldw;
+    void* C; long long ldc;
+    int M, N, K;
+    const __bf16* bias; const float* resid; __bf16* aux; float* csum;
+    int tiles_n, group_n, tm_main, tail_tm, n_main, n_tail, nt;
+    unsigned drop_t, drop_seed; float inv_keep;     // fused nn.Dropout (vit.py:22,24,48): threshold 0 = off
+    int tail_first;
+    int dbg;            // experiments: bit 0 = skip the epilogue, bit 1 = start-up stagger of the workgroups of an XCD
+};
+
+template <int N_> __device__ __forceinline__ void q_wait_vm() {
+    if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N_ == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N_ == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N_ == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else static_assert(N_ < 0, "unsupported vmcnt");
+}
+
+// 8-wide forms of common.h's gelu_fast2 / gelu_grad_fast2 (same polynomial, same operation order per element): written on
+// 8-vectors so that every Horner step is four INDEPENDENT v_pk_fma_f32 -- the 2-wide form compiled to one dependent chain
+// per pair with a stall slot after every step.
+typedef float q_f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ q_f32x8 q_splat8(float v) { return q_f32x8{v, v, v, v, v, v, v, v}; }
+__device__ __forceinline__ q_f32x8 q_phi8(q_f32x8 x) {
+    q_f32x8 xc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xc[e] = __builtin_amdgcn_fmed3f(x[e], -4.5f, 4.5f);
+    const q_f32x8 u = xc * xc;
+    q_f32x8 q = __builtin_elementwise_fma(u, q_splat8(3.619783835e-11f), q_splat8(-3.842468662e-09f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(1.789582063e-07f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(-4.853476327e-06f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(8.614045158e-05f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(-1.069849927e-03f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(9.707349039e-03f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(-6.620850869e-02f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(3.988530737e-01f));
+    return __builtin_elementwise_fma(xc, q, q_splat8(0.5f));
+}
+__device__ __forceinline__ q_f32x8 q_gelu8(q_f32x8 x) { return x * q_phi8(x); }
+__device__ __forceinline__ q_f32x8 q_gelu_grad8(q_f32x8 x) {
+    const q_f32x8 w = x * x * q_splat8(-0.72134752044448170368f);
+    q_f32x8 e;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(w[i]);
+    return __builtin_elementwise_fma(x * q_splat8(0.39894228040143267794f), e, q_phi8(x));
+}
+__device__ __forceinline__ q_f32x8 q_widen8(bf16x8 v) {
+    q_f32x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
+    return r;
+}
+__device__ __forceinline__ bf16x8 q_narrow8(q_f32x8 v) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
+    return r;
+}
+
+// stores a wave issues in the epilogue of an interior tile (no row / column masking: every store instruction is issued)
+template <int EPI> __host__ __device__ constexpr int q_stores_per_frag_row() {
+    return (EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_RESID) ? 4 : 2;
+}
+
+template <int EPI> __host__ __device__ constexpr bool q_has_bias() {
+    return EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_RESID;
+}
+
+__device__ __forceinline__ unsigned q_dpp_xor1(unsigned v) {       // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned q_pack2(float a, float b) {
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI, bool EXACT>
+__global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool grp_b = wave >= 4;
+
+    // ---- this workgroup's tiles: XCD x owns a contiguous run of the main list and of the tail list; its workgroups take
+    //      every L-th tile of the concatenation, so the tiles an XCD works on at one time are neighbours in the grouped order
+    //      (shared activation panel in ONE L2).  Placement b % 8 is the observed one; only speed depends on it.
+    //      tail_first: the 128-row tiles lead, which leaves the workgroups that own one half a tile out of phase with the
+    //      others for the rest of the launch (their store bursts then fall into the others' main loops).
+    const int xcd = blockIdx.x & 7, l0 = blockIdx.x >> 3, L = gridDim.x >> 3;
+    const int ms = (int)(((long long)xcd * p.n_main) >> 3), cm = (int)(((long long)(xcd + 1) * p.n_main) >> 3) - ms;
+    const int ts = (int)(((long long)xcd * p.n_tail) >> 3), ct = (int)(((long long)(xcd + 1) * p.n_tail) >> 3) - ts;
+    const int count = cm + ct;
+    if (l0 >= count) return;
+    const int ntiles = (count - l0 + L - 1) / L;
+    const int total_steps = ntiles * p.nt;
+    const int c_first = p.tail_first ? ct : cm;          // length of the leading run
+
+    auto decode = [&](int idx, int& m0, int& half, int& n0, int& mt) {
+        int tm, tn;
+        const bool lead = idx < c_first;
+        const int k = lead ? idx : idx - c_first;
+        if (lead != (p.tail_first != 0)) {
+            q_grouped_tile(ms + k, p.tm_main, p.tiles_n, p.group_n, tm, tn);
+            m0 = tm * 256; half = 0; mt = tm;
+        } else {
+            q_grouped_tile(ts + k, p.tail_tm, p.tiles_n, p.group_n, tm, tn);
+            m0 = p.tm_main * 256 + tm * 128; half = 1; mt = p.tm_main + tm;
+        }
+        n0 = tn * 256;
+    };
+
+    // ---- producer: the LDS-DMA stream runs three K-steps ahead of the consumer, across tile boundaries ----
+    // 64-byte rows, a wave instruction fills 16 rows; wave w owns LDS row groups 2w, 2w+1 of each operand tile.  The LDS image
+    // is lane-linear, so the bank swizzle sits in the SOURCE address: position s of LDS row R holds logical 16-byte chunk
+    // s ^ q_swz(R >> 2).  Activation tile: LDS row R = tile row R.  W tile: LDS row R = 64 q + 16 fn + c holds W row
+    // 64 q + 4 c + fn (see the header: a lane's four B fragments are then 4 consecutive output columns).
+    const int srow = lane >> 2, spos = lane & 3;
+    const int schunk = spos ^ q_swz(lane >> 4);
+    const char* a_src[2];
+    const char* w_src[2];
+    int p_idx = l0, p_kt = 0, p_g = 0;
+    bool p_more = true;
+    auto setup_src = [&](int idx) {
+        int m0, half, n0, mt;
+        decode(idx, m0, half, n0, mt);
+        int mlast = m0 + (half ? 128 : 256);
+        mlast = (mlast < p.M ? mlast : p.M) - 1;            // rows past the tile (half tiles) or past M re-read its last row
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rg = wave * 2 + j;
+            int ar = m0 + rg * 16 + srow; ar = ar < mlast ? ar : mlast;
+            int wr = n0 + (rg >> 2) * 64 + 4 * srow + (rg & 3); wr = wr < p.N ? wr : p.N - 1;
+            a_src[j] = p.A + (long long)ar * p.lda * 2 + schunk * 16;
+            w_src[j] = p.W + (long long)wr * p.ldw * 2 + schunk * 16;
+        }
+    };
+    auto issue_a = [&]() {
+        if (!p_more) return;
+        char* base = lds + (p_g & 3) * Q_STAGE_BYTES + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + p_kt * 64),
+                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
+    };
+    auto issue_w = [&]() {
+        if (!p_more) return;
+        char* base = lds + (p_g & 3) * Q_STAGE_BYTES + Q_TILE_BYTES + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + p_kt * 64),
+                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
+        ++p_g;
+        if (++p_kt == p.nt) {
+            p_kt = 0;
+            p_idx += L;
+            if (p_idx < count) setup_src(p_idx); else p_more = false;
+        }
+    };
+
+    // ---- bias -> LDS (above the ring), once ----
+    const char* bias_lds = lds + Q_LDS_BYTES;
+    if constexpr (q_has_bias<EPI>()) {
+        const int ncols = p.tiles_n * 256;
+        for (int i = tid * 8; i < ncols; i += 512 * 8) {
+            bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.bias && i < p.N) v = *reinterpret_cast<const bf16x8*>(p.bias + i);
+            *reinterpret_cast<bf16x8*>(lds + Q_LDS_BYTES + i * 2) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // written before the prologue's barrier publishes it
+    }
+
+    // ---- consumer ----
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fpos = fg ^ q_swz(fi >> 2);
+    const int a_off8 = (wm * 128 + fi) * 64 + fpos * 16;                 // + f * 1024   (256-row tile)
+    const int a_off4 = (wm * 64 + fi) * 64 + fpos * 16;                  // + f * 1024   (128-row tile)
+    const int w_off = Q_TILE_BYTES + (wn * 64 + fi) * 64 + fpos * 16;    // + fn * 1024
+
+    int c_g = 0;            // global K-step counter of this workgroup
+    int st_steps = 0;       // K-steps during which the previous epilogue's stores are still younger than the awaited DMA
+    constexpr int S8 = 8 * q_stores_per_frag_row<EPI>();   // stores per wave, interior 256-row tile
+    // counted wait at the end of K-step c_g: the DMA of K-step c_g + 1 has landed; what may still be in flight is the
+    // DMA of K-steps c_g + 2 and c_g + 3 (4 instructions each) and, for the first two K-steps after an interior 256-row
+    // epilogue, that epilogue's S8 stores, which sit between them in issue order.
+    auto wait_next = [&]() {
+        const int rem = total_steps - (c_g + 2);
+        if (rem >= 2) {
+            if (EXACT && st_steps > 0) q_wait_vm<8 + S8>(); else q_wait_vm<8>();
+        } else if (rem == 1) q_wait_vm<4>();
+        else q_wait_vm<0>();
+        if (st_steps > 0) --st_steps;
+    };
+
+    auto run_tile = [&](auto fmw_c, int m0, int n0, int mt) {
+        constexpr int FMW = decltype(fmw_c)::value;      // m-fragments per wave: 8 (256-row tile) or 4 (128-row tile)
+        const int a_off = FMW == 8 ? a_off8 : a_off4;
+        f32x4 acc[4][FMW];                               // acc[fn][f][j]: row 16 f + 4 fg + j, column 4 fi + fn (of the wave tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < FMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < p.nt; ++kt) {
+            const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
+            bf16x8 wf[4], xf[4];
+            // ---- R0 ----
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(base + w_off + f * 1024);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + f * 1024);
+            issue_a();
+            if constexpr (FMW == 4) { issue_w(); wait_next(); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            QQ_BARRIER();
+            // ---- M0 ----
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][f], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            QQ_BARRIER();
+            if constexpr (FMW == 8) {
+                // ---- R1 ----
+#pragma unroll
+                for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
+                issue_w();
+                wait_next();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                QQ_BARRIER();
+                // ---- M1 ----
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][4 + f], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                QQ_BARRIER();
+            }
+            ++c_g;
+        }
+
+        // ---- epilogue: registers -> global, full lines, stores not waited for ----
+        const int mrow0 = m0 + wm * (16 * FMW) + 4 * fg;          // + 16 f + j
+        if (p.dbg & 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < FMW; ++j) asm volatile("" :: "v"(acc[i][j]));
+            return;
+        }
+        const bool interior = (m0 + 32 * FMW <= p.M) && (n0 + 256 <= p.N);
+        auto body = [&](auto int_c) {
+            constexpr bool INT = decltype(int_c)::value;
+            const int ncol4 = n0 + wn * 64 + 4 * fi;               // this lane's 4 columns before any exchange
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (q_has_bias<EPI>()) {
+                const bf16x4 bb = *reinterpret_cast<const bf16x4*>(bias_lds + ncol4 * 2);
+                b4 = f32x4{(float)bb[0], (float)bb[1], (float)bb[2], (float)bb[3]};
+            }
+            if constexpr (F32OUT) {
+                // lane: rows mrow0 + 16 f + j, 4 consecutive f32 columns: 16 lanes = 256 contiguous bytes of a row
+                const bool colok = INT || ncol4 < p.N;
+                float* Cf = reinterpret_cast<float*>(p.C);
+                f32x4 r[2][4];
+                auto fetch = [&](int f, f32x4 (&dst)[4]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int m = mrow0 + f * 16 + j;
+                        if (!INT) m = m < p.M ? m : p.M - 1;
+                        dst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (colok) dst[j] = *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldc + ncol4);
+                    }
+                };
+                fetch(0, r[0]);
+                fetch(1, r[1]);
+#pragma unroll
+                for (int f = 0; f < FMW; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = mrow0 + f * 16 + j;
+                        f32x4 v = f32x4{acc[0][f][j], acc[1][f][j], acc[2][f][j], acc[3][f][j]} + b4;
+                        if (p.drop_t) {       // nn.Dropout on the Linear output, before the residual add (vit.py:24,48 + :80-81)
+                            const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = drop_keep(hrow, (unsigned)(ncol4 + e), p.drop_t) ? v[e] * p.inv_keep : 0.f;
+                        }
+                        v += r[f & 1][j];
+                        if (INT || (m < p.M && colok)) *reinterpret_cast<f32x4*>(Cf + (long long)m * p.ldc + ncol4) = v;
+                    }
+                    if (f + 2 < FMW) fetch(f + 2, r[f & 1]);
+                }
+            } else {
+                // after the pair exchange: even lanes own row r = mrow0 + 16 f + 2 pr, odd lanes row r + 1, columns ncol8 .. + 7
+                const int odd = fi & 1;
+                const int ncol8 = n0 + wn * 64 + 8 * (fi >> 1);
+                const bool colok = INT || ncol8 < p.N;
+                __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+                bf16x8 hpre[2][2];             // GELU_BWD: saved pre-activations, fetched two fragment rows ahead
+                auto fetch_pre = [&](int f, bf16x8 (&dst)[2]) {
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        int m = mrow0 + f * 16 + 2 * pr + odd;
+                        if (!INT) m = m < p.M ? m : p.M - 1;
+                        dst[pr] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        if (colok) dst[pr] = *reinterpret_cast<const bf16x8*>(p.aux + (long long)m * p.ldc + ncol8);
+                    }
+                };
+                if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                    fetch_pre(0, hpre[0]);
+                    fetch_pre(1, hpre[1]);
+                }
+                float cs[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#pragma unroll
+                for (int f = 0; f < FMW; ++f) {
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        // rows j0 = 2 pr and j0 + 1 of this lane's 4 columns, rounded to the 16-bit type
+                        const int j0 = 2 * pr;
+                        const unsigned a0 = q_pack2(acc[0][f][j0] + b4[0], acc[1][f][j0] + b4[1]);
+                        const unsigned a1 = q_pack2(acc[2][f][j0] + b4[2], acc[3][f][j0] + b4[3]);
+                        const unsigned c0 = q_pack2(acc[0][f][j0 + 1] + b4[0], acc[1][f][j0 + 1] + b4[1]);
+                        const unsigned c1 = q_pack2(acc[2][f][j0 + 1] + b4[2], acc[3][f][j0 + 1] + b4[3]);
+                        // even lane keeps row j0 and receives the neighbour's 4 columns of it; odd lane likewise for row j0 + 1
+                        const unsigned r0 = q_dpp_xor1(odd ? a0 : c0), r1 = q_dpp_xor1(odd ? a1 : c1);
+                        const unsigned k0 = odd ? c0 : a0, k1 = odd ? c1 : a1;
+                        const q_u32x4 w4 = odd ? q_u32x4{r0, r1, k0, k1} : q_u32x4{k0, k1, r0, r1};
+                        const bf16x8 v = __builtin_bit_cast(bf16x8, w4);
+                        const int m = mrow0 + f * 16 + j0 + odd;
+                        const bool ok = INT || (m < p.M && colok);
+                        const long long o = (long long)m * p.ldc + ncol8;
+                        if constexpr (EPI == VITK_EPI_NONE || EPI == VITK_EPI_BIAS) {
+                            if (ok) *reinterpret_cast<bf16x8*>(Cb + o) = v;
+                        } else if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+                            if (ok) *reinterpret_cast<bf16x8*>(p.aux + o) = v;
+                            bf16x8 g8 = q_narrow8(q_gelu8(q_widen8(v)));     // of the ROUNDED pre-activation
+                            if (p.drop_t) {       // nn.Dropout after the GELU (vit.py:22): the saved pre-activation stays undropped
+                                const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    g8[e] = drop_keep(hrow, (unsigned)(ncol8 + e), p.drop_t) ? (__bf16)((float)g8[e] * p.inv_keep) : (__bf16)0.f;
+                            }
+                            if (ok) *reinterpret_cast<bf16x8*>(Cb + o) = g8;
+                        } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                            const bf16x8 h8 = hpre[f & 1][pr];
+                            q_f32x8 g = q_widen8(v) * q_gelu_grad8(q_widen8(h8));
+                            if (p.drop_t) {     // factor of the forward's dropout(gelu(pre)) at (m, n): same decision, same 1 / (1 - p)
+                                const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) g[e] *= drop_keep(hrow, (unsigned)(ncol8 + e), p.drop_t) ? p.inv_keep : 0.f;
+                            }
+                            const bf16x8 g8 = q_narrow8(g);
+                            if (ok) {
+                                *reinterpret_cast<bf16x8*>(Cb + o) = g8;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) cs[e] += (float)g8[e];     // of the ROUNDED values: what colsum(C) would read
+                            }
+                        }
+                    }
+                    if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                        if (f + 2 < FMW) fetch_pre(f + 2, hpre[f & 1]);
+                    }
+                }
+                if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                    if (p.csum) {
+                        // bias gradient by-product: the 8 lanes (c ^ 1, 4 row groups) that own the same 8 columns are summed in
+                        // registers; one partial row per (m-tile, wm)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float v = cs[e];
+                            v += __builtin_bit_cast(float, q_dpp_xor1(__builtin_bit_cast(unsigned, v)));
+                            unsigned u = __builtin_bit_cast(unsigned, v);
+                            auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                            v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+                            u = __builtin_bit_cast(unsigned, v);
+                            auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                            cs[e] = __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+                        }
+                        if (fg == 0 && !odd && colok) {
+                            float* cp = p.csum + (long long)(2 * mt + wm) * p.N + ncol8;
+                            *reinterpret_cast<f32x4*>(cp) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+                            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+                        }
+                    }
+                }
+            }
+        };
+        if (interior) {
+            body(std::integral_constant<bool, true>{});
+            st_steps = (FMW == 8) ? 2 : 0;
+        } else {
+            body(std::integral_constant<bool, false>{});
+            st_steps = 0;
+        }
+    };
+
+    if (p.dbg & 2) {        // experiment: de-phase the workgroups of an XCD by eighths of ~a tile time (K-step ~ 0.8 us)
+        const int ph = l0 & 7;
+        const long long t0 = __builtin_readcyclecounter();
+        const long long wait = (long long)ph * p.nt * 210;     // ~ nt * 0.8 us * 2.1 GHz / 8
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+    // ---- prologue: K-steps 0..2 in flight, K-step 0 landed ----
+    setup_src(p_idx);
+    issue_a(); issue_w();
+    issue_a(); issue_w();
+    issue_a(); issue_w();
+    if (total_steps > 2) q_wait_vm<8>();
+    else if (total_steps > 1) q_wait_vm<4>();
+    else q_wait_vm<0>();
+    QQ_BARRIER();              // also publishes the bias image
+    if (grp_b) QQ_BARRIER();   // group B runs one slot behind group A
+
+    for (int idx = l0; idx < count; idx += L) {
+        int m0, half, n0, mt;
+        decode(idx, m0, half, n0, mt);
+        if (half) run_tile(std::integral_constant<int, 4>{}, m0, n0, mt);
+        else run_tile(std::integral_constant<int, 8>{}, m0, n0, mt);
+    }
+    if (!grp_b) QQ_BARRIER();  // pairs with group B's extra barrier
+}
+
+template <typename Kern>
+int q_set_max_lds(Kern kernel, int bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int q_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) return 256;
+        return v;
+    }();
+    return n;
+}
+
+// makespan of the static assignment (see the kernel): XCD x owns main tiles [x n_main / 8, (x+1) n_main / 8) and the same share
+// of the tail tiles; its L workgroups take every L-th tile of (main ++ tail).
+long long q_makespan(int n_main, int n_tail, int L, long long c_full, long long c_half) {
+    long long worst = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int cm = (int)(((long long)(x + 1) * n_main) >> 3) - (int)(((long long)x * n_main) >> 3);
+        const int ct = (int)(((long long)(x + 1) * n_tail) >> 3) - (int)(((long long)x * n_tail) >> 3);
+        const int cnt = cm + ct;
+        for (int l = 0; l < L && l < cnt; ++l) {
+            const int nall = (cnt - l + L - 1) / L;
+            const int nm = l < cm ? (cm - l + L - 1) / L : 0;
+            const long long c = nm * c_full + (nall - nm) * c_half;
+            if (c > worst) worst = c;
+        }
+    }
+    return worst;
+}
+
+}  // namespace
+
+NtpPlan ntp_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
+    NtpPlan pl{};
+    pl.ok = (K % 32 == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux)) &&
+            M < (1 << 30) && N <= 16384 /* bias image: 32 KiB of LDS above the ring */ && !getenv("VITK_NO_256") && !getenv("VITK_NO_PERSIST");
+    if (!pl.ok) return pl;
+    struct Key { int64_t m, n, k; bool operator==(const Key& o) const { return m == o.m && n == o.n && k == o.k; } };
+    struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.m * 1000003 + k.n * 10007 + k.k); } };
+    static std::mutex mu;
+    static std::unordered_map<Key, NtpPlan, KeyHash> cache;
+    const Key key{M, N, K};
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    pl.tiles_n = (int)((N + 255) / 256);
+    pl.group_n = pl.tiles_n;
+    if (pl.tiles_n > 8) pl.group_n = (pl.tiles_n + (pl.tiles_n + 5) / 6 - 1) / ((pl.tiles_n + 5) / 6);
+    if (getenv("VITK_GROUP_N")) pl.group_n = atoi(getenv("VITK_GROUP_N")) > 0 ? atoi(getenv("VITK_GROUP_N")) : pl.tiles_n;
+    if (pl.group_n > pl.tiles_n) pl.group_n = pl.tiles_n;
+    pl.nt = (int)(K / 32);
+    pl.grid = q_num_cus() / 8 * 8;
+    const int L = pl.grid / 8;
+    // cost of a tile in barrier slots: 4 (2) per K-step of a 256-row (128-row) tile plus the epilogue
+    const long long e_full = getenv("VITK_NTP_EFULL") ? atoll(getenv("VITK_NTP_EFULL")) : 16;
+    const long long e_half = getenv("VITK_NTP_EHALF") ? atoll(getenv("VITK_NTP_EHALF")) : 12;
+    const long long c_full = 4LL * pl.nt + e_full, c_half = 2LL * pl.nt + e_half;
+    const int full_tm = (int)(M / 256);
+    // candidate 0: no tail (every tile 256 rows, the last m-tile partial)
+    int best_tm = (int)((M + 255) / 256), best_tail = 0;
+    long long best = q_makespan(best_tm * pl.tiles_n, 0, L, c_full, c_half);
+    const int dmax = full_tm < 512 ? full_tm : 512;
+    for (int d = 0; d <= dmax; ++d) {
+        const int tm_main = full_tm - d;
+        const int64_t rows_tail = M - 256LL * tm_main;
+        if (rows_tail <= 0) continue;
+        const int tail_tm = (int)((rows_tail + 127) / 128);
+        const long long c = q_makespan(tm_main * pl.tiles_n, tail_tm * pl.tiles_n, L, c_full, c_half);
+        if (c < best) { best = c; best_tm = tm_main; best_tail = tail_tm; }
+    }
+    if (getenv("VITK_NTP_TAIL")) {      // experiments: number of 256-row m-tiles moved to the tail
+        const int d = atoi(getenv("VITK_NTP_TAIL"));
+        if (d < 0) { best_tm = (int)((M + 255) / 256); best_tail = 0; }
+        else {
+            best_tm = full_tm - d < 0 ? 0 : full_tm - d;
+            best_tail = (int)((M - 256LL * best_tm + 127) / 128);
+        }
+    }
+    pl.tm_main = best_tm;
+    pl.tail_tm = best_tail;
+    pl.n_main = pl.tm_main * pl.tiles_n;
+    pl.n_tail = pl.tail_tm * pl.tiles_n;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        cache.emplace(key, pl);
+    }
+    return pl;
+}
+
+int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                    int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* csum, unsigned drop_t,
+                    unsigned drop_seed, float inv_keep, void* stream) {
+    NtpArgs a;
+    a.drop_t = drop_t; a.drop_seed = drop_seed; a.inv_keep = inv_keep;
+    a.A = (const char*)A; a.lda = lda; a.W = (const char*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.bias = (const __bf16*)bias; a.resid = resid; a.aux = (__bf16*)aux; a.csum = csum;
+    a.tiles_n = pl.tiles_n; a.group_n = pl.group_n; a.tm_main = pl.tm_main; a.tail_tm = pl.tail_tm;
+    a.n_main = pl.n_main; a.n_tail = pl.n_tail; a.nt = pl.nt;
+    static const int tail_first = getenv("VITK_NTP_TAIL_LAST") ? 0 : 1;
+    a.tail_first = tail_first;
+    a.dbg = getenv("VITK_NTP_DBG") ? atoi(getenv("VITK_NTP_DBG")) : 0;
+    const int lds_bytes = Q_LDS_BYTES + pl.tiles_n * 512;      // ring + bias image (tiles_n * 256 columns of 2 bytes)
+    hipStream_t st = (hipStream_t)stream;
+    static const bool exact = !getenv("VITK_NTP_NOEXACT");
+#define NTP_LAUNCH(E) do { \
+        if (exact) { \
+            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, true>, Q_LDS_MAX); \
+            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
+            hipLaunchKernelGGL((gemm_ntp_kernel<E, true>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+        } else { \
+            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, false>, Q_LDS_MAX); \
+            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
+            hipLaunchKernelGGL((gemm_ntp_kernel<E, false>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+        } } while (0)
+    switch (epilogue) {
+        case VITK_EPI_NONE: NTP_LAUNCH(VITK_EPI_NONE); break;
+        case VITK_EPI_BIAS: NTP_LAUNCH(VITK_EPI_BIAS); break;
+        case VITK_EPI_BIAS_GELU: NTP_LAUNCH(VITK_EPI_BIAS_GELU); break;
+        case VITK_EPI_RESID: NTP_LAUNCH(VITK_EPI_RESID); break;
+        case VITK_EPI_GELU_BWD: NTP_LAUNCH(VITK_EPI_GELU_BWD); break;
+        default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: bad epilogue %d", epilogue);
+    }
+#undef NTP_LAUNCH
+    VITK_CHECK_LAUNCH("gemm_nt_bf16 (persistent)");
+    return 0;
+}

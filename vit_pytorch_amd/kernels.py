@@ -129,6 +129,14 @@ def gemm_nt_colsum_rows(M: int, N: int, K: int, ldc: int) -> int:
     return int(L.load().vitk_gemm_nt_colsum_rows(M, N, K, ldc))
 
 
+def gemm_nt_plan(M: int, N: int, K: int, ldc: int) -> dict:
+    """Tile schedule of the persistent NT kernel (vitk_gemm_nt_plan)."""
+    import ctypes
+    out = (ctypes.c_int32 * 5)()
+    check(L.load().vitk_gemm_nt_plan(M, N, K, ldc, ctypes.cast(out, ctypes.c_void_p)), "gemm_nt_plan")
+    return {"persistent": bool(out[0]), "tiles_m256": out[1], "tiles_m128": out[2], "workgroups": out[3], "tiles_n": out[4]}
+
+
 def gemm_nt_bf16_gelu_bwd_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
                                  aux: Tensor, partials: Tensor):
     check(_lib_for(A, W, C, aux, partials).vitk_gemm_nt_bf16_gelu_bwd_colsum(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, _p(aux), _p(partials),
