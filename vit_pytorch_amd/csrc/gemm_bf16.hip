@@ -857,11 +857,13 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
         VITK_FAIL(VITK_E_ALIGN, "gemm_nt_bf16: lda/ldw %% 8, ldc %% 4 and 16-byte aligned pointers required");
     if (!fp8 && !f8.p && !f8.amax) {
         // 16-bit operands at M >= 1024: the persistent kernel (gemm_nt_persist.hip)
-        // Per-epilogue dispatch [measured, tools/nt_ab.py]: the persistent kernel wins where the epilogue is heavy (f32 residual
-        // 1.04-1.12x, bias+GELU 1.07x, GELU'+column sums 1.02x) and is level or slightly behind on plain 16-bit stores
-        // (0.94-1.0x), which therefore stay on the per-tile kernel.  VITK_NTP_EPIS = bit mask over VITK_EPI_* overrides.
+        // Every epilogue goes to the persistent kernel.  [measured] kernel by kernel (tools/nt_ab.py, one stream) it wins where the
+        // epilogue is heavy (f32 residual 1.04-1.12x, bias+GELU 1.07x) and is level or slightly behind on plain 16-bit stores
+        // (0.94-1.0x); inside the training step, with the weight-gradient GEMMs running beside it on the side stream, all five on
+        // the persistent kernel is the fastest setting: 40.17 ms/step vs 40.95 (plain stores per-tile) vs 41.60 (all per-tile).
+        // VITK_NTP_EPIS = bit mask over VITK_EPI_* overrides (GELU_BWD always: its column-sum rows follow the persistent plan).
         const NtpPlan q = ntp_plan(M, N, K, ldc, aux);
-        const unsigned epis = getenv("VITK_NTP_EPIS") ? (unsigned)atoi(getenv("VITK_NTP_EPIS")) : 0x1cu;
+        const unsigned epis = getenv("VITK_NTP_EPIS") ? (unsigned)atoi(getenv("VITK_NTP_EPIS")) : 0x1fu;
         if (q.ok && epilogue >= 0 && epilogue <= 4 && (((epis >> epilogue) & 1u) || epilogue == VITK_EPI_GELU_BWD)) {
             switch (epilogue) {
                 case VITK_EPI_NONE: break;

@@ -8,9 +8,8 @@
 //  * ONE RESIDENT WORKGROUP PER CU walks a static list of tiles.  The K-step stream (tile, k) is continuous: the LDS-DMA of the
 //    next tile's first three K-steps is issued during the last three K-steps of the current tile and stays in flight across
 //    the epilogue, so a tile has no pipeline fill.  At K = 768 (24 K-steps) fill + drain used to be ~20 % of a tile.
-//  * THE EPILOGUE NEVER TOUCHES THE DMA RING (so the ring keeps running under it) and its global stores are not waited
-//    for: the counted vmcnt of the following K-steps allows for them (vmcnt retires in order), they drain under the next
-//    tile's MFMAs.  Every store instruction still covers FULL 128-byte lines (a first version with 64-byte pieces of 16 rows
+//  * THE EPILOGUE NEVER TOUCHES THE DMA RING (so the ring keeps running under it).  Every store instruction covers FULL
+//    128-byte lines (a first version with 64-byte pieces of 16 rows
 //    per instruction measured 0.82-0.95x the per-tile kernel: the epilogue is store-ISSUE bound, cost ~ lines touched):
 //    the MFMA "A" operand is the activation fragment and "B" the W fragment, so a lane holds output rows 4g..4g+3 of ONE
 //    column; the LDS-DMA places W row  4c + fn  of the wave's 64 columns at LDS row  16 fn + c  (a per-lane SOURCE address,
@@ -67,16 +66,13 @@ struct NtpArgs {
     int tiles_n, group_n, tm_main, tail_tm, n_main, n_tail, nt;
     unsigned drop_t, drop_seed; float inv_keep;     // fused nn.Dropout (vit.py:22,24,48): threshold 0 = off
     int tail_first;
-    int dbg;            // experiments: bit 0 = skip the epilogue, bit 1 = start-up stagger of the workgroups of an XCD
+    int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone)
 };
 
 template <int N_> __device__ __forceinline__ void q_wait_vm() {
     if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N_ == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N_ == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if constexpr (N_ == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
     else static_assert(N_ < 0, "unsupported vmcnt");
 }
 
@@ -121,11 +117,6 @@ __device__ __forceinline__ bf16x8 q_narrow8(q_f32x8 v) {
     return r;
 }
 
-// stores a wave issues in the epilogue of an interior tile (no row / column masking: every store instruction is issued)
-template <int EPI> __host__ __device__ constexpr int q_stores_per_frag_row() {
-    return (EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_RESID) ? 4 : 2;
-}
-
 template <int EPI> __host__ __device__ constexpr bool q_has_bias() {
     return EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_RESID;
 }
@@ -139,7 +130,7 @@ __device__ __forceinline__ unsigned q_pack2(float a, float b) {
 }
 typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI, bool EXACT>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
@@ -245,18 +236,15 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     const int w_off = Q_TILE_BYTES + (wn * 64 + fi) * 64 + fpos * 16;    // + fn * 1024
 
     int c_g = 0;            // global K-step counter of this workgroup
-    int st_steps = 0;       // K-steps during which the previous epilogue's stores are still younger than the awaited DMA
-    constexpr int S8 = 8 * q_stores_per_frag_row<EPI>();   // stores per wave, interior 256-row tile
-    // counted wait at the end of K-step c_g: the DMA of K-step c_g + 1 has landed; what may still be in flight is the
-    // DMA of K-steps c_g + 2 and c_g + 3 (4 instructions each) and, for the first two K-steps after an interior 256-row
-    // epilogue, that epilogue's S8 stores, which sit between them in issue order.
+    // counted wait at the end of K-step c_g: the DMA of K-step c_g + 1 has landed; the DMA of K-steps c_g + 2 and c_g + 3
+    // (4 instructions each) may stay in flight.  After an epilogue this also waits for that epilogue's stores (they are older
+    // than the DMA of K-step c_g + 3): allowing for them with an exact count (vmcnt(8 + stores), legal because vmcnt
+    // retires in order) measured equal or slower -- whatever is queued behind a CU's stores waits for them anyway.
     auto wait_next = [&]() {
         const int rem = total_steps - (c_g + 2);
-        if (rem >= 2) {
-            if (EXACT && st_steps > 0) q_wait_vm<8 + S8>(); else q_wait_vm<8>();
-        } else if (rem == 1) q_wait_vm<4>();
+        if (rem >= 2) q_wait_vm<8>();
+        else if (rem == 1) q_wait_vm<4>();
         else q_wait_vm<0>();
-        if (st_steps > 0) --st_steps;
     };
 
     auto run_tile = [&](auto fmw_c, int m0, int n0, int mt) {
@@ -457,21 +445,10 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                 }
             }
         };
-        if (interior) {
-            body(std::integral_constant<bool, true>{});
-            st_steps = (FMW == 8) ? 2 : 0;
-        } else {
-            body(std::integral_constant<bool, false>{});
-            st_steps = 0;
-        }
+        if (interior) body(std::integral_constant<bool, true>{});
+        else body(std::integral_constant<bool, false>{});
     };
 
-    if (p.dbg & 2) {        // experiment: de-phase the workgroups of an XCD by eighths of ~a tile time (K-step ~ 0.8 us)
-        const int ph = l0 & 7;
-        const long long t0 = __builtin_readcyclecounter();
-        const long long wait = (long long)ph * p.nt * 210;     // ~ nt * 0.8 us * 2.1 GHz / 8
-        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
     // ---- prologue: K-steps 0..2 in flight, K-step 0 landed ----
     setup_src(p_idx);
     issue_a(); issue_w();
@@ -601,17 +578,11 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     a.dbg = getenv("VITK_NTP_DBG") ? atoi(getenv("VITK_NTP_DBG")) : 0;
     const int lds_bytes = Q_LDS_BYTES + pl.tiles_n * 512;      // ring + bias image (tiles_n * 256 columns of 2 bytes)
     hipStream_t st = (hipStream_t)stream;
-    static const bool exact = !getenv("VITK_NTP_NOEXACT");
 #define NTP_LAUNCH(E) do { \
-        if (exact) { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, true>, Q_LDS_MAX); \
-            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, true>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
-        } else { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, false>, Q_LDS_MAX); \
-            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, false>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
-        } } while (0)
+        static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E>, Q_LDS_MAX); \
+        if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
+        hipLaunchKernelGGL((gemm_ntp_kernel<E>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+    } while (0)
     switch (epilogue) {
         case VITK_EPI_NONE: NTP_LAUNCH(VITK_EPI_NONE); break;
         case VITK_EPI_BIAS: NTP_LAUNCH(VITK_EPI_BIAS); break;
