@@ -209,6 +209,32 @@ def test_hooks_and_submodules_match_fused_path():
     assert tuple(y.shape) == tuple(tokens.shape)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind,case_name", [("vit", "vit_cls_tiny"), ("simple", "cfg1_simple_vit_tiny")])
+def test_16bit_unfused_transformer_keeps_embedding_in_the_graph(kind, case_name, dtype):
+    """A 16-bit model whose embedding runs fused (f32 residual stream out) while the transformer runs op by op (forward hook on
+    `attend`): the dtype hand-over between the two is an autograd node, so cls / pos / patch-embedding parameters still get
+    gradients, and they agree with the fully fused run."""
+    case = CASES[case_name]
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000)
+    scale = 1024.0 if dtype == torch.float16 else 1.0
+    out_f, g_f = run_mine(kind, case["cfg"], params, img, dtype, loss_scale=scale)
+    m = build(kind, case["cfg"], params, dtype)
+    hs = [layer[0].attend.register_forward_hook(lambda mod, i, o: None) for layer in m.transformer.layers]
+    out_h = m(img.to(DEV, dtype=dtype))
+    (O.loss_fn(out_h) * scale).backward()
+    for h in hs:
+        h.remove()
+    assert rel(out_h, out_f) < 2e-2
+    for k, p in m.named_parameters():
+        if p.numel():
+            assert p.grad is not None, f"{k} fell out of the graph"
+            assert rel(p.grad.float() / scale, g_f[k]) < 0.1, k
+    emb = [k for k, _ in m.named_parameters() if k.startswith(("to_patch_embedding", "cls_token", "pos_embedding"))]
+    assert emb and all(g_f[k].abs().sum().item() > 0 for k in emb if g_f[k].numel())
+
+
 def test_cpu_input_fails_loudly():
     m = ViT(**CASES["vit_cls_tiny"]["cfg"])
     with pytest.raises(RuntimeError, match="HIP"):

@@ -177,6 +177,7 @@ class TransformerFn(torch.autograd.Function):
             xs = ops.empty((B, N, D), F32, x)
             K.cast(x, xs)
         saved = []
+        keep = any(ctx.needs_input_grad)      # no_grad / eval: drop each layer's activations as soon as the layer is done
         if drop_p > 0.0 and (lp[3] is None or lp[8] is None or not dropout_fusable(T, B, N, D, heads, dim_head, lp[7].shape[0])):
             raise VitkError("TransformerFn: this shape does not take the fused dropout path (caller must check dropout_fusable)")
         site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
@@ -231,7 +232,8 @@ class TransformerFn(torch.autograd.Function):
                 st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2)
                 act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True, drop=site(li, 2))
                 x3 = ops.linear_fwd(act, w2, b2, M, resid=x2, drop=site(li, 3))
-            saved.append((xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act))
+            if keep:
+                saved.append((xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act))
             xs = x3
         if use8:
             fp8.end_of_forward()
@@ -259,6 +261,8 @@ class TransformerFn(torch.autograd.Function):
         bf = T != F32
         M = B * N
         scale = dim_head ** -0.5
+        if ctx.x_last is None:
+            raise RuntimeError("vit_pytorch_amd: backward through this fused stage a second time -- its saved activations were released during the first backward (retain_graph is not supported by the fused engine)")
         dy = dy.contiguous()
         grads: List[Optional[Tensor]] = [None] * len(lp)
 
@@ -402,6 +406,8 @@ class PatchEmbedFn(torch.autograd.Function):
         sv = ctx.saved_tensors
         ln1w, ln1b, w, ln2w, ln2b = sv[:5]
         bparam = sv[5] if len(sv) > 5 else None
+        if ctx.inter is None:
+            raise RuntimeError("vit_pytorch_amd: backward through this fused stage a second time -- its saved activations were released during the first backward (retain_graph is not supported by the fused engine)")
         patches, st1, pn, y, st2 = ctx.inter
         ctx.inter = None
         B, Np, N, P, D, ncls, has_b, has_cls, pos_grad, pos_shape = ctx.meta
@@ -451,6 +457,19 @@ class PatchEmbedFn(torch.autograd.Function):
         return (None, None, None, _ret(dl1w), _ret(dl1b), _ret(dw), _ret(db), _ret(dl2w), _ret(dl2b), _ret(dcls), _ret(dpos))
 
 
+def _head_dx(dl, w, out, ldo, B, D, C):
+    """d(pooled) = dl . W  (B x C by C x D).  16-bit: an NT GEMM on the MFMA kernel against the cached W^T, the class dimension
+    zero-padded to a multiple of 32 (C = 1000 -> 1024); it used to run on the VALU coverage kernel (0.2 ms of the ViT-B step)."""
+    T = w.dtype
+    if T in ops.HALF and D % 4 == 0 and ldo % 4 == 0:
+        Cp = (C + 31) // 32 * 32
+        wt = ops.transpose_weight(w, pad_to=Cp)                         # (D, Cp)
+        dlp = dl if Cp == C else ops.pad_cols(dl, B, C, Cp)
+        K.gemm_nt_bf16(dlp, Cp, wt, Cp, out, ldo, B, D, Cp)
+    else:
+        K.gemm_generic(K.mat(dl, C, 1), K.mat(w, D, 1), K.mat(out, ldo, 1), B, D, C)
+
+
 class HeadFn(torch.autograd.Function):
     """pool ('cls' -> row 0, 'mean' -> mean over tokens) + Linear head (vit.py:135-138)."""
 
@@ -492,10 +511,10 @@ class HeadFn(torch.autograd.Function):
         ops.linear_dw(dl, src, B, dw, db if has_b else None, ldx=ld)       # dW = dl^T . pooled rows (+ db = colsum(dl))
         if pool_mean:
             dpooled = ops.empty((B, D), T, dl)
-            K.gemm_generic(K.mat(dl, C, 1), K.mat(w, D, 1), K.mat(dpooled, D, 1), B, D, C)
+            _head_dx(dl, w, dpooled, D, B, D, C)
             K.mean_pool_bwd(dpooled, dy, B, N, D)
         else:
-            K.gemm_generic(K.mat(dl, C, 1), K.mat(w, D, 1), K.mat(dy, N * D, 1), B, D, C)  # writes row 0 of each image
+            _head_dx(dl, w, dy, N * D, B, D, C)      # writes row 0 of each image
         s = _sink()
         if s is not None:
             s.stage_done("head")
@@ -543,6 +562,7 @@ class PackedTransformerFn(torch.autograd.Function):
             xs = ops.empty((Tn, D), F32, x)
             K.cast(x, xs)
         saved = []
+        keep = any(ctx.needs_input_grad)      # no_grad / eval: drop each layer's activations as soon as the layer is done
         for li in range(depth):
             ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
             a1 = ops.empty((Tn, D), T, xs)
@@ -563,7 +583,8 @@ class PackedTransformerFn(torch.autograd.Function):
             st2 = ops.ln_fwd(x2, ln2g, None, Tn, D, a2)
             act, pre = ops.linear_fwd(a2, w1, b1, Tn, gelu=True)
             x3 = ops.linear_fwd(act, w2, b2, Tn, resid=x2)
-            saved.append((xs, a1, st1, wcat, qkv, gqf, gkf, qn, kn, rq, rk, o, lse, x2, a2, st2, pre, act))
+            if keep:
+                saved.append((xs, a1, st1, wcat, qkv, gqf, gkf, qn, kn, rq, rk, o, lse, x2, a2, st2, pre, act))
             xs = x3
         y = ops.empty((Tn, D), T, xs)
         stf = ops.ln_fwd(xs, norm_g, None, Tn, D, y)
@@ -581,6 +602,8 @@ class PackedTransformerFn(torch.autograd.Function):
         T = norm_g.dtype
         I = heads * d
         dy = dy.contiguous()
+        if ctx.x_last is None:
+            raise RuntimeError("vit_pytorch_amd: backward through this fused stage a second time -- its saved activations were released during the first backward (retain_graph is not supported by the fused engine)")
         grads: List[Optional[Tensor]] = [None] * len(lp)
         fork = _Fork(dy.device)
 

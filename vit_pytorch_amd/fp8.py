@@ -10,7 +10,8 @@ forward for the QKV / FF1 inputs, the GELU epilogue of FF1 for the FF2 input -- 
 scale decided from the PREVIOUS step's amax while recording this step's amax (64 atomicMax words per tensor), so no extra
 pass over any activation exists and the step never waits for its own statistics; `vitk_fp8_update_scales` folds the
 records after every forward.  The first forward (no scales yet) runs the 16-bit GEMMs and only records.  Weights are
-quantised with their current amax whenever their version counter changes (once per optimizer step).  The out-projection
+quantised with their current amax whenever their values change (torch version counter, or the epoch this package's fused
+optimizer bumps; once per optimizer step).  The out-projection
 (8 % of the layer's GEMM FLOPs; its input comes out of the attention kernel) stays 16-bit.
 
 Values beyond the delayed scale's range saturate at +-448 * 1/scale; accumulation is f32; everything the backward reads
@@ -24,6 +25,7 @@ import torch
 
 from . import kernels as K
 from ._lib import VitkError
+from ._epoch import weight_key
 
 SLOTS_PER_LAYER = 3      # LN1 output (QKV input), LN2 output (FF1 input), GELU output (FF2 input)
 
@@ -45,13 +47,15 @@ class Fp8State:
 
     def weight(self, w: torch.Tensor):
         """e4m3 copy of a (N, K) weight and its scale pair; re-quantised when the parameter changed."""
+        key = weight_key(w)       # data_ptr, torch version counter AND the epoch the fused optimizer bumps (it writes through raw pointers)
         ent = self._w.get(id(w))
-        if ent is None or ent[0] != w._version or ent[1].device != w.device or ent[1].shape != w.shape:
+        # while a HIP graph is captured the quantisation must be part of the graph (replays then see the current weights)
+        if ent is None or ent[0] != key or ent[1].device != w.device or torch.cuda.is_current_stream_capturing():
             sc = torch.empty(2, dtype=torch.float32, device=w.device)
             w8 = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
             K.fp8_amax_scale(w, sc)
             K.quantize_fp8(w, w8, scale_dev=sc)
-            ent = (w._version, w8, sc)
+            ent = (key, w8, sc)
             self._w[id(w)] = ent
         return ent[1], ent[2]
 

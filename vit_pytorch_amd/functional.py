@@ -43,6 +43,25 @@ def _to(x: Tensor, dtype) -> Tensor:
     return y
 
 
+class CastFn(torch.autograd.Function):
+    """dtype conversion INSIDE the autograd graph (the raw `_to` is for use inside other Functions only): the gradient is
+    converted back to the input's dtype.  Needed where a fused stage hands its f32 residual stream to op-by-op modules of a
+    16-bit model (hooks on `attend`, Identity `to_out`, dropout at shapes the fused-dropout kernels do not serve)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return _to(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _to(g, ctx.src), None
+
+
+def cast(x: Tensor, dtype) -> Tensor:
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):

@@ -13,6 +13,7 @@ dtype policy
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -20,6 +21,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from ._lib import IDENT, RowMap
+from ._epoch import weight_key
 from .segments import uniform_segments
 
 Tensor = torch.Tensor
@@ -125,10 +127,27 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
     return y
 
 
-def transpose_weight(W: Tensor) -> Tensor:
+_WT_CACHE = {}      # id(W) -> (weakref to W, weight_key, pad, Wt); entries die with their parameter
+
+
+def transpose_weight(W: Tensor, pad_to: int = 0) -> Tensor:
+    """W (N, K) -> W^T (K, N) (optionally with zero columns up to pad_to): the operand that makes dX = dY . W an NT GEMM.
+    Cached per parameter until its values change (weight_key: data_ptr, torch version counter, and the epoch this package's
+    own optimizer bumps) -- a training step used to re-transpose every weight (0.28 ms of the ViT-B/16 step).  Never cached
+    while a HIP graph is being captured: the transpose must then be part of the graph so that replays see current weights."""
     N, Kd = W.shape
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = weight_key(W)
+    ent = _WT_CACHE.get(id(W))
+    if not capturing and ent is not None and ent[0]() is W and ent[1] == key and ent[2] == pad_to:
+        return ent[3]
     Wt = empty((Kd, N), W.dtype, W)
     K.transpose(W, Wt, N, Kd)
+    if pad_to and pad_to > N:
+        Wt = pad_cols(Wt, Kd, N, pad_to)
+    if not capturing and isinstance(W, torch.nn.Parameter):
+        wid = id(W)
+        _WT_CACHE[wid] = (weakref.ref(W, lambda _r, wid=wid: _WT_CACHE.pop(wid, None)), key, pad_to, Wt)
     return Wt
 
 

@@ -20,6 +20,7 @@ import torch
 
 from . import kernels as K
 from ._lib import VitkError
+from ._epoch import bump_weights_epoch
 from .parallel import DataParallel, FlatGradSink
 
 
@@ -57,6 +58,7 @@ class Adam:
         self.t += 1
         K.adam_step(self.flat_p, self.sink.flat, self.exp_avg, self.exp_avg_sq, self.master, self.sink.total, self.lr,
                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.decoupled, self.t, grad_scale)
+        bump_weights_epoch()      # the kernel wrote the parameters through raw pointers: caches derived from them are stale
 
     def zero_grad(self, set_to_none: bool = False):
         """Kept for drop-in use after `optim.step()` (train_vit_decorr.py:111); `dp.backward` zeroes the buffer anyway."""

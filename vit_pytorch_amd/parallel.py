@@ -168,6 +168,10 @@ class FlatGradSink:
         E.set_grad_sink(None)
         # gradients autograd produced outside the sink (foreign modules / non-fused paths): copy them in
         missing = [i for i in range(len(self.params)) if i not in self._filled]
+        if missing and self.world > 1 and self.side is not None:
+            # a segment covering one of these slots may still be in flight on the side stream (e.g. the head ran op by op while
+            # the fused transformer already handed the early segment to the collective): writing the slot now would race with it
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
         for i in missing:
             p = self.params[i]
             if p.grad is not None and p.grad.data_ptr() != self.views[i].data_ptr():

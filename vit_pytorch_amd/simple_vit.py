@@ -81,7 +81,7 @@ class Transformer(nn.Module):
 
     def forward(self, x):
         if not self._fusable():
-            x = Fn._to(x, self.norm.weight.dtype)
+            x = Fn.cast(x, self.norm.weight.dtype)       # in the graph: the embedding stage may have produced an f32 stream
             for attn, ff in self.layers:
                 x = Fn.AddFn.apply(attn(x), x)
                 x = Fn.AddFn.apply(ff(x), x)

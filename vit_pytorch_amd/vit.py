@@ -120,7 +120,7 @@ class Transformer(Module):
                 seed = (int(torch.initial_seed()) + 0x9E3779B1 * Transformer._drop_calls[0] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
                 Transformer._drop_calls[0] += 1
             return E.TransformerFn.apply(x, self._heads, self._dim_head, float(p), seed, getattr(self, "_fp8", None), self.norm.weight, self.norm.bias, *params)
-        x = Fn._to(x, self.norm.weight.dtype)
+        x = Fn.cast(x, self.norm.weight.dtype)       # in the graph: the embedding stage may have produced an f32 stream
         for attn, ff in self.layers:
             x = Fn.AddFn.apply(attn(x), x)
             x = Fn.AddFn.apply(ff(x), x)
