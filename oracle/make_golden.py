@@ -31,7 +31,8 @@ sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from oracle.params import CASES, NAVIT_CASES, make_images, make_navit_images, make_navit_params, make_params  # noqa: E402
+from oracle.params import (CASES, NAVIT_CASES, WIDE_CASES, make_images, make_navit_images, make_navit_params, make_params,  # noqa: E402
+                           sample_index)
 from oracle.vit_oracle import loss_fn  # noqa: E402
 
 REF = "/root/reference/vit_pytorch"
@@ -45,13 +46,15 @@ def load_ref(name: str):
     return mod
 
 
-def run_reference(kind: str, cfg: dict, params, img):
+def run_reference(kind: str, cfg: dict, params, img, dtype=torch.float32):
     mod = load_ref("vit" if kind == "vit" else "simple_vit")
     cls = mod.ViT if kind == "vit" else mod.SimpleViT
     model = cls(**cfg)
     missing = model.load_state_dict(params, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     model.train()  # dropout p = 0 in every case, so train == eval numerically
+    if dtype != torch.float32:
+        model = model.to(dtype); img = img.to(dtype)
     out = model(img)
     loss = loss_fn(out)
     loss.backward()
@@ -79,6 +82,29 @@ def main():
               f"{len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def main_wide():
+    """Compact goldens at the layer shapes of BASELINE configs 2 / 3 / 5 (oracle/params.py::WIDE_CASES): the reference in f32 and
+    -- as the yardstick a 16-bit pipeline is held against -- the reference's OWN pure-bf16 run on the same inputs."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name, case in WIDE_CASES.items():
+        if ONLY and name not in ONLY:
+            continue
+        params = make_params(case["kind"], case["cfg"], case["seed"])
+        img = make_images(case["cfg"], case["batch"], case["seed"] + 1000)
+        out, loss, grads = run_reference(case["kind"], case["cfg"], params, img)
+        out16, _, grads16 = run_reference(case["kind"], case["cfg"], params, img, torch.bfloat16)
+        blob = {"logits": out.numpy(), "loss": loss.numpy(), "bf16::logits": out16.float().numpy()}
+        for k, g in grads.items():
+            idx = sample_index(g.numel())
+            blob["gnorm::" + k] = np.float64(g.double().norm().item())
+            blob["gsample::" + k] = g.flatten().numpy()[idx]
+            blob["bf16::gsample::" + k] = grads16[k].float().flatten().numpy()[idx]
+        path = os.path.join(outdir, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(f"{name}: logits {tuple(out.shape)} loss {float(loss):.6f} {len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main_navit():
     outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
     mod = load_ref("na_vit")
@@ -104,3 +130,4 @@ def main_navit():
 if __name__ == "__main__":
     main()
     main_navit()
+    main_wide()

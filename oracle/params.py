@@ -130,6 +130,30 @@ CASES = {
 }
 
 
+# Cases at the LAYER SHAPES of BASELINE configs 2, 3 and 5 (depth cut to 2 / 1 so the reference finishes on the CPU in seconds,
+# batches sized so that M = batch * N >= 1024: the production NT GEMM (persistent kernel) and the whole-head / chunked attention
+# kernels are what the GPU runs).  Their goldens are COMPACT (oracle/make_golden.py::main_wide): full logits, and per parameter
+# gradient its L2 norm plus the elements at `sample_index(numel)`.
+WIDE_CASES = {
+    "vit_b16_width": dict(kind="vit", batch=6, seed=11,
+                          cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=2, heads=12, mlp_dim=3072)),
+    "simple_vit_b16_width": dict(kind="simple_vit", batch=6, seed=12,
+                                 cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=2, heads=12, mlp_dim=3072)),
+    "vit_l16_width": dict(kind="vit", batch=6, seed=13,
+                          cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=2, heads=16, mlp_dim=4096)),
+    "vit_h14_width": dict(kind="vit", batch=2, seed=14,
+                          cfg=dict(image_size=336, patch_size=14, num_classes=1000, dim=1280, depth=1, heads=16, dim_head=80, mlp_dim=5120)),
+}
+GOLD_SAMPLE = 4096
+
+
+def sample_index(numel: int) -> np.ndarray:
+    """The (at most GOLD_SAMPLE) flat positions of a gradient tensor that a compact golden stores: a fixed stride walk."""
+    if numel <= GOLD_SAMPLE:
+        return np.arange(numel, dtype=np.int64)
+    return (np.arange(GOLD_SAMPLE, dtype=np.int64) * 7919) % numel
+
+
 # ---- NaViT (BASELINE config 4) --------------------------------------------------------------------------------
 def navit_param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
     """state_dict key -> shape of na_vit.NaViT in registration order (buffers `beta` included)."""

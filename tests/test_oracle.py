@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import vit_oracle as O
-from oracle.params import CASES, make_images, make_params
+from oracle.params import CASES, WIDE_CASES, make_images, make_params, sample_index
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 REL_TOL_FP32 = 2e-6   # fp32 oracle vs fp32 reference (different op order only)
@@ -40,6 +40,26 @@ def test_oracle_matches_reference_golden(name, dtype):
             continue
         # gradient tolerance: relative to the gradient's own norm, a few ulps of fp32 accumulation
         assert rel_l2(grads[k], g_ref) <= 2e-5, (k, rel_l2(grads[k], g_ref))
+
+
+@pytest.mark.parametrize("name", ["vit_b16_width", "vit_h14_width"])
+def test_oracle_matches_compact_golden_at_production_widths(name):
+    """BASELINE config 2 / 5 layer shapes (dim 768 x 12 heads, dim 1280 x 16 heads of 80): the restatement against the compact
+    goldens the reference produced (full logits; per gradient its norm and a fixed 4096-element sample)."""
+    case = WIDE_CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000)
+    out, grads = O.run_fwd_bwd(case["kind"], case["cfg"], params, img, dtype=torch.float32)
+    assert rel_l2(out, torch.from_numpy(gold["logits"])) <= 1e-5
+    for k in params:
+        if params[k].numel() == 0:
+            continue
+        g = grads[k].flatten()
+        ref = torch.from_numpy(gold["gsample::" + k])
+        got = g[torch.from_numpy(sample_index(g.numel()))]
+        assert abs(g.double().norm().item() - float(gold["gnorm::" + k])) <= 1e-4 * float(gold["gnorm::" + k]), k
+        assert (got.double() - ref.double()).norm().item() <= 1e-4 * float(gold["gnorm::" + k]) * (ref.numel() / g.numel()) ** 0.5 + 1e-12, k
 
 
 def test_patchify_is_channel_fastest():
