@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 120
+#define VITK_VERSION 121
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -298,6 +298,15 @@ int vitk_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dt, int6
  * extent is not a multiple of 32, e.g. patch_dim = 588 of ViT-H/14, so that the MFMA GEMMs can take it)          */
 int vitk_copy_cols(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int dt, int64_t rows, int64_t cols_copy,
                    int64_t cols_dst, void* stream);
+/* out[b, i, :] = (i < F ? front[i, :] : x[b, i - F, :]) + (pos ? pos[i, :] : 0) for i < Np + F: torch.cat((tokens, x), dim = 1)
+ * + pos[:N] of vit.py:122-127 for all images in one launch; also the register tokens of
+ * simple_vit_with_register_tokens.py:113-115 (placed in front: the transformer is equivariant to the token order).       */
+int vitk_concat_tokens(const void* x, const void* front, const void* pos, void* out, int dt, int64_t B, int64_t Np,
+                       int64_t F, int64_t D, void* stream);
+/* scatter = 0: dst[b, j, :] = src[b, idx[b, j], :] (x[batch_indices, patch_indices_keep] of vit_with_patch_dropout.py:32);
+ * scatter = 1: dst[b, idx[b, j], :] = src[b, j, :] (its adjoint; dst zeroed by the caller).  idx: int32 [B, Kp], distinct per b. */
+int vitk_gather_tokens(const void* src, const int32_t* idx, void* dst, int dt, int64_t B, int64_t Np, int64_t Kp, int64_t D,
+                       int scatter, void* stream);
 /* One Adam (decoupled = 0; torch.optim.Adam as used by train_vit_decorr.py:68-70,110) or AdamW (decoupled = 1) step over a
  * flat range of n elements: param, grad of dtype dt; exp_avg, exp_avg_sq (and the optional f32 master copy of bf16
  * parameters) f32.  step counts from 1 (bias corrections 1 - beta^step are formed on the host in double).  grad is read as

@@ -31,7 +31,7 @@ sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from oracle.params import (CASES, NAVIT_CASES, WIDE_CASES, make_images, make_navit_images, make_navit_params, make_params,  # noqa: E402
+from oracle.params import (CASES, NAVIT_CASES, VARIANT_CASES, WIDE_CASES, make_params_for, make_images, make_navit_images, make_navit_params, make_params,  # noqa: E402
                            sample_index)
 from oracle.vit_oracle import loss_fn  # noqa: E402
 
@@ -105,6 +105,34 @@ def main_wide():
         print(f"{name}: logits {tuple(out.shape)} loss {float(loss):.6f} {len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def main_variants():
+    """The sibling variants (oracle/params.py::VARIANT_CASES): reference in eval mode (dropouts off), f32; the golden also records
+    the reference's state_dict keys and shapes, which the drop-in's module must reproduce."""
+    import json
+    from collections import OrderedDict
+    outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name, case in VARIANT_CASES.items():
+        if ONLY and name not in ONLY:
+            continue
+        mod = load_ref(case["module"])
+        model = getattr(mod, case["cls"])(**case["cfg"])
+        shapes = OrderedDict((k, tuple(v.shape)) for k, v in model.state_dict().items())
+        params = make_params_for(shapes, case["seed"])
+        model.load_state_dict(params, strict=True)
+        model.eval()
+        img = make_images(case["cfg"], case["batch"], case["seed"] + 1000)
+        out = model(img)
+        loss = loss_fn(out)
+        loss.backward()
+        blob = {"logits": out.detach().numpy(), "loss": loss.detach().numpy(),
+                "state_dict_shapes": np.frombuffer(json.dumps([[k, list(v)] for k, v in shapes.items()]).encode(), dtype=np.uint8)}
+        for k, p in model.named_parameters():
+            blob["grad::" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        path = os.path.join(outdir, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(f"{name}: logits {tuple(out.shape)} loss {float(loss):.6f} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main_navit():
     outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
     mod = load_ref("na_vit")
@@ -131,3 +159,4 @@ if __name__ == "__main__":
     main()
     main_navit()
     main_wide()
+    main_variants()

@@ -154,6 +154,45 @@ def sample_index(numel: int) -> np.ndarray:
     return (np.arange(GOLD_SAMPLE, dtype=np.int64) * 7919) % numel
 
 
+# ---- sibling variants: simple_vit_with_qk_norm.py, simple_vit_with_register_tokens.py, vit_with_patch_dropout.py
+VARIANT_CASES = {
+    "qk_norm_tiny": dict(module="simple_vit_with_qk_norm", cls="SimpleViT", batch=3, seed=31,
+                         cfg=dict(image_size=32, patch_size=8, num_classes=7, dim=64, depth=2, heads=2, dim_head=64, mlp_dim=96)),
+    "register_tokens_tiny": dict(module="simple_vit_with_register_tokens", cls="SimpleViT", batch=3, seed=32,
+                                 cfg=dict(image_size=32, patch_size=8, num_classes=7, dim=64, depth=2, heads=2, dim_head=64, mlp_dim=96,
+                                          num_register_tokens=4)),
+    "patch_dropout_eval_tiny": dict(module="vit_with_patch_dropout", cls="ViT", batch=3, seed=33,
+                                    cfg=dict(image_size=32, patch_size=8, num_classes=7, dim=64, depth=2, heads=2, dim_head=64, mlp_dim=96,
+                                             pool="cls", patch_dropout=0.25)),
+}
+
+
+def make_params_for(shapes: "OrderedDict[str, Tuple[int, ...]]", seed: int) -> Dict[str, torch.Tensor]:
+    """Deterministic values for any state_dict given its (key, shape) list -- same value rules as make_params: 2-D tensors are
+    Linear weights U(-1/sqrt(fan_in), ..), LayerNorm weights 1 + 0.1 N(0,1) and biases 0.1 N(0,1), Linear biases U(-0.05, 0.05),
+    token / positional tables N(0,1), q/k norm gammas (heads, 1, d) around their 1/sqrt(d) initial value."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, torch.Tensor] = OrderedDict()
+    for name, shape in shapes.items():
+        n = int(np.prod(shape)) if len(shape) else 1
+        last = name.split(".")[-1]
+        if last == "gamma" and len(shape) == 3:
+            a = (1.0 + 0.1 * rng.standard_normal(n)) / np.sqrt(shape[-1])
+        elif "token" in name or "pos_embedding" in name:
+            a = rng.standard_normal(n)
+        elif len(shape) == 2:
+            bound = 1.0 / np.sqrt(shape[1])
+            a = rng.uniform(-bound, bound, n)
+        elif last == "weight":                       # 1-D weight: a LayerNorm gamma
+            a = 1.0 + 0.1 * rng.standard_normal(n)
+        elif last == "bias" and ("norm" in name or name.endswith("net.0.bias")):
+            a = 0.1 * rng.standard_normal(n)         # LayerNorm beta
+        else:
+            a = rng.uniform(-0.05, 0.05, n)
+        out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape)).clone()
+    return out
+
+
 # ---- NaViT (BASELINE config 4) --------------------------------------------------------------------------------
 def navit_param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
     """state_dict key -> shape of na_vit.NaViT in registration order (buffers `beta` included)."""

@@ -341,7 +341,69 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const T* __restrict__ sr
     }
 }
 
+// out[b, i, :] = (i < F ? front[i, :] : x[b, i - F, :]) + (pos ? pos[i, :] : 0): torch.cat((front tokens, x), dim=1) (+ pos[:N])
+// for every image in ONE launch (vit.py:122-127 cls + pos; simple_vit_with_register_tokens.py:113-115 register tokens)
+template <typename T>
+__global__ __launch_bounds__(256) void concat_tokens_kernel(const T* __restrict__ x, const T* __restrict__ front, const T* __restrict__ pos,
+                                                             T* __restrict__ out, long long B, int Np, int F, int D4) {
+    const int N = Np + F;
+    const long long total = B * N * D4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const long long r = i / D4;
+        const int t = (int)(r % N);
+        const long long b = r / N;
+        f32x4 v = t < F ? load4<T>(front + ((long long)t * D4 + c) * 4) : load4<T>(x + ((b * Np + (t - F)) * D4 + c) * 4);
+        if (pos) v += load4<T>(pos + ((long long)t * D4 + c) * 4);
+        store4<T>(out + i * 4, v);
+    }
+}
+
+// out[b, j, :] = x[b, idx[b, j], :]  (PatchDropout: vit_with_patch_dropout.py:28-32) and its adjoint dx[b, idx[b, j], :] = g[b, j, :]
+// (the indices of one image are distinct, dx is zeroed by the caller)
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(256) void gather_tokens_kernel(const T* __restrict__ src, const int* __restrict__ idx, T* __restrict__ dst,
+                                                             long long B, int Np, int Kp, int D4) {
+    const long long total = B * Kp * D4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const long long r = i / D4;
+        const int j = (int)(r % Kp);
+        const long long b = r / Kp;
+        const int t = idx[b * Kp + j];
+        const long long full = ((b * Np + t) * D4 + c) * 4;
+        if (SCATTER) store4<T>(dst + full, load4<T>(src + i * 4));
+        else store4<T>(dst + i * 4, load4<T>(src + full));
+    }
+}
+
 }  // namespace
+
+extern "C" int vitk_concat_tokens(const void* x, const void* front, const void* pos, void* out, int dt, int64_t B, int64_t Np,
+                                  int64_t F, int64_t D, void* stream) {
+    if (!x || !out || (F > 0 && !front)) VITK_FAIL(VITK_E_ARG, "concat_tokens: null pointer");
+    if (B <= 0 || Np < 0 || F < 0 || Np + F <= 0 || D <= 0 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "concat_tokens: need D %% 4 == 0 and a non-empty sequence");
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((concat_tokens_kernel<T>), dim3(ew_blocks(B * (Np + F) * D / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)x, (const T*)front, (const T*)pos, (T*)out, (long long)B, (int)Np, (int)F, (int)(D / 4)));
+    VITK_CHECK_LAUNCH("concat_tokens");
+    return 0;
+}
+
+extern "C" int vitk_gather_tokens(const void* src, const int32_t* idx, void* dst, int dt, int64_t B, int64_t Np, int64_t Kp, int64_t D,
+                                  int scatter, void* stream) {
+    if (!src || !idx || !dst) VITK_FAIL(VITK_E_ARG, "gather_tokens: null pointer");
+    if (B <= 0 || Np <= 0 || Kp <= 0 || Kp > Np || D <= 0 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "gather_tokens: need 0 < Kp <= Np and D %% 4 == 0");
+    const unsigned blocks = ew_blocks(B * Kp * D / 4);
+    if (scatter) {
+        VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((gather_tokens_kernel<T, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                                    (const T*)src, (const int*)idx, (T*)dst, (long long)B, (int)Np, (int)Kp, (int)(D / 4)));
+    } else {
+        VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((gather_tokens_kernel<T, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                                    (const T*)src, (const int*)idx, (T*)dst, (long long)B, (int)Np, (int)Kp, (int)(D / 4)));
+    }
+    VITK_CHECK_LAUNCH("gather_tokens");
+    return 0;
+}
 
 extern "C" int vitk_patchify(const void* img, void* out, int dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p1,
                              int64_t p2, void* stream) {

@@ -345,6 +345,91 @@ class MeanTokensFn(torch.autograd.Function):
 
 
 # ---- nn.Module shells (same classes / state_dict keys as the reference's children) -------------
+class ConcatTokensFn(torch.autograd.Function):
+    """torch.cat((front tokens broadcast over the batch, x), dim=1) + pos[:N]: the cls token + positional table of vit.py:122-127,
+    the register tokens of simple_vit_with_register_tokens.py:113-115 (front / pos may be None).  One launch for all images."""
+
+    @staticmethod
+    def forward(ctx, x, front, pos):
+        K.require_device(x)
+        x = x.contiguous()
+        B, Np, D = x.shape
+        F_ = 0 if front is None else front.shape[0]
+        N = Np + F_
+        if D % 4:
+            raise VitkError(f"token width {D} must be a multiple of 4")
+        fr = None if front is None or F_ == 0 else _to(front.reshape(F_, D), x.dtype)
+        ps = None if pos is None else _to(pos[:N].contiguous(), x.dtype)
+        out = torch.empty((B, N, D), dtype=x.dtype, device=x.device)
+        K.concat_tokens(x, fr, ps, out, B, Np, F_ if fr is not None else 0, D)
+        ctx.meta = (B, Np, F_, D, None if front is None else (front.shape, front.dtype), None if pos is None else (pos.shape, pos.dtype))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Np, F_, D, front_meta, pos_meta = ctx.meta
+        N = Np + F_
+        g = g.contiguous()
+        dx = torch.empty((B, Np, D), dtype=g.dtype, device=g.device)
+        K.copy_cols(g.view(B, N * D)[:, F_ * D:], N * D, dx, Np * D, B, Np * D, Np * D)        # rows F.. of every image
+        dfront = dpos = None
+        if front_meta is not None or pos_meta is not None:
+            gsum = torch.empty((N, D), dtype=g.dtype, device=g.device)
+            ops.colsum(g, B, N * D, gsum)                                                     # sum over the batch
+            if front_meta is not None:
+                dfront = _to(gsum[:F_].contiguous(), front_meta[1]).reshape(front_meta[0]) if F_ else torch.zeros(front_meta[0], dtype=front_meta[1], device=g.device)
+            if pos_meta is not None:
+                dpos = torch.zeros(pos_meta[0], dtype=pos_meta[1], device=g.device)
+                K.cast(gsum, dpos[:N])
+        return dx, dfront, dpos
+
+
+class TokenSliceFn(torch.autograd.Function):
+    """x[:, start:] as a contiguous tensor (unpack of the register tokens: simple_vit_with_register_tokens.py:119)."""
+
+    @staticmethod
+    def forward(ctx, x, start: int):
+        x = x.contiguous()
+        B, N, D = x.shape
+        out = torch.empty((B, N - start, D), dtype=x.dtype, device=x.device)
+        K.copy_cols(x.view(B, N * D)[:, start * D:], N * D, out, (N - start) * D, B, (N - start) * D, (N - start) * D)
+        ctx.meta = (B, N, D, start)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D, start = ctx.meta
+        g = g.contiguous()
+        dx = torch.zeros((B, N, D), dtype=g.dtype, device=g.device)
+        K.copy_cols(g, (N - start) * D, dx.view(B, N * D)[:, start * D:], N * D, B, (N - start) * D, (N - start) * D)
+        return dx, None
+
+
+class GatherTokensFn(torch.autograd.Function):
+    """x[batch_indices, keep] (vit_with_patch_dropout.py:32): keep is int32 (B, Kp) with distinct entries per image."""
+
+    @staticmethod
+    def forward(ctx, x, keep):
+        K.require_device(x)
+        x = x.contiguous()
+        B, Np, D = x.shape
+        keep = keep.to(torch.int32).contiguous()
+        Kp = keep.shape[1]
+        out = torch.empty((B, Kp, D), dtype=x.dtype, device=x.device)
+        K.gather_tokens(x, keep, out, B, Np, Kp, D)
+        ctx.keep = keep
+        ctx.meta = (B, Np, Kp, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Np, Kp, D = ctx.meta
+        g = g.contiguous()
+        dx = torch.zeros((B, Np, D), dtype=g.dtype, device=g.device)
+        K.gather_tokens(g, ctx.keep, dx, B, Np, Kp, D, scatter=True)
+        return dx, None
+
+
 class LayerNorm(nn.LayerNorm):
     def forward(self, x):
         return LayerNormFn.apply(x, self.weight, self.bias)

@@ -295,6 +295,14 @@ def copy_cols(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, col
     check(_lib_for(src, dst).vitk_copy_cols(_p(src), ld_src, _p(dst), ld_dst, dt(src), rows, cols_copy, cols_dst, _stream()), "copy_cols")
 
 
+def concat_tokens(x: Tensor, front: Optional[Tensor], pos: Optional[Tensor], out: Tensor, B: int, Np: int, F: int, D: int):
+    check(_lib_for(x, front, pos, out).vitk_concat_tokens(_p(x), _p(front), _p(pos), _p(out), dt(x), B, Np, F, D, _stream()), "concat_tokens")
+
+
+def gather_tokens(src: Tensor, idx: Tensor, dst: Tensor, B: int, Np: int, Kp: int, D: int, scatter: bool = False):
+    check(_lib_for(src, dst).vitk_gather_tokens(_p(src), _p(idx), _p(dst), dt(src), B, Np, Kp, D, int(scatter), _stream()), "gather_tokens")
+
+
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, master: Optional[Tensor], n: int, lr: float,
               beta1: float, beta2: float, eps: float, weight_decay: float, decoupled: bool, step: int, grad_scale: float = 1.0):
     check(_lib_for(param, grad, exp_avg, exp_avg_sq).vitk_adam_step(_p(param), _p(grad), dt(param), _p(exp_avg), _p(exp_avg_sq), _p(master), n, lr, beta1, beta2,

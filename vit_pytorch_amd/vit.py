@@ -194,40 +194,6 @@ class _ClsRowFn(torch.autograd.Function):
         return dx
 
 
-class _ClsPosFn(torch.autograd.Function):
-    """cat(cls, x) + pos[:seq] (vit.py:122-127) for the non-fused embedding path."""
-
-    @staticmethod
-    def forward(ctx, x, cls, pos):
-        from . import kernels as K
-        x = x.contiguous()
-        B, Np, D = x.shape
-        ncls = cls.shape[0]
-        N = Np + ncls
-        out = torch.empty((B, N, D), dtype=x.dtype, device=x.device)
-        posN = pos[:N].contiguous()
-        # token rows: out[b, ncls + p] = x[b, p] + pos[ncls + p]; written through a strided view of `out`
-        for b in range(B):  # B strided row blocks (this is the slow observability path, not the fused one)
-            K.add_rows(x[b], posN[ncls:], None, out[b, ncls:], Np, D)
-        if ncls:
-            K.write_cls_rows(out, cls, posN, B, N, D, ncls)
-        ctx.meta = (B, Np, N, D, ncls, pos.shape)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        from . import ops
-        from . import kernels as K
-        B, Np, N, D, ncls, pos_shape = ctx.meta
-        g = g.contiguous()
-        gsum = torch.empty((N, D), dtype=g.dtype, device=g.device)
-        ops.colsum(g, B, N * D, gsum)
-        dpos = torch.zeros(pos_shape, dtype=g.dtype, device=g.device)
-        K.cast(gsum, dpos[:N])
-        dcls = gsum[:ncls].contiguous()
-        dx = g[:, ncls:].contiguous()
-        return dx, dcls, dpos
-
-
 def _prepend_cls_add_pos(x, cls, pos):
-    return _ClsPosFn.apply(x, cls, pos)
+    """cat(cls, x) + pos[:seq] (vit.py:122-127) for the non-fused embedding path: one launch for the whole batch."""
+    return Fn.ConcatTokensFn.apply(x, cls, pos)
