@@ -32,46 +32,37 @@ from ._lib import VitkError
 F32 = torch.float32
 
 
-def exists(val):
-    return val is not None
-
-
-def default(val, d):
-    return val if exists(val) else d
-
-
-def always(val):
-    return lambda *args: val
-
-
 def pair(t):
     return t if isinstance(t, tuple) else (t, t)
 
 
-def divisible_by(numer, denom):
-    return (numer % denom) == 0
+def _token_count(image: Tensor, patch_size: int, drop_fraction) -> int:
+    """Tokens an image contributes to a pack: its patch grid, shrunk by the token-dropout fraction for its size (floored)."""
+    height, width = image.shape[-2:]
+    frac = drop_fraction(height, width) if callable(drop_fraction) else (0.0 if drop_fraction is None else float(drop_fraction))
+    return int((height // patch_size) * (width // patch_size) * (1 - frac))
 
 
 def group_images_by_max_seq_len(images: List[Tensor], patch_size: int, calc_token_dropout=None, max_seq_len=2048) -> List[List[Tensor]]:
-    """Greedy packing of images into groups whose token count stays <= max_seq_len (na_vit.py:38-77)."""
-    calc_token_dropout = default(calc_token_dropout, always(0.))
-    groups, group, seq_len = [], [], 0
-    if isinstance(calc_token_dropout, (float, int)):
-        calc_token_dropout = always(calc_token_dropout)
+    """First-fit packing IN INPUT ORDER: an image joins the current group unless that would push the group's token count
+    past `max_seq_len`, in which case the group is closed and the image opens the next one (the behaviour of na_vit.py:38-77;
+    `calc_token_dropout` may be None, a number, or a callable (height, width) -> fraction)."""
+    packs: List[List[Tensor]] = []
+    current: List[Tensor] = []
+    used = 0
     for image in images:
-        assert isinstance(image, Tensor)
-        image_dims = image.shape[-2:]
-        ph, pw = map(lambda t: t // patch_size, image_dims)
-        image_seq_len = int((ph * pw) * (1 - calc_token_dropout(*image_dims)))
-        assert image_seq_len <= max_seq_len, f'image with dimensions {image_dims} exceeds maximum sequence length'
-        if (seq_len + image_seq_len) > max_seq_len:
-            groups.append(group)
-            group, seq_len = [], 0
-        group.append(image)
-        seq_len += image_seq_len
-    if len(group) > 0:
-        groups.append(group)
-    return groups
+        if not isinstance(image, Tensor):
+            raise AssertionError("group_images_by_max_seq_len expects a list of image tensors")
+        need = _token_count(image, patch_size, calc_token_dropout)
+        assert need <= max_seq_len, f'image with dimensions {tuple(image.shape[-2:])} exceeds maximum sequence length'
+        if used + need > max_seq_len:
+            packs.append(current)
+            current, used = [], 0
+        current.append(image)
+        used += need
+    if current:
+        packs.append(current)
+    return packs
 
 
 from .segments import Segments  # noqa: E402  (re-exported: tests and users import it from here)
@@ -261,7 +252,7 @@ class Attention(nn.Module):
     def forward(self, x, segs: Segments, context=None):
         """x: (Tq, dim) packed query-side tokens; context: (Tk, dim) packed key-side tokens (default: x)."""
         x = self.norm(x)
-        kv_input = default(context, x)
+        kv_input = x if context is None else context
         q = self.to_q(x)
         kv = self.to_kv(kv_input)
         p, seed = 0.0, 0
@@ -324,7 +315,7 @@ class NaViT(nn.Module):
             token_dropout_prob = float(token_dropout_prob)
             self.calc_token_dropout = lambda height, width: token_dropout_prob
 
-        assert divisible_by(image_height, patch_size) and divisible_by(image_width, patch_size), 'Image dimensions must be divisible by the patch size.'
+        assert image_height % patch_size == 0 and image_width % patch_size == 0, 'Image dimensions must be divisible by the patch size.'
 
         patch_height_dim, patch_width_dim = (image_height // patch_size), (image_width // patch_size)
         patch_dim = channels * (patch_size ** 2)
@@ -361,7 +352,7 @@ class NaViT(nn.Module):
 
     def forward(self, batched_images, group_images=False, group_max_seq_len=2048):
         p, c, device = self.patch_size, self.channels, self.device
-        has_token_dropout = exists(self.calc_token_dropout) and self.training
+        has_token_dropout = self.calc_token_dropout is not None and self.training
         dtype = self.pos_embed_height.dtype
 
         if group_images:
@@ -378,7 +369,7 @@ class NaViT(nn.Module):
         for image in images:
             assert image.ndim == 3 and image.shape[0] == c
             ih, iw = image.shape[-2:]
-            assert divisible_by(ih, p) and divisible_by(iw, p), f'height and width {(ih, iw)} of images must be divisible by patch size {p}'
+            assert ih % p == 0 and iw % p == 0, f'height and width {(ih, iw)} of images must be divisible by patch size {p}'
             ph, pw = ih // p, iw // p
             hi = np.repeat(np.arange(ph, dtype=np.int32), pw)
             wi = np.tile(np.arange(pw, dtype=np.int32), ph)
