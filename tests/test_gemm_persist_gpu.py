@@ -56,6 +56,17 @@ def _all_epilogues(M, N, Kd, A, W, bias, resid, h):
     return out
 
 
+def test_slot_main_loop_in_a_subprocess():
+    """The R/M-slot flavour of the main loop (VITK_NTP_PIPE=0 is read once per process): same checks on two shapes."""
+    import subprocess, sys
+    code = ("import os, tests.test_gemm_persist_gpu as t\n"
+            "for s in [(12608, 768, 768), (9000, 1000, 32), (4100, 2304, 128)]: t.test_persistent_nt_against_float64(*s)\nprint('slot-ok')")
+    env = dict(os.environ, VITK_NTP_PIPE="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "slot-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("M,N,Kd", SHAPES)
 def test_persistent_nt_against_float64(M, N, Kd):
     plan = K.gemm_nt_plan(M, N, Kd, N)

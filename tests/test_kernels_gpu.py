@@ -205,7 +205,13 @@ def test_gemm_nt_rejects_bad_shapes():
 
 @pytest.mark.parametrize("M,N,Kd", [(4096, 256, 256), (5000, 768, 768), (6304, 2304, 768), (4500, 264, 520), (64, 128, 128), (1000, 768, 768), (197 * 16, 2304, 768), (333, 136, 72), (197 * 8, 768, 3072), (5000, 64, 256)])
 @pytest.mark.parametrize("odt", [BF, F32])
-def test_gemm_tn(M, N, Kd, odt):
+@pytest.mark.parametrize("variant", ["default", "VITK_TN_DMA", "VITK_TN_DMA+XREG"])
+def test_gemm_tn(M, N, Kd, odt, variant, monkeypatch):
+    """variant: the register-staged kernel (default) or gemm_tn_dma.hip (LDS-DMA ring; +XREG: the X tile through registers)."""
+    if variant != "default":
+        monkeypatch.setenv("VITK_TN_DMA", "1")
+        if variant.endswith("XREG"):
+            monkeypatch.setenv("VITK_TN_XREG", "1")
     dY = rnd(M, N, dtype=BF, seed=51) * (M ** -0.5); X = rnd(M, Kd, dtype=BF, seed=52)
     ref = dY.double().t() @ X.double()
     splits = K.gemm_tn_splits(M, N, Kd)

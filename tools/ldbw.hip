@@ -10,13 +10,26 @@ template <int MODE, int DEPTH>
 __global__ __launch_bounds__(512) void fill(const char* __restrict__ src, long long region, int iters, int* sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long base = ((long long)blockIdx.x * 4096 * 131) % region;  // different start per WG
+    const long long base = (MODE == 3) ? 0 : ((long long)blockIdx.x * 4096 * 131) % region;  // different start per WG (MODE 3: the same for all)
     i32x4 r[DEPTH][4];
     int acc = 0;
     for (int it = 0; it < iters; ++it) {
         const long long off = (base + (long long)it * 32768) % region;
         char* st = lds + (it % DEPTH) * 32768;
-        if (MODE == 0) {
+        if (MODE == 2) {      // GEMM-like: half of the tile is a panel every workgroup reads at the same time, half is private
+            const long long shared_off = ((long long)it * 16384) % region;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* p = (j < 2) ? src + shared_off + (wave * 2 + j) * 1024 + lane * 16 : src + off + (wave * 2 + j - 2) * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)p,
+                                                 (void __attribute__((address_space(3)))*)(st + (wave * 4 + j) * 1024), 16, 0, 0);
+            }
+            if (it >= DEPTH - 1) {
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                acc += *(int*)(lds + ((it + 1) % DEPTH) * 32768 + tid * 4);
+            }
+        } else if (MODE == 0 || MODE == 3) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + off + (wave * 4 + j) * 1024 + lane * 16),
@@ -62,6 +75,8 @@ int main() {
     int* sink; hipMalloc(&sink, 4);
     for (long long region : {2LL << 20, 64LL << 20, big}) {   // 2 MiB (L2), 64 MiB (MALL), 2 GiB (HBM)
         run<0, 4>("lds-dma depth4", d, region, 512, sink);
+        run<3, 4>("lds-dma depth4 SAME addr", d, region, 512, sink);
+        run<2, 4>("lds-dma depth4 half shared", d, region, 512, sink);
         run<0, 2>("lds-dma depth2", d, region, 512, sink);
         run<1, 2>("reg-stage depth2", d, region, 512, sink);
         run<1, 4>("reg-stage depth4", d, region, 512, sink);

@@ -937,6 +937,10 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 }
 }  // namespace
 
+// gemm_tn_dma.hip: the LDS-DMA / ping-pong kernel that serves the large shapes
+int gemm_tn_dma_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* ws, int64_t M, int64_t N, int64_t K,
+                       int64_t splits, void* stream);
+
 static bool tn_large(int64_t M, int64_t N, int64_t K) { return M >= 4096 && N >= 256 && K >= 256 && !getenv("VITK_NO_256"); }
 
 extern "C" int64_t vitk_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
@@ -966,7 +970,13 @@ extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int
     if ((ldy & 7) || (ldx & 7) || (ldo & 3) || !aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws))
         VITK_FAIL(VITK_E_ALIGN, "gemm_tn_bf16: ldy/ldx %% 8, ldo %% 4 and 16-byte aligned pointers required");
     hipStream_t st = (hipStream_t)stream;
-    if (tn_large(M, N, K)) {
+    // gemm_tn_dma.hip (LDS-DMA ring, ping-pong slots) and gemm_tn256_kernel (register staging) measure level -- 0.975x .. 1.037x box to
+    // box (tools/tn_ab.py): both are bound by the ds_read_b64_tr_b16 issue rate, not by how the tiles reach LDS.  The register-staged
+    // kernel stays the default; VITK_TN_DMA=1 selects the other.
+    if (tn_large(M, N, K) && getenv("VITK_TN_DMA") && atoi(getenv("VITK_TN_DMA"))) {
+        const int rc = gemm_tn_dma_launch(dY, ldy, X, ldx, ws, M, N, K, splits, stream);
+        if (rc != 0) return rc;
+    } else if (tn_large(M, N, K)) {
         const int tiles_n = (int)((N + 255) / 256), tiles_k = (int)((K + 255) / 256);
         const int nwg = tiles_n * tiles_k;
         long long rps = (M + splits - 1) / splits;

@@ -67,12 +67,14 @@ struct NtpArgs {
     unsigned drop_t, drop_seed; float inv_keep;     // fused nn.Dropout (vit.py:22,24,48): threshold 0 = off
     int tail_first;
     int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone)
+    long long* stamps;  // experiments: s_memtime after the phases of K-steps 8..39 of one workgroup (VITK_NTP_STAMPS)
 };
 
 template <int N_> __device__ __forceinline__ void q_wait_vm() {
     if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else static_assert(N_ < 0, "unsupported vmcnt");
 }
 
@@ -130,7 +132,7 @@ __device__ __forceinline__ unsigned q_pack2(float a, float b) {
 }
 typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI>
+template <int EPI, bool PIPE>
 __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
@@ -216,6 +218,29 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
         }
     };
 
+    // PIPE: the four DMA instructions of a K-step as straight-line code (their block also holds MFMAs and must stay one basic
+    // block).  Issued on EVERY K-step: when the tile list is exhausted the producer stays on its last K-step and re-loads it
+    // into a stage nobody reads again, which keeps the counted waits uniform (always vmcnt(8)); the kernel drains before it ends.
+    auto issue4 = [&]() __attribute__((always_inline)) {
+        char* base = lds + (p_g & 3) * Q_STAGE_BYTES + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + p_kt * 64),
+                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + p_kt * 64),
+                                             (void __attribute__((address_space(3)))*)(base + Q_TILE_BYTES + j * 1024), 16, 0, 0);
+        }
+    };
+    auto advance4 = [&]() __attribute__((always_inline)) {
+        ++p_g;
+        if (!p_more) return;
+        if (++p_kt == p.nt) {
+            p_idx += L;
+            if (p_idx < count) { p_kt = 0; setup_src(p_idx); }
+            else { p_more = false; p_kt = p.nt - 1; }
+        }
+    };
+
     // ---- bias -> LDS (above the ring), once ----
     const char* bias_lds = lds + Q_LDS_BYTES;
     if constexpr (q_has_bias<EPI>()) {
@@ -247,6 +272,9 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
         else q_wait_vm<0>();
     };
 
+    const bool stamp_on = p.stamps && blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == 4);
+    long long* my_stamps = p.stamps ? p.stamps + (wave == 4 ? 1024 : 0) : nullptr;
+#define Q_STAMP(slot) do { if (stamp_on && c_g >= 8 && c_g < 40) my_stamps[(c_g - 8) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
     auto run_tile = [&](auto fmw_c, int m0, int n0, int mt) {
         constexpr int FMW = decltype(fmw_c)::value;      // m-fragments per wave: 8 (256-row tile) or 4 (128-row tile)
         const int a_off = FMW == 8 ? a_off8 : a_off4;
@@ -256,46 +284,135 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
 #pragma unroll
             for (int j = 0; j < FMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int kt = 0; kt < p.nt; ++kt) {
-            const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
-            bf16x8 wf[4], xf[4];
-            // ---- R0 ----
+        if constexpr (PIPE) {
+            // ---- software-pipelined main loop: no R slots.  The ds_reads of the NEXT fragments and the DMA issue sit between the
+            //      MFMAs of the wave (its partner on the SIMD fills the bubbles), one barrier B(g) per K-step: "stage g + 1 is
+            //      visible to everyone and stage g has been read by everyone" -- after it the DMA of K-step g + 4 may refill stage g.
+            //      [measured, s_memtime stamps] in the slot version a K-step costs ~2 R0 + 2 M: issuing 8 ds_read_b128 takes a
+            //      group ~230 cycles and issuing its 8 DMA pieces ~180 (the TA accepts one 1 KiB piece per ~21 cycles), all on the
+            //      critical path, against 16 MFMAs = 272.  Every M block below is ONE basic block (unconditional reads, DMA issue
+            //      without branches -- see issue4) so that the sched_group_barriers can interleave it.
+            bf16x8 f0w[4], f0x[4], f1w[4], f1x[4], xg[4];
+            {   // fragments of this tile's first K-step (exposed once per tile; its stage was made visible by the previous B)
+                const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(base + w_off + f * 1024);
+                for (int f = 0; f < 4; ++f) f0w[f] = *reinterpret_cast<const bf16x8*>(base + w_off + f * 1024);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + f * 1024);
-            issue_a();
-            if constexpr (FMW == 4) { issue_w(); wait_next(); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            QQ_BARRIER();
-            // ---- M0 ----
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][f], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            QQ_BARRIER();
-            if constexpr (FMW == 8) {
-                // ---- R1 ----
-#pragma unroll
-                for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
-                issue_w();
-                wait_next();
+                for (int f = 0; f < 4; ++f) f0x[f] = *reinterpret_cast<const bf16x8*>(base + a_off + f * 1024);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                QQ_BARRIER();
-                // ---- M1 ----
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][4 + f], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                QQ_BARRIER();
+                __builtin_amdgcn_sched_barrier(0);
             }
-            ++c_g;
+            // one K-step: MFMAs on (wf, xf), the next K-step's first fragments are read into (wn_, xn_)
+            auto kstep = [&](bf16x8 (&wf)[4], bf16x8 (&xf)[4], bf16x8 (&wn_)[4], bf16x8 (&xn_)[4]) __attribute__((always_inline)) {
+                const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
+                const char* nbase = lds + ((c_g + 1) & 3) * Q_STAGE_BYTES;
+                if constexpr (FMW == 8) {
+                    // ---- M0 + reads of this step's second half of the activation fragments ----
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) xg[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
+#pragma unroll
+                    for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][f], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                    __builtin_amdgcn_sched_barrier(0);             // (the asm wait below must not drift up between the MFMAs)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    q_wait_vm<8>();                                // own DMA of K-step c_g + 1 landed (c_g + 2, c_g + 3 may fly)
+                    QQ_BARRIER();                                  // B(c_g)
+                    // ---- M1 + reads of the next K-step's first fragments + DMA of K-step c_g + 4 into the stage just freed ----
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) wn_[f] = *reinterpret_cast<const bf16x8*>(nbase + w_off + f * 1024);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) xn_[f] = *reinterpret_cast<const bf16x8*>(nbase + a_off + f * 1024);
+                    issue4();
+#pragma unroll
+                    for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xg[f], wf[fn], acc[fn][4 + f], 0, 0, 0);
+                } else {
+                    q_wait_vm<8>();
+                    QQ_BARRIER();                                  // B(c_g): this step's fragments were read during the previous step
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) wn_[f] = *reinterpret_cast<const bf16x8*>(nbase + w_off + f * 1024);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) xn_[f] = *reinterpret_cast<const bf16x8*>(nbase + a_off + f * 1024);
+                    issue4();
+#pragma unroll
+                    for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][f], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {          // MFMA, read, MFMA, (DMA), ...: 16 MFMAs carry 8 ds_read_b128 and 4 DMA pieces
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                advance4();
+                ++c_g;
+            };
+            int kt = 0;
+            for (; kt + 1 < p.nt; kt += 2) { kstep(f0w, f0x, f1w, f1x); kstep(f1w, f1x, f0w, f0x); }
+            if (kt < p.nt) kstep(f0w, f0x, f1w, f1x);
+        } else {
+        for (int kt = 0; kt < p.nt; ++kt) {
+                const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
+                bf16x8 wf[4], xf[4];
+                Q_STAMP(0);
+                // ---- R0 ----
+    #pragma unroll
+                for (int f = 0; f < 4; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(base + w_off + f * 1024);
+    #pragma unroll
+                for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + f * 1024);
+                Q_STAMP(1);
+                issue_a();
+                if constexpr (FMW == 4) { issue_w(); wait_next(); }
+                Q_STAMP(2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Q_STAMP(3);
+                QQ_BARRIER();
+                Q_STAMP(4);
+                // ---- M0 ----
+                __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+    #pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][f], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                Q_STAMP(5);
+                QQ_BARRIER();
+                Q_STAMP(6);
+                if constexpr (FMW == 8) {
+                    // ---- R1 ----
+    #pragma unroll
+                    for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
+                    issue_w();
+                    wait_next();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    Q_STAMP(7);
+                    QQ_BARRIER();
+                    // ---- M1 ----
+                    __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+                    for (int fn = 0; fn < 4; ++fn)
+    #pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][4 + f], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    QQ_BARRIER();
+                }
+                ++c_g;
+            }
+    
         }
 
         // ---- epilogue: registers -> global, full lines, stores not waited for ----
@@ -451,14 +568,20 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
 
     // ---- prologue: K-steps 0..2 in flight, K-step 0 landed ----
     setup_src(p_idx);
-    issue_a(); issue_w();
-    issue_a(); issue_w();
-    issue_a(); issue_w();
-    if (total_steps > 2) q_wait_vm<8>();
-    else if (total_steps > 1) q_wait_vm<4>();
-    else q_wait_vm<0>();
+    if constexpr (PIPE) {
+        // four stages in flight: B(g) frees stage g half a step before its next use
+        issue4(); advance4(); issue4(); advance4(); issue4(); advance4(); issue4(); advance4();
+        q_wait_vm<12>();
+    } else {
+        issue_a(); issue_w();
+        issue_a(); issue_w();
+        issue_a(); issue_w();
+        if (total_steps > 2) q_wait_vm<8>();
+        else if (total_steps > 1) q_wait_vm<4>();
+        else q_wait_vm<0>();
+    }
     QQ_BARRIER();              // also publishes the bias image
-    if (grp_b) QQ_BARRIER();   // group B runs one slot behind group A
+    if (!PIPE && grp_b) QQ_BARRIER();   // group B runs one slot behind group A
 
     for (int idx = l0; idx < count; idx += L) {
         int m0, half, n0, mt;
@@ -466,7 +589,8 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
         if (half) run_tile(std::integral_constant<int, 4>{}, m0, n0, mt);
         else run_tile(std::integral_constant<int, 8>{}, m0, n0, mt);
     }
-    if (!grp_b) QQ_BARRIER();  // pairs with group B's extra barrier
+    if (!PIPE && !grp_b) QQ_BARRIER();  // pairs with group B's extra barrier
+    if constexpr (PIPE) q_wait_vm<0>();  // the surplus DMAs of the last K-steps must not outlive the workgroup's LDS allocation
 }
 
 template <typename Kern>
@@ -576,12 +700,23 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     static const int tail_first = getenv("VITK_NTP_TAIL_LAST") ? 0 : 1;
     a.tail_first = tail_first;
     a.dbg = getenv("VITK_NTP_DBG") ? atoi(getenv("VITK_NTP_DBG")) : 0;
+    a.stamps = getenv("VITK_NTP_STAMPS") ? (long long*)strtoull(getenv("VITK_NTP_STAMPS"), nullptr, 0) : nullptr;
     const int lds_bytes = Q_LDS_BYTES + pl.tiles_n * 512;      // ring + bias image (tiles_n * 256 columns of 2 bytes)
     hipStream_t st = (hipStream_t)stream;
+    // main-loop flavour: software-pipelined (default) or the R/M slot ping-pong (VITK_NTP_PIPE=0).  [measured] kernel by kernel the
+    // pipelined loop is ~5 % ahead (8-shape sum 1.688 vs 1.783 ms), inside the training step the two are level (42.7-43.1 vs
+    // 43.0-43.2 ms on the same box).
+    static const bool pipe = !(getenv("VITK_NTP_PIPE") && atoi(getenv("VITK_NTP_PIPE")) == 0);
 #define NTP_LAUNCH(E) do { \
-        static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E>, Q_LDS_MAX); \
-        if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-        hipLaunchKernelGGL((gemm_ntp_kernel<E>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+        if (pipe) { \
+            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, true>, Q_LDS_MAX); \
+            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
+            hipLaunchKernelGGL((gemm_ntp_kernel<E, true>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+        } else { \
+            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, false>, Q_LDS_MAX); \
+            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
+            hipLaunchKernelGGL((gemm_ntp_kernel<E, false>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+        } \
     } while (0)
     switch (epilogue) {
         case VITK_EPI_NONE: NTP_LAUNCH(VITK_EPI_NONE); break;
