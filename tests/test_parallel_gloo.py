@@ -94,3 +94,125 @@ def _worker(rank, world, port, staged):
 def test_data_parallel_two_ranks_gloo(staged):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, staged), nprocs=2, join=True)
+
+
+# ---- world size 8, ViT-L depth: the chunk plan ---------------------------------------------------------------------------
+class _SinkFn(torch.autograd.Function):
+    """y = tanh(x * w) with the parameter gradient written into the sink's buffer and the stage announced, like the fused engine's
+    Functions do (head -> final norm -> layers depth-1 .. 0, then ("transformer")).  late = True: the gradient is returned to
+    autograd instead (a foreign module inside the stack): it reaches the flat buffer only in finish_step."""
+
+    @staticmethod
+    def forward(ctx, x, w, li, late):
+        ctx.save_for_backward(x, w)
+        ctx.li, ctx.late = li, late
+        return torch.tanh(x * w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        y = torch.tanh(x * w)
+        gz = g * (1 - y * y)
+        gw = (gz * x).sum(0)
+        sink = E._sink()
+        if ctx.late:
+            ret = gw
+        else:
+            buf = E._grad_buf(w)
+            buf.copy_(gw)
+            ret = E._ret(buf)
+        if sink is not None and ctx.li >= 0:
+            if sink.wants_layer(ctx.li):
+                sink.stage_done("layer", ctx.li)
+            if ctx.li == 0:
+                sink.stage_done("transformer")
+        return gz * w, ret, None, None
+
+
+class _DeepToy(torch.nn.Module):
+    """Parameter names laid out like ViT-L/16: 24 layers, final norm, head, and the late patch-embedding stage."""
+
+    def __init__(self, depth=24, width=13, late_layer=None):          # width 13: slices of 13 elements, padded to 16 in the flat buffer
+        super().__init__()
+        self.to_patch_embedding = torch.nn.Linear(6, width)
+        self.transformer = torch.nn.Module()
+        self.transformer.layers = torch.nn.ModuleList()
+        for _ in range(depth):
+            blk = torch.nn.Module()
+            blk.w = torch.nn.Parameter(1 + 0.1 * torch.randn(width))
+            self.transformer.layers.append(blk)
+        self.transformer.norm = torch.nn.Module()
+        self.transformer.norm.weight = torch.nn.Parameter(1 + 0.1 * torch.randn(width))
+        self.mlp_head = torch.nn.Module()
+        self.mlp_head.weight = torch.nn.Parameter(1 + 0.1 * torch.randn(width))
+        self.late_layer = late_layer
+
+    def forward(self, x):
+        x = self.to_patch_embedding(x)
+        for li, blk in enumerate(self.transformer.layers):
+            x = _SinkFn.apply(x, blk.w, li, li == self.late_layer)
+        x = _SinkFn.apply(x, self.transformer.norm.weight, -1, False)
+        return _SinkFn.apply(x, self.mlp_head.weight, -1, False)
+
+
+def _worker8(rank, world, port, lpc, late_layer):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(7)
+        model = _DeepToy(late_layer=late_layer)
+        dp = DataParallel(model, layers_per_chunk=lpc)
+        sink = dp.sink
+        plan = sink.chunk_plan()
+        # the plan tiles the flat buffer exactly once, in order, on 8-element (16-byte) boundaries
+        cur = 0
+        for off, n, _ in plan:
+            assert off == cur and n > 0 and off % 8 == 0
+            cur += n
+        assert cur == sink.total and sink.total == (24 + 2) * 16 + sink.total - sink.boundary
+        in_backward = [c for c in plan if c[2].startswith("layers")]
+        assert len(in_backward) == ((24 + lpc - 1) // lpc if lpc > 0 else 0)
+        if lpc == 3:        # head + norm + layers 23, 22, 21 in the first message, then three layers each
+            assert [n for _, n, _ in in_backward] == [5 * 16] + [3 * 16] * 7
+        torch.manual_seed(100 + rank)
+        x = torch.randn(4, 6)
+        sink.log = []
+        dp.backward(dp(x).square().mean())
+        # every element is reduced exactly once -- except a gradient that arrived late: its slot went out with its chunk (stale
+        # content) and is reduced again on its own from finish_step, which is the value that counts
+        covered = torch.zeros(sink.total, dtype=torch.int32)
+        for off, n in sink.log:
+            covered[off:off + n] += 1
+        expect = torch.ones(sink.total, dtype=torch.int32)
+        if late_layer is not None:
+            i = next(k for k, p in enumerate(sink.params) if p is model.transformer.layers[late_layer].w)
+            expect[sink.offsets[i]:sink.offsets[i] + 13] += 1
+        assert torch.equal(covered, expect), (late_layer, sorted(sink.log))
+        assert [tuple(c[:2]) for c in plan] == sorted(sink.log)[:len(plan)] or late_layer is not None
+        # result = average over ranks of the local gradients
+        sink.log = None
+        E.set_grad_sink(None)
+        for p in model.parameters():
+            p.grad = None
+        model(x).square().mean().backward()
+        exp = []
+        for p in sink.params:
+            g = p.grad.detach().clone()
+            dist.all_reduce(g); g /= world
+            exp.append(g)
+        dp.backward(dp(x).square().mean())
+        for i, p in enumerate(sink.params):
+            assert torch.allclose(p.grad, exp[i], atol=1e-6), (i, late_layer)
+        model_ms = sink.comm_model(world=8)
+        assert len(model_ms) == len(plan) and all(m["ring_ms"] >= m["direct_ms"] > 0 for m in model_ms)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lpc,late_layer", [(3, None), (4, 13), (0, None), (24, 5)])
+def test_chunk_plan_world_size_8_depth_24(lpc, late_layer):
+    """ViT-L depth on 8 ranks (BASELINE config 3's topology): offsets of the in-backward chunks, every slice reduced exactly once,
+    a gradient that arrives outside the sink after its chunk has gone out (late_layer) is reduced again on its own, result = average."""
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, lpc, late_layer), nprocs=8, join=True)

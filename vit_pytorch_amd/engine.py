@@ -154,6 +154,24 @@ def dropout_fusable(T, B: int, N: int, D: int, heads: int, dim_head: int, F: int
             and ops.fused_dropout_ok(T, M, F, D) and ops.fused_dropout_ok(T, M, D, F))
 
 
+def _recompute_policy(saved_bytes: int, device) -> bool:
+    """Keep every activation of the stack (the default: 1.4 GB / layer at ViT-B/16 batch 256, nothing but the attention
+    probabilities is ever recomputed) unless that would not fit: when the activations a forward pass is about to save exceed
+    45 % of the device memory -- BASELINE config 5, ViT-H/14 at 336 px and batch 256 / GPU: 6.8 GB x 32 layers = 217 GB of 288 --
+    the three cheapest-to-rebuild tensors of a layer are dropped and rebuilt in its backward: the GELU output (one elementwise pass
+    over the saved pre-activation) and the two LayerNorm outputs (one LayerNorm forward each from the saved residual stream):
+    2.3 of the 6.8 GB.  VITK_RECOMPUTE=0 / 1 overrides."""
+    import os
+    v = os.environ.get("VITK_RECOMPUTE")
+    if v is not None:
+        return v not in ("0", "")
+    try:
+        total = torch.cuda.get_device_properties(device).total_memory
+    except Exception:
+        return False
+    return saved_bytes > 0.45 * total
+
+
 class TransformerFn(torch.autograd.Function):
     """Transformer.forward (vit.py:78-83 / simple_vit.py:74-78).  drop_p > 0 (training): the four dropouts of a layer --
     attention matrix (vit.py:60), after to_out (:48), after the GELU (:22), after the second FeedForward Linear (:24) --
@@ -178,6 +196,10 @@ class TransformerFn(torch.autograd.Function):
             K.cast(x, xs)
         saved = []
         keep = any(ctx.needs_input_grad)      # no_grad / eval: drop each layer's activations as soon as the layer is done
+        esz = 4 if T == F32 else 2
+        Fh0 = lp[7].shape[0] if depth else 0
+        per_layer = M * (2 * D * 4 + (2 * D + 4 * I + 2 * Fh0) * esz)          # xs, x2 (f32) + a1, a2, qkv, o, pre, act
+        recompute = bool(keep and depth and drop_p == 0.0 and fp8 is None and _recompute_policy(per_layer * depth, xs.device))
         if drop_p > 0.0 and (lp[3] is None or lp[8] is None or not dropout_fusable(T, B, N, D, heads, dim_head, lp[7].shape[0])):
             raise VitkError("TransformerFn: this shape does not take the fused dropout path (caller must check dropout_fusable)")
         site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
@@ -233,7 +255,8 @@ class TransformerFn(torch.autograd.Function):
                 act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True, drop=site(li, 2))
                 x3 = ops.linear_fwd(act, w2, b2, M, resid=x2, drop=site(li, 3))
             if keep:
-                saved.append((xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act))
+                saved.append((xs, None, st1, qkv, o, att_saved, x2, None, st2, pre, None) if recompute
+                             else (xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act))
             xs = x3
         if use8:
             fp8.end_of_forward()
@@ -283,6 +306,13 @@ class TransformerFn(torch.autograd.Function):
             ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
             xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act = ctx.saved[li]
             ctx.saved[li] = None
+            if act is None:         # recompute mode (_recompute_policy): rebuild the GELU output and the LayerNorm outputs of this layer
+                act = ops.empty(pre.shape, T, pre)
+                K.gelu_fwd(pre, act)
+                a2 = ops.empty((M, D), T, x2)
+                ops.ln_fwd(x2, ln2w, ln2b, M, D, a2)
+                a1 = ops.empty((M, D), T, xs)
+                ops.ln_fwd(xs, ln1w, ln1b, M, D, a1)
             gT = gb if bf else g
             base = li * NLP
             # ---- feed-forward branch (vit.py:18-25) ----

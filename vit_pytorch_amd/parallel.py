@@ -64,12 +64,23 @@ def _ordered_params(model: torch.nn.Module):
 class FlatGradSink:
     """Owns the flat gradient buffer; handed to the engine as the gradient sink."""
 
-    def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True, layers_per_chunk: int = 3):
+    def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True, layers_per_chunk: Optional[int] = None,
+                 comm_priority: Optional[int] = None):
+        """layers_per_chunk: transformer layers per in-backward all-reduce (0 = one message for the whole stack when its backward
+        ends); default 3, env VITK_DP_LAYERS_PER_CHUNK.  comm_priority: HIP stream priority of the side stream that carries the
+        collectives (lower = more urgent; default -1 so that RCCL's kernels are scheduled ahead of the GEMM workgroups that
+        would otherwise hold every CU), env VITK_DP_COMM_PRIORITY."""
+        import os
         self.model = model
         self.group = process_group
         self.average = average
         self.params, self.n_early, layer_end = _ordered_params(model)
+        if layers_per_chunk is None:
+            layers_per_chunk = int(os.environ.get("VITK_DP_LAYERS_PER_CHUNK", "3"))
+        if comm_priority is None:
+            comm_priority = int(os.environ.get("VITK_DP_COMM_PRIORITY", "-1"))
         self.layers_per_chunk = layers_per_chunk
+        self.comm_priority = comm_priority
         p0 = self.params[0]
         self.dtype, self.device = p0.dtype, p0.device
         assert all(p.dtype == self.dtype and p.device == self.device for p in self.params), \
@@ -89,10 +100,44 @@ class FlatGradSink:
         self._by_ptr: Dict[int, int] = {p.data_ptr(): i for i, p in enumerate(self.params) if p.numel()}
         self._view_ptrs = {v.data_ptr() for v, p in zip(self.views, self.params) if p.numel()}
         self._filled = set()
-        self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.side = torch.cuda.Stream(device=self.device, priority=comm_priority) if self.device.type == "cuda" else None
+        self.log = None      # tests: list collecting (offset, length) of every all-reduce this rank issues
         self._early_launched = False
         self._late_launched = False
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def chunk_plan(self):
+        """[(offset, elements, label)] of the collectives one step issues, in issue order: the in-backward chunks of the transformer
+        stack (every `layers_per_chunk` layers, counted from layer 0 upwards, so the first chunk also holds the head and the final
+        norm), the rest of the early segment, and the patch-embedding segment.  Together they tile [0, total) exactly once."""
+        plan, cur = [], 0
+        depth = len(self.layer_end_off)
+        if self.layers_per_chunk > 0:
+            for li in range(depth - 1, -1, -1):
+                end = self.layer_end_off[li]
+                if li % self.layers_per_chunk == 0 and end > cur:
+                    plan.append((cur, end - cur, f"layers {li}.. (chunk ending at layer {li})"))
+                    cur = end
+        if self.boundary > cur:
+            plan.append((cur, self.boundary - cur, "rest of the early segment"))
+            cur = self.boundary
+        if self.total > cur:
+            plan.append((cur, self.total - cur, "patch embedding, cls, pos"))
+        return plan
+
+    def comm_model(self, world: int = 8, link_gbs: float = 153.0, links: int = 7, step_ms: Optional[float] = None):
+        """Bytes and modelled time of every collective of chunk_plan() on one xGMI node (a MODEL: no multi-GPU run backs it).
+        All-reduce of S bytes over `world` fully connected GPUs: a ring moves 2 (w-1)/w S per GPU over ONE link per direction
+        (link_gbs); the direct (all-to-all reduce-scatter + all-gather) schedule spreads the same bytes over min(links, w-1)
+        links.  Returns a list of dicts."""
+        esz = torch.empty((), dtype=self.dtype).element_size()
+        out = []
+        for off, n, label in self.chunk_plan():
+            S = n * esz
+            moved = 2.0 * (world - 1) / world * S
+            out.append({"label": label, "offset": off, "bytes": S, "ring_ms": moved / (link_gbs * 1e9) * 1e3,
+                        "direct_ms": moved / (link_gbs * 1e9 * min(links, world - 1)) * 1e3})
+        return out
 
     def refresh_param_ptrs(self):
         """Re-index the parameters after their storage moved (optim.Adam re-homes them into one flat buffer)."""
@@ -147,6 +192,8 @@ class FlatGradSink:
             self._allreduce(seg)
 
     def _allreduce(self, seg: torch.Tensor):
+        if self.log is not None:
+            self.log.append(((seg.data_ptr() - self.flat.data_ptr()) // seg.element_size(), seg.numel()))
         if self.average and dist.get_backend(self.group) == "nccl":
             dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)
         else:
@@ -206,10 +253,10 @@ class DataParallel(torch.nn.Module):
     """
 
     def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True, broadcast: bool = True,
-                 layers_per_chunk: int = 3):
+                 layers_per_chunk: Optional[int] = None, comm_priority: Optional[int] = None):
         super().__init__()
         self.module = model
-        self.sink = FlatGradSink(model, process_group, average, layers_per_chunk)
+        self.sink = FlatGradSink(model, process_group, average, layers_per_chunk, comm_priority)
         if broadcast and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             for p in model.parameters():
                 dist.broadcast(p.data, src=0, group=process_group)
