@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 121
+#define VITK_VERSION 122
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -298,6 +298,13 @@ int vitk_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, int dt, int6
  * extent is not a multiple of 32, e.g. patch_dim = 588 of ViT-H/14, so that the MFMA GEMMs can take it)          */
 int vitk_copy_cols(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int dt, int64_t rows, int64_t cols_copy,
                    int64_t cols_dst, void* stream);
+/* f32 validation mode ON THE MFMA KERNELS: x (f32) is written as six blocks of its three-term bf16 split hi + mid + lo -- block
+ * order {hi,hi,mid,hi,lo,mid} (operand_b = 0) or {hi,mid,hi,lo,hi,mid} (operand_b = 1) -- so that ONE 16-bit GEMM over the six-fold
+ * reduction extent sums hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid = the f32 product to ~2^-22.  Block b lands at
+ * out + b * block_stride (+ r * ld_out + c): block_stride = cols, ld_out = 6 * cols concatenates along K (vitk_gemm_nt_bf16);
+ * block_stride = rows * ld_out concatenates along M (vitk_gemm_tn_bf16).  bfloat16 library only.                              */
+int vitk_split_bf16x3(const float* x, int64_t ldx, void* out, int64_t ld_out, int64_t block_stride, int64_t rows,
+                      int64_t cols, int operand_b, void* stream);
 /* out[b, i, :] = (i < F ? front[i, :] : x[b, i - F, :]) + (pos ? pos[i, :] : 0) for i < Np + F: torch.cat((tokens, x), dim = 1)
  * + pos[:N] of vit.py:122-127 for all images in one launch; also the register tokens of
  * simple_vit_with_register_tokens.py:113-115 (placed in front: the transformer is equivariant to the token order).       */

@@ -197,6 +197,32 @@ def test_gemm_nt_gelu_bwd_with_bias_gradient(M, N, Kd):
         K.gemm_nt_bf16_gelu_bwd_colsum(A[:128], Kd, W[:128], Kd, C1, 128, 128, 128, Kd, h, part)
 
 
+@pytest.mark.parametrize("M,N,Kd", [(1200, 768, 768), (4200, 1032, 320)])
+def test_f32_linear_on_the_mfma_kernels_via_bf16x3_split(M, N, Kd, monkeypatch):
+    """f32 validation mode: ops.linear_fwd / linear_dx / linear_dw on float32 tensors run the PRODUCTION MFMA kernels (persistent NT,
+    split-M TN) over three-term bfloat16 splits of both operands; the result must be f32-accurate (the bound here is 3e-6 of the
+    float64 product; a plain bf16 product would sit at ~3e-3)."""
+    from vit_pytorch_amd import ops
+    x = rnd(M, Kd, seed=71); W = torch.nn.Parameter(rnd(N, Kd, seed=72) * Kd ** -0.5); b = rnd(N, seed=73); r = rnd(M, N, seed=74)
+    assert K.gemm_nt_plan(M, N, 6 * Kd, N)["persistent"]
+    ref = x.double() @ W.double().t()
+    y = ops.linear_fwd(x, W, b, M)
+    assert y.dtype == F32 and rel(y, ref + b.double()) < 3e-6
+    yr = ops.linear_fwd(x, W, b, M, resid=r)
+    assert rel(yr, ref + b.double() + r.double()) < 3e-6
+    act, pre = ops.linear_fwd(x, W, b, M, gelu=True)
+    assert rel(pre, ref + b.double()) < 3e-6 and rel(act, torch.nn.functional.gelu(ref + b.double())) < 3e-6
+    dy = rnd(M, N, seed=75)
+    dx = ops.linear_dx(dy, W, M)
+    assert rel(dx, dy.double() @ W.double()) < 3e-6
+    dW = torch.empty(N, Kd, device=DEV)
+    ops.linear_dw(dy, x, M, dW)
+    assert rel(dW, dy.double().t() @ x.double()) < (3e-6 if M >= 4096 else 1e-5)
+    # and the same numbers (to round-off) with the mode switched off, i.e. on the VALU coverage kernel
+    monkeypatch.setenv("VITK_F32_MFMA", "0")
+    assert rel(ops.linear_fwd(x, W, b, M), y) < 3e-6
+
+
 def test_gemm_nt_rejects_bad_shapes():
     A = rnd(64, 40, dtype=BF); W = rnd(64, 40, dtype=BF); C = torch.empty(64, 64, dtype=BF, device=DEV)
     with pytest.raises(L.VitkError):
@@ -205,13 +231,11 @@ def test_gemm_nt_rejects_bad_shapes():
 
 @pytest.mark.parametrize("M,N,Kd", [(4096, 256, 256), (5000, 768, 768), (6304, 2304, 768), (4500, 264, 520), (64, 128, 128), (1000, 768, 768), (197 * 16, 2304, 768), (333, 136, 72), (197 * 8, 768, 3072), (5000, 64, 256)])
 @pytest.mark.parametrize("odt", [BF, F32])
-@pytest.mark.parametrize("variant", ["default", "VITK_TN_DMA", "VITK_TN_DMA+XREG"])
+@pytest.mark.parametrize("variant", ["default", "VITK_TN_DMA"])
 def test_gemm_tn(M, N, Kd, odt, variant, monkeypatch):
-    """variant: the register-staged kernel (default) or gemm_tn_dma.hip (LDS-DMA ring; +XREG: the X tile through registers)."""
+    """variant: the register-staged kernel (default) or gemm_tn_dma.hip (LDS-DMA ring)."""
     if variant != "default":
         monkeypatch.setenv("VITK_TN_DMA", "1")
-        if variant.endswith("XREG"):
-            monkeypatch.setenv("VITK_TN_XREG", "1")
     dY = rnd(M, N, dtype=BF, seed=51) * (M ** -0.5); X = rnd(M, Kd, dtype=BF, seed=52)
     ref = dY.double().t() @ X.double()
     splits = K.gemm_tn_splits(M, N, Kd)

@@ -16,7 +16,7 @@ LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit t
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3, 4
-VITK_VERSION = 121
+VITK_VERSION = 122
 
 
 class RowMap(C.Structure):
@@ -97,6 +97,7 @@ SIGNATURES = {
     "vitk_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _u64, _u64, _vp]),
     "vitk_dropout_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp]),
     "vitk_copy_cols": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _i64, _vp]),
+    "vitk_split_bf16x3": (_i, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp]),
     "vitk_concat_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
     "vitk_gather_tokens": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i, _vp]),
     "vitk_transpose": (_i, [_vp, _vp, _i, _i64, _i64, _vp]),

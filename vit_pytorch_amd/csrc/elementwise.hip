@@ -377,7 +377,47 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const T* __restrict_
     }
 }
 
+// x (f32) = hi + mid + lo with three bf16 terms (8 + 8 + 8 significant bits: exact for every normal f32 whose low terms do not
+// underflow); the six products  hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid  of two split operands reproduce the f32 product
+// to ~2^-22.  This kernel writes the six-block image one operand needs: block b of operand A holds part {0,0,1,0,2,1}[b], of operand
+// B part {0,1,0,2,0,1}[b]; blocks are `block_stride` elements apart (K-concatenation for the NT kernel: block_stride = K,
+// ld_out = 6 K; M-concatenation for the TN kernel: block_stride = M * ld_out).
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long long ldx, __bf16* __restrict__ out, long long ldo,
+                                                      long long block_stride, long long rows, int cols4, int operand_b) {
+    const long long total = rows * cols4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols4;
+        const int c = (int)(i % cols4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+        f32x4 part[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 h = (__bf16)v[e];
+            const float r1 = v[e] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            const float r2 = r1 - (float)m;
+            part[0][e] = (float)h; part[1][e] = (float)m; part[2][e] = (float)(__bf16)r2;
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int which = ((operand_b ? 0x010201 : 0x001021) >> (4 * (5 - b))) & 0xf;      // one hex digit per block
+            store4<__bf16>(out + b * block_stride + r * ldo + c, part[which]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int vitk_split_bf16x3(const float* x, int64_t ldx, void* out, int64_t ld_out, int64_t block_stride, int64_t rows,
+                                 int64_t cols, int operand_b, void* stream) {
+    if (!x || !out) VITK_FAIL(VITK_E_ARG, "split_bf16x3: null pointer");
+    if (rows <= 0 || cols <= 0 || (cols & 3) || (ldx & 3) || (ld_out & 3) || (block_stride & 3) || !aligned16(x) || !aligned8(out))
+        VITK_FAIL(VITK_E_SHAPE, "split_bf16x3: extents and strides must be multiples of 4");
+    hipLaunchKernelGGL(split3_kernel, dim3(ew_blocks(rows * cols / 4)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx,
+                       (__bf16*)out, (long long)ld_out, (long long)block_stride, (long long)rows, (int)(cols / 4), operand_b);
+    VITK_CHECK_LAUNCH("split_bf16x3");
+    return 0;
+}
 
 extern "C" int vitk_concat_tokens(const void* x, const void* front, const void* pos, void* out, int dt, int64_t B, int64_t Np,
                                   int64_t F, int64_t D, void* stream) {

@@ -56,16 +56,10 @@ __device__ __forceinline__ bf16x8 t_frag(unsigned stage, int off_lo, int off_hi)
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// XREG: the X tile does not use the LDS-DMA path but global_load -> registers -> ds_write (three steps of 2 x 16 B per thread in
-// flight).  [measured] with both operands on LDS-DMA the DMA side alone (no MFMA) takes longer than the compute side alone
-// (237 vs 199 us on dW1): the DMA path delivers ~15 B/clk per CU.  Splitting the traffic over both load paths lifts that bound.
-// The register loads are inline asm: hipcc would drain the DMA queue (vmcnt(0)) at the first use of an ordinary load issued next
-// to LDS-DMA; here both kinds are counted by hand (every K-step issues 2 + 2 vector memory instructions per wave either way).
-__device__ __forceinline__ void t_gload16(bf16x8& dst, const char* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-
-template <bool XREG>
+// [measured] Moving the X tile off the LDS-DMA path (global_load -> registers -> ds_write, inline-asm loads counted by hand in the
+// same vmcnt protocol) was built and removed: 0.84x (the "no MFMA" time rose from 237 to 307 us) -- the load side is not limited by
+// the DMA path itself.  What bounds both TN kernels is the issue rate of ds_read_b64_tr_b16: a group's 16 transpose reads take ~405
+// cycles to issue (tools/tn_stamps.py), against 272 for the 16 MFMAs they feed.
 __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(
     const __bf16* __restrict__ dY, long long ldy, const __bf16* __restrict__ X, long long ldx,
     float* __restrict__ ws, int M, int N, int K, int rows_per_split, int tiles_k, int nwg, int dbg, long long* stamps) {
@@ -111,34 +105,6 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(
         }
     };
 
-    // XREG producer: thread loads chunks c = tid and tid + 512 of the 32 x 512 B X tile (row c >> 5, 16-byte chunk c & 31)
-    int xg_row[2], xg_img[2];
-    bool xg_colok[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = tid + 512 * j;
-        xg_row[j] = c >> 5;
-        xg_img[j] = T_OPER_BYTES + t_img(c >> 5, (c & 31) * 16);
-        xg_colok[j] = k0 + (c & 31) * 8 < K;
-    }
-    auto xload = [&](int step, bf16x8 (&r)[2]) {          // always issued (the op count is part of the vmcnt protocol): clamped address
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int m = mbeg + step * 32 + xg_row[j];
-            m = m < mend ? m : mend - 1;
-            t_gload16(r[j], reinterpret_cast<const char*>(X + (long long)m * ldx + (xg_colok[j] ? k0 + ((tid + 512 * j) & 31) * 8 : 0)));
-        }
-    };
-    auto xstore = [&](int step, bf16x8 (&r)[2]) {         // after the counted wait that covers `step`
-        char* base = lds + (step & 3) * T_STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool ok = xg_colok[j] && (mbeg + step * 32 + xg_row[j] < mend);
-            const bf16x8 v = ok ? r[j] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<bf16x8*>(base + xg_img[j]) = v;
-        }
-    };
-
     // ---- consumer: fragment addresses.  Lane (fi, fg): row 4 fg + (fi >> 2) (and + 16), bytes (fi & 3) * 8 of a 32-byte block.
     const int fi = lane & 15, fg = lane >> 4;
     const int r_lo = 4 * fg + (fi >> 2), r_hi = r_lo + 16;
@@ -161,9 +127,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(
     const bool stamp_on = stamps && blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == 4);
     long long* my_stamps = stamps ? stamps + (wave == 4 ? 1024 : 0) : nullptr;
 #define T_STAMP(t, slot) do { if (stamp_on && (t) >= 8 && (t) < 40) my_stamps[((t) - 8) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
-    bf16x8 xr0[2], xr1[2], xr2[2];                         // XREG: X tiles of three K-steps in flight (ring by step % 3)
-    auto body = [&](int t, bf16x8 (&xw)[2], bf16x8 (&xl)[2]) __attribute__((always_inline)) {
-        // xw holds the X tile of step t + 1 (written to LDS here, after the wait that covers it), xl receives that of step t + 3
+    auto body = [&](int t) __attribute__((always_inline)) {
         const unsigned base = lds_base + (t & 3) * T_STAGE_BYTES;
         const bool more = t + 3 < nsteps;
         bf16x8 xf[4], yf[4];
@@ -198,12 +162,11 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(
         // ---- R1: dY fragments 4..7, X tile of step t + 3 (DMA or register loads), counted wait for step t + 1 ----
 #pragma unroll
         for (int f = 0; f < 4; ++f) yf[f] = t_frag(base, y_lo[4 + f], y_hi[4 + f]);
-        if (more && !(dbg & 1)) { if constexpr (XREG) xload(t + 3, xl); else issue(t + 3, true); }
+        if (more && !(dbg & 1)) issue(t + 3, true);
         if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (t + 2 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (XREG) { if (t + 1 < nsteps && !(dbg & 1)) xstore(t + 1, xw); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         T_STAMP(t, 7);
         TT_BARRIER();
@@ -223,22 +186,17 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(
     };
 
     if (nsteps > 0) {
-        // prologue: steps 0..2 in flight, step 0 landed (XREG: and its X tile written)
-        issue(0, false); if constexpr (XREG) xload(0, xr0); else issue(0, true);
-        if (nsteps > 1) { issue(1, false); if constexpr (XREG) xload(1, xr1); else issue(1, true); }
-        if (nsteps > 2) { issue(2, false); if constexpr (XREG) xload(2, xr2); else issue(2, true); }
+        // prologue: steps 0..2 in flight, step 0 landed
+        issue(0, false); issue(0, true);
+        if (nsteps > 1) { issue(1, false); issue(1, true); }
+        if (nsteps > 2) { issue(2, false); issue(2, true); }
         if (nsteps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (XREG) { xstore(0, xr0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         TT_BARRIER();
         if (grp_b) TT_BARRIER();   // group B runs one slot behind group A
 
-        for (int t = 0; t < nsteps; t += 3) {
-            body(t, xr1, xr0);
-            if (t + 1 < nsteps) body(t + 1, xr2, xr1);
-            if (t + 2 < nsteps) body(t + 2, xr0, xr2);
-        }
+        for (int t = 0; t < nsteps; ++t) body(t);
         if (!grp_b) TT_BARRIER();  // pairs with group B's extra barrier
     }
 
@@ -264,17 +222,10 @@ int gemm_tn_dma_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, 
     const int nwg = tiles_n * tiles_k;
     long long rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
-    static const int rc0__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma_kernel<false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-    static const int rc__ = rc0__ ? rc0__ : (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma_kernel<true>),
-                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    static const int rc__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     if (rc__ != 0) VITK_FAIL(rc__, "gemm_tn_bf16: cannot enable %d B of LDS", T_LDS_BYTES);
-    if (getenv("VITK_TN_XREG") && atoi(getenv("VITK_TN_XREG")))
-        hipLaunchKernelGGL(gemm_tn_dma_kernel<true>, dim3((unsigned)(nwg * splits)), dim3(512), T_LDS_BYTES, (hipStream_t)stream,
-                           (const __bf16*)dY, (long long)ldy, (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg,
-                           getenv("VITK_TN_DBG") ? atoi(getenv("VITK_TN_DBG")) : 0, (long long*)nullptr);
-    else
-    hipLaunchKernelGGL(gemm_tn_dma_kernel<false>, dim3((unsigned)(nwg * splits)), dim3(512), T_LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((unsigned)(nwg * splits)), dim3(512), T_LDS_BYTES, (hipStream_t)stream,
                        (const __bf16*)dY, (long long)ldy, (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg,
                        getenv("VITK_TN_DBG") ? atoi(getenv("VITK_TN_DBG")) : 0,
                        getenv("VITK_TN_STAMPS") ? (long long*)strtoull(getenv("VITK_TN_STAMPS"), nullptr, 0) : (long long*)nullptr);

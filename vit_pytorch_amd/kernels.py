@@ -295,6 +295,11 @@ def copy_cols(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, col
     check(_lib_for(src, dst).vitk_copy_cols(_p(src), ld_src, _p(dst), ld_dst, dt(src), rows, cols_copy, cols_dst, _stream()), "copy_cols")
 
 
+def split_bf16x3(x: Tensor, ldx: int, out: Tensor, ld_out: int, block_stride: int, rows: int, cols: int, operand_b: bool):
+    """f32 -> six blocks of its hi / mid / lo bfloat16 split (vitk_split_bf16x3); always the bfloat16 library."""
+    check(L.load().vitk_split_bf16x3(_p(x), ldx, _p(out), ld_out, block_stride, rows, cols, int(operand_b), _stream()), "split_bf16x3")
+
+
 def concat_tokens(x: Tensor, front: Optional[Tensor], pos: Optional[Tensor], out: Tensor, B: int, Np: int, F: int, D: int):
     check(_lib_for(x, front, pos, out).vitk_concat_tokens(_p(x), _p(front), _p(pos), _p(out), dt(x), B, Np, F, D, _stream()), "concat_tokens")
 

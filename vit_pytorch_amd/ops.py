@@ -84,6 +84,61 @@ def fp8_gemm_ok(M: int, D: int, I: int, Fh: int) -> bool:
             and K.gemm_nt_colsum_rows(M, D, Fh, D) > 0)
 
 
+# ---- f32 validation mode on the production MFMA kernels ------------------------------------------------------------------------
+# The float32 mode (params float32: the mode that proves the host logic and the kernels' arithmetic to round-off) used to run every
+# Linear on the VALU coverage kernel, i.e. it validated different kernels than the ones production runs.  For shapes the production
+# kernels serve, an f32 GEMM is now ONE launch of the SAME 16-bit MFMA kernel (persistent NT kernel / split-M TN kernel) over a
+# six-fold reduction extent: both operands are split into three bfloat16 terms (vitk_split_bf16x3) and the six cross products that
+# matter are summed by the kernel's own f32 accumulation -- tiling, LDS swizzles, DMA ring, epilogue addressing and the split-M
+# reduction are exactly the production ones; the result is f32-accurate (~2^-22).  VITK_F32_MFMA=0 restores the coverage kernel.
+import os as _os
+
+_SPLIT_CACHE = {}       # id(W) -> (weakref, weight_key, operand_b, six-block image): weights are split once per value
+
+
+def f32_on_mfma() -> bool:
+    return _os.environ.get("VITK_F32_MFMA", "1") not in ("0", "")
+
+
+def _split_k(x: Tensor, rows: int, cols: int, ld: int, operand_b: bool) -> Tensor:
+    """(rows, cols) f32 -> (rows, 6 cols) bf16: the six blocks side by side along the reduction (K) extent."""
+    out = empty((rows, 6 * cols), BF16, x)
+    K.split_bf16x3(x, ld, out, 6 * cols, cols, rows, cols, operand_b)
+    return out
+
+
+def _split_weight_k(W: Tensor) -> Tensor:
+    key = weight_key(W)
+    ent = _SPLIT_CACHE.get(id(W))
+    if ent is not None and ent[0]() is W and ent[1] == key and not torch.cuda.is_current_stream_capturing():
+        return ent[2]
+    N, Kd = W.shape
+    out = _split_k(W, N, Kd, Kd, True)
+    if isinstance(W, torch.nn.Parameter) and not torch.cuda.is_current_stream_capturing():
+        wid = id(W)
+        _SPLIT_CACHE[wid] = (weakref.ref(W, lambda _r, wid=wid: _SPLIT_CACHE.pop(wid, None)), key, out)
+    return out
+
+
+def _f32_nt_ok(x: Tensor, M: int, N: int, Kd: int) -> bool:
+    return (x.dtype == F32 and f32_on_mfma() and Kd % 32 == 0 and N % 8 == 0 and K.gemm_nt_plan(M, N, 6 * Kd, N)["persistent"])
+
+
+def _gemm_nt_f32(x: Tensor, W: Tensor, M: int, resid: Optional[Tensor], bias: Optional[Tensor], w_is_split: bool = False) -> Tensor:
+    """out (M, N) f32 = x @ W^T (+ resid) (+ bias) on the persistent NT kernel (f32 residual epilogue; a zero residual when there is none)."""
+    N = W.shape[0]
+    Kd = W.shape[1] // 6 if w_is_split else W.shape[1]
+    a6 = _split_k(x, M, Kd, Kd, False)
+    w6 = W if w_is_split else _split_weight_k(W)
+    out = empty((M, N), F32, x)
+    r = resid if resid is not None else torch.zeros((M, N), dtype=F32, device=x.device)
+    K.gemm_nt_bf16(a6, 6 * Kd, w6, 6 * Kd, out, N, M, N, 6 * Kd, L.EPI_RESID, resid=r)
+    if bias is not None:
+        z = r if resid is None else torch.zeros((M, N), dtype=F32, device=x.device)
+        K.add_rows(out, z, bias, out, M, N)
+    return out
+
+
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bool = False,
                resid: Optional[Tensor] = None, out_dtype=None, drop: Optional[Tuple[float, int]] = None):
     """y = x @ W^T + b  (vit.py:20,23,44,47,102).  x: (M,K) T contiguous; W: (N,K) T.
@@ -95,6 +150,13 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
     T = x.dtype
     if drop is not None and not fused_dropout_ok(T, M, N, Kd):
         raise L.VitkError("linear_fwd: fused dropout needs a shape served by the 256-row kernel (caller must check fused_dropout_ok)")
+    if drop is None and _f32_nt_ok(x, M, N, Kd) and (out_dtype is None or out_dtype == F32):
+        y = _gemm_nt_f32(x, W, M, resid, bias)
+        if gelu:
+            act = empty((M, N), F32, x)
+            K.gelu_fwd(y, act)
+            return act, y
+        return y
     if resid is not None:
         out = empty((M, N), F32, x)
         if drop is not None:
@@ -159,6 +221,11 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
     produced `pre`, was written to db as a by-product of the GEMM epilogue (otherwise the caller still owes it)."""
     N, Kd = W.shape
     T = dy.dtype
+    if drop is None and _f32_nt_ok(dy, M, Kd, N):
+        dx = _gemm_nt_f32(dy, transpose_weight(W), M, None, None)          # (M, N) @ (Kd, N)^T
+        if gelu_pre is not None:
+            K.gelu_bwd(dx, gelu_pre, dx)
+        return (dx, False) if db is not None else dx
     dx = empty((M, Kd), T, dy)
     if T in HALF and N % 32 == 0 and Kd % 4 == 0:
         Wt = transpose_weight(W)  # (K, N): makes dX an NT GEMM with reduction dim N contiguous
@@ -196,7 +263,16 @@ def linear_dw(dy: Tensor, x: Tensor, M: int, dW: Tensor, db: Optional[Tensor] = 
     N, Kd = dW.shape
     ldy = ldy or N
     ldx = ldx or Kd
-    if dy.dtype in HALF and N % 8 == 0 and Kd % 8 == 0 and ldy % 8 == 0 and ldx % 8 == 0:
+    if (dy.dtype == F32 and f32_on_mfma() and dW.dtype == F32 and N % 8 == 0 and Kd % 8 == 0 and ldy % 4 == 0 and ldx % 4 == 0
+            and M >= 4096 and N >= 256 and Kd >= 256):
+        # f32 validation mode on the production split-M TN kernel: the six bf16 blocks stacked along the reduction (token) extent
+        y6 = empty((6 * M, N), BF16, dy); x6 = empty((6 * M, Kd), BF16, dy)
+        K.split_bf16x3(dy, ldy, y6, N, M * N, M, N, False)
+        K.split_bf16x3(x, ldx, x6, Kd, M * Kd, M, Kd, True)
+        splits = K.gemm_tn_splits(6 * M, N, Kd)
+        ws = empty((splits * N * Kd,), F32, dy)
+        K.gemm_tn_bf16(y6, N, x6, Kd, dW, Kd, 6 * M, N, Kd, ws, splits)
+    elif dy.dtype in HALF and N % 8 == 0 and Kd % 8 == 0 and ldy % 8 == 0 and ldx % 8 == 0:
         splits = K.gemm_tn_splits(M, N, Kd)
         ws = empty((splits * N * Kd,), F32, dy)
         K.gemm_tn_bf16(dy, ldy, x, ldx, dW, Kd, M, N, Kd, ws, splits)
