@@ -118,7 +118,7 @@ def pmc_traffic_bytes():
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 ks = json.load(f)["kernels"]
-            return next(v["traffic_bytes"] for k, v in ks.items() if "EPI_BIAS_GELU" in k or "Li2E" in k), f"profiles/{name} (static: collected in a separate rocprofv3 --pmc run)"
+            return next(v["traffic_bytes"] for k, v in ks.items() if "FF1 bias+GELU" in k or "EPI_BIAS_GELU" in k or "Li2E" in k), f"profiles/{name} (static: collected in a separate rocprofv3 --pmc run)"
         except Exception:
             continue
     return None, None

@@ -1,22 +1,51 @@
-"""Run a few launches of selected kernels (for rocprofv3 --pmc): python tools/kprof.py"""
+"""A few launches of each GEMM of a ViT-B/16 batch-256 layer, in a FIXED ORDER, for rocprofv3 --pmc: python tools/kprof.py
+tools/pmc_traffic_json.py labels the launch groups by this order (LABELS)."""
 import torch
 from vit_pytorch_amd import kernels as K, _lib as L
 dev = "cuda"; BF = torch.bfloat16
 M, D, F = 50432, 768, 3072
-def run(n, k, epi, iters=3):
+ITERS = 3
+# (label, N, K, algorithmic bytes per launch: operands once + output once (+ aux / residual once))
+LABELS = []
+
+
+def run(label, n, k, epi):
     A = torch.randn(M, k, device=dev).to(BF); W = (torch.randn(n, k, device=dev) * k ** -0.5).to(BF)
     bias = torch.randn(n, device=dev).to(BF)
+    alg = 2 * (M * k + n * k)
     if epi == L.EPI_RESID:
         C = torch.zeros(M, n, device=dev); resid = C; aux = None
+        alg += 8 * M * n                                   # f32 residual read + f32 write
     else:
         C = torch.empty(M, n, dtype=BF, device=dev); resid = None; aux = torch.randn(M, n, device=dev).to(BF)
-    for _ in range(iters):
-        K.gemm_nt_bf16(A, k, W, k, C, n, M, n, k, epi, bias=bias, resid=resid, aux=aux)
+        alg += 2 * M * n * (2 if epi in (L.EPI_BIAS_GELU, L.EPI_GELU_BWD) else 1)   # + pre-activation written (FF1) / read (dFF1)
+    for _ in range(ITERS):
+        if epi == L.EPI_GELU_BWD:
+            rows = K.gemm_nt_colsum_rows(M, n, k, n)
+            cs = torch.empty(rows * n, device=dev)
+            K.gemm_nt_bf16_gelu_bwd_colsum(A, k, W, k, C, n, M, n, k, aux, cs)
+        else:
+            K.gemm_nt_bf16(A, k, W, k, C, n, M, n, k, epi, bias=bias, resid=resid, aux=aux)
     torch.cuda.synchronize()
-run(3 * D, D, L.EPI_NONE); run(F, D, L.EPI_BIAS_GELU); run(D, D, L.EPI_RESID); run(D, F, L.EPI_RESID)
-for n, k in ((3 * D, D), (F, D)):
+    LABELS.append((label, n, k, alg))
+
+
+def run_tn(label, n, k):
     dY = torch.randn(M, n, device=dev).to(BF); X = torch.randn(M, k, device=dev).to(BF)
     s = K.gemm_tn_splits(M, n, k); ws = torch.empty(s * n * k, device=dev); dW = torch.empty(n, k, dtype=BF, device=dev)
-    for _ in range(3):
+    for _ in range(ITERS):
         K.gemm_tn_bf16(dY, n, X, k, dW, k, M, n, k, ws, s)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    LABELS.append((label, n, k, 2 * (M * n + M * k + n * k)))
+
+
+PLAN = (("QKV", 3 * D, D, L.EPI_NONE), ("FF1 bias+GELU", F, D, L.EPI_BIAS_GELU), ("out-proj + f32 residual", D, D, L.EPI_RESID),
+        ("FF2 + f32 residual", D, F, L.EPI_RESID), ("dFF1 GELU' + column sums", F, D, L.EPI_GELU_BWD), ("dX of FF1 (K=3072)", D, F, L.EPI_NONE))
+TN_PLAN = (("dW qkv", 3 * D, D), ("dW ff1", F, D))
+
+if __name__ == "__main__":
+    for a in PLAN:
+        run(*a)
+    for a in TN_PLAN:
+        run_tn(*a)
+    torch.cuda.synchronize()

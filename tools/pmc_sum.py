@@ -1,9 +1,17 @@
-"""Summarise rocprofv3 --pmc CSVs: mean counter value per kernel (last launches only).  python tools/pmc_sum.py <dir> [filter]"""
-import csv, glob, os, re, sys
+"""Summarise rocprofv3 --pmc CSVs: mean counter value per kernel (last launches only).
+python tools/pmc_sum.py <dir> [filter] [--json out.json]   (the JSON adds mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024)
+when both counters are there)"""
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
+jout = None
+if "--json" in sys.argv:
+    i = sys.argv.index("--json")
+    jout = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 root = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
+doc = {}
 vals = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(list)
 for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
@@ -21,6 +29,16 @@ for k in sorted(vals):
         continue
     d = sorted(dur[k])
     print(f"{k}   (median {d[len(d)//2]:.1f} us under the profiler)")
+    ent = {"median_us_profiled": round(d[len(d) // 2], 1), "counters": {}}
     for c, v in sorted(vals[k].items()):
         v = v[len(v) // 2:]                      # skip warm-up launches
         print(f"    {c:32s} {sum(v) / len(v):16.0f}")
+        ent["counters"][c] = round(sum(v) / len(v))
+    cn = ent["counters"]
+    if cn.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in cn:
+        ent["mfma_util"] = round(cn["SQ_VALU_MFMA_BUSY_CYCLES"] / (cn["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
+    doc[k] = ent
+if jout:
+    with open(jout, "w") as f:
+        json.dump({"note": "rocprofv3 --pmc, one counter group per pass, kernel trace only; whole-GPU sums per launch (mean of the later half of "
+                           "the launches); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)", "kernels": doc}, f, indent=1)

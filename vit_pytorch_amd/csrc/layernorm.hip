@@ -98,7 +98,19 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 // NW waves per block: 8 for rows up to 768 columns (<= 128 VGPRs: two blocks per CU), 4 for wider rows, whose three
 // column accumulators push the kernel to ~155-170 VGPRs -- three 4-wave blocks then fit a CU (12 waves) where a single
 // 8-wave block would (8 waves).
-template <typename DYT, typename XT, typename WT, typename DXT, int MAXC, int NW>
+template <bool NT> __device__ __forceinline__ f32x4 ld16(const float* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return *reinterpret_cast<const f32x4*>(p);
+}
+template <bool NT> __device__ __forceinline__ f32x4 ldrow(const float* p) { return ld16<NT>(p); }
+template <bool NT> __device__ __forceinline__ f32x4 ldrow(const __bf16* p) {
+    const bf16x4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p)) : *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// R rows per wave and iteration: the loads of all R rows are issued before the first reduction (R x the bytes in flight per
+// wave).  NT: the row streams (dy, x, gin) are read once -- nontemporal loads.
+template <typename DYT, typename XT, typename WT, typename DXT, int MAXC, int NW, int R, bool NT>
 __global__ __launch_bounds__(NW * WAVE) void ln_bwd_kernel(
     const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -120,60 +132,84 @@ __global__ __launch_bounds__(NW * WAVE) void ln_bwd_kernel(
         acc_b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc_x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (long long row = (long long)blockIdx.x * NW + wave; row < rows; row += (long long)gridDim.x * NW) {
-        const DYT* dyr = dy + map_row(dymap, row) * (long long)D;
-        const XT* xr = x + map_row(xmap, row) * (long long)D;
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        const long long orow = map_row(dxmap, row);
-        f32x4 g[MAXC], xh[MAXC], gi[MAXC];
-        float s1 = 0.f, s2 = 0.f;
-        // every load of the row -- incoming stream gradient included -- is issued before the first reduction, so a row
-        // costs one memory round trip, not two
-        constexpr bool EARLY_GIN = MAXC <= 3;     // wider rows: the 4*MAXC extra registers would cost a wave per SIMD
+    const long long rstep = (long long)gridDim.x * NW;
+    for (long long row0 = (long long)blockIdx.x * NW + wave; row0 < rows; row0 += rstep * R) {
+        // every load of the rows -- incoming stream gradient included -- is issued before the first reduction, so R rows
+        // cost one memory round trip
+        constexpr bool EARLY_GIN = MAXC * R <= 6;     // wider rows: the extra registers would cost a wave per SIMD
+        f32x4 g[R][MAXC], xh[R][MAXC], gi[R][MAXC];
+        float mean[R], rstd[R];
+        long long orow[R];
 #pragma unroll
-        for (int t = 0; t < MAXC; ++t) {
-            const int c = lane + 64 * t;
-            gi[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EARLY_GIN && gin && want_dx && c < nchunk) gi[t] = *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
-        }
+        for (int r = 0; r < R; ++r) {
+            const long long row = row0 + r * rstep;
+            const bool live = row < rows;             // wave-uniform
+            orow[r] = live ? map_row(dxmap, row) : 0;
+            mean[r] = live ? mean_in[row] : 0.f;
+            rstd[r] = live ? rstd_in[row] : 0.f;
 #pragma unroll
-        for (int t = 0; t < MAXC; ++t) {
-            const int c = lane + 64 * t;
-            if (c < nchunk) {
-                const f32x4 d = load4<DYT>(dyr + 4 * c);
-                const f32x4 xv = load4<XT>(xr + 4 * c);
+            for (int t = 0; t < MAXC; ++t) {
+                const int c = lane + 64 * t;
+                gi[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EARLY_GIN && gin && want_dx && live && c < nchunk) gi[r][t] = ld16<NT>(gin + orow[r] * D + 4 * c);
+            }
+            const DYT* dyr = dy + (live ? map_row(dymap, row) : 0) * (long long)D;
+            const XT* xr = x + (live ? map_row(xmap, row) : 0) * (long long)D;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xh[t][e] = (xv[e] - mean) * rstd;
-                    g[t][e] = d[e] * wv[t][e];
-                    s1 += g[t][e];
-                    s2 += g[t][e] * xh[t][e];
-                    acc_w[t][e] += d[e] * xh[t][e];
-                    acc_b[t][e] += d[e];
+            for (int t = 0; t < MAXC; ++t) {
+                const int c = lane + 64 * t;
+                g[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                xh[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (live && c < nchunk) {
+                    g[r][t] = ldrow<NT>(dyr + 4 * c);          // raw dy for now
+                    xh[r][t] = ldrow<NT>(xr + 4 * c);          // raw x for now
                 }
             }
         }
-        if (want_dx) {
-            const float c1 = wave_sum(s1) * invD;
-            const float c2 = wave_sum(s2) * invD;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long long row = row0 + r * rstep;
+            if (row >= rows) break;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int t = 0; t < MAXC; ++t) {
                 const int c = lane + 64 * t;
                 if (c < nchunk) {
-                    f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2);
-                    if (EARLY_GIN) o += gi[t];
-                    else if (gin) o += *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
-                    if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow * D + 4 * c) = o;
-                    if (drop_t) {           // dx_t / its column sums are the gradient at the OUTPUT of the preceding Linear, whose
-                                            // dropout (vit.py:24,48) kept element (row, col) by the same hash; the f32 stream is not masked
-                        const unsigned hrow = drop_row((unsigned)orow, drop_seed);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = drop_keep(hrow, (unsigned)(4 * c + e), drop_t) ? o[e] * inv_keep : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = g[r][t][e];
+                        const float h = (xh[r][t][e] - mean[r]) * rstd[r];
+                        xh[r][t][e] = h;
+                        g[r][t][e] = d * wv[t][e];
+                        s1 += g[r][t][e];
+                        s2 += g[r][t][e] * h;
+                        acc_w[t][e] += d * h;
+                        acc_b[t][e] += d;
                     }
-                    if (dx_t) store4<DXT>(dx_t + orow * D + 4 * c, o);
-                    if (colsum_dx) acc_x[t] += o;
+                }
+            }
+            if (want_dx) {
+                const float c1 = wave_sum(s1) * invD;
+                const float c2 = wave_sum(s2) * invD;
+#pragma unroll
+                for (int t = 0; t < MAXC; ++t) {
+                    const int c = lane + 64 * t;
+                    if (c < nchunk) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = rstd[r] * (g[r][t][e] - c1 - xh[r][t][e] * c2);
+                        if (EARLY_GIN) o += gi[r][t];
+                        else if (gin) o += ld16<NT>(gin + orow[r] * D + 4 * c);
+                        if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow[r] * D + 4 * c) = o;
+                        if (drop_t) {       // dx_t / its column sums are the gradient at the OUTPUT of the preceding Linear, whose
+                                            // dropout (vit.py:24,48) kept element (row, col) by the same hash; the f32 stream is not masked
+                            const unsigned hrow = drop_row((unsigned)orow[r], drop_seed);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = drop_keep(hrow, (unsigned)(4 * c + e), drop_t) ? o[e] * inv_keep : 0.f;
+                        }
+                        if (dx_t) store4<DXT>(dx_t + orow[r] * D + 4 * c, o);
+                        if (colsum_dx) acc_x[t] += o;
+                    }
                 }
             }
         }
@@ -317,15 +353,24 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
     const int nchunk = D / 4;
     const int maxc = (nchunk + 63) / 64;
     const long long blocks = vitk_layernorm_bwd_blocks(rows, D);
-#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC, (MC >= 4 ? 4 : 8)>), dim3((unsigned)blocks), dim3((MC >= 4 ? 4 : 8) * WAVE), 0, st, \
+#define LN_BWD_CASE_(MC, RR, NTL) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC, (MC >= 4 ? 4 : 8), RR, NTL>), dim3((unsigned)blocks), dim3((MC >= 4 ? 4 : 8) * WAVE), 0, st, \
         (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om, drop_t, drop_seed, inv_keep)
+#define LN_BWD_CASE(MC) LN_BWD_CASE_(MC, 1, false)
+    static const int xr = getenv("VITK_LNB_R") ? atoi(getenv("VITK_LNB_R")) : 1;
+    static const int xnt = getenv("VITK_LNB_NT") ? atoi(getenv("VITK_LNB_NT")) : 0;
     if (maxc <= 1) LN_BWD_CASE(1);
-    else if (maxc <= 3) LN_BWD_CASE(3);
+    else if (maxc <= 3) {
+        if (xr == 2 && xnt) LN_BWD_CASE_(3, 2, true);
+        else if (xr == 2) LN_BWD_CASE_(3, 2, false);
+        else if (xnt) LN_BWD_CASE_(3, 1, true);
+        else LN_BWD_CASE(3);
+    }
     else if (maxc <= 4) LN_BWD_CASE(4);
     else if (maxc <= 5) LN_BWD_CASE(5);
     else if (maxc <= 8) LN_BWD_CASE(8);
     else LN_BWD_CASE(16);
 #undef LN_BWD_CASE
+#undef LN_BWD_CASE_
     VITK_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }
@@ -368,8 +413,11 @@ extern "C" int64_t vitk_layernorm_bwd_blocks(int64_t rows, int64_t D) {
     // one partial row per block; the block shape follows the row width (see ln_bwd_kernel): 8 waves and up to 1024
     // blocks (4 per CU) up to 768 columns, 4 waves and up to 768 blocks (3 per CU, all resident at once) beyond
     const bool wide = (D / 4 + 63) / 64 >= 4;
-    const int64_t nw = wide ? 4 : LNB_WAVES, cap = wide ? 768 : LNB_MAX_BLOCKS;
+    const int64_t nw = wide ? 4 : LNB_WAVES;
+    int64_t cap = wide ? 768 : LNB_MAX_BLOCKS;
     int64_t blocks = (rows + nw - 1) / nw;
+    static const int64_t xcap = getenv("VITK_LNB_BLOCKS") ? atoll(getenv("VITK_LNB_BLOCKS")) : 0;
+    if (xcap > 0 && !wide) cap = xcap;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return blocks;
