@@ -98,20 +98,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 // NW waves per block: 8 for rows up to 768 columns (<= 128 VGPRs: two blocks per CU), 4 for wider rows, whose three
 // column accumulators push the kernel to ~155-170 VGPRs -- three 4-wave blocks then fit a CU (12 waves) where a single
 // 8-wave block would (8 waves).
-template <bool NT> __device__ __forceinline__ f32x4 ld16(const float* p) {
-    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-    return *reinterpret_cast<const f32x4*>(p);
-}
-template <bool NT> __device__ __forceinline__ f32x4 ldrow(const float* p) { return ld16<NT>(p); }
-template <bool NT> __device__ __forceinline__ f32x4 ldrow(const __bf16* p) {
-    const bf16x4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p)) : *reinterpret_cast<const bf16x4*>(p);
-    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-}
-
-// R rows per wave and iteration: the loads of all R rows are issued before the first reduction (R x the bytes in flight per
-// wave).  NT: the row streams (dy, x, gin) are read once -- nontemporal loads.
-template <typename DYT, typename XT, typename WT, typename DXT, int MAXC, int NW, int R, bool NT>
-__global__ __launch_bounds__(NW * WAVE) void ln_bwd_kernel(
+template <typename DYT, typename XT, typename WT, typename DXT, int MAXC, int NW>
+__global__ __launch_bounds__(NW * WAVE, (MAXC <= 3 ? 4 : 1)) void ln_bwd_kernel(
     const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
@@ -132,84 +120,60 @@ __global__ __launch_bounds__(NW * WAVE) void ln_bwd_kernel(
         acc_b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc_x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const long long rstep = (long long)gridDim.x * NW;
-    for (long long row0 = (long long)blockIdx.x * NW + wave; row0 < rows; row0 += rstep * R) {
-        // every load of the rows -- incoming stream gradient included -- is issued before the first reduction, so R rows
-        // cost one memory round trip
-        constexpr bool EARLY_GIN = MAXC * R <= 6;     // wider rows: the extra registers would cost a wave per SIMD
-        f32x4 g[R][MAXC], xh[R][MAXC], gi[R][MAXC];
-        float mean[R], rstd[R];
-        long long orow[R];
+    for (long long row = (long long)blockIdx.x * NW + wave; row < rows; row += (long long)gridDim.x * NW) {
+        const DYT* dyr = dy + map_row(dymap, row) * (long long)D;
+        const XT* xr = x + map_row(xmap, row) * (long long)D;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const long long orow = map_row(dxmap, row);
+        f32x4 g[MAXC], xh[MAXC], gi[MAXC];
+        float s1 = 0.f, s2 = 0.f;
+        // every load of the row -- incoming stream gradient included -- is issued before the first reduction, so a row
+        // costs one memory round trip, not two
+        constexpr bool EARLY_GIN = MAXC <= 3;     // wider rows: the 4*MAXC extra registers would cost a wave per SIMD
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const long long row = row0 + r * rstep;
-            const bool live = row < rows;             // wave-uniform
-            orow[r] = live ? map_row(dxmap, row) : 0;
-            mean[r] = live ? mean_in[row] : 0.f;
-            rstd[r] = live ? rstd_in[row] : 0.f;
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            gi[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EARLY_GIN && gin && want_dx && c < nchunk) gi[t] = *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
+        }
 #pragma unroll
-            for (int t = 0; t < MAXC; ++t) {
-                const int c = lane + 64 * t;
-                gi[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (EARLY_GIN && gin && want_dx && live && c < nchunk) gi[r][t] = ld16<NT>(gin + orow[r] * D + 4 * c);
-            }
-            const DYT* dyr = dy + (live ? map_row(dymap, row) : 0) * (long long)D;
-            const XT* xr = x + (live ? map_row(xmap, row) : 0) * (long long)D;
+        for (int t = 0; t < MAXC; ++t) {
+            const int c = lane + 64 * t;
+            if (c < nchunk) {
+                const f32x4 d = load4<DYT>(dyr + 4 * c);
+                const f32x4 xv = load4<XT>(xr + 4 * c);
 #pragma unroll
-            for (int t = 0; t < MAXC; ++t) {
-                const int c = lane + 64 * t;
-                g[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                xh[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (live && c < nchunk) {
-                    g[r][t] = ldrow<NT>(dyr + 4 * c);          // raw dy for now
-                    xh[r][t] = ldrow<NT>(xr + 4 * c);          // raw x for now
+                for (int e = 0; e < 4; ++e) {
+                    xh[t][e] = (xv[e] - mean) * rstd;
+                    g[t][e] = d[e] * wv[t][e];
+                    s1 += g[t][e];
+                    s2 += g[t][e] * xh[t][e];
+                    acc_w[t][e] += d[e] * xh[t][e];
+                    acc_b[t][e] += d[e];
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const long long row = row0 + r * rstep;
-            if (row >= rows) break;
-            float s1 = 0.f, s2 = 0.f;
+        if (want_dx) {
+            const float c1 = wave_sum(s1) * invD;
+            const float c2 = wave_sum(s2) * invD;
 #pragma unroll
             for (int t = 0; t < MAXC; ++t) {
                 const int c = lane + 64 * t;
                 if (c < nchunk) {
+                    f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = g[r][t][e];
-                        const float h = (xh[r][t][e] - mean[r]) * rstd[r];
-                        xh[r][t][e] = h;
-                        g[r][t][e] = d * wv[t][e];
-                        s1 += g[r][t][e];
-                        s2 += g[r][t][e] * h;
-                        acc_w[t][e] += d * h;
-                        acc_b[t][e] += d;
-                    }
-                }
-            }
-            if (want_dx) {
-                const float c1 = wave_sum(s1) * invD;
-                const float c2 = wave_sum(s2) * invD;
-#pragma unroll
-                for (int t = 0; t < MAXC; ++t) {
-                    const int c = lane + 64 * t;
-                    if (c < nchunk) {
-                        f32x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = rstd[r] * (g[r][t][e] - c1 - xh[r][t][e] * c2);
-                        if (EARLY_GIN) o += gi[r][t];
-                        else if (gin) o += ld16<NT>(gin + orow[r] * D + 4 * c);
-                        if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow[r] * D + 4 * c) = o;
-                        if (drop_t) {       // dx_t / its column sums are the gradient at the OUTPUT of the preceding Linear, whose
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2);
+                    if (EARLY_GIN) o += gi[t];
+                    else if (gin) o += *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
+                    if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow * D + 4 * c) = o;
+                    if (drop_t) {           // dx_t / its column sums are the gradient at the OUTPUT of the preceding Linear, whose
                                             // dropout (vit.py:24,48) kept element (row, col) by the same hash; the f32 stream is not masked
-                            const unsigned hrow = drop_row((unsigned)orow[r], drop_seed);
+                        const unsigned hrow = drop_row((unsigned)orow, drop_seed);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = drop_keep(hrow, (unsigned)(4 * c + e), drop_t) ? o[e] * inv_keep : 0.f;
-                        }
-                        if (dx_t) store4<DXT>(dx_t + orow[r] * D + 4 * c, o);
-                        if (colsum_dx) acc_x[t] += o;
+                        for (int e = 0; e < 4; ++e) o[e] = drop_keep(hrow, (unsigned)(4 * c + e), drop_t) ? o[e] * inv_keep : 0.f;
                     }
+                    if (dx_t) store4<DXT>(dx_t + orow * D + 4 * c, o);
+                    if (colsum_dx) acc_x[t] += o;
                 }
             }
         }
@@ -235,6 +199,155 @@ __global__ __launch_bounds__(NW * WAVE) void ln_bwd_kernel(
                 }
                 __syncthreads();
             }
+        }
+    }
+}
+
+template <bool NT> __device__ __forceinline__ f32x4 ld16(const float* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return *reinterpret_cast<const f32x4*>(p);
+}
+
+// The transformer-layer case of ln_bwd_kernel, specialised: full chunks (D == 256 * MAXC), identity row maps, stream gradient
+// in, both dx outputs and the column sums of dx_t out, no dropout.  The general kernel spends most of its issue slots on
+// predicates it does not need here (a branch around every chunk, five optional-pointer tests per chunk, the row-map
+// divisions); this one keeps the row index in SGPRs (readfirstlane), so the per-row statistics are scalar loads and every
+// vector access is base + lane offset + immediate, and does its arithmetic on float pairs (v_pk_fma_f32 / v_pk_mul_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { using type = f32x4; };
+template <> struct Raw4<__bf16> { using type = bf16x4; };
+template <bool NT, typename T> __device__ __forceinline__ typename Raw4<T>::type ldraw(const T* p) {
+    using R = typename Raw4<T>::type;
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const R*>(p));
+    return *reinterpret_cast<const R*>(p);
+}
+// keeps a loop-invariant packed value packed: without it the compiler hoists the unpacked copy out of the loop (and spills)
+__device__ __forceinline__ void opaque(bf16x4& v) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    asm volatile("" : "+v"(u));
+    v = __builtin_bit_cast(bf16x4, u);
+}
+__device__ __forceinline__ void opaque(f32x4&) {}
+__device__ __forceinline__ f32x2 widen2(const f32x4& v, int p) { return f32x2{v[2 * p], v[2 * p + 1]}; }
+__device__ __forceinline__ f32x2 widen2(const bf16x4& v, int p) { return f32x2{(float)v[2 * p], (float)v[2 * p + 1]}; }
+template <typename DYT, typename XT, typename WT, typename DXT, int MAXC, int NW, int WPE, bool NT, bool PIPE, bool DROP>
+__global__ __launch_bounds__(NW * WAVE, WPE) void ln_bwd_fast_kernel(
+    const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
+    float* __restrict__ partials, long long rows, unsigned drop_t, unsigned drop_seed, float inv_keep) {
+    constexpr int D = 256 * MAXC;
+    constexpr float invD = 1.0f / (float)D;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    typename Raw4<WT>::type wraw[MAXC];          // gamma stays in its storage type: half the registers, one unpack per use
+    f32x2 aw[MAXC][2], ab[MAXC][2], ax[MAXC][2];
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+        wraw[t] = ldraw<false>(w + 4 * (lane + 64 * t));
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { aw[t][p] = f32x2{0.f, 0.f}; ab[t][p] = f32x2{0.f, 0.f}; ax[t][p] = f32x2{0.f, 0.f}; }
+    }
+    const long long rstep = (long long)gridDim.x * NW;
+    long long row = (long long)blockIdx.x * NW + wave;
+    // software pipeline: the loads of row i+1 are issued as soon as row i has left the registers they land in (dy and x after
+    // the first pass, the stream gradient after the second), so they fly under row i's reductions, second pass and stores
+    f32x4 gi[MAXC];
+    typename Raw4<DYT>::type dv[MAXC];
+    typename Raw4<XT>::type xv[MAXC];
+    float mean = 0.f, rstd = 0.f;
+    if (PIPE && row < rows) {
+        const long long ro = row * D + 4 * lane;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) gi[t] = ld16<NT>(gin + ro + 256 * t);
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) { dv[t] = ldraw<NT>(dy + ro + 256 * t); xv[t] = ldraw<NT>(x + ro + 256 * t); }
+        mean = mean_in[row]; rstd = rstd_in[row];
+    }
+    for (; row < rows; row += rstep) {
+        const long long ro = row * D + 4 * lane;
+        // the last iteration prefetches its own row again (in bounds, never used): no branch around the loads
+        const long long nrow = row + rstep < rows ? row + rstep : row;    // scalar
+        const long long nro = nrow * D + 4 * lane;
+        if (!PIPE) {
+#pragma unroll
+            for (int t = 0; t < MAXC; ++t) gi[t] = ld16<NT>(gin + ro + 256 * t);
+#pragma unroll
+            for (int t = 0; t < MAXC; ++t) { dv[t] = ldraw<NT>(dy + ro + 256 * t); xv[t] = ldraw<NT>(x + ro + 256 * t); }
+            mean = mean_in[row]; rstd = rstd_in[row];
+        }
+        const float nm = -mean * rstd;
+        const f32x2 rs2 = {rstd, rstd}, nm2 = {nm, nm};
+        const float rstd_c = rstd;
+        f32x2 g[MAXC][2], h[MAXC][2];
+        f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            opaque(wraw[t]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const f32x2 d = widen2(dv[t], p);
+                const f32x2 xx = widen2(xv[t], p);
+                h[t][p] = xx * rs2 + nm2;
+                g[t][p] = d * widen2(wraw[t], p);
+                s1v += g[t][p];
+                s2v += g[t][p] * h[t][p];
+                aw[t][p] += d * h[t][p];
+                ab[t][p] += d;
+            }
+        }
+        if (PIPE) {
+#pragma unroll
+            for (int t = 0; t < MAXC; ++t) { dv[t] = ldraw<NT>(dy + nro + 256 * t); xv[t] = ldraw<NT>(x + nro + 256 * t); }
+            mean = mean_in[nrow]; rstd = rstd_in[nrow];
+        }
+        const float c1r = wave_sum(s1v[0] + s1v[1]) * (invD * rstd_c);
+        const float c2r = wave_sum(s2v[0] + s2v[1]) * (invD * rstd_c);
+        const f32x2 c1 = {c1r, c1r}, c2 = {c2r, c2r};
+        float* of = dx_f32 + ro;
+        DXT* ot = dx_t + ro;
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            f32x2 o[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                o[p] = g[t][p] * rs2 - c1;
+                o[p] = o[p] - h[t][p] * c2;
+                o[p] += f32x2{gi[t][2 * p], gi[t][2 * p + 1]};
+                if (!DROP) ax[t][p] += o[p];
+            }
+            const f32x4 ov = {o[0][0], o[0][1], o[1][0], o[1][1]};
+            if (PIPE) gi[t] = ld16<NT>(gin + nro + 256 * t);
+            *reinterpret_cast<f32x4*>(of + 256 * t) = ov;
+            if (DROP) {     // dx_t and its column sums are the gradient at the OUTPUT of the preceding Linear, whose dropout
+                            // (vit.py:24,48) kept element (row, col) by the same hash; the f32 stream is not masked
+                const unsigned hrow = drop_row((unsigned)row, drop_seed);
+                f32x4 om;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) om[e] = drop_keep(hrow, (unsigned)(4 * (lane + 64 * t) + e), drop_t) ? ov[e] * inv_keep : 0.f;
+                ax[t][0] += f32x2{om[0], om[1]}; ax[t][1] += f32x2{om[2], om[3]};
+                store4<DXT>(ot + 256 * t, om);
+            } else store4<DXT>(ot + 256 * t, ov);
+        }
+    }
+    // block reduce the per-wave column accumulators through LDS, one slab at a time (same partial layout as ln_bwd_kernel)
+    __shared__ f32x4 red[NW][64];
+    for (int slab = 0; slab < 3; ++slab) {
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t) {
+            const f32x2 a0 = slab == 0 ? aw[t][0] : (slab == 1 ? ab[t][0] : ax[t][0]);
+            const f32x2 a1 = slab == 0 ? aw[t][1] : (slab == 1 ? ab[t][1] : ax[t][1]);
+            red[wave][lane] = f32x4{a0[0], a0[1], a1[0], a1[1]};
+            __syncthreads();
+            if (wave == 0) {
+                f32x4 sum = red[0][lane];
+#pragma unroll
+                for (int wv_ = 1; wv_ < NW; ++wv_) sum += red[wv_][lane];
+                *reinterpret_cast<f32x4*>(partials + ((long long)slab * gridDim.x + blockIdx.x) * D + 4 * (lane + 64 * t)) = sum;
+            }
+            __syncthreads();
         }
     }
 }
@@ -353,24 +466,38 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
     const int nchunk = D / 4;
     const int maxc = (nchunk + 63) / 64;
     const long long blocks = vitk_layernorm_bwd_blocks(rows, D);
-#define LN_BWD_CASE_(MC, RR, NTL) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC, (MC >= 4 ? 4 : 8), RR, NTL>), dim3((unsigned)blocks), dim3((MC >= 4 ? 4 : 8) * WAVE), 0, st, \
-        (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om, drop_t, drop_seed, inv_keep)
-#define LN_BWD_CASE(MC) LN_BWD_CASE_(MC, 1, false)
-    static const int xr = getenv("VITK_LNB_R") ? atoi(getenv("VITK_LNB_R")) : 1;
-    static const int xnt = getenv("VITK_LNB_NT") ? atoi(getenv("VITK_LNB_NT")) : 0;
-    if (maxc <= 1) LN_BWD_CASE(1);
-    else if (maxc <= 3) {
-        if (xr == 2 && xnt) LN_BWD_CASE_(3, 2, true);
-        else if (xr == 2) LN_BWD_CASE_(3, 2, false);
-        else if (xnt) LN_BWD_CASE_(3, 1, true);
-        else LN_BWD_CASE(3);
+    static const int no_fast = getenv("VITK_LNB_FAST") ? !atoi(getenv("VITK_LNB_FAST")) : 0;
+    if (!no_fast && gin && dxf && dxt && colsum_dx && dm.group <= 0 && xm.group <= 0 && om.group <= 0 && (D == 768 || D == 1024 || D == 1280)) {
+        // nontemporal loads of the three row streams: 123 -> 99 us at 50432 x 768 (6.3 TB/s); prefetching the next row (PIPE) on
+        // top of them costs 10 us, so it stays a switch
+#define LN_BWD_FAST(MC, NWV, WPE, NTL, PIPE, DROP) hipLaunchKernelGGL((ln_bwd_fast_kernel<DYT, XT, WT, DXT, MC, NWV, WPE, NTL, PIPE, DROP>), \
+        dim3((unsigned)blocks), dim3(NWV * WAVE), 0, st, \
+        (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, rows, drop_t, drop_seed, inv_keep)
+        static const int fnt = getenv("VITK_LNB_NT") ? atoi(getenv("VITK_LNB_NT")) : 1;
+        static const int fpipe = getenv("VITK_LNB_PIPE") ? atoi(getenv("VITK_LNB_PIPE")) : 0;
+#define LN_BWD_FAST_D(MC, NWV, WPE) \
+        if (drop_t) LN_BWD_FAST(MC, NWV, WPE, true, false, true); \
+        else if (fnt && fpipe) LN_BWD_FAST(MC, NWV, WPE, true, true, false); \
+        else if (fnt) LN_BWD_FAST(MC, NWV, WPE, true, false, false); \
+        else if (fpipe) LN_BWD_FAST(MC, NWV, WPE, false, true, false); \
+        else LN_BWD_FAST(MC, NWV, WPE, false, false, false)
+        if (D == 768) { LN_BWD_FAST_D(3, 8, 4); }
+        else if (D == 1024) { LN_BWD_FAST_D(4, 4, 3); }
+        else { LN_BWD_FAST_D(5, 4, 2); }
+#undef LN_BWD_FAST_D
+#undef LN_BWD_FAST
+        VITK_CHECK_LAUNCH("layernorm_bwd");
+        return 0;
     }
+#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC, (MC >= 4 ? 4 : 8)>), dim3((unsigned)blocks), dim3((MC >= 4 ? 4 : 8) * WAVE), 0, st, \
+        (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om, drop_t, drop_seed, inv_keep)
+    if (maxc <= 1) LN_BWD_CASE(1);
+    else if (maxc <= 3) LN_BWD_CASE(3);
     else if (maxc <= 4) LN_BWD_CASE(4);
     else if (maxc <= 5) LN_BWD_CASE(5);
     else if (maxc <= 8) LN_BWD_CASE(8);
     else LN_BWD_CASE(16);
 #undef LN_BWD_CASE
-#undef LN_BWD_CASE_
     VITK_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }
@@ -413,11 +540,8 @@ extern "C" int64_t vitk_layernorm_bwd_blocks(int64_t rows, int64_t D) {
     // one partial row per block; the block shape follows the row width (see ln_bwd_kernel): 8 waves and up to 1024
     // blocks (4 per CU) up to 768 columns, 4 waves and up to 768 blocks (3 per CU, all resident at once) beyond
     const bool wide = (D / 4 + 63) / 64 >= 4;
-    const int64_t nw = wide ? 4 : LNB_WAVES;
-    int64_t cap = wide ? 768 : LNB_MAX_BLOCKS;
+    const int64_t nw = wide ? 4 : LNB_WAVES, cap = wide ? 768 : LNB_MAX_BLOCKS;
     int64_t blocks = (rows + nw - 1) / nw;
-    static const int64_t xcap = getenv("VITK_LNB_BLOCKS") ? atoll(getenv("VITK_LNB_BLOCKS")) : 0;
-    if (xcap > 0 && !wide) cap = xcap;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return blocks;
