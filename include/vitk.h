@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 122
+#define VITK_VERSION 123
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -129,6 +129,15 @@ int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc);
 /* Tile schedule of the persistent NT kernel for (M, N, K) (tests, tuning): out[0] = 1 when the shape is served by it,
  * out[1] = 256-row m-tiles, out[2] = 128-row m-tiles of the tail region, out[3] = resident workgroups, out[4] = n-tiles. */
 int vitk_gemm_nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, int32_t* out5);
+/* K-blocked copy of a weight for the persistent NT kernel (no reference counterpart: nn.Linear's weight, vit.py:20,23,44,47,
+ * stays as it is; this is a derived cache like the transposed copy).  W is N x K row-major 16-bit.  `out` receives the operand
+ * of y = x . W^T (rows N, reduction K; K % 32 == 0; vitk_pack_w_nt_bytes(N, K) bytes), `out_t` the operand of dX = dY . W
+ * (rows K, reduction N; N % 32 == 0; vitk_pack_w_nt_bytes(K, N) bytes); either may be null.  Pass the packed buffer to
+ * vitk_gemm_nt_bf16 / _gelu_bwd_colsum / _drop as W with ldw == 0; only shapes vitk_gemm_nt_plan() reports as served accept
+ * it (anything else fails with VITK_E_SHAPE).  Layout: for every (256-row tile, 32-element K-step) the 16 KiB image of the
+ * kernel's LDS stage, so its LDS-DMA reads whole 128-byte lines (see gemm_nt_persist.hip).                                    */
+int64_t vitk_pack_w_nt_bytes(int64_t rows, int64_t reduction);
+int vitk_pack_w_nt(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, void* out_t, void* stream);
 int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, const void* W, int64_t ldw,
                                       void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                       void* aux, float* colsum_partials, void* stream);

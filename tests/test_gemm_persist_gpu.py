@@ -112,3 +112,60 @@ def test_persistent_nt_in_place_residual_and_strided_operands():
     L.check(L.load().vitk_gemm_nt_bf16(A.data_ptr(), ld, W.data_ptr(), Kd, x.data_ptr(), N, M, N, Kd, L.EPI_RESID, None, x.data_ptr(), None,
                                        torch.cuda.current_stream().cuda_stream), "gemm_nt_bf16")
     assert rel(x, x0.double() + ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,Kd", [(12608, 768, 768), (4100, 2304, 128), (9000, 1000, 32), (70001, 520, 96), (12608, 768, 3072)])
+def test_k_blocked_weight_gives_identical_results(M, N, Kd):
+    """vitk_pack_w_nt: the K-blocked copy of W (ldw = 0) feeds the same arithmetic -- every epilogue bit-identical to the
+    row-major operand; the transposed flavour equals packing an explicit transpose."""
+    A = rnd(M, Kd, dtype=BF, seed=21); W = (rnd(N, Kd, seed=22) * Kd ** -0.5).to(BF)
+    bias = rnd(N, dtype=BF, seed=23); resid = rnd(M, N, seed=24); h = rnd(M, N, dtype=BF, seed=25)
+    pf = torch.empty(K.pack_w_nt_bytes(N, Kd) // 2, dtype=BF, device=DEV)
+    pt = torch.empty(K.pack_w_nt_bytes(Kd, N) // 2, dtype=BF, device=DEV) if N % 32 == 0 else None
+    K.pack_w_nt(W, Kd, N, Kd, pf, pt)
+    ref = _all_epilogues(M, N, Kd, A, W, bias, resid, h)
+
+    def packed_epilogues(P):
+        out = {}
+        C = torch.empty(M, N, dtype=BF, device=DEV)
+        K.gemm_nt_bf16(A, Kd, P, 0, C, N, M, N, Kd)
+        out["none"] = C.clone()
+        K.gemm_nt_bf16(A, Kd, P, 0, C, N, M, N, Kd, L.EPI_BIAS, bias=bias)
+        out["bias"] = C.clone()
+        aux = torch.empty(M, N, dtype=BF, device=DEV)
+        K.gemm_nt_bf16(A, Kd, P, 0, C, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=aux)
+        out["gelu"] = C.clone(); out["pre"] = aux
+        o32 = torch.empty(M, N, device=DEV)
+        K.gemm_nt_bf16(A, Kd, P, 0, o32, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid)
+        out["resid"] = o32
+        R = K.gemm_nt_colsum_rows(M, N, Kd, N)
+        part = torch.full((R * N,), float("nan"), device=DEV)
+        C2 = torch.empty(M, N, dtype=BF, device=DEV)
+        K.gemm_nt_bf16_gelu_bwd_colsum(A, Kd, P, 0, C2, N, M, N, Kd, h, part)
+        out["gbwd"] = C2; out["part"] = part.view(R, N)
+        return out
+
+    got = packed_epilogues(pf)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
+    if pt is not None and K.gemm_nt_plan(M, Kd, N, Kd)["persistent"]:
+        # dX = dY . W  ==  NT GEMM with the operand W^T (rows Kd, reduction N)
+        dY = rnd(M, N, dtype=BF, seed=26)
+        Wt = W.t().contiguous()
+        d1 = torch.empty(M, Kd, dtype=BF, device=DEV); d2 = torch.empty(M, Kd, dtype=BF, device=DEV)
+        K.gemm_nt_bf16(dY, N, Wt, N, d1, Kd, M, Kd, N)
+        K.gemm_nt_bf16(dY, N, pt, 0, d2, Kd, M, Kd, N)
+        assert torch.equal(d1, d2)
+        pt2 = torch.empty_like(pt)
+        K.pack_w_nt(Wt, N, Kd, N, pt2, None)
+        assert torch.equal(pt, pt2)
+
+
+def test_k_blocked_weight_refused_where_the_persistent_kernel_does_not_run():
+    M, N, Kd = 512, 768, 768
+    A = rnd(M, Kd, dtype=BF, seed=31); W = rnd(N, Kd, dtype=BF, seed=32)
+    pf = torch.empty(K.pack_w_nt_bytes(N, Kd) // 2, dtype=BF, device=DEV)
+    K.pack_w_nt(W, Kd, N, Kd, pf, None)
+    C = torch.empty(M, N, dtype=BF, device=DEV)
+    with pytest.raises(L.VitkError):
+        K.gemm_nt_bf16(A, Kd, pf, 0, C, N, M, N, Kd)

@@ -855,6 +855,7 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     if ((lda & 7) || (ldw & 7) || (ldc & 3) || !aligned16(A) || !aligned16(W) || !aligned16(C) || (bias && !aligned8(bias)) ||
         (resid && !aligned16(resid)) || (aux && !aligned8(aux)))
         VITK_FAIL(VITK_E_ALIGN, "gemm_nt_bf16: lda/ldw %% 8, ldc %% 4 and 16-byte aligned pointers required");
+    if (ldw == 0 && (fp8 || f8.p || f8.amax)) VITK_FAIL(VITK_E_ARG, "gemm_nt: a K-blocked W (ldw == 0) goes with 16-bit operands only");
     if (!fp8 && !f8.p && !f8.amax) {
         // 16-bit operands at M >= 1024: the persistent kernel (gemm_nt_persist.hip)
         // Every epilogue goes to the persistent kernel.  [measured] kernel by kernel (tools/nt_ab.py, one stream) it wins where the
@@ -878,6 +879,7 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
             return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);
         }
     }
+    if (ldw == 0) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: a K-blocked W (ldw == 0, vitk_pack_w_nt) is read by the persistent kernel only (vitk_gemm_nt_plan() says which shapes it serves)");
     const NtPlan pl = nt_plan(M, N, K, ldc, aux);
     const bool large = pl.large;
     const int fm = pl.fm;

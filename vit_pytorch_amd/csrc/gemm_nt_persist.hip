@@ -22,6 +22,10 @@
 //  * TILE HEIGHTS 256 AND 128 in one launch (gemm_nt_plan.h): the rows that would form a mostly idle last round of 256-row
 //    tiles are cut into 128-row tiles (wave tile 64 x 64, two barrier slots per K-step instead of four).
 //  * the bias-gradient column sums of the GELU' epilogue are reduced in registers (DPP + v_permlane swaps).
+//  * W may arrive K-BLOCKED (ldw == 0; vitk_pack_w_nt below, done once per weight value): what bounds the main loop is the
+//    LDS-DMA feed, and the feed is bound by REQUESTS -- [measured, tools/ldrow.hip] a CU streams a 32 KiB K-step in 0.59 us as
+//    64-byte row pieces (16 half lines per instruction) and in 0.34-0.38 us as full 128-byte lines, against 0.49 us of MFMA work.
+//    With the W half of every K-step contiguous the eight ViT-B/16 GEMM shapes run 1.696 -> 1.585 ms (K = 3072: -10 %).
 //
 // Scheduling of slots per K-step (group A = waves 0-3, group B = waves 4-7 one slot behind):
 //   256-row tile:  R0 (read W + X[0..3] fragments, DMA A of K-step +3)  M0 (16 MFMA)  R1 (read X[4..7], DMA W of +3, counted
@@ -75,8 +79,6 @@ template <int N_> __device__ __forceinline__ void q_wait_vm() {
     else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N_ == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N_ == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else static_assert(N_ < 0, "unsupported vmcnt");
 }
 
@@ -84,7 +86,6 @@ template <int N_> __device__ __forceinline__ void q_wait_vm() {
 // 8-vectors so that every Horner step is four INDEPENDENT v_pk_fma_f32 -- the 2-wide form compiled to one dependent chain
 // per pair with a stall slot after every step.
 typedef float q_f32x8 __attribute__((ext_vector_type(8)));
-typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ q_f32x8 q_splat8(float v) { return q_f32x8{v, v, v, v, v, v, v, v}; }
 __device__ __forceinline__ q_f32x8 q_phi8(q_f32x8 x) {
     q_f32x8 xc;
@@ -122,19 +123,6 @@ __device__ __forceinline__ bf16x8 q_narrow8(q_f32x8 v) {
     return r;
 }
 
-template <int B, int E, typename F> __device__ __forceinline__ void q_static_for(F&& f) {
-    if constexpr (B < E) { f(std::integral_constant<int, B>{}); q_static_for<B + 1, E>(f); }
-}
-
-// MFMA with the accumulator pinned to the AGPR (INA) or the VGPR file.  The 4-wave flavour holds 64 accumulator tuples; left to
-// itself the register allocator parks some of them in the other file and shuffles them through v_accvgpr_read / _write around
-// every MFMA.  An opaque asm statement also stays where it is written relative to the other asm statements of the loop.
-template <bool INA>
-__device__ __forceinline__ void q_mfma_pinned(f32x4& c, const q_u32x4& av, const q_u32x4& bv) {
-    if constexpr (INA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
-    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
-}
-
 template <int EPI> __host__ __device__ constexpr bool q_has_bias() {
     return EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_RESID;
 }
@@ -146,24 +134,16 @@ __device__ __forceinline__ unsigned q_pack2(float a, float b) {
     const bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, v);
 }
+typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
 
-// NH = 64-column quads per wave: 1 -> 8 waves (2 x 4), wave tile 128 x 64, two waves per SIMD;  2 -> 4 waves (2 x 2), wave tile
-// 128 x 128 with 256 accumulator registers, ONE wave per SIMD: a K-step then reads 64 KiB of fragments from LDS instead of 96
-// (each activation fragment is read by 2 waves instead of 4) for the same 256 MFMAs.
-template <int EPI, bool PIPE, int NH, int ABL = 0, bool PAIR = false>
-__global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const NtpArgs p) {
+template <int EPI, bool PIPE>
+__global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    static_assert(NH == 1 || PIPE, "the 4-wave flavour has the pipelined main loop only");
-    static_assert(!PAIR || (PIPE && NH == 1), "paired DMA issue belongs to the 8-wave pipelined loop");
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
-    constexpr int NWV = NH == 2 ? 4 : 8;          // waves
-    constexpr int WNW = NWV / 2;                  // waves along N
-    constexpr int RGW = 16 / NWV;                 // 16-row groups of each operand tile a wave's DMA fills
-    constexpr int NG = 4 * NH;                    // W fragments per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WNW, wn = wave % WNW;
+    const int wm = wave >> 2, wn = wave & 3;
     const bool grp_b = wave >= 4;
 
     // ---- this workgroup's tiles: XCD x owns a contiguous run of the main list and of the tail list; its workgroups take
@@ -201,8 +181,8 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
     // 64 q + 4 c + fn (see the header: a lane's four B fragments are then 4 consecutive output columns).
     const int srow = lane >> 2, spos = lane & 3;
     const int schunk = spos ^ q_swz(lane >> 4);
-    const char* a_src[RGW];
-    const char* w_src[RGW];
+    const char* a_src[2];
+    const char* w_src[2];
     int p_idx = l0, p_kt = 0, p_g = 0;
     bool p_more = true;
     auto setup_src = [&](int idx) {
@@ -211,19 +191,23 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
         int mlast = m0 + (half ? 128 : 256);
         mlast = (mlast < p.M ? mlast : p.M) - 1;            // rows past the tile (half tiles) or past M re-read its last row
 #pragma unroll
-        for (int j = 0; j < RGW; ++j) {
-            const int rg = wave * RGW + j;
+        for (int j = 0; j < 2; ++j) {
+            const int rg = wave * 2 + j;
             int ar = m0 + rg * 16 + srow; ar = ar < mlast ? ar : mlast;
             int wr = n0 + (rg >> 2) * 64 + 4 * srow + (rg & 3); wr = wr < p.N ? wr : p.N - 1;
             a_src[j] = p.A + (long long)ar * p.lda * 2 + schunk * 16;
             w_src[j] = p.W + (long long)wr * p.ldw * 2 + schunk * 16;
+            // K-blocked W (ldw == 0, vitk_pack_w_nt): block (n-tile, K-step) IS the 16 KiB LDS image, so a DMA instruction reads one
+            // contiguous KiB (8 full lines) instead of 16 half lines
+            if (p.ldw == 0) w_src[j] = p.W + (long long)(n0 >> 8) * p.nt * Q_TILE_BYTES + rg * 1024 + lane * 16;
         }
     };
+    const int w_kstride = p.ldw == 0 ? Q_TILE_BYTES : 64;      // bytes between consecutive K-steps of a W row group
     auto issue_a = [&]() {
         if (!p_more) return;
         char* base = lds + (p_g & 3) * Q_STAGE_BYTES + wave * 2048;
 #pragma unroll
-        for (int j = 0; j < (RGW < 2 ? RGW : 2); ++j)
+        for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + p_kt * 64),
                                              (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
     };
@@ -231,8 +215,8 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
         if (!p_more) return;
         char* base = lds + (p_g & 3) * Q_STAGE_BYTES + Q_TILE_BYTES + wave * 2048;
 #pragma unroll
-        for (int j = 0; j < (RGW < 2 ? RGW : 2); ++j)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + p_kt * 64),
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + p_kt * w_kstride),
                                              (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
         ++p_g;
         if (++p_kt == p.nt) {
@@ -246,40 +230,13 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
     // block).  Issued on EVERY K-step: when the tile list is exhausted the producer stays on its last K-step and re-loads it
     // into a stage nobody reads again, which keeps the counted waits uniform (always vmcnt(8)); the kernel drains before it ends.
     auto issue4 = [&]() __attribute__((always_inline)) {
-        char* base = lds + (p_g & 3) * Q_STAGE_BYTES + wave * (RGW * 1024);
+        char* base = lds + (p_g & 3) * Q_STAGE_BYTES + wave * 2048;
 #pragma unroll
-        for (int j = 0; j < RGW; ++j) {
+        for (int j = 0; j < 2; ++j) {
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + p_kt * 64),
                                              (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + p_kt * 64),
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + p_kt * w_kstride),
                                              (void __attribute__((address_space(3)))*)(base + Q_TILE_BYTES + j * 1024), 16, 0, 0);
-        }
-    };
-    // PAIR: the DMA pieces of K-steps (2i, 2i + 1) -- the two 64-byte halves of the same 128-byte lines -- are issued back to back,
-    // every second K-step, into two ring stages.  [measured, tools/ldrow.hip] a CU streams 32 KiB K-steps of 64-byte row pieces at
-    // 0.59 us each (L2-hot operands shared by three workgroups), 0.44 us when the halves of a line are requested together, 0.38 us
-    // with 128-byte pieces: the feed, not the MFMA pipe (0.49 us per K-step), is what the main loop waits for.
-    auto issue8_pair = [&]() __attribute__((always_inline)) {
-        char* b0 = lds + (p_g & 3) * Q_STAGE_BYTES + wave * 2048;
-        char* b1 = lds + ((p_g + 1) & 3) * Q_STAGE_BYTES + wave * 2048;
-#pragma unroll
-        for (int j = 0; j < (RGW < 2 ? RGW : 2); ++j) {
-            const char* ga = a_src[j] + p_kt * 64;
-            const char* gw = w_src[j] + p_kt * 64;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(ga), (void __attribute__((address_space(3)))*)(b0 + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(ga + 64), (void __attribute__((address_space(3)))*)(b1 + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gw), (void __attribute__((address_space(3)))*)(b0 + Q_TILE_BYTES + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gw + 64), (void __attribute__((address_space(3)))*)(b1 + Q_TILE_BYTES + j * 1024), 16, 0, 0);
-        }
-    };
-    auto advance_pair = [&]() __attribute__((always_inline)) {
-        p_g += 2;
-        if (!p_more) return;
-        p_kt += 2;
-        if (p_kt == p.nt) {
-            p_idx += L;
-            if (p_idx < count) { p_kt = 0; setup_src(p_idx); }
-            else { p_more = false; p_kt = p.nt - 2; }
         }
     };
     auto advance4 = [&]() __attribute__((always_inline)) {
@@ -296,7 +253,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
     const char* bias_lds = lds + Q_LDS_BYTES;
     if constexpr (q_has_bias<EPI>()) {
         const int ncols = p.tiles_n * 256;
-        for (int i = tid * 8; i < ncols; i += NWV * 64 * 8) {
+        for (int i = tid * 8; i < ncols; i += 512 * 8) {
             bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (p.bias && i < p.N) v = *reinterpret_cast<const bf16x8*>(p.bias + i);
             *reinterpret_cast<bf16x8*>(lds + Q_LDS_BYTES + i * 2) = v;
@@ -309,7 +266,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
     const int fpos = fg ^ q_swz(fi >> 2);
     const int a_off8 = (wm * 128 + fi) * 64 + fpos * 16;                 // + f * 1024   (256-row tile)
     const int a_off4 = (wm * 64 + fi) * 64 + fpos * 16;                  // + f * 1024   (128-row tile)
-    const int w_off = Q_TILE_BYTES + (wn * (64 * NH) + fi) * 64 + fpos * 16;    // + g * 1024, g = 4 h + fn
+    const int w_off = Q_TILE_BYTES + (wn * 64 + fi) * 64 + fpos * 16;    // + fn * 1024
 
     int c_g = 0;            // global K-step counter of this workgroup
     // counted wait at the end of K-step c_g: the DMA of K-step c_g + 1 has landed; the DMA of K-steps c_g + 2 and c_g + 3
@@ -329,82 +286,13 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
     auto run_tile = [&](auto fmw_c, int m0, int n0, int mt) {
         constexpr int FMW = decltype(fmw_c)::value;      // m-fragments per wave: 8 (256-row tile) or 4 (128-row tile)
         const int a_off = FMW == 8 ? a_off8 : a_off4;
-        f32x4 acc[NG][FMW];                              // acc[4 h + fn][f][j]: row 16 f + 4 fg + j, column 64 h + 4 fi + fn (of the wave tile)
+        f32x4 acc[4][FMW];                               // acc[fn][f][j]: row 16 f + 4 fg + j, column 4 fi + fn (of the wave tile)
 #pragma unroll
-        for (int i = 0; i < NG; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < FMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        if constexpr (PIPE && NH == 2) {
-            // ---- one wave per SIMD: all overlap is inside the wave's own instruction stream.  K-step c: [16 MFMAs] wait for the own
-            //      DMA of K-step c + 1, B(c) [reads of the 16 fragments of K-step c + 1, DMA of K-step c + 4 into the stage B(c) freed,
-            //      48 (16) MFMAs].  Stage c was read into registers during K-step c - 1 (or by the tile's first-step reads below, which
-            //      precede B(c)), so after B(c) nobody reads it any more.
-            //      Everything in the loop is written as asm statements IN ISSUE ORDER (they keep their order): with one wave per SIMD a
-            //      cluster of 16 ds_reads + 8 DMA pieces after the barrier is ~700 cycles in which no MFMA issues (measured: 0.7x the
-            //      8-wave kernel); spread out -- a read after every second MFMA, then a DMA piece after every third -- the LDS work
-            //      of a K-step (64 KiB read, 32 KiB written) fits under its 1030 cycles of MFMA.
-            q_u32x4 f0w[NG], f0x[FMW], f1w[NG], f1x[FMW];
-            const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)lds;
-            {
-                const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) f0w[g] = *reinterpret_cast<const q_u32x4*>(base + w_off + g * 1024);
-#pragma unroll
-                for (int f = 0; f < FMW; ++f) f0x[f] = *reinterpret_cast<const q_u32x4*>(base + a_off + f * 1024);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            auto kstep = [&](q_u32x4 (&wf)[NG], q_u32x4 (&xf)[FMW], q_u32x4 (&wn_)[NG], q_u32x4 (&xn_)[FMW]) __attribute__((always_inline)) {
-                constexpr int G1 = FMW == 8 ? 1 : 2;               // W fragments of the part before the barrier: 8 MFMAs
-                constexpr int GA = FMW == 8 ? 6 : 8;               // accumulator tuples of W fragments < GA live in AGPRs (192), the rest in VGPRs
-                constexpr int N2 = (NG - G1) * FMW;                // MFMAs after the barrier: 56 (24)
-                constexpr int NRD = NG + FMW;                      // fragment reads: 16 (12)
-                constexpr int RD_EVERY = FMW == 8 ? 2 : 1;         // a read after every RD_EVERY-th MFMA ...
-                constexpr int DMA0 = NRD * RD_EVERY;               // ... then a DMA piece after every DMA_EVERY-th
-                constexpr int DMA_EVERY = FMW == 8 ? 3 : 1;
-                static_assert(DMA0 + (2 * RGW - 1) * DMA_EVERY < N2, "the schedule does not fit the K-step");
-                const unsigned nst = lds0 + ((c_g + 1) & 3) * Q_STAGE_BYTES;
-                const unsigned wa = nst + w_off, xa = nst + a_off;
-                char* dbase = lds + (p_g & 3) * Q_STAGE_BYTES + wave * (RGW * 1024);
-                const int dko = p_kt * 64;
-                constexpr bool x_dma = !(ABL & 2), x_mfma = !(ABL & 4), x_rd = !(ABL & 8);     // ablation switches (experiments)
-                q_static_for<0, G1 * FMW>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, g = i / FMW, f = i % FMW;
-                    if constexpr (x_mfma) q_mfma_pinned<(g < GA)>(acc[g][f], xf[f], wf[g]);
-                });
-                q_wait_vm<16>();                                   // own DMA of K-step c_g + 1 landed (c_g + 2, c_g + 3 may fly)
-                QQ_BARRIER();                                      // B(c_g)
-                q_static_for<0, N2>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, g = G1 + i / FMW, f = i % FMW;
-                    if constexpr (x_mfma) q_mfma_pinned<(g < GA)>(acc[g][f], xf[f], wf[g]);
-                    if constexpr (i % RD_EVERY == 0 && i / RD_EVERY < NRD) {
-                        constexpr int r = i / RD_EVERY;
-                        if constexpr (!x_rd) {}
-                        else if constexpr (r < NG) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wn_[r]) : "v"(wa), "n"(r * 1024));
-                        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xn_[r - NG]) : "v"(xa), "n"((r - NG) * 1024));
-                    }
-                    if constexpr (i >= DMA0 && (i - DMA0) % DMA_EVERY == 0 && (i - DMA0) / DMA_EVERY < 2 * RGW) {
-                        constexpr int d = (i - DMA0) / DMA_EVERY, j = d >> 1;
-                        if constexpr (!x_dma) {}
-                        else if constexpr ((d & 1) == 0)
-                            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + dko),
-                                                             (void __attribute__((address_space(3)))*)(dbase + j * 1024), 16, 0, 0);
-                        else
-                            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + dko),
-                                                             (void __attribute__((address_space(3)))*)(dbase + Q_TILE_BYTES + j * 1024), 16, 0, 0);
-                    }
-                });
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                advance4();
-                ++c_g;
-            };
-            int kt = 0;
-            for (; kt + 1 < p.nt; kt += 2) { kstep(f0w, f0x, f1w, f1x); kstep(f1w, f1x, f0w, f0x); }
-            if (kt < p.nt) kstep(f0w, f0x, f1w, f1x);
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // the last MFMAs' results before the epilogue reads them (asm: no hazard tracking)
-        } else if constexpr (PIPE) {
+        if constexpr (PIPE) {
             // ---- software-pipelined main loop: no R slots.  The ds_reads of the NEXT fragments and the DMA issue sit between the
             //      MFMAs of the wave (its partner on the SIMD fills the bubbles), one barrier B(g) per K-step: "stage g + 1 is
             //      visible to everyone and stage g has been read by everyone" -- after it the DMA of K-step g + 4 may refill stage g.
@@ -423,18 +311,9 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
                 __builtin_amdgcn_sched_barrier(0);
             }
             // one K-step: MFMAs on (wf, xf), the next K-step's first fragments are read into (wn_, xn_)
-            auto kstep = [&](auto odd_c, bf16x8 (&wf)[4], bf16x8 (&xf)[4], bf16x8 (&wn_)[4], bf16x8 (&xn_)[4]) __attribute__((always_inline)) {
-                constexpr bool ODD = decltype(odd_c)::value;        // PAIR: odd K-steps wait for the pair issued two steps ago and issue the next one
+            auto kstep = [&](bf16x8 (&wf)[4], bf16x8 (&xf)[4], bf16x8 (&wn_)[4], bf16x8 (&xn_)[4]) __attribute__((always_inline)) {
                 const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
                 const char* nbase = lds + ((c_g + 1) & 3) * Q_STAGE_BYTES;
-                auto wait_dma = [&]() __attribute__((always_inline)) {
-                    if constexpr (!PAIR) q_wait_vm<8>();           // own DMA of K-step c_g + 1 landed (c_g + 2, c_g + 3 may fly)
-                    else if constexpr (ODD) q_wait_vm<0>();        // the pair (c_g + 1, c_g + 2), issued after B(c_g - 2)
-                };
-                auto issue_dma = [&]() __attribute__((always_inline)) {
-                    if constexpr (!PAIR) issue4();
-                    else if constexpr (ODD) issue8_pair();         // K-steps c_g + 3, c_g + 4 into the stages B(c_g - 1), B(c_g) freed
-                };
                 if constexpr (FMW == 8) {
                     // ---- M0 + reads of this step's second half of the activation fragments ----
 #pragma unroll
@@ -448,27 +327,27 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
                     for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
                     __builtin_amdgcn_sched_barrier(0);             // (the asm wait below must not drift up between the MFMAs)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    wait_dma();
+                    q_wait_vm<8>();                                // own DMA of K-step c_g + 1 landed (c_g + 2, c_g + 3 may fly)
                     QQ_BARRIER();                                  // B(c_g)
                     // ---- M1 + reads of the next K-step's first fragments + DMA of K-step c_g + 4 into the stage just freed ----
 #pragma unroll
                     for (int f = 0; f < 4; ++f) wn_[f] = *reinterpret_cast<const bf16x8*>(nbase + w_off + f * 1024);
 #pragma unroll
                     for (int f = 0; f < 4; ++f) xn_[f] = *reinterpret_cast<const bf16x8*>(nbase + a_off + f * 1024);
-                    issue_dma();
+                    issue4();
 #pragma unroll
                     for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
                         for (int f = 0; f < 4; ++f)
                             acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xg[f], wf[fn], acc[fn][4 + f], 0, 0, 0);
                 } else {
-                    wait_dma();
+                    q_wait_vm<8>();
                     QQ_BARRIER();                                  // B(c_g): this step's fragments were read during the previous step
 #pragma unroll
                     for (int f = 0; f < 4; ++f) wn_[f] = *reinterpret_cast<const bf16x8*>(nbase + w_off + f * 1024);
 #pragma unroll
                     for (int f = 0; f < 4; ++f) xn_[f] = *reinterpret_cast<const bf16x8*>(nbase + a_off + f * 1024);
-                    issue_dma();
+                    issue4();
 #pragma unroll
                     for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
@@ -480,20 +359,17 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (PAIR ? ODD : (i & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (i & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!PAIR) advance4();
-                else if constexpr (ODD) advance_pair();
+                advance4();
                 ++c_g;
             };
-            constexpr std::integral_constant<bool, false> even_c{};
-            constexpr std::integral_constant<bool, true> odd_c{};
             int kt = 0;
-            for (; kt + 1 < p.nt; kt += 2) { kstep(even_c, f0w, f0x, f1w, f1x); kstep(odd_c, f1w, f1x, f0w, f0x); }
-            if (kt < p.nt) kstep(even_c, f0w, f0x, f1w, f1x);     // (never with PAIR: K is a multiple of 64 there)
+            for (; kt + 1 < p.nt; kt += 2) { kstep(f0w, f0x, f1w, f1x); kstep(f1w, f1x, f0w, f0x); }
+            if (kt < p.nt) kstep(f0w, f0x, f1w, f1x);
         } else {
         for (int kt = 0; kt < p.nt; ++kt) {
                 const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
@@ -551,17 +427,15 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
         const int mrow0 = m0 + wm * (16 * FMW) + 4 * fg;          // + 16 f + j
         if (p.dbg & 1) {
 #pragma unroll
-            for (int i = 0; i < NG; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < FMW; ++j) asm volatile("" :: "v"(acc[i][j]));
             return;
         }
         const bool interior = (m0 + 32 * FMW <= p.M) && (n0 + 256 <= p.N);
-        auto body = [&](auto int_c, auto h_c) {
+        auto body = [&](auto int_c) {
             constexpr bool INT = decltype(int_c)::value;
-            constexpr int H4 = 4 * decltype(h_c)::value;           // first accumulator row of this 64-column quad
-            const int ncolq = n0 + wn * (64 * NH) + 16 * H4;       // first column of the quad
-            const int ncol4 = ncolq + 4 * fi;                      // this lane's 4 columns before any exchange
+            const int ncol4 = n0 + wn * 64 + 4 * fi;               // this lane's 4 columns before any exchange
             f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (q_has_bias<EPI>()) {
                 const bf16x4 bb = *reinterpret_cast<const bf16x4*>(bias_lds + ncol4 * 2);
@@ -588,7 +462,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int m = mrow0 + f * 16 + j;
-                        f32x4 v = f32x4{acc[H4 + 0][f][j], acc[H4 + 1][f][j], acc[H4 + 2][f][j], acc[H4 + 3][f][j]} + b4;
+                        f32x4 v = f32x4{acc[0][f][j], acc[1][f][j], acc[2][f][j], acc[3][f][j]} + b4;
                         if (p.drop_t) {       // nn.Dropout on the Linear output, before the residual add (vit.py:24,48 + :80-81)
                             const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
 #pragma unroll
@@ -602,7 +476,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
             } else {
                 // after the pair exchange: even lanes own row r = mrow0 + 16 f + 2 pr, odd lanes row r + 1, columns ncol8 .. + 7
                 const int odd = fi & 1;
-                const int ncol8 = ncolq + 8 * (fi >> 1);
+                const int ncol8 = n0 + wn * 64 + 8 * (fi >> 1);
                 const bool colok = INT || ncol8 < p.N;
                 __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
                 bf16x8 hpre[2][2];             // GELU_BWD: saved pre-activations, fetched two fragment rows ahead
@@ -628,10 +502,10 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
                     for (int pr = 0; pr < 2; ++pr) {
                         // rows j0 = 2 pr and j0 + 1 of this lane's 4 columns, rounded to the 16-bit type
                         const int j0 = 2 * pr;
-                        const unsigned a0 = q_pack2(acc[H4 + 0][f][j0] + b4[0], acc[H4 + 1][f][j0] + b4[1]);
-                        const unsigned a1 = q_pack2(acc[H4 + 2][f][j0] + b4[2], acc[H4 + 3][f][j0] + b4[3]);
-                        const unsigned c0 = q_pack2(acc[H4 + 0][f][j0 + 1] + b4[0], acc[H4 + 1][f][j0 + 1] + b4[1]);
-                        const unsigned c1 = q_pack2(acc[H4 + 2][f][j0 + 1] + b4[2], acc[H4 + 3][f][j0 + 1] + b4[3]);
+                        const unsigned a0 = q_pack2(acc[0][f][j0] + b4[0], acc[1][f][j0] + b4[1]);
+                        const unsigned a1 = q_pack2(acc[2][f][j0] + b4[2], acc[3][f][j0] + b4[3]);
+                        const unsigned c0 = q_pack2(acc[0][f][j0 + 1] + b4[0], acc[1][f][j0 + 1] + b4[1]);
+                        const unsigned c1 = q_pack2(acc[2][f][j0 + 1] + b4[2], acc[3][f][j0 + 1] + b4[3]);
                         // even lane keeps row j0 and receives the neighbour's 4 columns of it; odd lane likewise for row j0 + 1
                         const unsigned r0 = q_dpp_xor1(odd ? a0 : c0), r1 = q_dpp_xor1(odd ? a1 : c1);
                         const unsigned k0 = odd ? c0 : a0, k1 = odd ? c1 : a1;
@@ -696,24 +570,16 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512) void gemm_ntp_kernel(const Ntp
                 }
             }
         };
-        if (interior) {
-            body(std::integral_constant<bool, true>{}, std::integral_constant<int, 0>{});
-            if constexpr (NH == 2) body(std::integral_constant<bool, true>{}, std::integral_constant<int, 1>{});
-        } else {
-            body(std::integral_constant<bool, false>{}, std::integral_constant<int, 0>{});
-            if constexpr (NH == 2) body(std::integral_constant<bool, false>{}, std::integral_constant<int, 1>{});
-        }
+        if (interior) body(std::integral_constant<bool, true>{});
+        else body(std::integral_constant<bool, false>{});
     };
 
     // ---- prologue: K-steps 0..2 in flight, K-step 0 landed ----
     setup_src(p_idx);
-    if constexpr (PAIR) {
-        issue8_pair(); advance_pair(); issue8_pair(); advance_pair();
-        q_wait_vm<8>();        // K-steps 0 and 1 landed, the second pair flies
-    } else if constexpr (PIPE) {
+    if constexpr (PIPE) {
         // four stages in flight: B(g) frees stage g half a step before its next use
         issue4(); advance4(); issue4(); advance4(); issue4(); advance4(); issue4(); advance4();
-        q_wait_vm<6 * RGW>();
+        q_wait_vm<12>();
     } else {
         issue_a(); issue_w();
         issue_a(); issue_w();
@@ -849,34 +715,15 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     // pipelined loop is ~5 % ahead (8-shape sum 1.688 vs 1.783 ms), inside the training step the two are level (42.7-43.1 vs
     // 43.0-43.2 ms on the same box).
     static const bool pipe = !(getenv("VITK_NTP_PIPE") && atoi(getenv("VITK_NTP_PIPE")) == 0);
-    static const bool pair_ok = getenv("VITK_NTP_PAIR") && atoi(getenv("VITK_NTP_PAIR")) != 0;   // experiment, off: measured level or slower
-    static const int w4_mask = getenv("VITK_NTP_W4") ? atoi(getenv("VITK_NTP_W4")) : 0;     // bit e: epilogue e on the 4-wave flavour
-    static const int abl = getenv("VITK_NTP_ABL") ? atoi(getenv("VITK_NTP_ABL")) : 0;
-    if (abl && epilogue == VITK_EPI_NONE) {       // experiments: 4-wave main loop with parts removed (bit 1 DMA, 2 MFMA, 3 fragment reads)
-#define NTP_ABL(X) case X: { static const int rc__ = q_set_max_lds(gemm_ntp_kernel<VITK_EPI_NONE, true, 2, X>, Q_LDS_MAX); (void)rc__; \
-            hipLaunchKernelGGL((gemm_ntp_kernel<VITK_EPI_NONE, true, 2, X>), dim3((unsigned)pl.grid), dim3(256), lds_bytes, st, a); break; }
-        switch (abl) { NTP_ABL(2) NTP_ABL(4) NTP_ABL(8) NTP_ABL(6) NTP_ABL(10) NTP_ABL(12) NTP_ABL(14) default: break; }
-#undef NTP_ABL
-        VITK_CHECK_LAUNCH("gemm_nt_bf16 (ablation)");
-        return 0;
-    }
 #define NTP_LAUNCH(E) do { \
-        if ((w4_mask >> E) & 1) { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, true, 2>, Q_LDS_MAX); \
+        if (pipe) { \
+            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, true>, Q_LDS_MAX); \
             if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, true, 2>), dim3((unsigned)pl.grid), dim3(256), lds_bytes, st, a); \
-        } else if (pipe && pair_ok && K % 64 == 0) { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, true, 1, 0, true>, Q_LDS_MAX); \
-            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, true, 1, 0, true>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
-        } else if (pipe) { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, true, 1>, Q_LDS_MAX); \
-            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, true, 1>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+            hipLaunchKernelGGL((gemm_ntp_kernel<E, true>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
         } else { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, false, 1>, Q_LDS_MAX); \
+            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, false>, Q_LDS_MAX); \
             if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, false, 1>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+            hipLaunchKernelGGL((gemm_ntp_kernel<E, false>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
         } \
     } while (0)
     switch (epilogue) {
@@ -889,5 +736,58 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     }
 #undef NTP_LAUNCH
     VITK_CHECK_LAUNCH("gemm_nt_bf16 (persistent)");
+    return 0;
+}
+
+// ---- K-blocked weights ---------------------------------------------------------------------------------------------------
+// vitk_pack_w_nt: W (N x K, row-major) -> for every (256-column tile tn, K-step kt) the 16 KiB image the persistent kernel's
+// LDS stage holds for it, blocks ordered (tn, kt): LDS row R = 64 q + 16 fn + c (64 bytes) is W row 256 tn + 64 q + 4 c + fn
+// (rows past N repeat row N - 1), and position s of the row holds its 16-byte chunk s ^ q_swz(R >> 2) of K-step kt.
+// The transposed flavour packs W^T (K x N) -- the operand of dX = dY . W -- straight from W.
+namespace {
+template <bool TR>
+__global__ __launch_bounds__(256) void pack_w_kernel(const __bf16* __restrict__ W, long long ldw, int N, int K, char* __restrict__ out) {
+    // logical operand: rows = TR ? K : N ("n"), reduction = TR ? N : K ("k")
+    const int rows = TR ? K : N, red = TR ? N : K;
+    const int nt = red >> 5;
+    const long long chunk = (long long)blockIdx.x * 256 + threadIdx.x;       // one 16-byte chunk per thread
+    const long long total = (long long)((rows + 255) >> 8) * nt * 1024;
+    if (chunk >= total) return;
+    const int spos = (int)(chunk & 3), R = (int)((chunk >> 2) & 255);
+    const long long blk = chunk >> 10;
+    const int kt = (int)(blk % nt), tn = (int)(blk / nt);
+    int n = tn * 256 + (R >> 6) * 64 + 4 * (R & 15) + ((R >> 4) & 3);
+    n = n < rows ? n : rows - 1;
+    const int k0 = kt * 32 + 8 * (spos ^ q_swz(R >> 2));
+    bf16x8 v;
+    if (!TR) v = *reinterpret_cast<const bf16x8*>(W + (long long)n * ldw + k0);
+    else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = W[(long long)(k0 + e) * ldw + n];
+    }
+    *reinterpret_cast<bf16x8*>(out + chunk * 16) = v;
+}
+}  // namespace
+
+extern "C" int64_t vitk_pack_w_nt_bytes(int64_t rows, int64_t red) {
+    if (rows <= 0 || red <= 0 || (red & 31)) return 0;
+    return ((rows + 255) / 256) * 256 * red * 2;
+}
+
+extern "C" int vitk_pack_w_nt(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, void* out_t, void* stream) {
+    if (!W || (!out && !out_t)) VITK_FAIL(VITK_E_ARG, "pack_w_nt: null pointer");
+    if (N <= 0 || K <= 0 || ldw < K || (ldw & 7) || N > (1 << 24) || K > (1 << 24)) VITK_FAIL(VITK_E_SHAPE, "pack_w_nt: bad shape N=%lld K=%lld ldw=%lld", (long long)N, (long long)K, (long long)ldw);
+    if ((out && (K & 31)) || (out_t && (N & 31))) VITK_FAIL(VITK_E_SHAPE, "pack_w_nt: the reduction dimension must be a multiple of 32");
+    if (!aligned16(W) || (out && !aligned16(out)) || (out_t && !aligned16(out_t))) VITK_FAIL(VITK_E_ALIGN, "pack_w_nt: 16-byte aligned pointers required");
+    hipStream_t st = (hipStream_t)stream;
+    if (out) {
+        const long long chunks = vitk_pack_w_nt_bytes(N, K) / 16;
+        hipLaunchKernelGGL((pack_w_kernel<false>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const __bf16*)W, (long long)ldw, (int)N, (int)K, (char*)out);
+    }
+    if (out_t) {
+        const long long chunks = vitk_pack_w_nt_bytes(K, N) / 16;
+        hipLaunchKernelGGL((pack_w_kernel<true>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const __bf16*)W, (long long)ldw, (int)N, (int)K, (char*)out_t);
+    }
+    VITK_CHECK_LAUNCH("pack_w_nt");
     return 0;
 }

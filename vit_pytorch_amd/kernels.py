@@ -137,6 +137,15 @@ def gemm_nt_plan(M: int, N: int, K: int, ldc: int) -> dict:
     return {"persistent": bool(out[0]), "tiles_m256": out[1], "tiles_m128": out[2], "workgroups": out[3], "tiles_n": out[4]}
 
 
+def pack_w_nt_bytes(rows: int, reduction: int) -> int:
+    return int(L.load().vitk_pack_w_nt_bytes(rows, reduction))
+
+
+def pack_w_nt(W: Tensor, ldw: int, N: int, Kd: int, out: Optional[Tensor], out_t: Optional[Tensor]):
+    """K-blocked copies of a weight (see vitk.h): `out` for y = x W^T, `out_t` for dX = dY W; pass them as W with ldw = 0."""
+    check(_lib_for(W, out, out_t).vitk_pack_w_nt(_p(W), ldw, N, Kd, _p(out), _p(out_t), _stream()), "pack_w_nt")
+
+
 def gemm_nt_bf16_gelu_bwd_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
                                  aux: Tensor, partials: Tensor):
     check(_lib_for(A, W, C, aux, partials).vitk_gemm_nt_bf16_gelu_bwd_colsum(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, _p(aux), _p(partials),

@@ -157,12 +157,13 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
             K.gelu_fwd(y, act)
             return act, y
         return y
+    Wn, ldw = nt_weight(W, M, False) if _fast_nt(x, N, Kd) else (W, Kd)
     if resid is not None:
         out = empty((M, N), F32, x)
         if drop is not None:
-            K.gemm_nt_bf16_drop(x, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, drop[0], drop[1], bias=bias, resid=resid)
+            K.gemm_nt_bf16_drop(x, Kd, Wn, ldw, out, N, M, N, Kd, L.EPI_RESID, drop[0], drop[1], bias=bias, resid=resid)
         elif _fast_nt(x, N, Kd):
-            K.gemm_nt_bf16(x, Kd, W, Kd, out, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid)
+            K.gemm_nt_bf16(x, Kd, Wn, ldw, out, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid)
         else:
             y = empty((M, N), T, x)
             K.gemm_generic(K.mat(x, Kd, 1), K.mat(W, 1, Kd), K.mat(y, N, 1), M, N, Kd, bias=bias)
@@ -174,22 +175,73 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
         if drop is not None:
             if bias is None:
                 raise L.VitkError("linear_fwd: the fused GELU + dropout epilogue needs a bias")
-            K.gemm_nt_bf16_drop(x, Kd, W, Kd, act, N, M, N, Kd, L.EPI_BIAS_GELU, drop[0], drop[1], bias=bias, aux=pre)
+            K.gemm_nt_bf16_drop(x, Kd, Wn, ldw, act, N, M, N, Kd, L.EPI_BIAS_GELU, drop[0], drop[1], bias=bias, aux=pre)
         elif _fast_nt(x, N, Kd) and bias is not None:
-            K.gemm_nt_bf16(x, Kd, W, Kd, act, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=pre)
+            K.gemm_nt_bf16(x, Kd, Wn, ldw, act, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=pre)
         else:
             K.gemm_generic(K.mat(x, Kd, 1), K.mat(W, 1, Kd), K.mat(pre, N, 1), M, N, Kd, bias=bias)
             K.gelu_fwd(pre, act)
         return act, pre
     y = empty((M, N), out_dtype or T, x)
     if _fast_nt(x, N, Kd) and y.dtype in HALF:
-        K.gemm_nt_bf16(x, Kd, W, Kd, y, N, M, N, Kd, L.EPI_BIAS if bias is not None else L.EPI_NONE, bias=bias)
+        K.gemm_nt_bf16(x, Kd, Wn, ldw, y, N, M, N, Kd, L.EPI_BIAS if bias is not None else L.EPI_NONE, bias=bias)
     else:
         K.gemm_generic(K.mat(x, Kd, 1), K.mat(W, 1, Kd), K.mat(y, N, 1), M, N, Kd, bias=bias)
     return y
 
 
 _WT_CACHE = {}      # id(W) -> (weakref to W, weight_key, pad, Wt); entries die with their parameter
+_WP_CACHE = {}      # id(W) -> [weakref to W, weight_key, packed for y = x W^T, packed for dX = dY W]
+_PERSIST_OK = {}    # (M, N, K) -> the persistent NT kernel serves the shape (vitk_gemm_nt_plan)
+
+
+def _persistent_nt(M: int, N: int, Kd: int) -> bool:
+    key = (M, N, Kd)
+    v = _PERSIST_OK.get(key)
+    if v is None:
+        v = _PERSIST_OK[key] = bool(K.gemm_nt_plan(M, N, Kd, N)["persistent"])
+    return v
+
+
+def packed_weights_on() -> bool:
+    """K-blocked weight copies for the persistent NT kernel (VITK_PACK_W=0 turns them off; so does an explicit VITK_NTP_EPIS
+    mask, which may route an epilogue to the per-tile kernel that does not read them)."""
+    return _os.environ.get("VITK_PACK_W", "1") not in ("0", "") and "VITK_NTP_EPIS" not in _os.environ
+
+
+def nt_weight(W: Tensor, M: int, transposed: bool):
+    """(operand, ldw) for the NT GEMM whose "W" is this weight: `transposed=False` -- y = x W^T (rows N, reduction K);
+    `transposed=True` -- dX = dY W (rows K, reduction N).  For shapes the persistent kernel serves, a K-blocked copy
+    (vitk_pack_w_nt, ldw = 0) cached per parameter VALUE like the transposed copies (weight_key): the kernel's LDS-DMA then
+    reads whole 128-byte lines of W (the 8 GEMM shapes of a ViT-B/16 layer: 1.70 -> 1.59 ms).  Both copies are made by one
+    call on the first forward use while gradients are enabled; never cached during HIP-graph capture."""
+    N, Kd = W.shape
+    rows, red = (Kd, N) if transposed else (N, Kd)
+    if (W.dtype in HALF and isinstance(W, torch.nn.Parameter) and W.is_contiguous() and red % 32 == 0 and packed_weights_on()
+            and _persistent_nt(M, rows, red)):
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = weight_key(W)
+        ent = _WP_CACHE.get(id(W))
+        if capturing or ent is None or ent[0]() is not W or ent[1] != key:
+            wid = id(W)
+            ent = [weakref.ref(W, lambda _r, wid=wid: _WP_CACHE.pop(wid, None)), key, None, None]
+            if not capturing:
+                _WP_CACHE[wid] = ent
+        idx = 3 if transposed else 2
+        if ent[idx] is None:
+            want_f = not transposed and Kd % 32 == 0
+            want_t = (transposed or (torch.is_grad_enabled() and W.requires_grad and ent[3] is None)) and N % 32 == 0
+            pf = empty((K.pack_w_nt_bytes(N, Kd) // 2,), W.dtype, W) if want_f else None
+            pt = empty((K.pack_w_nt_bytes(Kd, N) // 2,), W.dtype, W) if want_t else None
+            K.pack_w_nt(W, Kd, N, Kd, pf, pt)
+            if pf is not None:
+                ent[2] = pf
+            if pt is not None:
+                ent[3] = pt
+        return ent[idx], 0
+    if transposed:
+        return transpose_weight(W), N
+    return W, Kd
 
 
 def transpose_weight(W: Tensor, pad_to: int = 0) -> Tensor:
@@ -228,13 +280,13 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
         return (dx, False) if db is not None else dx
     dx = empty((M, Kd), T, dy)
     if T in HALF and N % 32 == 0 and Kd % 4 == 0:
-        Wt = transpose_weight(W)  # (K, N): makes dX an NT GEMM with reduction dim N contiguous
+        Wt, ldt = nt_weight(W, M, True)  # W^T (K, N): makes dX an NT GEMM with reduction dim N contiguous (K-blocked copy or plain transpose)
         if drop is not None:        # backward of dropout(gelu(pre)): same keep decisions, fused with GELU' (and db)
             R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
             if gelu_pre is None or R == 0:
                 raise L.VitkError("linear_dx: fused dropout backward needs gelu_pre and a shape served by the 256-row kernel")
             part = empty((R * Kd,), F32, dy) if db is not None else None
-            K.gemm_nt_bf16_drop(dy, N, Wt, N, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, drop[0], drop[1], aux=gelu_pre, partials=part)
+            K.gemm_nt_bf16_drop(dy, N, Wt, ldt, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, drop[0], drop[1], aux=gelu_pre, partials=part)
             if db is not None:
                 K.colsum_partials(part, R, Kd, Kd, db)
                 return dx, True
@@ -243,13 +295,13 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
             R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
             if R > 0:
                 part = empty((R * Kd,), F32, dy)
-                K.gemm_nt_bf16_gelu_bwd_colsum(dy, N, Wt, N, dx, Kd, M, Kd, N, gelu_pre, part)
+                K.gemm_nt_bf16_gelu_bwd_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_pre, part)
                 K.colsum_partials(part, R, Kd, Kd, db)
                 return dx, True
         if gelu_pre is not None:
-            K.gemm_nt_bf16(dy, N, Wt, N, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, aux=gelu_pre)
+            K.gemm_nt_bf16(dy, N, Wt, ldt, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, aux=gelu_pre)
         else:
-            K.gemm_nt_bf16(dy, N, Wt, N, dx, Kd, M, Kd, N)
+            K.gemm_nt_bf16(dy, N, Wt, ldt, dx, Kd, M, Kd, N)
     else:
         K.gemm_generic(K.mat(dy, N, 1), K.mat(W, Kd, 1), K.mat(dx, Kd, 1), M, Kd, N)
         if gelu_pre is not None:
