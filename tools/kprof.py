@@ -1,5 +1,6 @@
 """A few launches of each GEMM of a ViT-B/16 batch-256 layer, in a FIXED ORDER, for rocprofv3 --pmc: python tools/kprof.py
 tools/pmc_traffic_json.py labels the launch groups by this order (LABELS)."""
+import os
 import torch
 from vit_pytorch_amd import kernels as K, _lib as L
 dev = "cuda"; BF = torch.bfloat16
@@ -10,9 +11,15 @@ LABELS = []
 
 
 def run(label, n, k, epi):
-    A = torch.randn(M, k, device=dev).to(BF); W = (torch.randn(n, k, device=dev) * k ** -0.5).to(BF)
+    A = torch.randn(M, k, device=dev).to(BF); Wrow = (torch.randn(n, k, device=dev) * k ** -0.5).to(BF)
     bias = torch.randn(n, device=dev).to(BF)
     alg = 2 * (M * k + n * k)
+    # the operand production uses: the K-blocked copy (vitk_pack_w_nt; KPROF_ROW_MAJOR=1 for the plain weight)
+    if os.environ.get("KPROF_ROW_MAJOR"):
+        W, ldw = Wrow, k
+    else:
+        W, ldw = torch.empty(K.pack_w_nt_bytes(n, k) // 2, dtype=BF, device=dev), 0
+        K.pack_w_nt(Wrow, k, n, k, W, None)
     if epi == L.EPI_RESID:
         C = torch.zeros(M, n, device=dev); resid = C; aux = None
         alg += 8 * M * n                                   # f32 residual read + f32 write
@@ -23,9 +30,9 @@ def run(label, n, k, epi):
         if epi == L.EPI_GELU_BWD:
             rows = K.gemm_nt_colsum_rows(M, n, k, n)
             cs = torch.empty(rows * n, device=dev)
-            K.gemm_nt_bf16_gelu_bwd_colsum(A, k, W, k, C, n, M, n, k, aux, cs)
+            K.gemm_nt_bf16_gelu_bwd_colsum(A, k, W, ldw, C, n, M, n, k, aux, cs)
         else:
-            K.gemm_nt_bf16(A, k, W, k, C, n, M, n, k, epi, bias=bias, resid=resid, aux=aux)
+            K.gemm_nt_bf16(A, k, W, ldw, C, n, M, n, k, epi, bias=bias, resid=resid, aux=aux)
     torch.cuda.synchronize()
     LABELS.append((label, n, k, alg))
 

@@ -15,7 +15,7 @@ def groups(root, counter):
             if r["Counter_Name"] != counter:
                 continue
             n = r["Kernel_Name"]
-            if "gemm_" not in n or "reduce" in n:
+            if "gemm_" not in n or "reduce" in n or "pack_w" in n:
                 continue
             rows.append((int(r["Dispatch_Id"]), n, float(r["Counter_Value"])))
     rows.sort()

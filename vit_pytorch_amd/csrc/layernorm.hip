@@ -11,10 +11,10 @@ namespace {
 
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / WAVE;
-// backward is latency-bound (3 input streams per row): 8 waves per block, up to 1024 blocks = 32 waves per CU
+// backward: 8 waves per block, up to 512 blocks = 16 waves per CU (4 per SIMD at <= 128 VGPRs)
 constexpr int LNB_THREADS = 512;
 constexpr int LNB_WAVES = LNB_THREADS / WAVE;
-constexpr int LNB_MAX_BLOCKS = 1024;
+constexpr int LNB_MAX_BLOCKS = 512;   // two 8-wave blocks per CU: all resident at once; 1024 measured the same kernel time and doubles the partial rows the finalize reads
 
 template <typename XT, typename YT, typename WT, int MAXC>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
@@ -537,7 +537,7 @@ extern "C" int vitk_layernorm_fwd_fp8(const void* x, int xdt, const void* w, con
 }
 
 extern "C" int64_t vitk_layernorm_bwd_blocks(int64_t rows, int64_t D) {
-    // one partial row per block; the block shape follows the row width (see ln_bwd_kernel): 8 waves and up to 1024
+    // one partial row per block; the block shape follows the row width (see ln_bwd_kernel): 8 waves and up to 512
     // blocks (4 per CU) up to 768 columns, 4 waves and up to 768 blocks (3 per CU, all resident at once) beyond
     const bool wide = (D / 4 + 63) / 64 >= 4;
     const int64_t nw = wide ? 4 : LNB_WAVES, cap = wide ? 768 : LNB_MAX_BLOCKS;
