@@ -1,7 +1,9 @@
-"""A/B of the NT GEMM kernels at the ViT-B/16 (batch 256) shapes of one layer's forward and backward:
-persistent kernel (gemm_nt_persist.hip) vs the per-tile kernel (VITK_NO_PERSIST=1), interleaved rounds in one process.
+"""A/B of the NT GEMM at the ViT-B/16 (batch 256) shapes of one layer's forward and backward, interleaved rounds in one process:
+persistent kernel reading the K-blocked weight copy (vitk_pack_w_nt; production) vs the same kernel on the row-major weight
+(NTAB_VS=rowmajor, default) or vs the per-tile kernel (NTAB_VS=pertile: VITK_NO_PERSIST=1, row-major both).
     python tools/nt_ab.py [rounds]
-Process-level switches (read once): VITK_NTP_NOEXACT=1 (conservative store waits), VITK_NTP_TAIL=-1 (no 128-row tail tiles)."""
+Process-level switches (read once): VITK_NTP_TAIL=-1 (no 128-row tail tiles), VITK_NTP_EFULL / VITK_NTP_EHALF (plan cost model),
+VITK_NTP_DBG=1 (main loop alone)."""
 import os
 import sys
 import statistics
@@ -48,21 +50,29 @@ def main():
         else:
             C = torch.empty(M, n, dtype=BF, device=dev); resid = None; aux = torch.randn(M, n, device=dev).to(BF)
 
+        vs_pertile = os.environ.get("NTAB_VS", "rowmajor") == "pertile"
+        Wp = torch.empty(K.pack_w_nt_bytes(n, k) // 2, dtype=BF, device=dev)
+        K.pack_w_nt(W, k, n, k, Wp, None)
+        op = [Wp, 0]
+
         def run():
+            W, ldw = op
             if epi == L.EPI_GELU_BWD:
                 R = K.gemm_nt_colsum_rows(M, n, k, n)
                 nonlocal part
                 if part is None or part.numel() != R * n:
                     part = torch.empty(R * n, device=dev)
-                K.gemm_nt_bf16_gelu_bwd_colsum(A, k, W, k, C, n, M, n, k, aux, part)
+                K.gemm_nt_bf16_gelu_bwd_colsum(A, k, W, ldw, C, n, M, n, k, aux, part)
             else:
-                K.gemm_nt_bf16(A, k, W, k, C, n, M, n, k, epi, bias=bias if epi in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_RESID) else None,
+                K.gemm_nt_bf16(A, k, W, ldw, C, n, M, n, k, epi, bias=bias if epi in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_RESID) else None,
                                resid=resid, aux=aux)
         tn, to = [], []
         for r in range(rounds + 1):
-            os.environ.pop("VITK_NO_PERSIST", None)
+            op[:] = [W if vs_pertile else Wp, k if vs_pertile else 0]
             t1 = time_once(run)
-            os.environ["VITK_NO_PERSIST"] = "1"
+            op[:] = [W, k]
+            if vs_pertile:
+                os.environ["VITK_NO_PERSIST"] = "1"
             t0 = time_once(run)
             os.environ.pop("VITK_NO_PERSIST", None)
             if r:
@@ -70,9 +80,9 @@ def main():
         a, b = statistics.median(tn), statistics.median(to)
         fl = 2 * M * n * k
         tot_new += a; tot_old += b
-        print(f"{name} N={n:5d} K={k:5d}: persistent {a * 1e3:7.1f} us {fl / a / 1e9:7.1f} TF/s (min {min(tn) * 1e3:6.1f}) | per-tile {b * 1e3:7.1f} us {fl / b / 1e9:7.1f} TF/s"
+        print(f"{name} N={n:5d} K={k:5d}: {'persistent' if vs_pertile else 'K-blocked W'} {a * 1e3:7.1f} us {fl / a / 1e9:7.1f} TF/s (min {min(tn) * 1e3:6.1f}) | {'per-tile' if vs_pertile else 'row-major W'} {b * 1e3:7.1f} us {fl / b / 1e9:7.1f} TF/s"
               f" | x{b / a:.3f}  plan={K.gemm_nt_plan(M, n, k, n)}")
-    print(f"sum: persistent {tot_new:.3f} ms, per-tile {tot_old:.3f} ms (x{tot_old / tot_new:.3f}); per 12-layer step x12 = {12 * tot_new:.2f} vs {12 * tot_old:.2f} ms")
+    print(f"sum: first {tot_new:.3f} ms, second {tot_old:.3f} ms (x{tot_old / tot_new:.3f}); per 12-layer step x12 = {12 * tot_new:.2f} vs {12 * tot_old:.2f} ms")
 
 
 if __name__ == "__main__":
