@@ -69,13 +69,13 @@ def test_host_side_validation_without_gpu(lib):
     p = (p + 255) // 256 * 256
     rc = lib.vitk_gemm_nt_bf16(p, 40, p, 40, p, 64, 64, 64, 40, 0, None, None, None, None)   # K % 32 != 0
     assert rc == -2 and b"K % 32" in lib.vitk_last_error()
-    rc = lib.vitk_layernorm_fwd(p, 0, p, p, 0, p, 0, p, p, 4, 30, 1e-5, L.IDENT, L.IDENT, None, 0, 0, None)  # D % 4 != 0
+    rc = lib.vitk_layernorm_fwd(p, 0, p, p, 0, p, 0, p, p, 4, 5000, 1e-5, L.IDENT, L.IDENT, None, 0, 0, None)  # D > 4096
     assert rc == -2
     q = L.BHND(p, 64, 64, 64)
     rc = lib.vitk_attn_fwd_bf16(q, q, q, q, p, 1, 1, 16, 80, 0.1, None)  # dim_head != 64 on the fused path
     assert rc == -2 and b"dim_head" in lib.vitk_last_error()
     assert lib.vitk_gemm_tn_splits(50432, 2304, 768) >= 1
-    assert lib.vitk_layernorm_bwd_blocks(50432, 768) == 1024 and lib.vitk_layernorm_bwd_blocks(50432, 1024) == 768
+    assert lib.vitk_layernorm_bwd_blocks(50432, 768) == 512 and lib.vitk_layernorm_bwd_blocks(50432, 1024) == 768
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -122,35 +122,75 @@ def test_extractor_and_netwrapper_wiring_end_to_end():
     assert _rel(v.mlp_head(got["hidden"]), plain) < 1e-5
 
 
+def _torch_block(t, x, r, dim, heads, dim_head):
+    """The block of `t` in plain torch (vit.py:51-64, 18-25, 78-83), float64: output and input gradient for the cotangent r."""
+    B, N = x.shape[:2]
+    attn, ff = t.layers[0]
+    xd = x.detach().double().requires_grad_(True)
+    ln = lambda z, m: torch.nn.functional.layer_norm(z, (dim,), m.weight.double(), m.bias.double())
+    h = ln(xd, attn.norm)
+    q, k, vv = (h @ attn.to_qkv.weight.double().t()).chunk(3, dim=-1)
+    sp = lambda z: z.view(B, N, heads, dim_head).transpose(1, 2)
+    a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * dim_head ** -0.5, dim=-1) @ sp(vv)
+    a = a.transpose(1, 2).reshape(B, N, heads * dim_head)
+    if not isinstance(attn.to_out, torch.nn.Identity):
+        a = a @ attn.to_out[0].weight.double().t() + attn.to_out[0].bias.double()
+    x1 = a + xd
+    f = ff.net
+    h2 = torch.nn.functional.gelu(ln(x1, f[0]) @ f[1].weight.double().t() + f[1].bias.double())
+    x2 = h2 @ f[4].weight.double().t() + f[4].bias.double() + x1
+    ref = ln(x2, t.norm)
+    (ref * r.double()).sum().backward()
+    return ref, xd.grad
+
+
 @gpu
 def test_standalone_transformer_as_t2t_and_mae_use_it():
-    """t2t.py:45 builds Transformer(dim = d, heads = 1, depth = 1, dim_head = d, mlp_dim = d): one head as wide as the model and
-    an Identity output projection; mae.py:37 builds an ordinary decoder Transformer.  Widths must be multiples of 4 here."""
+    """t2t.py:45 builds Transformer(dim = d, heads = 1, depth = 1, dim_head = d, mlp_dim = d) with d = 3 * 7 * 7 = 147 and
+    147 * 9 = 1323: one head as wide as the model, an Identity output projection, and widths that are NOT multiples of 4 (they
+    run op by op on the any-width kernels); mae.py:37 builds an ordinary decoder Transformer."""
     from vit_pytorch_amd.vit import Transformer
     torch.manual_seed(0)
-    for dim, heads, dim_head in ((144, 1, 144), (64, 4, 16)):
+    for dim, heads, dim_head in ((147, 1, 147), (1323, 1, 1323), (144, 1, 144), (64, 4, 16)):
         t = Transformer(dim=dim, depth=1, heads=heads, dim_head=dim_head, mlp_dim=dim).to("cuda")
         x = torch.randn(2, 49, dim, device="cuda", requires_grad=True)
         r = torch.randn(2, 49, dim, device="cuda")      # a generic cotangent (mean(y^2) of a LayerNorm output with gamma = 1, beta = 0
         y = t(x)                                        # has an analytically ZERO input gradient: pure cancellation, not a test)
         (y * r).sum().backward()
-        # the same block in plain torch (vit.py:51-64, 18-25, 78-83), float64
-        attn, ff = t.layers[0]
-        xd = x.detach().double().requires_grad_(True)
-        ln = lambda z, m: torch.nn.functional.layer_norm(z, (dim,), m.weight.double(), m.bias.double())
-        h = ln(xd, attn.norm)
-        q, k, vv = (h @ attn.to_qkv.weight.double().t()).chunk(3, dim=-1)
-        sp = lambda z: z.view(2, 49, heads, dim_head).transpose(1, 2)
-        a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * dim_head ** -0.5, dim=-1) @ sp(vv)
-        a = a.transpose(1, 2).reshape(2, 49, heads * dim_head)
-        if not isinstance(attn.to_out, torch.nn.Identity):
-            a = a @ attn.to_out[0].weight.double().t() + attn.to_out[0].bias.double()
-        x1 = a + xd
-        f = ff.net
-        h2 = torch.nn.functional.gelu(ln(x1, f[0]) @ f[1].weight.double().t() + f[1].bias.double())
-        x2 = h2 @ f[4].weight.double().t() + f[4].bias.double() + x1
-        ref = ln(x2, t.norm)
-        (ref * r.double()).sum().backward()
-        assert _rel(y, ref) < 1e-5 and _rel(x.grad, xd.grad) < 1e-4, (dim, _rel(y, ref), _rel(x.grad, xd.grad))
-    with pytest.raises(Exception, match="multiple of 4"):
-        Transformer(dim=147, depth=1, heads=1, dim_head=147, mlp_dim=147).to("cuda")(torch.randn(1, 9, 147, device="cuda"))
+        ref, gref = _torch_block(t, x, r, dim, heads, dim_head)
+        assert _rel(y, ref) < 1e-5 and _rel(x.grad, gref) < 1e-4, (dim, _rel(y, ref), _rel(x.grad, gref))
+        for p_ in t.parameters():
+            assert p_.grad is not None and torch.isfinite(p_.grad).all()
+
+
+@gpu
+def test_t2t_width_in_bfloat16():
+    """The same odd-width block with 16-bit parameters: every op of the op-by-op path has an element-at-a-time form."""
+    from vit_pytorch_amd.vit import Transformer
+    torch.manual_seed(1)
+    dim = 147
+    t32 = Transformer(dim=dim, depth=1, heads=1, dim_head=dim, mlp_dim=dim).to("cuda")
+    t = Transformer(dim=dim, depth=1, heads=1, dim_head=dim, mlp_dim=dim).to("cuda")
+    t.load_state_dict(t32.state_dict())
+    t = t.to(torch.bfloat16)
+    x = torch.randn(2, 81, dim, device="cuda")
+    r = torch.randn(2, 81, dim, device="cuda")
+    xb = x.to(torch.bfloat16).requires_grad_(True)
+    y = t(xb)
+    (y.float() * r).sum().backward()
+    ref, gref = _torch_block(t32, x, r, dim, 1, dim)
+    assert _rel(y, ref) < 3e-2 and _rel(xb.grad, gref) < 6e-2, (_rel(y, ref), _rel(xb.grad, gref))
+
+
+@needs_ref
+def test_reference_t2t_vit_builds_on_the_drop_in_transformer():
+    """t2t.py:5 imports vit_pytorch.vit.Transformer; with the alias its token-to-token layers (t2t.py:45) and its main
+    transformer (t2t.py:57) are the drop-in's modules, including the 147- and 1323-wide ones."""
+    import vit_pytorch_amd.vit as mine
+    mod = _load_ref_module("t2t")
+    v = mod.T2TViT(image_size=64, num_classes=10, dim=64, depth=2, heads=2, mlp_dim=128)
+    ts = [m for m in v.modules() if isinstance(m, mine.Transformer)]
+    assert len(ts) == 3
+    assert sorted(t.norm.weight.shape[0] for t in ts) == [64, 147, 1323]
+    for t in ts[:2]:
+        assert isinstance(t.layers[0][0].to_out, torch.nn.Identity)      # heads == 1 and dim_head == dim (vit.py:45)

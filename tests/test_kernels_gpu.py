@@ -35,7 +35,7 @@ def rnd(*shape, dtype=F32, scale=1.0, seed=None):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("xdt,ydt,wdt", [(F32, F32, F32), (F32, BF, BF), (F32, F32, BF), (BF, BF, BF), (BF, F32, BF)])
-@pytest.mark.parametrize("rows,D", [(37, 64), (1000, 768), (50, 1024), (9, 1280), (5, 3072), (6, 48)])
+@pytest.mark.parametrize("rows,D", [(37, 64), (1000, 768), (50, 1024), (9, 1280), (5, 3072), (6, 48), (98, 147), (25, 1323), (11, 3)])
 def test_layernorm_fwd(xdt, ydt, wdt, rows, D):
     x = rnd(rows, D, dtype=xdt, seed=1) * 2 + 0.5
     w = (1 + 0.1 * rnd(D, seed=2)).to(wdt); b = (0.1 * rnd(D, seed=3)).to(wdt)
@@ -71,7 +71,7 @@ def test_layernorm_fwd_rowmaps_and_posadd():
 
 
 @pytest.mark.parametrize("dydt,xdt,wdt", [(F32, F32, F32), (BF, F32, BF), (BF, BF, BF), (F32, F32, BF)])
-@pytest.mark.parametrize("rows,D", [(333, 768), (40, 64), (7, 1280), (2100, 256), (3100, 1024), (2600, 1280)])
+@pytest.mark.parametrize("rows,D", [(333, 768), (40, 64), (7, 1280), (2100, 256), (3100, 1024), (2600, 1280), (6272, 147), (700, 1323), (33, 5)])
 def test_layernorm_bwd(dydt, xdt, wdt, rows, D):
     x = rnd(rows, D, dtype=xdt, seed=11) * 1.5 + 0.3
     dy = rnd(rows, D, dtype=dydt, seed=12)
@@ -397,6 +397,30 @@ def test_gelu(dtype):
     dx = torch.empty_like(x)
     K.gelu_bwd(dy, x, dx)
     assert rel(dx, xd.grad) < (3e-6 if dtype == F32 else 4e-3)
+
+
+def test_elementwise_extents_that_are_not_multiples_of_four():
+    """T2T-ViT's 147- and 1323-wide layers (t2t.py:45): GELU and the residual add at odd extents, with and without a bias."""
+    for dtype in (F32, BF):
+        x = rnd(49, 147, dtype=dtype, seed=201) * 3
+        y = torch.empty_like(x)
+        K.gelu_fwd(x, y)
+        xd = x.double().requires_grad_(True)
+        yr = torch.nn.functional.gelu(xd)
+        assert rel(y, yr) < (2e-6 if dtype == F32 else 4e-3)
+        dy = rnd(49, 147, dtype=dtype, seed=202)
+        yr.backward(dy.double())
+        dx = torch.empty_like(x)
+        K.gelu_bwd(dy, x, dx)
+        assert rel(dx, xd.grad) < (3e-6 if dtype == F32 else 4e-3)
+    rows, cols = 51, 1323
+    a = rnd(rows, cols, seed=203); b = rnd(rows, cols, dtype=BF, seed=204); bias = rnd(cols, dtype=BF, seed=205)
+    out = torch.empty(rows, cols, device=DEV)
+    K.add_rows(a, b, bias, out, rows, cols)
+    assert rel(out, a.double() + b.double() + bias.double()) < 1e-6
+    ab = a.to(BF); outb = torch.empty(rows, cols, dtype=BF, device=DEV)
+    K.add_rows(ab, b, None, outb, rows, cols)
+    assert rel(outb, ab.double() + b.double()) < 4e-3
 
 
 def test_add_rows_cast_cls_meanpool_transpose():

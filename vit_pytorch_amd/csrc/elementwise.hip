@@ -78,6 +78,28 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy,
     }
 }
 
+// Element-at-a-time forms for extents that are not multiples of 4 (T2T-ViT's token-to-token layers, t2t.py:45, are 147 and 1323
+// wide): rare and small, so one scalar kernel each instead of tail handling in the vector kernels.
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_scalar_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = from_f32<T>(gelu_erf(to_f32<T>(x[i])));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_scalar_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dx[i] = from_f32<T>(to_f32<T>(dy[i]) * gelu_erf_grad(to_f32<T>(x[i])));
+}
+template <typename AT, typename BT, typename OT>
+__global__ __launch_bounds__(256) void add_rows_scalar_kernel(const AT* __restrict__ a, const BT* __restrict__ b, const BT* __restrict__ bias,
+                                                               OT* __restrict__ out, long long n, long long cols) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = to_f32<AT>(a[i]) + to_f32<BT>(b[i]);
+        if (bias) v += to_f32<BT>(bias[i % cols]);
+        out[i] = from_f32<OT>(v);
+    }
+}
+
 template <typename AT, typename BT, typename OT>
 __global__ __launch_bounds__(256) void add_rows_kernel(const AT* __restrict__ a, const BT* __restrict__ b,
                                                         const BT* __restrict__ bias, OT* __restrict__ out, long long rows,
@@ -458,7 +480,13 @@ extern "C" int vitk_patchify(const void* img, void* out, int dt, int64_t B, int6
 
 extern "C" int vitk_gelu_fwd(const void* x, void* y, int dt, int64_t n, void* stream) {
     if (!x || !y) VITK_FAIL(VITK_E_ARG, "gelu_fwd: null pointer");
-    if (n <= 0 || (n & 3)) VITK_FAIL(VITK_E_SHAPE, "gelu_fwd: n %% 4 != 0");
+    if (n <= 0) VITK_FAIL(VITK_E_SHAPE, "gelu_fwd: empty");
+    if (n & 3) {
+        VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((gelu_fwd_scalar_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+                                                    (const T*)x, (T*)y, (long long)n));
+        VITK_CHECK_LAUNCH("gelu_fwd");
+        return 0;
+    }
     VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((gelu_fwd_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream,
                                                 (const T*)x, (T*)y, (long long)(n / 4)));
     VITK_CHECK_LAUNCH("gelu_fwd");
@@ -466,7 +494,13 @@ extern "C" int vitk_gelu_fwd(const void* x, void* y, int dt, int64_t n, void* st
 }
 extern "C" int vitk_gelu_bwd(const void* dy, const void* x, void* dx, int dt, int64_t n, void* stream) {
     if (!dy || !x || !dx) VITK_FAIL(VITK_E_ARG, "gelu_bwd: null pointer");
-    if (n <= 0 || (n & 3)) VITK_FAIL(VITK_E_SHAPE, "gelu_bwd: n %% 4 != 0");
+    if (n <= 0) VITK_FAIL(VITK_E_SHAPE, "gelu_bwd: empty");
+    if (n & 3) {
+        VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((gelu_bwd_scalar_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+                                                    (const T*)dy, (const T*)x, (T*)dx, (long long)n));
+        VITK_CHECK_LAUNCH("gelu_bwd");
+        return 0;
+    }
     VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream,
                                                 (const T*)dy, (const T*)x, (T*)dx, (long long)(n / 4)));
     VITK_CHECK_LAUNCH("gelu_bwd");
@@ -476,12 +510,17 @@ extern "C" int vitk_gelu_bwd(const void* dy, const void* x, void* dx, int dt, in
 extern "C" int vitk_add_rows(const void* a, int adt, const void* b, int bdt, const void* bias, int biasdt, void* out, int odt,
                              int64_t rows, int64_t cols, void* stream) {
     if (!a || !b || !out) VITK_FAIL(VITK_E_ARG, "add_rows: null pointer");
-    if (rows <= 0 || cols <= 0 || (cols & 3)) VITK_FAIL(VITK_E_SHAPE, "add_rows: cols %% 4 != 0");
+    if (rows <= 0 || cols <= 0) VITK_FAIL(VITK_E_SHAPE, "add_rows: empty");
     if (bias && biasdt != bdt) VITK_FAIL(VITK_E_DTYPE, "add_rows: bias dtype must equal b dtype");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned blocks = ew_blocks(rows * cols / 4);
-#define ADD_CASE(AT, BT, OT) hipLaunchKernelGGL((add_rows_kernel<AT, BT, OT>), dim3(blocks), dim3(256), 0, st, (const AT*)a, \
-        (const BT*)b, (const BT*)bias, (OT*)out, (long long)rows, (int)(cols / 4))
+    const bool vec = (cols & 3) == 0;
+    const unsigned blocks = ew_blocks(vec ? rows * cols / 4 : rows * cols);
+#define ADD_CASE(AT, BT, OT) do { \
+        if (vec) hipLaunchKernelGGL((add_rows_kernel<AT, BT, OT>), dim3(blocks), dim3(256), 0, st, (const AT*)a, \
+                                    (const BT*)b, (const BT*)bias, (OT*)out, (long long)rows, (int)(cols / 4)); \
+        else hipLaunchKernelGGL((add_rows_scalar_kernel<AT, BT, OT>), dim3(blocks), dim3(256), 0, st, (const AT*)a, \
+                                (const BT*)b, (const BT*)bias, (OT*)out, (long long)(rows * cols), (long long)cols); \
+    } while (0)
     if (adt == VITK_F32 && bdt == VITK_F32 && odt == VITK_F32) ADD_CASE(float, float, float);
     else if (adt == VITK_F32 && bdt == VITK_BF16 && odt == VITK_F32) ADD_CASE(float, __bf16, float);
     else if (adt == VITK_F32 && bdt == VITK_BF16 && odt == VITK_BF16) ADD_CASE(float, __bf16, __bf16);

@@ -437,6 +437,90 @@ __global__ __launch_bounds__(256) void colsum_stage1_scalar_kernel(const XT* __r
     if (ph == 0 && c < cols) ws[(long long)blockIdx.y * cols + c] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
 }
 
+// ---- any row width (D % 4 != 0): element-at-a-time forms of the two kernels ------------------------------------------------
+// T2T-ViT's token-to-token layers (t2t.py:45) are Transformers of width 3 * 7 * 7 = 147 and 147 * 9 = 1323.  Same maths and the
+// same outputs (statistics, partial rows for vitk_layernorm_bwd_finalize) as the vector kernels; a lane owns the columns
+// c = lane (mod 64) of every row its wave visits, so the column accumulators of the backward live in a per-wave LDS slab that
+// only that lane touches (no atomics, fixed order).
+template <typename XT, typename YT, typename WT>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_any_kernel(
+    const XT* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b, YT* __restrict__ y,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, long long rows, int D, float eps, RowMap imap, RowMap omap,
+    const WT* __restrict__ add, long long add_group, long long add_off) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invD = 1.0f / (float)D;
+    for (long long row = (long long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long long)gridDim.x * LN_WAVES) {
+        const XT* xr = x + map_row(imap, row) * (long long)D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += to_f32<XT>(xr[c]);
+        const float mean = wave_sum(s) * invD;
+        float q = 0.f;
+        for (int c = lane; c < D; c += 64) { const float d = to_f32<XT>(xr[c]) - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * invD + eps);
+        YT* yr = y + map_row(omap, row) * (long long)D;
+        const WT* ar = add ? add + ((add_group > 0 ? row % add_group : row) + add_off) * (long long)D : nullptr;
+        for (int c = lane; c < D; c += 64) {
+            float o = (to_f32<XT>(xr[c]) - mean) * rstd * to_f32<WT>(w[c]) + (b ? to_f32<WT>(b[c]) : 0.f);
+            if (ar) o += to_f32<WT>(ar[c]);
+            yr[c] = from_f32<YT>(o);
+        }
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+}
+
+template <typename DYT, typename XT, typename WT, typename DXT, int NW>
+__global__ __launch_bounds__(NW * WAVE) void ln_bwd_any_kernel(
+    const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
+    float* __restrict__ partials, int colsum_dx,
+    long long rows, int D, RowMap dymap, RowMap xmap, RowMap dxmap, unsigned drop_t, unsigned drop_seed, float inv_keep) {
+    extern __shared__ float acc_s[];                 // [NW][3][D]: dgamma, dbeta, colsum(dx_t) per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invD = 1.0f / (float)D;
+    const bool want_dx = (dx_f32 != nullptr) || (dx_t != nullptr);
+    float* mine = acc_s + (long long)wave * 3 * D;
+    for (int c = lane; c < 3 * D; c += 64) mine[c] = 0.f;
+    for (long long row = (long long)blockIdx.x * NW + wave; row < rows; row += (long long)gridDim.x * NW) {
+        const DYT* dyr = dy + map_row(dymap, row) * (long long)D;
+        const XT* xr = x + map_row(xmap, row) * (long long)D;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const long long orow = map_row(dxmap, row);
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float d = to_f32<DYT>(dyr[c]);
+            const float xh = (to_f32<XT>(xr[c]) - mean) * rstd;
+            const float g = d * to_f32<WT>(w[c]);
+            s1 += g; s2 += g * xh;
+            mine[c] += d * xh;
+            mine[D + c] += d;
+        }
+        if (want_dx) {
+            const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+            const unsigned hrow = drop_row((unsigned)orow, drop_seed);
+            for (int c = lane; c < D; c += 64) {
+                const float xh = (to_f32<XT>(xr[c]) - mean) * rstd;
+                const float g = to_f32<DYT>(dyr[c]) * to_f32<WT>(w[c]);
+                float o = rstd * (g - c1 - xh * c2);
+                if (gin) o += gin[orow * D + c];
+                if (dx_f32) dx_f32[orow * D + c] = o;
+                if (drop_t) o = drop_keep(hrow, (unsigned)c, drop_t) ? o * inv_keep : 0.f;      // as in ln_bwd_kernel: dx_t / its sums only
+                if (dx_t) dx_t[orow * D + c] = from_f32<DXT>(o);
+                if (colsum_dx) mine[2 * D + c] += o;
+            }
+        }
+    }
+    __syncthreads();
+    const int nslab = colsum_dx ? 3 : 2;
+    for (int i = threadIdx.x; i < nslab * D; i += NW * WAVE) {
+        const int slab = i / D, c = i - slab * D;
+        float sum = 0.f;
+#pragma unroll
+        for (int wv_ = 0; wv_ < NW; ++wv_) sum += acc_s[((long long)wv_ * 3 + slab) * D + c];
+        partials[((long long)slab * gridDim.x + blockIdx.x) * D + c] = sum;
+    }
+}
+
 template <typename XT, typename YT, typename WT>
 int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, long long rows, int D,
                   float eps, RowMap im, RowMap om, const void* add, long long ag, long long ao, hipStream_t st, F8Out f8) {
@@ -446,6 +530,12 @@ int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* m
     if (blocks > 8192) blocks = 8192;
     if (f8.amax && blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
+    if (D & 3) {
+        hipLaunchKernelGGL((ln_fwd_any_kernel<XT, YT, WT>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, (const XT*)x, (const WT*)w,
+                           (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao);
+        VITK_CHECK_LAUNCH("layernorm_fwd");
+        return 0;
+    }
 #define LN_FWD_CASE(MC) hipLaunchKernelGGL((ln_fwd_kernel<XT, YT, WT, MC>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, \
         (const XT*)x, (const WT*)w, (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao, f8)
     if (maxc <= 1) LN_FWD_CASE(1);
@@ -466,6 +556,22 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
     const int nchunk = D / 4;
     const int maxc = (nchunk + 63) / 64;
     const long long blocks = vitk_layernorm_bwd_blocks(rows, D);
+    if (D & 3) {
+        const bool wide = (D / 4 + 63) / 64 >= 4;          // the block shape vitk_layernorm_bwd_blocks assumed
+        const size_t lds = (size_t)(wide ? 4 : 8) * 3 * D * sizeof(float);
+        if (lds > 150 * 1024) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd: widths that are not multiples of 4 are served up to D = 3200 (got %d)", D);
+#define LN_BWD_ANY(NWV) do { \
+            static const int rc__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_any_kernel<DYT, XT, WT, DXT, NWV>), \
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            if (rc__ != 0) VITK_FAIL(rc__, "layernorm_bwd: cannot enable 150 KiB of LDS"); \
+            hipLaunchKernelGGL((ln_bwd_any_kernel<DYT, XT, WT, DXT, NWV>), dim3((unsigned)blocks), dim3(NWV * WAVE), lds, st, (const DYT*)dy, \
+                               (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om, drop_t, drop_seed, inv_keep); \
+        } while (0)
+        if (wide) LN_BWD_ANY(4); else LN_BWD_ANY(8);
+#undef LN_BWD_ANY
+        VITK_CHECK_LAUNCH("layernorm_bwd");
+        return 0;
+    }
     static const int no_fast = getenv("VITK_LNB_FAST") ? !atoi(getenv("VITK_LNB_FAST")) : 0;
     if (!no_fast && gin && dxf && dxt && colsum_dx && dm.group <= 0 && xm.group <= 0 && om.group <= 0 && (D == 768 || D == 1024 || D == 1280)) {
         // nontemporal loads of the three row streams: 123 -> 99 us at 50432 x 768 (6.3 TB/s); prefetching the next row (PIPE) on
@@ -518,9 +624,10 @@ extern "C" int vitk_layernorm_fwd_fp8(const void* x, int xdt, const void* w, con
     if (y8 && !scale8) VITK_FAIL(VITK_E_ARG, "layernorm_fwd_fp8: an fp8 output needs its scale");
     const F8Out f8{(unsigned char*)y8, scale8, (unsigned*)amax64};
     if (!x || !w || !y || !mean || !rstd) VITK_FAIL(VITK_E_ARG, "layernorm_fwd: null pointer");
-    if (rows < 0 || D <= 0 || (D & 3) || D > 4096) VITK_FAIL(VITK_E_SHAPE, "layernorm_fwd: need D %% 4 == 0 and D <= 4096, got D=%lld", (long long)D);
+    if (rows < 0 || D <= 0 || D > 4096) VITK_FAIL(VITK_E_SHAPE, "layernorm_fwd: need 0 < D <= 4096, got D=%lld", (long long)D);
+    if ((D & 3) && (y8 || amax64)) VITK_FAIL(VITK_E_SHAPE, "layernorm_fwd_fp8: the fp8 side output needs D %% 4 == 0");
     if (rows == 0) return 0;
-    if (!aligned16(x) || !aligned16(y) || !aligned8(w) || (b && !aligned8(b)) || (add && !aligned8(add)))
+    if (!(D & 3) && (!aligned16(x) || !aligned16(y) || !aligned8(w) || (b && !aligned8(b)) || (add && !aligned8(add))))
         VITK_FAIL(VITK_E_ALIGN, "layernorm_fwd: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const RowMap im = to_map(imap), om = to_map(omap);
@@ -563,8 +670,8 @@ extern "C" int vitk_layernorm_bwd_drop(const void* dy, int dydt, const void* x, 
     if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "layernorm_bwd: dropout p must be in [0, 1) (got %g)", (double)drop_p);
     const unsigned drop_t = drop_thresh(drop_p);
     const float inv_keep = 1.0f / (1.0f - drop_p);
-    if (rows <= 0 || D <= 0 || (D & 3) || D > 4096) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd: need rows > 0, D %% 4 == 0, D <= 4096");
-    if (!aligned16(dy) || !aligned16(x) || (gin && !aligned16(gin)) || (dx_f32 && !aligned16(dx_f32)) || (dx_t && !aligned16(dx_t)))
+    if (rows <= 0 || D <= 0 || D > 4096) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd: need rows > 0, 0 < D <= 4096");
+    if (!(D & 3) && (!aligned16(dy) || !aligned16(x) || (gin && !aligned16(gin)) || (dx_f32 && !aligned16(dx_f32)) || (dx_t && !aligned16(dx_t))))
         VITK_FAIL(VITK_E_ALIGN, "layernorm_bwd: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const RowMap dm = to_map(dymap), xm = to_map(xmap), om = to_map(dxmap);

@@ -99,6 +99,13 @@ class Transformer(Module):
                 return False
         if _has_fwd_hooks(self.norm):
             return False
+        # widths that are not multiples of 4 (T2T-ViT's token-to-token layers: 147, 1323 -- t2t.py:45) run op by op on the
+        # any-width kernels; the fused engine's vector kernels need 16-byte rows
+        widths = [self.norm.weight.shape[0]]
+        for attn, ff in self.layers:
+            widths += [attn.to_qkv.weight.shape[0], ff.net[1].weight.shape[0]]
+        if any(w % 4 for w in widths):
+            return False
         p = self._dropout_p()
         if p is None:
             return False
