@@ -232,11 +232,13 @@ def FeedForward(dim, hidden_dim, dropout=0.):
 
 
 class Attention(nn.Module):
-    _drop_calls = [0]
+    _instances = [0]       # construction index: per-instance dropout seed sequences (see vit.Transformer)
 
     def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
         super().__init__()
         inner_dim = dim_head * heads
+        self._drop_calls, self._drop_salt = 0, Attention._instances[0]
+        Attention._instances[0] += 1
         self.heads = heads
         self.norm = LayerNorm(dim)
         self.q_norm = RMSNorm(heads, dim_head)
@@ -258,8 +260,8 @@ class Attention(nn.Module):
         p, seed = 0.0, 0
         if self.training and self.dropout_p > 0.:       # F.scaled_dot_product_attention(dropout_p=...) of na_vit.py:163, in-kernel
             p = float(self.dropout_p)
-            seed = (int(torch.initial_seed()) + 0x9E3779B1 * Attention._drop_calls[0] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
-            Attention._drop_calls[0] += 1
+            seed = (int(torch.initial_seed()) + 0x9E3779B1 * self._drop_calls + 0x85EBCA6B * self._drop_salt + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
+            self._drop_calls += 1
         out = _QKNormAttnFn.apply(q, kv, self.q_norm.gamma, self.k_norm.gamma, segs, self.heads, p, seed)
         return self.to_out(out)
 

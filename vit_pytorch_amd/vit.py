@@ -73,6 +73,8 @@ class Transformer(Module):
         self.norm = Fn.LayerNorm(dim)
         self.layers = ModuleList([])
         self._heads, self._dim_head = heads, dim_head
+        self._drop_calls, self._drop_salt = 0, Transformer._instances[0]
+        Transformer._instances[0] += 1
 
         for _ in range(depth):
             self.layers.append(ModuleList([
@@ -80,7 +82,9 @@ class Transformer(Module):
                 FeedForward(dim, mlp_dim, dropout=dropout),
             ]))
 
-    _drop_calls = [0]      # every training call draws fresh dropout seeds (with torch.initial_seed(): reproducible runs)
+    # every training call draws fresh dropout seeds from torch.initial_seed(), THIS module's call count and its construction
+    # index (instance state: two models in one process neither interleave their sequences nor share masks); not in state_dict
+    _instances = [0]
 
     def _dropout_p(self):
         """The common p of the block's active dropouts (0.0 if inactive); None if the modules disagree (a user edited them)."""
@@ -124,8 +128,8 @@ class Transformer(Module):
             p = self._dropout_p()
             seed = 0
             if p > 0.:
-                seed = (int(torch.initial_seed()) + 0x9E3779B1 * Transformer._drop_calls[0] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
-                Transformer._drop_calls[0] += 1
+                seed = (int(torch.initial_seed()) + 0x9E3779B1 * self._drop_calls + 0x85EBCA6B * self._drop_salt + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
+                self._drop_calls += 1
             return E.TransformerFn.apply(x, self._heads, self._dim_head, float(p), seed, getattr(self, "_fp8", None), self.norm.weight, self.norm.bias, *params)
         x = Fn.cast(x, self.norm.weight.dtype)       # in the graph: the embedding stage may have produced an f32 stream
         for attn, ff in self.layers:
