@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 123
+#define VITK_VERSION 124
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -42,6 +42,8 @@ extern "C" {
 #define VITK_E_SHAPE (-2)    /* unsupported extent */
 #define VITK_E_ALIGN (-3)    /* pointer or leading dimension not aligned as required */
 #define VITK_E_DTYPE (-4)    /* unsupported dtype combination */
+#define VITK_E_UNAVAILABLE (-5)  /* an optional component is not present (vitk_comm_*: librccl could not be opened) */
+#define VITK_E_COMM (-6)     /* RCCL reported an error (vitk_last_error() carries its text) */
 
 int vitk_version(void);
 int vitk_half_type(void);    /* VITK_BF16 or VITK_F16: what dtype tag 1 means in this library */
@@ -333,6 +335,21 @@ int vitk_adam_step(void* param, const void* grad, int dt, float* exp_avg, float*
                    float grad_scale, void* stream);
 /* 2-D transpose out[c][r] = in[r][c] (weights: W^T for the dX GEMMs) */
 int vitk_transpose(const void* in, void* out, int dt, int64_t rows, int64_t cols, void* stream);
+
+/* ---- data-parallel gradient exchange -----------------------------------------------------------------
+ * What accelerate / DistributedDataParallel do for the reference's training script (train_vit_decorr.py:68-78: all-reduce of
+ * every parameter's .grad across ranks), for hosts that bind this library directly: ONE in-place all-reduce of a contiguous
+ * gradient range (the flat buffer, or a chunk of it) over RCCL on the caller's stream.  One process per GPU.  Rank 0 calls
+ * vitk_comm_unique_id and hands the 128 bytes to the other ranks by its own means (a file, a socket, MPI); every rank then
+ * calls vitk_comm_init.  dt: VITK_F32 or the library's 16-bit type; average != 0 divides by the world size (ncclAvg).
+ * librccl is opened at first use (no link-time dependency): VITK_E_UNAVAILABLE if it is not there, VITK_E_COMM for RCCL
+ * errors.  The Python package itself exchanges gradients through torch.distributed (backend "nccl" = RCCL).              */
+#define VITK_COMM_ID_BYTES 128
+typedef void* vitk_comm_t;
+int vitk_comm_unique_id(void* out128);
+int vitk_comm_init(const void* id128, int rank, int world, vitk_comm_t* out);
+int vitk_comm_allreduce(vitk_comm_t comm, void* buf, int64_t n, int dt, int average, void* stream);
+int vitk_comm_destroy(vitk_comm_t comm);
 
 #ifdef __cplusplus
 }

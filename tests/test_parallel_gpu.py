@@ -110,3 +110,28 @@ def test_rccl_single_rank_in_backward_allreduce():
     p.join(300)
     assert p.exitcode == 0
     assert q.get(timeout=5) == "ok"
+
+
+@pytest.mark.gpu
+def test_native_comm_entry_points_world_size_one():
+    """vitk_comm_* (include/vitk.h): RCCL opened by the library itself, one rank -- the all-reduce is the identity for sum and
+    for average, in f32 and in the library's 16-bit type, on the caller's stream.  (Two ranks need two GPUs: the gpurun boxes
+    have one; the multi-rank exchange is covered through torch.distributed by the tests above and the gloo suite.)"""
+    from vit_pytorch_amd.comm import NativeComm
+    uid = NativeComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    c = NativeComm(0, 1, uid)
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn(1 << 20, device="cuda").to(dtype)
+        ref = x.clone()
+        c.all_reduce(x, average=True)
+        c.all_reduce(x, average=False)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y = torch.ones(4096, device="cuda")
+        c.all_reduce(y)
+    s.synchronize()
+    assert torch.equal(y, torch.ones_like(y))
+    c.close()

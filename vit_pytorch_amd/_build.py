@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitk.so")
 LIB_F16 = os.path.join(HERE, "libvitk_f16.so")
-SOURCES = ["elementwise.hip", "layernorm.hip", "gemm_bf16.hip", "gemm_nt_persist.hip", "gemm_tn_dma.hip", "gemm_generic.hip", "attention.hip"]
+SOURCES = ["elementwise.hip", "layernorm.hip", "gemm_bf16.hip", "gemm_nt_persist.hip", "gemm_tn_dma.hip", "gemm_generic.hip", "attention.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_nt_plan.h"), os.path.join(os.path.dirname(HERE), "include", "vitk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -58,7 +58,7 @@ def _build_one(lib: str, bdir: str, extra, force: bool, verbose: bool) -> str:
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl"])
     return lib
 
 

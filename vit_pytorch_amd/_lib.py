@@ -16,7 +16,7 @@ LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit t
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3, 4
-VITK_VERSION = 123
+VITK_VERSION = 124
 
 
 class RowMap(C.Structure):
@@ -65,6 +65,10 @@ SIGNATURES = {
     "vitk_fp8_update_scales": (_i, [_vp, _vp, _i64, _vp]),
     "vitk_gemm_nt_colsum_rows": (_i64, [_i64, _i64, _i64, _i64]),
     "vitk_gemm_nt_plan": (_i, [_i64, _i64, _i64, _i64, _vp]),
+    "vitk_comm_unique_id": (_i, [_vp]),
+    "vitk_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "vitk_comm_allreduce": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "vitk_comm_destroy": (_i, [_vp]),
     "vitk_pack_w_nt_bytes": (_i64, [_i64, _i64]),
     "vitk_pack_w_nt": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_nt_bf16_gelu_bwd_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
