@@ -367,22 +367,30 @@ class NaViT(nn.Module):
         K.require_device(*images)
 
         # ---- host side: token counts, positions, (optional) token dropout ----
-        lens, h_list, w_list, keeps = [], [], [], []
+        # token dropout (na_vit.py:307-313) draws its kept indices on the GPU; ALL images' draws are queued first and come back in
+        # ONE device-to-host copy (a copy per image used to stall the launch queue once per image)
+        grids, keeps = [], []
         for image in images:
             assert image.ndim == 3 and image.shape[0] == c
             ih, iw = image.shape[-2:]
             assert ih % p == 0 and iw % p == 0, f'height and width {(ih, iw)} of images must be divisible by patch size {p}'
             ph, pw = ih // p, iw // p
-            hi = np.repeat(np.arange(ph, dtype=np.int32), pw)
-            wi = np.tile(np.arange(pw, dtype=np.int32), ph)
+            grids.append((ph, pw))
             keep = None
             if has_token_dropout:
                 n = ph * pw
                 num_keep = max(1, int(n * (1 - self.calc_token_dropout(ih, iw))))
                 keep = torch.randn((n,), device=device).topk(num_keep, dim=-1).indices     # na_vit.py:311
-                ki = keep.cpu().numpy()
-                hi, wi = hi[ki], wi[ki]
             keeps.append(keep)
+        keep_host = torch.cat(keeps).cpu().numpy() if has_token_dropout else None
+        lens, h_list, w_list, k0 = [], [], [], 0
+        for (ph, pw), keep in zip(grids, keeps):
+            hi = np.repeat(np.arange(ph, dtype=np.int32), pw)
+            wi = np.tile(np.arange(pw, dtype=np.int32), ph)
+            if keep is not None:
+                ki = keep_host[k0:k0 + keep.numel()]
+                k0 += keep.numel()
+                hi, wi = hi[ki], wi[ki]
             lens.append(len(hi)); h_list.append(hi); w_list.append(wi)
         T = int(sum(lens))
         P = c * p * p
