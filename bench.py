@@ -260,6 +260,9 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "ms_per_step_all": [round(d / args.steps * 1e3, 3) for d in dts], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (randn images, randint labels, random-init weights)",
+            "memory": {"peak_allocated_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                       "peak_reserved_gib": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
+                       "allocator_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0))},
             "config": {"workload": f"{args.config} fwd+bwd, batch {batch}/GPU, {isz}x{isz}, cross-entropy loss, no optimizer"
                                    + (", flat-buffer RCCL all-reduce overlapped with patch-embed backward" if world > 1 else ""),
                        "global_batch": batch * world, "per_gpu_batch": batch, "seq_len": N, "parallelism": f"dp{world}"},

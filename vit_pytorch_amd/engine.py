@@ -87,12 +87,20 @@ class _Fork:
     Within one layer's backward the dW GEMMs (TN) depend on tensors the chain has already produced but
     nothing on the chain depends on them, so they can fill the CUs the chain leaves idle (the tail of
     every 591-tile N=768 GEMM on 256 CUs, the HBM-bound LayerNorm/attention phases).  `run` orders the
-    side stream behind everything enqueued so far, `record_stream`s the inputs so the caching allocator
-    does not recycle them early, and `join` makes the main stream wait for the side work."""
+    side stream behind everything enqueued so far; `join` makes the main stream wait for the side work.
+
+    Lifetime of the side stream's inputs: NOT `record_stream`.  A block recorded on another stream can only be recycled once an
+    event on that stream has completed, and the host runs far ahead of the GPU: every big temporary the backward frees (1.5 GB
+    each at ViT-H/14, batch 256) would be replaced by a fresh allocation, the reserved pool grows until the device is full
+    (measured: 146 GiB allocated, 287 GiB reserved, allocator retries, 4 s instead of 0.85 s per step).  Instead the inputs of
+    the last LAG launches are held here, and before a launch's inputs are let go the MAIN stream waits for that launch's event:
+    whatever main-stream kernel reuses the memory is ordered behind the side-stream reader by the streams themselves."""
+    LAG = int(__import__("os").environ.get("VITK_DW_LAG", "6"))    # launches (6 = a layer and a half) whose inputs stay referenced
 
     def __init__(self, device):
         import os
         self.enabled = device.type == "cuda" and os.environ.get("VITK_DW_STREAM", "1") != "0"
+        self._held = []
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
             self.side = _side_stream(device)
@@ -106,13 +114,17 @@ class _Fork:
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
             fn()
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.side)
+        done = torch.cuda.Event()
+        done.record(self.side)
+        self._held.append((done, tensors))
+        while len(self._held) > self.LAG:
+            old, _ = self._held.pop(0)
+            self.main.wait_event(old)
 
     def join(self):
         if self.enabled:
             self.main.wait_stream(self.side)
+            self._held.clear()
 
 
 def _check_dims(D: int, what: str):
