@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 124
+#define VITK_VERSION 125
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -95,6 +95,11 @@ int vitk_layernorm_bwd_drop(const void* dy, int dydt, const void* x, int xdt, co
  * column sums dcol of dx, from the `partials` buffer of that call (nblk = vitk_layernorm_bwd_blocks(rows, D)). */
 int vitk_layernorm_bwd_finalize(const float* partials, int64_t nblk, int64_t D, void* dw, void* db, int odt,
                                 float* dcol, void* stream);
+/* The same with the column sums of dx written in the parameter dtype when dcol_dt == odt (float32 when dcol_dt == VITK_F32): they
+ * ARE the bias gradient of the Linear in front of the LayerNorm (autograd of vit.py:23,47), so the engine lets this kernel write
+ * them straight into that gradient's buffer instead of casting a float32 temporary.                                             */
+int vitk_layernorm_bwd_finalize_ex(const float* partials, int64_t nblk, int64_t D, void* dw, void* db, int odt,
+                                   void* dcol, int dcol_dt, void* stream);
 
 /* out[c] (dtype odt) = (accumulate ? out[c] : 0) + sum_{p < nparts} partials[p * ld + c], c < cols */
 int vitk_colsum_partials(const float* partials, int64_t nparts, int64_t ld, int64_t cols,

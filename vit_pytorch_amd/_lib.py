@@ -16,7 +16,7 @@ LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit t
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3, 4
-VITK_VERSION = 124
+VITK_VERSION = 125
 
 
 class RowMap(C.Structure):
@@ -49,6 +49,7 @@ SIGNATURES = {
     "vitk_layernorm_bwd_blocks": (_i64, [_i64, _i64]),
     "vitk_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i64, RowMap, RowMap, RowMap, _vp]),
     "vitk_layernorm_bwd_finalize": (_i, [_vp, _i64, _i64, _vp, _vp, _i, _vp, _vp]),
+    "vitk_layernorm_bwd_finalize_ex": (_i, [_vp, _i64, _i64, _vp, _vp, _i, _vp, _i, _vp]),
     "vitk_colsum_partials": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _i, _vp]),
     "vitk_colsum_ws_floats": (_i64, [_i64, _i64]),
     "vitk_colsum": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _vp, _vp]),

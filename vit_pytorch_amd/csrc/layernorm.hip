@@ -378,7 +378,8 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
 // (1024 threads = 64 columns x 16 partial phases; dw/db in the parameter dtype, dcol in f32).
 template <typename OT>
 __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int D,
-                                                                OT* __restrict__ dw, OT* __restrict__ db, float* __restrict__ dcol) {
+                                                                OT* __restrict__ dw, OT* __restrict__ db, float* __restrict__ dcol,
+                                                                OT* __restrict__ dcol_t) {
     __shared__ float red[16][64];
     const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
         if (slab == 0) { if (dw) dw[c] = from_f32<OT>(t); }
         else if (slab == 1) { if (db) db[c] = from_f32<OT>(t); }
         else if (dcol) dcol[c] = t;
+        else if (dcol_t) dcol_t[c] = from_f32<OT>(t);
     }
 }
 
@@ -690,11 +692,19 @@ extern "C" int vitk_layernorm_bwd_drop(const void* dy, int dydt, const void* x, 
 
 extern "C" int vitk_layernorm_bwd_finalize(const float* partials, int64_t nblk, int64_t D, void* dw, void* db, int odt,
                                            float* dcol, void* stream) {
+    return vitk_layernorm_bwd_finalize_ex(partials, nblk, D, dw, db, odt, dcol, VITK_F32, stream);
+}
+
+extern "C" int vitk_layernorm_bwd_finalize_ex(const float* partials, int64_t nblk, int64_t D, void* dw, void* db, int odt,
+                                              void* dcol, int dcol_dt, void* stream) {
     if (!partials) VITK_FAIL(VITK_E_ARG, "layernorm_bwd_finalize: null pointer");
     if (nblk <= 0 || D <= 0) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd_finalize: empty");
+    if (dcol && dcol_dt != VITK_F32 && dcol_dt != odt) VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd_finalize: dcol is float32 or of the parameter dtype");
     const dim3 grid((unsigned)((D + 63) / 64), dcol ? 3u : 2u);
+    float* dcol_f = (dcol && dcol_dt == VITK_F32) ? (float*)dcol : nullptr;
+    void* dcol_t = (dcol && dcol_dt != VITK_F32) ? dcol : nullptr;
     VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((ln_bwd_finalize_kernel<OT>), grid, dim3(1024), 0, (hipStream_t)stream, partials,
-                                                  (int)nblk, (int)D, (OT*)dw, (OT*)db, dcol));
+                                                  (int)nblk, (int)D, (OT*)dw, (OT*)db, dcol_f, (OT*)dcol_t));
     VITK_CHECK_LAUNCH("layernorm_bwd_finalize");
     return 0;
 }

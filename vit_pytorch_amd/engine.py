@@ -309,7 +309,11 @@ class TransformerFn(torch.autograd.Function):
         # final LayerNorm (vit.py:83)
         g, gb = newg()
         dnw, dnb = _grad_buf(norm_w), _grad_buf(norm_b)
-        dcol = ops.empty((D,), F32, dy)  # colsum of g == bias gradient of the last layer's second FF Linear
+        # colsum of g == bias gradient of the last layer's second FF Linear: the LayerNorm backward's finalize writes it straight into
+        # that gradient's buffer (no float32 temporary, no cast launch)
+        def bias_target(param):
+            return _grad_buf(param) if param is not None else ops.empty((D,), F32, dy)
+        dcol = bias_target(lp[(depth - 1) * NLP + 10] if depth else None)
         # (with dropout: gb and dcol carry the keep decisions of the LAST layer's post-FF2 dropout; g, the stream gradient, does not)
         ops.ln_bwd(dy, ctx.x_last, norm_w, ctx.stf[0], ctx.stf[1], M, D, dx_f32=g, dx_t=gb, dw=dnw, db=dnb, dcol=dcol,
                    drop=site(depth - 1, 3) if depth else None)
@@ -332,9 +336,7 @@ class TransformerFn(torch.autograd.Function):
             fork.run(lambda: ops.linear_dw(gT, act, M, dw2), gT, act, dw2)
             grads[base + 9] = dw2
             if b2 is not None:
-                db2 = _grad_buf(b2)
-                K.cast(dcol, db2)
-                grads[base + 10] = db2
+                grads[base + 10] = dcol          # written by the LayerNorm backward above this layer (bias_target)
             dw1 = _grad_buf(w1)
             db1 = _grad_buf(b1) if b1 is not None else None
             if db1 is not None:
@@ -348,7 +350,7 @@ class TransformerFn(torch.autograd.Function):
             del dpre, pre, act
             g2, g2b = newg()
             dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
-            dcol2 = ops.empty((D,), F32, dy)
+            dcol2 = bias_target(bout if wout is not None else None)
             ops.ln_bwd(da2, x2, ln2w, st2[0], st2[1], M, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2w, db=dl2b, dcol=dcol2,
                        drop=site(li, 1))      # g2b / dcol2: gradient at to_out's output, behind its dropout
             grads[base + 5], grads[base + 6] = dl2w, dl2b
@@ -360,9 +362,7 @@ class TransformerFn(torch.autograd.Function):
                 fork.run(lambda: ops.linear_dw(g2T, o, M, dwo), g2T, o, dwo)
                 grads[base + 3] = dwo
                 if bout is not None:
-                    dbo = _grad_buf(bout)
-                    K.cast(dcol2, dbo)
-                    grads[base + 4] = dbo
+                    grads[base + 4] = dcol2
                 do = ops.linear_dx(g2T, wout, M)
             else:
                 do = g2T
@@ -374,7 +374,7 @@ class TransformerFn(torch.autograd.Function):
             del dqkv, do, qkv, o
             g1, g1b = newg()
             dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
-            dcol = ops.empty((D,), F32, dy)
+            dcol = bias_target(lp[(li - 1) * NLP + 10] if li > 0 else None)
             ops.ln_bwd(da1, xs, ln1w, st1[0], st1[1], M, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1w, db=dl1b, dcol=dcol,
                        drop=site(li - 1, 3) if li > 0 else None)   # feeds the layer below: behind ITS post-FF2 dropout
             grads[base + 0], grads[base + 1] = dl1w, dl1b

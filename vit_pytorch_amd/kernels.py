@@ -91,7 +91,9 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
 
 def layernorm_bwd_finalize(partials: Tensor, nblk: int, D: int, dw: Optional[Tensor], db: Optional[Tensor],
                            dcol: Optional[Tensor], odt: int):
-    check(_lib_for(partials, dw, db).vitk_layernorm_bwd_finalize(_p(partials), nblk, D, _p(dw), _p(db), odt, _p(dcol), _stream()),
+    """dcol: float32, or the parameter dtype (then it is written as the bias gradient it is: vitk_layernorm_bwd_finalize_ex)."""
+    check(_lib_for(partials, dw, db, dcol).vitk_layernorm_bwd_finalize_ex(_p(partials), nblk, D, _p(dw), _p(db), odt, _p(dcol),
+                                                                          F32 if dcol is None else dt(dcol), _stream()),
           "layernorm_bwd_finalize")
 
 

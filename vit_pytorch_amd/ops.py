@@ -52,13 +52,14 @@ def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, rows: i
            gin: Optional[Tensor] = None, dx_f32: Optional[Tensor] = None, dx_t: Optional[Tensor] = None,
            dw: Optional[Tensor] = None, db: Optional[Tensor] = None, dcol: Optional[Tensor] = None,
            dymap: RowMap = IDENT, xmap: RowMap = IDENT, dxmap: RowMap = IDENT, drop: Optional[Tuple[float, int]] = None):
-    """LayerNorm backward; dw/db are (D,) outputs of dtype T, dcol (D,) float32 = column sums of dx."""
+    """LayerNorm backward; dw/db are (D,) outputs of dtype T, dcol (D,) float32 or T = column sums of dx (the bias gradient of
+    the Linear in front of the norm)."""
     nblk = K.layernorm_bwd_blocks(rows, D)
     nslab = 3 if dcol is not None else 2
     partials = empty((nslab * nblk * D,), F32, x)
     K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap,
                     *(drop if drop else (0.0, 0)))
-    assert dcol is None or dcol.dtype == F32
+    assert dcol is None or dcol.dtype in (F32, w.dtype)
     K.layernorm_bwd_finalize(partials, nblk, D, dw, db, dcol, K.dt(w))
 
 
