@@ -38,6 +38,9 @@ struct BHND { __bf16* p; long long s_b, s_h, s_n; };
 // Two tiles at once with every global load of a batch in flight before the first LDS store: a plain
 // load -> store loop is serialised by the compiler (s_waitcnt vmcnt(0) per 16 bytes), which at ~2 us of
 // HBM latency per trip was most of a (batch, head) workgroup's life.
+// The staged rows are read once per workgroup: nontemporal loads (the same hint took the LayerNorm backward from 123 to 99 us;
+// here: forward 81 -> 77.5 us, backward 276 -> 270 us).  On the per-tile row loads (q, dO, O / k, v in registers) it costs ~2 %.
+__device__ __forceinline__ bf16x8 ld_nt8(const __bf16* p) { return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
 __device__ __forceinline__ void fill_tiles2(char* t0, const __bf16* s0, long long n0, char* t1, const __bf16* s1, long long n1,
                                             int N, int rows_pad, int tid) {
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -49,8 +52,8 @@ __device__ __forceinline__ void fill_tiles2(char* t0, const __bf16* s0, long lon
             const int c = c0 + j * AT_THREADS, row = c >> 3, col8 = c & 7;
             va[j] = zero8; vb[j] = zero8;
             if (c < lim && row < N) {
-                va[j] = *reinterpret_cast<const bf16x8*>(s0 + (long long)row * n0 + col8 * 8);
-                vb[j] = *reinterpret_cast<const bf16x8*>(s1 + (long long)row * n1 + col8 * 8);
+                va[j] = ld_nt8(s0 + (long long)row * n0 + col8 * 8);
+                vb[j] = ld_nt8(s1 + (long long)row * n1 + col8 * 8);
             }
         }
 #pragma unroll
