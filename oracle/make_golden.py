@@ -96,7 +96,7 @@ def main_wide():
         out16, _, grads16 = run_reference(case["kind"], case["cfg"], params, img, torch.bfloat16)
         blob = {"logits": out.numpy(), "loss": loss.numpy(), "bf16::logits": out16.float().numpy()}
         for k, g in grads.items():
-            idx = sample_index(g.numel())
+            idx = sample_index(g.numel(), case.get("sample", 4096))
             blob["gnorm::" + k] = np.float64(g.double().norm().item())
             blob["gsample::" + k] = g.flatten().numpy()[idx]
             blob["bf16::gsample::" + k] = grads16[k].float().flatten().numpy()[idx]

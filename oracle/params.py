@@ -143,15 +143,21 @@ WIDE_CASES = {
                           cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=2, heads=16, mlp_dim=4096)),
     "vit_h14_width": dict(kind="vit", batch=2, seed=14,
                           cfg=dict(image_size=336, patch_size=14, num_classes=1000, dim=1280, depth=1, heads=16, dim_head=80, mlp_dim=5120)),
+    # FULL DEPTH (round 3): BASELINE config 2 (ViT-B/16, 12 layers) and config 3 (ViT-L/16, 24 layers) exactly as benchmarked, at a
+    # batch the reference finishes on the CPU (M = 6 * 197 = 1,182 >= 1,024: production kernels).  1,024 samples per gradient.
+    "vit_b16_full": dict(kind="vit", batch=6, seed=21, sample=1024,
+                         cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072)),
+    "vit_l16_full": dict(kind="vit", batch=6, seed=22, sample=1024,
+                         cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096)),
 }
 GOLD_SAMPLE = 4096
 
 
-def sample_index(numel: int) -> np.ndarray:
-    """The (at most GOLD_SAMPLE) flat positions of a gradient tensor that a compact golden stores: a fixed stride walk."""
-    if numel <= GOLD_SAMPLE:
+def sample_index(numel: int, sample: int = GOLD_SAMPLE) -> np.ndarray:
+    """The (at most `sample`) flat positions of a gradient tensor that a compact golden stores: a fixed stride walk."""
+    if numel <= sample:
         return np.arange(numel, dtype=np.int64)
-    return (np.arange(GOLD_SAMPLE, dtype=np.int64) * 7919) % numel
+    return (np.arange(sample, dtype=np.int64) * 7919) % numel
 
 
 # ---- sibling variants (SURVEY 8f item 4): simple_vit_with_qk_norm.py, simple_vit_with_register_tokens.py, vit_with_patch_dropout.py

@@ -42,10 +42,11 @@ def test_oracle_matches_reference_golden(name, dtype):
         assert rel_l2(grads[k], g_ref) <= 2e-5, (k, rel_l2(grads[k], g_ref))
 
 
-@pytest.mark.parametrize("name", ["vit_b16_width", "vit_h14_width"])
+@pytest.mark.parametrize("name", ["vit_b16_width", "vit_h14_width", "vit_b16_full"])
 def test_oracle_matches_compact_golden_at_production_widths(name):
     """BASELINE config 2 / 5 layer shapes (dim 768 x 12 heads, dim 1280 x 16 heads of 80): the restatement against the compact
-    goldens the reference produced (full logits; per gradient its norm and a fixed 4096-element sample)."""
+    goldens the reference produced (full logits; per gradient its norm and a fixed 4096-element sample); round 3: also BASELINE
+    config 2 at FULL depth (12 layers, 1024-element samples)."""
     case = WIDE_CASES[name]
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     params = make_params(case["kind"], case["cfg"], case["seed"])
@@ -57,7 +58,7 @@ def test_oracle_matches_compact_golden_at_production_widths(name):
             continue
         g = grads[k].flatten()
         ref = torch.from_numpy(gold["gsample::" + k])
-        got = g[torch.from_numpy(sample_index(g.numel()))]
+        got = g[torch.from_numpy(sample_index(g.numel(), case.get("sample", 4096)))]
         assert abs(g.double().norm().item() - float(gold["gnorm::" + k])) <= 1e-4 * float(gold["gnorm::" + k]), k
         assert (got.double() - ref.double()).norm().item() <= 1e-4 * float(gold["gnorm::" + k]) * (ref.numel() / g.numel()) ** 0.5 + 1e-12, k
 

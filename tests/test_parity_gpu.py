@@ -120,7 +120,7 @@ def _wide_errors(name, dtype, loss_scale=1.0):
     worst = 0.0
     for k in keys:
         g = grads[k].detach().float().flatten().cpu()
-        idx = torch.from_numpy(sample_index(g.numel()))
+        idx = torch.from_numpy(sample_index(g.numel(), case.get("sample", 4096)))
         r = torch.from_numpy(gold["gsample::" + k]).float()
         mine.append(g[idx]); ref.append(r); ref16.append(torch.from_numpy(gold["bf16::gsample::" + k]).float())
         share = float(gold["gnorm::" + k]) * (r.numel() / g.numel()) ** 0.5        # expected norm of the sample
