@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 125
+#define VITK_VERSION 130
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -227,6 +227,16 @@ int vitk_attn_fwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, 
 int vitk_attn_bwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_bhnd dout, const float* lse,
                             float* delta, vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv, int64_t B, int64_t H, int64_t N,
                             int64_t d, float scale, float drop_p, uint32_t drop_seed, void* stream);
+/* f32-ACCURATE flavour of the same kernels, for the f32 validation mode (round 3; vit.py:55-63 again): every 16-bit operand
+ * arrives as TWO tensors hi + lo (vitk_split2: hi = round16(x), lo = round16(x - hi)), every product keeps hi.hi + hi.lo + lo.hi,
+ * the probabilities / dS are split the same way inside the kernel, outputs (o, dq, dk, dv: element strides of FLOAT tensors) are
+ * f32.  Same staging, pipelining, masking and softmax code as vitk_attn_fwd/bwd_bf16 at 32 < N <= 224, dim_head 64.          */
+int vitk_split2(const float* x, void* hi, void* lo, int64_t n, void* stream);
+int vitk_attn_fwd_x2(vitk_bhnd q_hi, vitk_bhnd q_lo, vitk_bhnd k_hi, vitk_bhnd k_lo, vitk_bhnd v_hi, vitk_bhnd v_lo, vitk_bhnd o_f32,
+                     float* lse, int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream);
+int vitk_attn_bwd_x2(vitk_bhnd q_hi, vitk_bhnd q_lo, vitk_bhnd k_hi, vitk_bhnd k_lo, vitk_bhnd v_hi, vitk_bhnd v_lo, vitk_bhnd o_f32,
+                     vitk_bhnd do_hi, vitk_bhnd do_lo, const float* lse, float* delta, vitk_bhnd dq_f32, vitk_bhnd dk_f32,
+                     vitk_bhnd dv_f32, int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream);
 /* keep[r * cols + c] = 1 if element (r, c) survives dropout(p) under `seed` in the fused kernels, else 0. */
 int vitk_dropout_keep(uint8_t* keep, int64_t rows, int64_t cols, float p, uint32_t seed, void* stream);
 

@@ -16,7 +16,7 @@ LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit t
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3, 4
-VITK_VERSION = 125
+VITK_VERSION = 130
 
 
 class RowMap(C.Structure):
@@ -80,6 +80,9 @@ SIGNATURES = {
     "vitk_attn_bwd_bf16": (_i, [BHND, BHND, BHND, BHND, BHND, _vp, _vp, BHND, BHND, BHND, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_attn_fwd_bf16_drop": (_i, [BHND, BHND, BHND, BHND, _vp, _i64, _i64, _i64, _i64, _f, _f, C.c_uint32, _vp]),
     "vitk_attn_bwd_bf16_drop": (_i, [BHND, BHND, BHND, BHND, BHND, _vp, _vp, BHND, BHND, BHND, _i64, _i64, _i64, _i64, _f, _f, C.c_uint32, _vp]),
+    "vitk_split2": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "vitk_attn_fwd_x2": (_i, [BHND] * 7 + [_vp, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_attn_bwd_x2": (_i, [BHND] * 9 + [_vp, _vp, BHND, BHND, BHND, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_dropout_keep": (_i, [_vp, _i64, _i64, _f, C.c_uint32, _vp]),
     "vitk_attn_varlen_fwd_bf16": (_i, [HND, HND, HND, HND, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_attn_varlen_bwd_bf16": (_i, [HND, HND, HND, HND, HND, _vp, _vp, HND, HND, HND, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _f, _vp]),

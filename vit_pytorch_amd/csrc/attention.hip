@@ -24,6 +24,7 @@
 // backward recomputes P from the saved row log-sum-exp.  LDS rows are padded to 160 B: conflict-free for both the b128 row
 // reads and the b64 transpose reads.
 #include "common.h"
+#include "attention_pipe.h"
 
 namespace {
 
@@ -970,6 +971,12 @@ extern "C" int vitk_attn_fwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vi
     if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "attn_fwd_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
     if (!bhnd_ok(q) || !bhnd_ok(k) || !bhnd_ok(v) || !bhnd_ok(o) || !lse)
         VITK_FAIL(VITK_E_ALIGN, "attn_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
+    if (attn_pipe_supported(N, d) && (attn_pipe_mask() & 1)) {        // persistent, LDS-DMA-pipelined kernel (attention_pipe.hip)
+        AttnPipeFwd a{};
+        a.ns = 1; a.q[0] = q; a.k[0] = k; a.v[0] = v; a.o = o; a.lse = lse; a.B = B; a.H = H; a.N = N;
+        a.scale = scale; a.drop_p = drop_p; a.drop_seed = drop_seed;
+        return attn_pipe_fwd(a, stream);
+    }
     const int rows_pad = (int)((N + 31) / 32 * 32);
     const int r = tiles_per_wave("VITK_ATTN_R_FWD", true, N);
     ATTN_LAUNCH(attn_fwd_kernel, "attn_fwd_bf16", r, (unsigned)(B * H), (size_t)2 * rows_pad * AT_LD, (hipStream_t)stream, to_bhnd(q),
@@ -993,18 +1000,57 @@ extern "C" int vitk_attn_bwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vi
     if (!bhnd_ok(q) || !bhnd_ok(k) || !bhnd_ok(v) || !bhnd_ok(o) || !bhnd_ok(dout) || !bhnd_ok(dq) || !bhnd_ok(dk) || !bhnd_ok(dv) ||
         !lse || !delta)
         VITK_FAIL(VITK_E_ALIGN, "attn_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
+    // per kernel: the pipelined flavour (attention_pipe.hip) where it is the faster one -- by default the dQ kernel only
+    const int pipe = attn_pipe_supported(N, d) ? (attn_pipe_mask() >> 1) & 3 : 0;
+    AttnPipeBwd pa{};
+    if (pipe) {
+        pa.ns = 1; pa.q[0] = q; pa.k[0] = k; pa.v[0] = v; pa.dout[0] = dout; pa.o = o; pa.dq = dq; pa.dk = dk; pa.dv = dv;
+        pa.lse = lse; pa.delta = delta; pa.B = B; pa.H = H; pa.N = N; pa.scale = scale; pa.drop_p = drop_p; pa.drop_seed = drop_seed;
+    }
     const int rows_pad = (int)((N + 31) / 32 * 32);
     const size_t lds1 = (size_t)2 * rows_pad * AT_LD;
     const size_t lds2 = lds1 + (size_t)3 * rows_pad * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int r1 = tiles_per_wave("VITK_ATTN_R_DQ", false, N), r2 = tiles_per_wave("VITK_ATTN_R_DKV", false, N);
-    ATTN_LAUNCH(attn_bwd_dq_kernel, "attn_bwd_dq", r1, (unsigned)(B * H), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(o),
-                to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
-    VITK_CHECK_LAUNCH("attn_bwd_dq");
+    if (pipe & 1) { if (int rc = attn_pipe_bwd(pa, stream, 1)) return rc; }
+    else {
+        ATTN_LAUNCH(attn_bwd_dq_kernel, "attn_bwd_dq", r1, (unsigned)(B * H), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(o),
+                    to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
+        VITK_CHECK_LAUNCH("attn_bwd_dq");
+    }
+    if (pipe & 2) return attn_pipe_bwd(pa, stream, 2);
     ATTN_LAUNCH(attn_bwd_dkv_kernel, "attn_bwd_dkv", r2, (unsigned)(B * H), lds2, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(dout),
                 lse, delta, to_bhnd(dk), to_bhnd(dv), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
     VITK_CHECK_LAUNCH("attn_bwd_dkv");
     return 0;
+}
+
+// f32-accurate flavour (validation mode): operands as hi + lo 16-bit terms (vitk_split2), f32 outputs -- attention_pipe.hip, NS = 2
+extern "C" int vitk_attn_fwd_x2(vitk_bhnd q_hi, vitk_bhnd q_lo, vitk_bhnd k_hi, vitk_bhnd k_lo, vitk_bhnd v_hi, vitk_bhnd v_lo, vitk_bhnd o_f32,
+                                float* lse, int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream) {
+    if (int rc = attn_shape_check("attn_fwd_x2", B, H, N, d, scale)) return rc;
+    if (!attn_pipe_supported(N, d)) VITK_FAIL(VITK_E_SHAPE, "attn_fwd_x2: needs 32 < N <= 224 (got %lld)", (long long)N);
+    if (!bhnd_ok(q_hi) || !bhnd_ok(q_lo) || !bhnd_ok(k_hi) || !bhnd_ok(k_lo) || !bhnd_ok(v_hi) || !bhnd_ok(v_lo) || !bhnd_ok(o_f32) || !lse)
+        VITK_FAIL(VITK_E_ALIGN, "attn_fwd_x2: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
+    AttnPipeFwd a{};
+    a.ns = 2; a.q[0] = q_hi; a.q[1] = q_lo; a.k[0] = k_hi; a.k[1] = k_lo; a.v[0] = v_hi; a.v[1] = v_lo; a.o = o_f32; a.lse = lse;
+    a.B = B; a.H = H; a.N = N; a.scale = scale; a.drop_p = 0.f; a.drop_seed = 0;
+    return attn_pipe_fwd(a, stream);
+}
+
+extern "C" int vitk_attn_bwd_x2(vitk_bhnd q_hi, vitk_bhnd q_lo, vitk_bhnd k_hi, vitk_bhnd k_lo, vitk_bhnd v_hi, vitk_bhnd v_lo, vitk_bhnd o_f32,
+                                vitk_bhnd do_hi, vitk_bhnd do_lo, const float* lse, float* delta, vitk_bhnd dq_f32, vitk_bhnd dk_f32,
+                                vitk_bhnd dv_f32, int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream) {
+    if (int rc = attn_shape_check("attn_bwd_x2", B, H, N, d, scale)) return rc;
+    if (!attn_pipe_supported(N, d)) VITK_FAIL(VITK_E_SHAPE, "attn_bwd_x2: needs 32 < N <= 224 (got %lld)", (long long)N);
+    if (!bhnd_ok(q_hi) || !bhnd_ok(q_lo) || !bhnd_ok(k_hi) || !bhnd_ok(k_lo) || !bhnd_ok(v_hi) || !bhnd_ok(v_lo) || !bhnd_ok(o_f32) ||
+        !bhnd_ok(do_hi) || !bhnd_ok(do_lo) || !bhnd_ok(dq_f32) || !bhnd_ok(dk_f32) || !bhnd_ok(dv_f32) || !lse || !delta)
+        VITK_FAIL(VITK_E_ALIGN, "attn_bwd_x2: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
+    AttnPipeBwd a{};
+    a.ns = 2; a.q[0] = q_hi; a.q[1] = q_lo; a.k[0] = k_hi; a.k[1] = k_lo; a.v[0] = v_hi; a.v[1] = v_lo; a.dout[0] = do_hi; a.dout[1] = do_lo;
+    a.o = o_f32; a.dq = dq_f32; a.dk = dk_f32; a.dv = dv_f32; a.lse = lse; a.delta = delta;
+    a.B = B; a.H = H; a.N = N; a.scale = scale; a.drop_p = 0.f; a.drop_seed = 0;
+    return attn_pipe_bwd(a, stream, 3);
 }
 
 extern "C" int vitk_softmax_fwd(const void* s, void* p, int dt, int64_t rows, int64_t cols, float scale, void* stream) {

@@ -1,0 +1,747 @@
+// attention_pipe.hip -- persistent, LDS-DMA-pipelined scaled-dot-product attention forward / backward for gfx950 (dim_head 64,
+// 32 < N <= 224 tokens: every ViT at 224^2 with patch 16 -- N = 197 / 196).
+//
+// Replaces vit.py:55-63 (simple_vit.py:54-61) and its autograd, like attention.hip, with the same fragment algebra (S^T = K Q^T,
+// P feeding P.V straight from the accumulators, lazy reference maximum, MFMA row sums; backward as a query-tile-outer dQ kernel
+// and a key-tile-outer dK/dV kernel that recompute P from the saved log-sum-exp).  What is different is HOW THE OPERANDS ARRIVE:
+//
+//   attention.hip     one workgroup per (batch, head): global -> VGPR -> ds_write of the whole head, barrier, compute.  Measured
+//                     (DESIGN section 4): staging alone 34 us, compute alone 54 us, together 83 us -- the two never overlap, because
+//                     every workgroup of a CU is in the same phase and nothing is in flight while a head is being multiplied.
+//   here              RESIDENT workgroups walk a list of (batch, head) items.  One PRODUCER wave per workgroup copies the NEXT
+//                     operands HBM -> LDS with global_load_lds (no VGPR round trip, no ds_write issue, nothing the compute waves
+//                     wait for) while the other waves multiply the CURRENT ones:
+//                       forward   2 workgroups / CU x 8 waves, ONE K|V buffer per workgroup split into two halves of the key
+//                                 range; half h + 1 is in flight while half h is multiplied (the online softmax walks the keys
+//                                 once, so a half is dead as soon as it has been read) -- 57 KB per workgroup;
+//                       backward  1 workgroup / CU x 16 waves, TWO whole-head buffers (K|V for dQ, Q|dO|lse|delta for dK/dV):
+//                                 item i + 1 loads while item i is multiplied -- 115-119 KB.
+//                     The rows each wave owns (its query / key tile) are fetched right after the wave's last step, before its
+//                     stores, so they are in flight across the epilogue and the item barrier.
+//
+// LDS image: 128-byte rows (64 x 16 bit), no padding -- an LDS-DMA instruction writes lane-linearly (8 rows x 128 B per wave
+// instruction), so the bank swizzle sits in the SOURCE address: position p of row r holds the row's 16-byte chunk p ^ (r & 7).
+// Both fragment shapes are conflict-free on it: ds_read_b128 row fragments (16 rows x one chunk: the 16 lanes of a group land on
+// 16 distinct 16-byte bank slots) and ds_read_b64_tr_b16 transpose fragments (8 rows x two chunks: 64 distinct banks).
+//
+// NS = 2 is the f32-ACCURATE flavour used by the f32 validation mode: every 16-bit operand arrives as hi + lo
+// (vitk_split2), every product keeps hi.hi + hi.lo + lo.hi, the probabilities / dS are split the same way, outputs are f32:
+// ~2^-16 per product instead of 2^-8, on the SAME staging, pipelining, masking and softmax code as the 16-bit kernels.
+#include "common.h"
+#include "attention_pipe.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+struct TND { const __bf16* p; long long s_b, s_h, s_n; };      // 16-bit operand, element strides
+struct OND { void* p; long long s_b, s_h, s_n; };              // output (16-bit, or f32 when NS == 2)
+
+// workgroup barrier that also tells the COMPILER that LDS changed: the compute waves never write LDS themselves (the producer
+// wave's DMA does), so without the clobber hipcc may keep or hoist fragment reads across items
+#define AP_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+#define AP_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <int NS> struct Fr { bf16x8 t[NS]; };
+// a . b with the terms hi.hi (+ hi.lo + lo.hi): small terms first
+template <int NS>
+__device__ __forceinline__ f32x4 mm(const Fr<NS>& a, const Fr<NS>& b, f32x4 c) {
+    if constexpr (NS == 2) { c = MFMA(a.t[1], b.t[0], c); c = MFMA(a.t[0], b.t[1], c); }
+    return MFMA(a.t[0], b.t[0], c);
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+    bf16x8 r = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+    return r;
+}
+// two f32 fragments -> NS 16-bit terms
+template <int NS>
+__device__ __forceinline__ Fr<NS> split_pack(f32x4 a, f32x4 b) {
+    Fr<NS> r;
+    r.t[0] = pack8(a, b);
+    if constexpr (NS == 2) {
+        f32x4 ra, rb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ra[e] = a[e] - (float)r.t[0][e]; rb[e] = b[e] - (float)r.t[0][4 + e]; }
+        r.t[1] = pack8(ra, rb);
+    }
+    return r;
+}
+__device__ __forceinline__ float groups_max(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    u = __builtin_bit_cast(unsigned, x);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float groups_sum(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    u = __builtin_bit_cast(unsigned, x);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
+// ---- swizzled LDS image -------------------------------------------------------------------------------------------------
+// 16 rows x (32 of the 64 columns) as an MFMA A/B operand: lane (i = lane & 15, g = lane >> 4) holds tile[row0 + i][ks*32 + 8g .. +7]
+__device__ __forceinline__ bf16x8 sw_row(const char* tile, int row0, int ks, int fi, int fg) {
+    const int row = row0 + fi;
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((ks * 4 + fg) ^ (row & 7)) << 4));
+}
+// transposed operand: lane (i, g) holds tile[row0 + {4g..4g+3, 16+4g..16+4g+3}][col0 + i]   (col0 a multiple of 16)
+__device__ __forceinline__ bf16x8 sw_tr(const char* tile, int row0, int col0, int fi, int fg) {
+    const int row = row0 + 4 * fg + (fi >> 2);
+    const char* p = tile + row * 128 + ((((col0 >> 3) + ((fi & 3) >> 1)) ^ (row & 7)) << 4) + ((fi & 1) << 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * 128));   // row + 16: same swizzle
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int NS>
+__device__ __forceinline__ Fr<NS> sw_row_n(const char* tile0, int term_stride, int row0, int ks, int fi, int fg) {
+    Fr<NS> r;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) r.t[t] = sw_row(tile0 + t * term_stride, row0, ks, fi, fg);
+    return r;
+}
+template <int NS>
+__device__ __forceinline__ Fr<NS> sw_tr_n(const char* tile0, int term_stride, int row0, int col0, int fi, int fg) {
+    Fr<NS> r;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) r.t[t] = sw_tr(tile0 + t * term_stride, row0, col0, fi, fg);
+    return r;
+}
+// producer: row groups [g0, g1) (8 rows each) of one (n, 64) head slice -> LDS tile; rows past N re-read row N - 1, so every LDS
+// row always holds finite data (padding keys are masked by value, padding queries by index)
+__device__ __forceinline__ void dma_rows(const __bf16* base, long long s_n, int N, char* tile, int g0, int g1, int lane) {
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);       // LDS row 8g + lrow, position lane & 7 <- chunk lchunk
+    for (int g = g0; g < g1; ++g) {
+        int row = 8 * g + lrow; row = row < N ? row : N - 1;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + (long long)row * s_n + lchunk * 8),
+                                         (void __attribute__((address_space(3)))*)(tile + g * 1024), 16, 0, 0);
+    }
+}
+// producer: n floats (n <= 256) -> LDS, indices past N re-read element N - 1
+__device__ __forceinline__ void dma_f32(const float* base, int N, char* dst, int n, int lane) {
+    for (int g = 0; g * 64 < n; ++g) {
+        int i = g * 64 + lane; i = i < N ? i : N - 1;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + i),
+                                         (void __attribute__((address_space(3)))*)(dst + g * 256), 4, 0, 0);
+    }
+}
+template <int NS>
+__device__ __forceinline__ void load_row_frags(Fr<NS> (&f)[2], const TND (&t)[NS], long long off, int fg) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const __bf16* p = t[i].p + off;
+        f[0].t[i] = *reinterpret_cast<const bf16x8*>(p + 8 * fg);
+        f[1].t[i] = *reinterpret_cast<const bf16x8*>(p + 32 + 8 * fg);
+    }
+}
+template <int NS> using out_t = std::conditional_t<NS == 1, __bf16, float>;
+
+// ==========================================================================================================================
+// forward
+// ==========================================================================================================================
+template <int NS> struct FwdArgs {
+    TND q[NS], k[NS], v[NS];
+    OND o;
+    float* lse;
+    int H, N, nitems;
+    float c;                 // scale * log2(e)
+    unsigned drop_t, drop_seed;
+    float inv_keep;
+    int dbg;                 // experiments (VITK_ATTN_DBG): bit 0 = producer issues no DMA, bit 1 = compute waves skip the steps
+};
+
+// 8 waves: 0-6 carry two 16-row query tiles each (N <= 224), wave 7 is the producer.  Two workgroups per CU (NS = 1).
+template <int NS, bool DROP>
+__global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void attn_fwd_pipe_kernel(const FwdArgs<NS> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, H = a.H;
+    const int nks = (N + 31) >> 5, nA = (nks + 1) >> 1;
+    const int tile_b = nks * 32 * 128;              // one tensor, one term
+    const int term_b = 2 * tile_b;                  // K | V of one term
+    char* const Ks = smem;
+    char* const Vs = smem + tile_b;
+    const int first = blockIdx.x, stride = gridDim.x;
+
+    if (wave == 7) {
+        // ---- producer: half h + 1 of the key range is in flight while the compute waves multiply half h ----
+        for (int item = first; item < a.nitems; item += stride) {
+            const int b = item / H, h = item - b * H;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int g0 = part ? 4 * nA : 0, g1 = part ? 4 * nks : 4 * nA;
+                if (!(a.dbg & 1)) {
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) {
+                        dma_rows(a.k[t].p + b * a.k[t].s_b + h * a.k[t].s_h, a.k[t].s_n, N, Ks + t * term_b, g0, g1, lane);
+                        dma_rows(a.v[t].p + b * a.v[t].s_b + h * a.v[t].s_h, a.v[t].s_n, N, Vs + t * term_b, g0, g1, lane);
+                    }
+                }
+                AP_WAIT_DMA();
+                AP_BARRIER();       // publishes this half; everyone has finished the half this buffer held before the PREVIOUS barrier
+            }
+        }
+        return;
+    }
+
+    // ---- compute waves ----
+    using TO = out_t<NS>;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int nqt = (N + 15) >> 4;
+    const int t0 = wave * 2;
+    const bool active = t0 < nqt;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    const float c = a.c;
+    Fr<NS> qf[2][2];
+    auto load_q = [&](int item) {
+        const int b = item / H, h = item - b * H;
+        int lane_o = lane;                             // opaque copy: the lane offsets are re-derived per item -- hoisted to kernel entry they
+        asm volatile("" : "+v"(lane_o));               // are spilled around the item loop (and a reload draws a vmcnt(0) between the loads)
+        const int fi_ = lane_o & 15, fg_ = lane_o >> 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int qi = (t0 + r) * 16 + fi_;
+            load_row_frags<NS>(qf[r], a.q, b * a.q[0].s_b + h * a.q[0].s_h + (long long)(qi < N ? qi : N - 1) * a.q[0].s_n, fg_);
+        }
+    };
+    if (active && first < a.nitems) load_q(first);
+
+    for (int item = first; item < a.nitems; item += stride) {
+        const int b = item / H, h = item - b * H;
+        float mref[2];
+        f32x4 acc[2][4], accl[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { mref[r] = -INFINITY; accl[r] = z4; acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = z4; }
+
+        auto step = [&](int s) {
+            Fr<NS> kf[2][2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                kf[hh][0] = sw_row_n<NS>(Ks, term_b, s * 32 + hh * 16, 0, fi, fg);
+                kf[hh][1] = sw_row_n<NS>(Ks, term_b, s * 32 + hh * 16, 1, fi, fg);
+            }
+            Fr<NS> pb[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                f32x4 st[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    st[hh] = mm<NS>(kf[hh][0], qf[r][0], z4);
+                    st[hh] = mm<NS>(kf[hh][1], qf[r][1], st[hh]);
+                }
+                if (s == nks - 1) {            // only the last 32-key step holds padding keys
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (s * 32 + hh * 16 + 4 * fg + e >= N) st[hh][e] = -INFINITY;
+                }
+                // lazy reference maximum, MFMA row sums, scale and -mref folded into the exp2 argument: see attention.hip
+                float mloc = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+                mloc = fmaxf(fmaxf(mloc, st[0][3]), st[1][0]);
+                mloc = fmaxf(fmaxf(mloc, st[1][1]), st[1][2]);
+                mloc = fmaxf(mloc, st[1][3]);
+                if (__builtin_amdgcn_ballot_w64(mloc * c > mref[r] + 8.0f) != 0) {
+                    const float m_new = fmaxf(mref[r], groups_max(mloc) * c);
+                    const float alpha = __builtin_amdgcn_exp2f(mref[r] - m_new);
+#pragma unroll
+                    for (int fd = 0; fd < 4; ++fd) acc[r][fd] *= alpha;
+                    accl[r] *= alpha;
+                    mref[r] = m_new;
+                }
+                const float nm = -mref[r];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
+                pb[r] = split_pack<NS>(st[0], st[1]);
+#pragma unroll
+                for (int t = 0; t < NS; ++t) accl[r] = MFMA(ones, pb[r].t[t], accl[r]);      // softmax denominators: of the UNDROPPED probabilities
+                if constexpr (DROP) {                          // nn.Dropout on the attention matrix (vit.py:60): zero P entries for P.V
+                    const unsigned hrow = drop_row((unsigned)(item * N + (t0 + r) * 16 + fi), a.drop_seed);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!drop_keep(hrow, (unsigned)(s * 32 + hh * 16 + 4 * fg + e), a.drop_t)) st[hh][e] = 0.f;
+                    pb[r] = split_pack<NS>(st[0], st[1]);
+                }
+            }
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                const Fr<NS> vf = sw_tr_n<NS>(Vs, term_b, s * 32, fd * 16, fi, fg);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r][fd] = mm<NS>(vf, pb[r], acc[r][fd]);
+            }
+        };
+
+        AP_BARRIER();                                  // first half of the keys has landed
+        const bool work = active && !(a.dbg & 2);
+        if (work) for (int s = 0; s < nA; ++s) step(s);
+        AP_BARRIER();                                  // second half has landed (and the first is free for the next item)
+        if (active) {
+            if (work) for (int s = nA; s < nks; ++s) step(s);
+            const int nxt = item + stride;
+            if (nxt < a.nitems) load_q(nxt);           // in flight across the stores below and the next item's barrier
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int qi = (t0 + r) * 16 + fi;
+                const float ls = accl[r][0];           // every row of 1^T P^T is the same sum
+                const float inv = a.inv_keep / ls;     // kept entries are scaled by 1 / (1 - p)
+                if (qi < N) {
+                    TO* op = reinterpret_cast<TO*>(a.o.p) + (b * a.o.s_b + h * a.o.s_h) + (qi * (int)a.o.s_n + 4 * fg);
+#pragma unroll
+                    for (int fd = 0; fd < 4; ++fd) store4<TO>(op + fd * 16, acc[r][fd] * inv);
+                    if (fg == 0) a.lse[(long long)item * N + qi] = (mref[r] + log2f(ls)) * LN2;
+                }
+            }
+        }
+    }
+}
+
+// ==========================================================================================================================
+// backward, dQ: query-tile outer; K | V of the whole head double-buffered in LDS (NS = 1)
+// ==========================================================================================================================
+template <int NS> struct DqArgs {
+    TND q[NS], k[NS], v[NS], dout[NS];
+    OND o;                   // the forward's output: 16-bit (NS = 1) or f32 (NS = 2)
+    const float* lse;
+    float* delta;
+    OND dq;
+    int H, N, nitems;
+    float scale;
+    unsigned drop_t, drop_seed;
+    float inv_keep;
+    int dbg;
+};
+
+// 16 waves: 0-14 carry one 16-row tile each (N <= 224: 14 tiles), wave 15 is the producer.  One workgroup per CU.
+template <int NS, bool DROP>
+__global__ __launch_bounds__(1024) void attn_dq_pipe_kernel(const DqArgs<NS> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NBUF = NS == 1 ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, H = a.H;
+    const int nks = (N + 31) >> 5;
+    const int tile_b = nks * 32 * 128, term_b = 2 * tile_b, buf_b = NS * term_b;
+    const int first = blockIdx.x, stride = gridDim.x;
+
+    if (wave == 15) {
+        auto issue = [&](int item, int buf) {
+            if (a.dbg & 1) return;
+            const int b = item / H, h = item - b * H;
+            char* base = smem + buf * buf_b;
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                dma_rows(a.k[t].p + b * a.k[t].s_b + h * a.k[t].s_h, a.k[t].s_n, N, base + t * term_b, 0, 4 * nks, lane);
+                dma_rows(a.v[t].p + b * a.v[t].s_b + h * a.v[t].s_h, a.v[t].s_n, N, base + t * term_b + tile_b, 0, 4 * nks, lane);
+            }
+        };
+        if constexpr (NBUF == 2) {
+            int j = 0;
+            if (first < a.nitems) issue(first, 0);
+            for (int item = first; item < a.nitems; item += stride, ++j) {
+                AP_WAIT_DMA();
+                AP_BARRIER();                          // item's buffer is published; everyone has left the other buffer
+                if (item + stride < a.nitems) issue(item + stride, (j + 1) & 1);
+            }
+        } else {
+            for (int item = first; item < a.nitems; item += stride) {
+                issue(item, 0);
+                AP_WAIT_DMA();
+                AP_BARRIER();
+                AP_BARRIER();                          // everyone has finished reading
+            }
+        }
+        return;
+    }
+
+    using TO = out_t<NS>;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int nqt = (N + 15) >> 4;
+    const bool active = wave < nqt;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const float c = a.scale * LOG2E;
+    const int qi = wave * 16 + fi;
+    const int qrow = qi < N ? qi : N - 1;
+
+    Fr<NS> qf[2], df[2];
+    float l2 = 0.f, dl = 0.f;
+    // the rows this wave owns: q, dO, the forward's output (for delta = rowsum(dO * O)), lse
+    struct Rows { Fr<NS> q[2], d[2]; std::conditional_t<NS == 1, bf16x8, f32x4> o[NS == 1 ? 2 : 4]; float lse; };
+    auto fetch_rows = [&](int item) {
+        Rows r;
+        const int b = item / H, h = item - b * H;
+        load_row_frags<NS>(r.q, a.q, b * a.q[0].s_b + h * a.q[0].s_h + (long long)qrow * a.q[0].s_n, fg);
+        load_row_frags<NS>(r.d, a.dout, b * a.dout[0].s_b + h * a.dout[0].s_h + (long long)qrow * a.dout[0].s_n, fg);
+        r.lse = a.lse[(long long)item * N + qrow];
+        const TO* op = reinterpret_cast<const TO*>(a.o.p) + b * a.o.s_b + h * a.o.s_h + (long long)qrow * a.o.s_n;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if constexpr (NS == 1) r.o[ks] = *reinterpret_cast<const bf16x8*>(op + ks * 32 + 8 * fg);
+            else { r.o[2 * ks] = *reinterpret_cast<const f32x4*>(op + ks * 32 + 8 * fg); r.o[2 * ks + 1] = *reinterpret_cast<const f32x4*>(op + ks * 32 + 8 * fg + 4); }
+        }
+        return r;
+    };
+    // first use of the rows (this is where the loads are waited for): delta = rowsum(dO * O), this lane's 16 columns
+    auto adopt = [&](const Rows& r) {
+        qf[0] = r.q[0]; qf[1] = r.q[1]; df[0] = r.d[0]; df[1] = r.d[1];
+        l2 = -r.lse * LOG2E;                                 // negated: the exp2 argument is one FMA
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float d = (float)r.d[ks].t[0][e];
+                if constexpr (NS == 2) d += (float)r.d[ks].t[1][e];
+                float o;
+                if constexpr (NS == 1) o = (float)r.o[ks][e]; else o = r.o[2 * ks + (e >> 2)][e & 3];
+                s = fmaf(d, o, s);
+            }
+        dl = s;                                              // summed over the 4 lane groups at use
+    };
+    if (active && first < a.nitems) {
+        adopt(fetch_rows(first));
+        // consume every row register HERE: left outstanding, the first item's loads make hipcc's merged counter state at the loop
+        // header "loads in flight" and it then waits vmcnt(0) at every item start -- i.e. for the previous item's stores
+        if constexpr (NS == 1) asm volatile("" :: "v"(qf[0].t[0]), "v"(qf[1].t[0]), "v"(df[0].t[0]), "v"(df[1].t[0]), "v"(l2), "v"(dl));
+    }
+
+    int j = 0;
+    for (int item = first; item < a.nitems; item += stride, ++j) {
+        const int b = item / H, h = item - b * H;
+        const char* Ks = smem + (NBUF == 2 ? (j & 1) * buf_b : 0);
+        const char* Vs = Ks + tile_b;
+        AP_BARRIER();
+        if (active) {
+            const float dsum = groups_sum(dl);
+            if (qi < N && fg == 0) a.delta[(long long)item * N + qi] = dsum;
+            // NS = 1: the next item's rows are requested NOW, into their own registers, and adopted after the last step: the
+            // loads have the whole item to land (fetched after the last step they cost a memory round trip per item -- and,
+            // vmcnt retiring in order, the completion of this item's stores on top of it)
+            // (UNCONDITIONAL, the last item re-fetches its own rows: under `if (more)` hipcc cannot pair the fetch with the adoption
+            //  below, assumes loads may be pending at the loop header and waits for this item's STORES before it re-uses a register)
+            const int nitem = item + stride < a.nitems ? item + stride : item;
+            Rows nxt;
+            if constexpr (NS == 1) nxt = fetch_rows(nitem);
+            f32x4 acc[4];
+            acc[0] = acc[1] = acc[2] = acc[3] = z4;
+            for (int s = 0; s < ((a.dbg & 2) ? 0 : nks); ++s) {
+                f32x4 ds[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int row0 = s * 32 + hh * 16;
+                    const Fr<NS> k0 = sw_row_n<NS>(Ks, term_b, row0, 0, fi, fg), k1 = sw_row_n<NS>(Ks, term_b, row0, 1, fi, fg);
+                    const Fr<NS> v0 = sw_row_n<NS>(Vs, term_b, row0, 0, fi, fg), v1 = sw_row_n<NS>(Vs, term_b, row0, 1, fi, fg);
+                    f32x4 st = mm<NS>(k0, qf[0], z4);
+                    st = mm<NS>(k1, qf[1], st);
+                    f32x4 dp = mm<NS>(v0, df[0], z4);
+                    dp = mm<NS>(v1, df[1], dp);
+                    if constexpr (DROP) {                   // dP = dP_dropped * keep / (1 - p)
+                        const unsigned hrow = drop_row((unsigned)(item * N + wave * 16 + fi), a.drop_seed);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            dp[e] = drop_keep(hrow, (unsigned)(row0 + 4 * fg + e), a.drop_t) ? dp[e] * a.inv_keep : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)           // the common factor `scale` of dS is applied once, to dQ
+                        ds[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], c, l2)) * (dp[e] - dsum);
+                    if (s == nks - 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (row0 + 4 * fg + e >= N) ds[hh][e] = 0.f;
+                    }
+                }
+                const Fr<NS> dsb = split_pack<NS>(ds[0], ds[1]);
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) acc[fd] = mm<NS>(sw_tr_n<NS>(Ks, term_b, s * 32, fd * 16, fi, fg), dsb, acc[fd]);
+            }
+            if constexpr (NS != 1) nxt = fetch_rows(nitem);
+            adopt(nxt);
+            // pin the adoption (and with it the wait for the row loads) IN FRONT of this item's stores: hipcc otherwise sinks it
+            // below them and its vmcnt(0) then waits for the stores' write round trip
+            if constexpr (NS == 1) asm volatile("" :: "v"(qf[0].t[0]), "v"(qf[1].t[0]), "v"(df[0].t[0]), "v"(df[1].t[0]), "v"(l2), "v"(dl) : "memory");
+            if (qi < N) {
+                TO* dqp = reinterpret_cast<TO*>(a.dq.p) + (b * a.dq.s_b + h * a.dq.s_h) + (qi * (int)a.dq.s_n + 4 * fg);
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) store4<TO>(dqp + fd * 16, acc[fd] * a.scale);
+            }
+        }
+        if constexpr (NBUF == 1) AP_BARRIER();
+    }
+}
+
+// ==========================================================================================================================
+// backward, dK / dV: key-tile outer; Q | dO (+ lse, delta) of the whole head double-buffered in LDS (NS = 1)
+// ==========================================================================================================================
+template <int NS> struct DkvArgs {
+    TND q[NS], k[NS], v[NS], dout[NS];
+    const float* lse;
+    const float* delta;
+    OND dk, dv;
+    int H, N, nitems;
+    float scale;
+    unsigned drop_t, drop_seed;
+    float inv_keep;
+    int dbg;
+};
+
+template <int NS, bool DROP>
+__global__ __launch_bounds__(1024) void attn_dkv_pipe_kernel(const DkvArgs<NS> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NBUF = NS == 1 ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, H = a.H;
+    const int nqs = (N + 31) >> 5;
+    const int tile_b = nqs * 32 * 128, term_b = 2 * tile_b, buf_b = NS * term_b + 2048;     // + lse, delta: 256 floats each
+    const int first = blockIdx.x, stride = gridDim.x;
+
+    if (wave == 15) {
+        auto issue = [&](int item, int buf) {
+            if (a.dbg & 1) return;
+            const int b = item / H, h = item - b * H;
+            char* base = smem + buf * buf_b;
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                dma_rows(a.q[t].p + b * a.q[t].s_b + h * a.q[t].s_h, a.q[t].s_n, N, base + t * term_b, 0, 4 * nqs, lane);
+                dma_rows(a.dout[t].p + b * a.dout[t].s_b + h * a.dout[t].s_h, a.dout[t].s_n, N, base + t * term_b + tile_b, 0, 4 * nqs, lane);
+            }
+            dma_f32(a.lse + (long long)item * N, N, base + NS * term_b, nqs * 32, lane);
+            dma_f32(a.delta + (long long)item * N, N, base + NS * term_b + 1024, nqs * 32, lane);
+        };
+        if constexpr (NBUF == 2) {
+            int j = 0;
+            if (first < a.nitems) issue(first, 0);
+            for (int item = first; item < a.nitems; item += stride, ++j) {
+                AP_WAIT_DMA();
+                AP_BARRIER();
+                if (item + stride < a.nitems) issue(item + stride, (j + 1) & 1);
+            }
+        } else {
+            for (int item = first; item < a.nitems; item += stride) {
+                issue(item, 0);
+                AP_WAIT_DMA();
+                AP_BARRIER();
+                AP_BARRIER();
+            }
+        }
+        return;
+    }
+
+    using TO = out_t<NS>;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int nkt = (N + 15) >> 4;
+    const bool active = wave < nkt;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const float c = a.scale * LOG2E;
+    const int ki = wave * 16 + fi;
+    const int krow = ki < N ? ki : N - 1;
+
+    Fr<NS> kf[2], vf[2];
+    auto fetch_rows = [&](int item) {
+        const int b = item / H, h = item - b * H;
+        load_row_frags<NS>(kf, a.k, b * a.k[0].s_b + h * a.k[0].s_h + (long long)krow * a.k[0].s_n, fg);
+        load_row_frags<NS>(vf, a.v, b * a.v[0].s_b + h * a.v[0].s_h + (long long)krow * a.v[0].s_n, fg);
+    };
+    if (active && first < a.nitems) fetch_rows(first);
+
+    int j = 0;
+    for (int item = first; item < a.nitems; item += stride, ++j) {
+        const int b = item / H, h = item - b * H;
+        const char* Qs = smem + (NBUF == 2 ? (j & 1) * buf_b : 0);
+        const char* Ds = Qs + tile_b;
+        const float* lse_s = reinterpret_cast<const float*>(Qs + NS * term_b);
+        const float* del_s = lse_s + 256;
+        AP_BARRIER();
+        if (active) {
+            f32x4 accK[4], accV[4];
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) { accK[fd] = z4; accV[fd] = z4; }
+            for (int s = 0; s < ((a.dbg & 2) ? 0 : nqs); ++s) {
+                f32x4 p[2], ds[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int row0 = s * 32 + hh * 16;
+                    const Fr<NS> q0 = sw_row_n<NS>(Qs, term_b, row0, 0, fi, fg), q1 = sw_row_n<NS>(Qs, term_b, row0, 1, fi, fg);
+                    const Fr<NS> d0 = sw_row_n<NS>(Ds, term_b, row0, 0, fi, fg), d1 = sw_row_n<NS>(Ds, term_b, row0, 1, fi, fg);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
+                    f32x4 st = mm<NS>(q0, kf[0], z4);      // S[q = row0 + 4g + e][key]
+                    st = mm<NS>(q1, kf[1], st);
+                    f32x4 dp = mm<NS>(d0, vf[0], z4);      // dP[q][key]
+                    dp = mm<NS>(d1, vf[1], dp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        p[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], c, -LOG2E * l4[e]));
+                        if constexpr (DROP) {              // dV takes P * keep / (1 - p); dP = dP_dropped * keep / (1 - p)
+                            const unsigned hq = drop_row((unsigned)(item * N + row0 + 4 * fg + e), a.drop_seed);
+                            const float km = drop_keep(hq, (unsigned)(wave * 16 + fi), a.drop_t) ? a.inv_keep : 0.f;
+                            ds[hh][e] = p[hh][e] * (dp[e] * km - d4[e]);
+                            p[hh][e] *= km;
+                        } else {
+                            ds[hh][e] = p[hh][e] * (dp[e] - d4[e]);      // `scale` is applied once, to dK
+                        }
+                    }
+                    if (s == nqs - 1) {                    // padding query rows only exist in the last step
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (row0 + 4 * fg + e >= N) { p[hh][e] = 0.f; ds[hh][e] = 0.f; }
+                    }
+                }
+                const Fr<NS> pb = split_pack<NS>(p[0], p[1]), dsb = split_pack<NS>(ds[0], ds[1]);
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) {
+                    accV[fd] = mm<NS>(sw_tr_n<NS>(Ds, term_b, s * 32, fd * 16, fi, fg), pb, accV[fd]);    // dV^T[d][key]
+                    accK[fd] = mm<NS>(sw_tr_n<NS>(Qs, term_b, s * 32, fd * 16, fi, fg), dsb, accK[fd]);   // dK^T[d][key]
+                }
+            }
+            if (item + stride < a.nitems) fetch_rows(item + stride);     // (an earlier fetch into spare registers, as in the dQ kernel, does not fit in 128 VGPRs here)
+            if (ki < N) {
+                TO* dkp = reinterpret_cast<TO*>(a.dk.p) + (b * a.dk.s_b + h * a.dk.s_h) + (ki * (int)a.dk.s_n + 4 * fg);
+                TO* dvp = reinterpret_cast<TO*>(a.dv.p) + (b * a.dv.s_b + h * a.dv.s_h) + (ki * (int)a.dv.s_n + 4 * fg);
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) { store4<TO>(dkp + fd * 16, accK[fd] * a.scale); store4<TO>(dvp + fd * 16, accV[fd]); }
+            }
+        }
+        if constexpr (NBUF == 1) AP_BARRIER();
+    }
+}
+
+// ---- elementwise split of an f32 tensor into hi + lo 16-bit terms ----
+__global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, __bf16* __restrict__ hi, __bf16* __restrict__ lo, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
+        *reinterpret_cast<bf16x4*>(hi + 4 * i) = h;
+        *reinterpret_cast<bf16x4*>(lo + 4 * i) = l;
+    }
+}
+
+int num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return 256;
+        return v;
+    }();
+    return n;
+}
+template <typename K> int set_lds(K kernel, int bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+constexpr int AP_MAX_LDS = 2 * (2 * 224 * 128 + 2048);      // the largest image any of the kernels asks for (two buffers of Q | dO + lse, delta)
+#define AP_SET_LDS(kernel, name) do { static const int rc__ = set_lds(kernel, AP_MAX_LDS); \
+    if (rc__ != 0) VITK_FAIL(rc__, "%s: hipFuncSetAttribute(max dynamic LDS) failed: %d", name, rc__); } while (0)
+
+TND tnd(const vitk_bhnd& t) { return TND{(const __bf16*)t.p, (long long)t.s_b, (long long)t.s_h, (long long)t.s_n}; }
+OND ond(const vitk_bhnd& t) { return OND{t.p, (long long)t.s_b, (long long)t.s_h, (long long)t.s_n}; }
+
+template <int NS> int launch_fwd(const AttnPipeFwd& p, hipStream_t st) {
+    FwdArgs<NS> a;
+    for (int t = 0; t < NS; ++t) { a.q[t] = tnd(p.q[t]); a.k[t] = tnd(p.k[t]); a.v[t] = tnd(p.v[t]); }
+    a.o = ond(p.o); a.lse = p.lse; a.H = (int)p.H; a.N = (int)p.N; a.nitems = (int)(p.B * p.H);
+    a.dbg = getenv("VITK_ATTN_DBG") ? atoi(getenv("VITK_ATTN_DBG")) : 0;
+    a.c = p.scale * LOG2E; a.drop_t = drop_thresh(p.drop_p); a.drop_seed = p.drop_seed; a.inv_keep = 1.0f / (1.0f - p.drop_p);
+    const int nks = (int)((p.N + 31) / 32);
+    const int lds = NS * 2 * nks * 32 * 128;
+    const int per_cu = NS == 1 ? 2 : 1;
+    int grid = per_cu * num_cus();
+    if (grid > a.nitems) grid = a.nitems;
+    if (NS == 1 && a.drop_t) {
+        AP_SET_LDS((attn_fwd_pipe_kernel<1, true>), "attn_fwd (pipelined)");
+        FwdArgs<1> a1; memcpy(&a1, &a, sizeof(a1) < sizeof(a) ? sizeof(a1) : sizeof(a));
+        hipLaunchKernelGGL((attn_fwd_pipe_kernel<1, true>), dim3((unsigned)grid), dim3(512), (size_t)lds, st, a1);
+    } else {
+        AP_SET_LDS((attn_fwd_pipe_kernel<NS, false>), "attn_fwd (pipelined)");
+        hipLaunchKernelGGL((attn_fwd_pipe_kernel<NS, false>), dim3((unsigned)grid), dim3(512), (size_t)lds, st, a);
+    }
+    VITK_CHECK_LAUNCH("attn_fwd (pipelined)");
+    return 0;
+}
+// which: bit 0 = the dQ kernel (also writes delta), bit 1 = the dK / dV kernel (reads delta)
+template <int NS> int launch_bwd(const AttnPipeBwd& p, hipStream_t st, int which) {
+    const int nks = (int)((p.N + 31) / 32);
+    const int nbuf = NS == 1 ? 2 : 1;
+    const int nitems = (int)(p.B * p.H);
+    int grid = num_cus();
+    if (grid > nitems) grid = nitems;
+    const unsigned drop_t = drop_thresh(p.drop_p);
+    const float inv_keep = 1.0f / (1.0f - p.drop_p);
+    const int dbg = getenv("VITK_ATTN_DBG") ? atoi(getenv("VITK_ATTN_DBG")) : 0;
+    if (which & 1) {
+        DqArgs<NS> a;
+        a.dbg = dbg;
+        for (int t = 0; t < NS; ++t) { a.q[t] = tnd(p.q[t]); a.k[t] = tnd(p.k[t]); a.v[t] = tnd(p.v[t]); a.dout[t] = tnd(p.dout[t]); }
+        a.o = ond(p.o); a.lse = p.lse; a.delta = p.delta; a.dq = ond(p.dq);
+        a.H = (int)p.H; a.N = (int)p.N; a.nitems = nitems; a.scale = p.scale; a.drop_t = drop_t; a.drop_seed = p.drop_seed; a.inv_keep = inv_keep;
+        const size_t lds = (size_t)(nbuf * NS * 2 * nks * 32 * 128);
+        if (NS == 1 && drop_t) {
+            AP_SET_LDS((attn_dq_pipe_kernel<1, true>), "attn_bwd_dq (pipelined)");
+            DqArgs<1> a1; memcpy(&a1, &a, sizeof(a1) < sizeof(a) ? sizeof(a1) : sizeof(a));
+            hipLaunchKernelGGL((attn_dq_pipe_kernel<1, true>), dim3((unsigned)grid), dim3(1024), lds, st, a1);
+        } else {
+            AP_SET_LDS((attn_dq_pipe_kernel<NS, false>), "attn_bwd_dq (pipelined)");
+            hipLaunchKernelGGL((attn_dq_pipe_kernel<NS, false>), dim3((unsigned)grid), dim3(1024), lds, st, a);
+        }
+        VITK_CHECK_LAUNCH("attn_bwd_dq (pipelined)");
+    }
+    if (which & 2) {
+        DkvArgs<NS> a;
+        a.dbg = dbg;
+        for (int t = 0; t < NS; ++t) { a.q[t] = tnd(p.q[t]); a.k[t] = tnd(p.k[t]); a.v[t] = tnd(p.v[t]); a.dout[t] = tnd(p.dout[t]); }
+        a.lse = p.lse; a.delta = p.delta; a.dk = ond(p.dk); a.dv = ond(p.dv);
+        a.H = (int)p.H; a.N = (int)p.N; a.nitems = nitems; a.scale = p.scale; a.drop_t = drop_t; a.drop_seed = p.drop_seed; a.inv_keep = inv_keep;
+        const size_t lds = (size_t)(nbuf * (NS * 2 * nks * 32 * 128 + 2048));
+        if (NS == 1 && drop_t) {
+            AP_SET_LDS((attn_dkv_pipe_kernel<1, true>), "attn_bwd_dkv (pipelined)");
+            DkvArgs<1> a1; memcpy(&a1, &a, sizeof(a1) < sizeof(a) ? sizeof(a1) : sizeof(a));
+            hipLaunchKernelGGL((attn_dkv_pipe_kernel<1, true>), dim3((unsigned)grid), dim3(1024), lds, st, a1);
+        } else {
+            AP_SET_LDS((attn_dkv_pipe_kernel<NS, false>), "attn_bwd_dkv (pipelined)");
+            hipLaunchKernelGGL((attn_dkv_pipe_kernel<NS, false>), dim3((unsigned)grid), dim3(1024), lds, st, a);
+        }
+        VITK_CHECK_LAUNCH("attn_bwd_dkv (pipelined)");
+    }
+    return 0;
+}
+
+}  // namespace
+
+bool attn_pipe_supported(int64_t N, int64_t d) { return d == 64 && N > 32 && N <= 224; }
+// Which 16-bit kernels run pipelined by default: bit 0 forward, bit 1 dQ, bit 2 dK/dV.  [measured, ViT-B/16 batch 256, rocprofv3
+// averages, pipelined vs one-workgroup-per-head] forward 89 vs 81 us, dQ 110 vs 118 us, dK/dV 150 vs 143 us: only the dQ kernel -- the
+// one whose per-wave rows are prefetched a whole item ahead -- gains, so only it is on.  VITK_ATTN_PIPE=<mask> overrides (tests: 7).
+int attn_pipe_mask() {
+    const char* e = getenv("VITK_ATTN_PIPE");
+    return e ? atoi(e) : 2;
+}
+int attn_pipe_fwd(const AttnPipeFwd& a, void* stream) {
+    return a.ns == 2 ? launch_fwd<2>(a, (hipStream_t)stream) : launch_fwd<1>(a, (hipStream_t)stream);
+}
+int attn_pipe_bwd(const AttnPipeBwd& a, void* stream, int which) {
+    return a.ns == 2 ? launch_bwd<2>(a, (hipStream_t)stream, which) : launch_bwd<1>(a, (hipStream_t)stream, which);
+}
+
+extern "C" int vitk_split2(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+    if (!x || !hi || !lo) VITK_FAIL(VITK_E_ARG, "split2: null pointer");
+    if (n <= 0 || (n & 3)) VITK_FAIL(VITK_E_SHAPE, "split2: element count must be a positive multiple of 4 (got %lld)", (long long)n);
+    if (!aligned16(x) || !aligned8(hi) || !aligned8(lo)) VITK_FAIL(VITK_E_ALIGN, "split2: x must be 16-byte, hi / lo 8-byte aligned");
+    long long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)hi, (__bf16*)lo, (long long)(n / 4));
+    VITK_CHECK_LAUNCH("split2");
+    return 0;
+}

@@ -7,7 +7,7 @@ return immediately.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -194,6 +194,22 @@ def attn_bwd_bf16(q: BHND, k: BHND, v: BHND, o: BHND, dout: BHND, lse: Tensor, d
     check(_lib_for(q, k, v, o, dout, lse, delta, dq, dk, dv).vitk_attn_bwd_bf16_drop(q, k, v, o, dout, _p(lse), _p(delta), dq, dk, dv, B, H, N, d, scale,
                                                                                     drop_p, drop_seed & 0xffffffff, _stream()),
           "attn_bwd_bf16")
+
+
+def split2(x: Tensor, hi: Tensor, lo: Tensor):
+    """f32 tensor -> hi + lo 16-bit terms (operands of the f32-accurate attention flavour)."""
+    check(_lib_for(hi, lo).vitk_split2(_p(x), _p(hi), _p(lo), x.numel(), _stream()), "split2")
+
+
+def attn_fwd_x2(q: Tuple[BHND, BHND], k: Tuple[BHND, BHND], v: Tuple[BHND, BHND], o: BHND, lse: Tensor, B: int, H: int, N: int, d: int,
+                scale: float):
+    check(_lib_for(q[0], k[0], v[0]).vitk_attn_fwd_x2(q[0], q[1], k[0], k[1], v[0], v[1], o, _p(lse), B, H, N, d, scale, _stream()), "attn_fwd_x2")
+
+
+def attn_bwd_x2(q: Tuple[BHND, BHND], k: Tuple[BHND, BHND], v: Tuple[BHND, BHND], o: BHND, dout: Tuple[BHND, BHND], lse: Tensor,
+                delta: Tensor, dq: BHND, dk: BHND, dv: BHND, B: int, H: int, N: int, d: int, scale: float):
+    check(_lib_for(q[0], k[0], v[0]).vitk_attn_bwd_x2(q[0], q[1], k[0], k[1], v[0], v[1], o, dout[0], dout[1], _p(lse), _p(delta), dq, dk, dv,
+                                                      B, H, N, d, scale, _stream()), "attn_bwd_x2")
 
 
 def softmax_fwd(s: Tensor, p: Tensor, rows: int, cols: int, scale: float):
