@@ -19,7 +19,14 @@ Extra objects in the line:
                 bias+GELU epilogue, 50,432 x 3072 x 768): algorithmic FLOPs per launch / mean launch duration
                 measured live with HIP events on the launch stream; peak = 2516.6 TFLOP/s dense bf16 MFMA.
                 `traffic` is STATIC (profiles/rNN_pmc_traffic.json, see `traffic_source`); `other_kernels` holds the
-                dFF1 GEMM (GELU' epilogue), the NT GEMM furthest below its roof.
+                dFF1 GEMM (GELU' epilogue), the NT GEMM furthest below its roof.  Both are timed in extra steps with the
+                weight-gradient side stream OFF (`timed_in`): beside a concurrent dW GEMM a launch's duration measures the
+                contention, not the kernel (round 2's line reported 0.596 ms for a 0.317 ms kernel that way).
+  weight_cache_rebuild_ms
+                the timed steady state never changes the weights, so the K-blocked / transposed weight copies are built once;
+                a real training step (optimizer after every backward) rebuilds them every step.  This is the extra time of ONE
+                step right after `invalidate_weight_caches()` (what every step of a real run pays), measured after the timed
+                region: `ms_per_step + weight_cache_rebuild_ms` is the fwd+bwd time inside a training loop.
   model         whole-step algorithmic TFLOP/s (105.383 GF/img for ViT-B/16) and its fraction of peak.
   cpu_baseline  the CPU oracle (oracle/vit_oracle.py, kind "port") timed on this host's cores on a bounded
                 sample of the same workload (same model, f32, batch 32, best of a thread sweep), rank 0 at N = 1 only.
@@ -93,12 +100,18 @@ def time_dominant_kernel(step_fn, nsteps: int = 3):
         return bracket("dff1", 2.0 * a[6] * a[7] * a[8], orig_bwd, a, kw)
 
     K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum = tapped_nt, tapped_bwd
+    prev = os.environ.get("VITK_DW_STREAM")
+    os.environ["VITK_DW_STREAM"] = "0"          # serialized: engine._Fork reads it per backward
     try:
         for _ in range(nsteps):
             step_fn()
         torch.cuda.synchronize()
     finally:
         K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum = orig_nt, orig_bwd
+        if prev is None:
+            os.environ.pop("VITK_DW_STREAM", None)
+        else:
+            os.environ["VITK_DW_STREAM"] = prev
     out = {}
     for key, tl in taps.items():
         if tl:
@@ -106,7 +119,7 @@ def time_dominant_kernel(step_fn, nsteps: int = 3):
     return out
 
 
-TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def pmc_traffic_bytes():
@@ -168,12 +181,62 @@ def cpu_baseline(cfg, budget_s: float = 30.0):
                       f"({time.perf_counter() - t_begin:.0f} s in total)"}
 
 
+def bench_navit(args, dev):
+    """BASELINE config 4 (`--config navit`): a packed variable-resolution batch -- images a*16 x b*16 px with a, b ~ U{4..40}
+    (64-640 px) until ~32k tokens, grouped into packs of <= 4096 tokens, NaViT dim 1024 / depth 24 / heads 16 / mlp 4096, bf16,
+    forward + cross-entropy + backward.  One JSON line; the metric is tokens/s (images/s alongside), single GPU only."""
+    import numpy as np
+    from vit_pytorch_amd.na_vit import NaViT
+    rng = np.random.default_rng(0)
+    sizes, tok = [], 0
+    while tok < 32768:
+        a, b = rng.integers(4, 41, 2)
+        sizes.append((int(a) * 16, int(b) * 16)); tok += int(a) * int(b)
+    depth, D, F, H, I = 24, 1024, 4096, 16, 1024
+    torch.manual_seed(0)
+    m = NaViT(image_size=1024, patch_size=16, num_classes=1000, dim=D, depth=depth, heads=H, mlp_dim=F).to(dev, dtype=torch.bfloat16)
+    imgs = [torch.randn(3, h, w, device=dev).to(torch.bfloat16) for h, w in sizes]
+    labels = torch.randint(0, 1000, (len(imgs),), device=dev)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        out = m(imgs, group_images=True, group_max_seq_len=4096)
+        torch.nn.functional.cross_entropy(out.float(), labels).backward()
+
+    for _ in range(args.warmup):
+        step()
+    dts = []
+    for _ in range(max(1, args.repeats)):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[len(dts) // 2] / args.steps
+    lens = [(h // 16) * (w // 16) for h, w in sizes]
+    gemm = depth * tok * (2 * D * 3 * I + 2 * I * D + 4 * D * F)
+    attn = depth * sum(4 * H * n * n * 64 for n in lens)
+    tf = 3 * (gemm + attn) / dt / 1e12
+    print(json.dumps({
+        "metric": "tokens/sec (fwd+bwd) NaViT packed variable-resolution batch, bf16", "value": round(tok / dt, 1), "unit": "tokens/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
+        "ms_per_step_all": [round(d / args.steps * 1e3, 3) for d in dts], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (randn images of random sizes, randint labels, random-init weights)",
+        "config": {"workload": f"navit dim {D} depth {depth} heads {H} mlp {F}: {len(imgs)} images of 64-640 px, {tok} tokens, packs of <= 4096 tokens, "
+                               "cross-entropy loss, no optimizer", "images": len(imgs), "tokens": tok, "max_tokens_per_image": max(lens), "parallelism": "dp1"},
+        "images_per_s": round(len(imgs) / dt, 2),
+        "model": {"tflops_per_gpu": round(tf, 2), "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4),
+                  "attention_share_of_flops": round(attn / (gemm + attn), 4)},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="vit_b16", choices=list(CONFIGS))
+    ap.add_argument("--config", default="vit_b16", choices=list(CONFIGS) + ["navit"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (invalidates the headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=3,
@@ -191,6 +254,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.config == "navit":
+        if world > 1:
+            raise SystemExit("--config navit is a single-GPU benchmark")
+        bench_navit(args, dev)
+        return
 
     from vit_pytorch_amd import ViT
     from vit_pytorch_amd.parallel import DataParallel
@@ -240,6 +309,21 @@ def main():
     assert torch.isfinite(loss).item(), "loss is not finite"
     taps = time_dominant_kernel(step)      # every rank: the steps contain the collectives
 
+    # one step with every weight-derived cache invalidated (= what each step of a real training loop pays) vs a steady step
+    from vit_pytorch_amd import invalidate_weight_caches
+
+    def one_step_ms(invalidate: bool) -> float:
+        sync()
+        if invalidate:
+            invalidate_weight_caches()
+        t0 = time.perf_counter()
+        step()
+        sync()
+        return (time.perf_counter() - t0) * 1e3
+    one_step_ms(False)
+    rebuild = [one_step_ms(True) - one_step_ms(False) for _ in range(3)]
+    weight_cache_rebuild_ms = sorted(rebuild)[1]
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         total_imgs = batch * world * args.steps
@@ -258,7 +342,8 @@ def main():
         line = {
             "metric": "images/sec (fwd+bwd) ViT-B/16 224^2 bf16" if args.config == "vit_b16" else f"images/sec (fwd+bwd) {args.config} bf16",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "ms_per_step_all": [round(d / args.steps * 1e3, 3) for d in dts], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 3), "ms_per_step_all": [round(d / args.steps * 1e3, 3) for d in dts],
+            "weight_cache_rebuild_ms": round(weight_cache_rebuild_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (randn images, randint labels, random-init weights)",
             "memory": {"peak_allocated_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                        "peak_reserved_gib": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
@@ -272,6 +357,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_ntp_kernel<EPI_BIAS_GELU> (persistent NT GEMM, FF1: tokens x mlp_dim x dim at this batch)",
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(kms, 4), "launches_timed": klaunches,
+                         "timed_in": "3 extra steps after the timed region, weight-gradient side stream off (serialized launches)",
                          "traffic": traffic, "traffic_source": traffic_src, "other_kernels": others},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -164,3 +164,42 @@ def test_gpu_only_helpers_refuse_cpu_models():
         GraphedForward(m, torch.zeros(1, 3, 32, 32))
     with pytest.raises(TypeError):
         Adam(m)
+
+
+def test_dropout_seed_state_survives_deepcopy_and_old_pickles():
+    """the per-instance dropout sequence state is plain instance state -- a deepcopy must not share its source's salt (an
+    EMA / teacher copy would draw the same masks) and a module unpickled without the attributes must not raise."""
+    import copy
+    from vit_pytorch_amd.vit import Transformer
+    t = Transformer(64, 2, 2, 32, 128, dropout=0.1)
+    t2 = copy.deepcopy(t)
+    assert t2._drop_state()[1] != t._drop_state()[1]
+    assert [k for k, _ in t2.state_dict().items()] == [k for k, _ in t.state_dict().items()]
+    del t.__dict__["_drop_salt"], t.__dict__["_drop_calls"]            # what an old pickle looks like
+    calls, salt = t._drop_state()
+    assert calls == 0 and salt not in (t2._drop_state()[1],)
+
+
+def test_caller_grad_mode_is_thread_local_and_defaults_to_on():
+    import threading
+    from vit_pytorch_amd import _epoch as E
+    E.note_grad_mode(False)
+    seen = []
+    th = threading.Thread(target=lambda: seen.append(E.caller_grad_mode()))
+    th.start(); th.join()
+    assert seen == [True] and E.caller_grad_mode() is False
+    E.note_grad_mode(True)
+
+
+def test_weight_cache_switches(monkeypatch):
+    import torch
+    from vit_pytorch_amd import _epoch as E, invalidate_weight_caches
+    w = torch.nn.Parameter(torch.zeros(4, 4))
+    k0 = E.weight_key(w)
+    assert E.weight_key(w) == k0
+    w.data.add_(1)                       # invisible to torch's version counter ...
+    assert E.weight_key(w) == k0
+    invalidate_weight_caches()           # ... hence the explicit call
+    assert E.weight_key(w) != k0
+    monkeypatch.setenv("VITK_WEIGHT_CACHE", "0")
+    assert E.weight_key(w) != E.weight_key(w)

@@ -15,6 +15,9 @@ def __getattr__(name):
     if name == "SimpleViT":
         from .simple_vit import SimpleViT
         return SimpleViT
+    if name == "invalidate_weight_caches":   # after raw `.data` writes to parameters (see _epoch.py)
+        from ._epoch import invalidate_weight_caches
+        return invalidate_weight_caches
     if name == "NaViT":   # reference: `from vit_pytorch.na_vit import NaViT` (README.md:154)
         from .na_vit import NaViT
         return NaViT

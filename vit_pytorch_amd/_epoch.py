@@ -13,5 +13,36 @@ def bump_weights_epoch() -> None:
     _EPOCH[0] += 1
 
 
+_NOCACHE = [0]
+
+
 def weight_key(w):
+    import os
+    if os.environ.get("VITK_WEIGHT_CACHE", "1") == "0":       # never equal to a stored key: every use re-derives the copies
+        _NOCACHE[0] += 1
+        return (w.data_ptr(), w._version, _EPOCH[0], tuple(w.shape), w.dtype, _NOCACHE[0])
     return (w.data_ptr(), w._version, _EPOCH[0], tuple(w.shape), w.dtype)
+
+
+def invalidate_weight_caches() -> None:
+    """Call after writing parameter VALUES behind torch's back -- `p.data.mul_()`, `p.data.copy_()`, `dist.broadcast(p.data)`, a raw
+    pointer write: `tensor.data` views do not bump `p._version`, so the caches keyed on it (K-blocked / transposed / split / e4m3
+    weight copies) would keep serving the old values.  `load_state_dict`, optimizers and every in-place op ON THE PARAMETER ITSELF
+    are seen without it.  `VITK_WEIGHT_CACHE=0` disables the caches altogether (every call re-derives its copies: debugging)."""
+    bump_weights_epoch()
+
+
+# ---- grad mode of the CALLER of a fused autograd.Function -------------------------------------------------------------
+# Inside autograd.Function.forward torch.is_grad_enabled() is always False and ctx.needs_input_grad mirrors requires_grad even under
+# torch.no_grad(), so the module-level caller records the mode here (thread-local) right before .apply().
+import threading as _threading
+
+_TLS = _threading.local()
+
+
+def note_grad_mode(enabled: bool) -> None:
+    _TLS.grad = bool(enabled)
+
+
+def caller_grad_mode() -> bool:
+    return getattr(_TLS, "grad", True)

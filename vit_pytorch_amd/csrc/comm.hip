@@ -8,8 +8,23 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <string.h>
-#include <rccl/rccl.h>
 #include <mutex>
+#include <string>
+
+// The handful of RCCL (= NCCL API) declarations used here, stated locally so that libvitk builds on hosts without the RCCL
+// headers (the library is dlopen'ed, never linked).  Values are those of rccl.h (NCCL ABI: stable across 2.x).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclAvg = 4 } ncclRedOp_t;
+typedef enum { ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat = 7, ncclBfloat16 = 9 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char* ncclGetErrorString(ncclResult_t result);
+}
 
 namespace {
 
@@ -21,6 +36,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) destroy = nullptr;
     decltype(&ncclGetErrorString) err = nullptr;
     bool ok = false;
+    std::string why;        // dlerror() text captured ONCE where dlopen failed (a second dlerror() call returns NULL)
 };
 
 const Rccl& rccl() {
@@ -30,6 +46,8 @@ const Rccl& rccl() {
         for (const char* name : {"librccl.so.1", "librccl.so"}) {
             r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.h) break;
+            const char* e = dlerror();
+            r.why = e ? e : "dlopen failed";
         }
         if (!r.h) return;
         r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.h, "ncclGetUniqueId");
@@ -38,6 +56,7 @@ const Rccl& rccl() {
         r.destroy = (decltype(r.destroy))dlsym(r.h, "ncclCommDestroy");
         r.err = (decltype(r.err))dlsym(r.h, "ncclGetErrorString");
         r.ok = r.get_unique_id && r.init_rank && r.all_reduce && r.destroy && r.err;
+        if (!r.ok) r.why = "symbols missing";
     });
     return r;
 }
@@ -46,7 +65,7 @@ struct Comm { ncclComm_t c; int rank, world; };
 
 }  // namespace
 
-#define VITK_RCCL_OR_FAIL(R) do { if (!(R).ok) VITK_FAIL(VITK_E_UNAVAILABLE, "vitk_comm: librccl.so.1 could not be opened (%s)", dlerror() ? dlerror() : "symbols missing"); } while (0)
+#define VITK_RCCL_OR_FAIL(R) do { if (!(R).ok) VITK_FAIL(VITK_E_UNAVAILABLE, "vitk_comm: librccl.so.1 could not be opened (%s)", (R).why.c_str()); } while (0)
 #define VITK_RCCL_CALL(R, expr, what) do { const ncclResult_t rc__ = (expr); if (rc__ != ncclSuccess) VITK_FAIL(VITK_E_COMM, "%s: %s", what, (R).err(rc__)); } while (0)
 
 extern "C" int vitk_comm_unique_id(void* out128) {

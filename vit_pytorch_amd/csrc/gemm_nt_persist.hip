@@ -82,6 +82,41 @@ template <int N_> __device__ __forceinline__ void q_wait_vm() {
     else static_assert(N_ < 0, "unsupported vmcnt");
 }
 
+// ---- epilogue operand loads the compiler does not count (interior tiles) ---------------------------------------------------
+// hipcc waits vmcnt(0) for an ordinary VGPR-destination load whenever an LDS-DMA is in flight -- and in this kernel one always is
+// (the next tile's first K-steps).  CDNA4's vmcnt counts stores too and retires in order, so every use of a residual row (f32
+// residual epilogue) or of a saved pre-activation row (GELU' epilogue) drained the ring AND waited for the completion of every
+// store issued so far: a write round trip per fragment row, 4-8 of them per tile [the ISA showed vmcnt(0) / vmcnt(1) in front of
+// every second row; FF2 + residual: ~26 us of epilogue per 256 x 256 tile against ~9 us of store issue].  Issued here as asm
+// and waited for by an EXACT count: D fragment rows are in flight, and the stores issued after a row's loads may stay in flight.
+// (Form (ii) of the guide's 5.7: "=v" loads, then a wait statement naming every destination "+v"; the epilogue is straight-line
+// code, so no destination is loop-carried; tools/asm_inflight_audit.py checks the .s for compiler accesses in between.)
+#ifndef Q_EPI_DEPTH_RESID
+#define Q_EPI_DEPTH_RESID 3      // fragment rows of the residual in flight (16 VGPRs each)
+#endif
+#ifndef Q_EPI_DEPTH_PRE
+#define Q_EPI_DEPTH_PRE 2        // fragment rows of the saved pre-activation in flight (8 VGPRs each)
+#endif
+__device__ __forceinline__ void q_gload_f32x4(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void q_gload_bf16x8(bf16x8& d, const __bf16* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// ops issued between the loads of fragment row f and their wait: PER_F loads + PER_F stores per row, D rows of loads in flight
+__host__ __device__ constexpr int q_epi_younger(int f, int fmw, int d, int per_f) {
+    const int last = f + d - 1 < fmw - 1 ? f + d - 1 : fmw - 1;
+    return per_f * ((last - f) + (f < d ? f : d - 1));
+}
+#define Q_WAIT_CASE(n) else if constexpr (N_ == n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+template <int N_, typename T> __device__ __forceinline__ void q_wait_regs4(T& a, T& b, T& c, T& d) {
+    if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
+    Q_WAIT_CASE(4); Q_WAIT_CASE(6); Q_WAIT_CASE(8); Q_WAIT_CASE(10); Q_WAIT_CASE(12); Q_WAIT_CASE(16); Q_WAIT_CASE(20); Q_WAIT_CASE(24);
+    else static_assert(N_ < 0, "unsupported vmcnt");
+}
+#define Q_WAIT2_CASE(n) else if constexpr (N_ == n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b) :: "memory")
+template <int N_, typename T> __device__ __forceinline__ void q_wait_regs2(T& a, T& b) {
+    if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) :: "memory");
+    Q_WAIT2_CASE(2); Q_WAIT2_CASE(4); Q_WAIT2_CASE(6); Q_WAIT2_CASE(8); Q_WAIT2_CASE(10); Q_WAIT2_CASE(12);
+    else static_assert(N_ < 0, "unsupported vmcnt");
+}
+
 // 8-wide forms of common.h's gelu_fast2 / gelu_grad_fast2 (same polynomial, same operation order per element): written on
 // 8-vectors so that every Horner step is four INDEPENDENT v_pk_fma_f32 -- the 2-wide form compiled to one dependent chain
 // per pair with a stall slot after every step.
@@ -445,33 +480,70 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                 // lane: rows mrow0 + 16 f + j, 4 consecutive f32 columns: 16 lanes = 256 contiguous bytes of a row
                 const bool colok = INT || ncol4 < p.N;
                 float* Cf = reinterpret_cast<float*>(p.C);
-                f32x4 r[2][4];
-                auto fetch = [&](int f, f32x4 (&dst)[4]) {
+                if constexpr (INT) {
+                    // interior tile: residual rows by uncounted asm loads, D fragment rows ahead, exact-count waits (see q_gload_f32x4)
+                    constexpr int D = Q_EPI_DEPTH_RESID;
+                    f32x4 r[D][4];
+                    const float* rp = p.resid + (long long)mrow0 * p.ldc + ncol4;
+                    auto fetch = [&](int f, f32x4 (&dst)[4]) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int m = mrow0 + f * 16 + j;
-                        if (!INT) m = m < p.M ? m : p.M - 1;
-                        dst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (colok) dst[j] = *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldc + ncol4);
-                    }
-                };
-                fetch(0, r[0]);
-                fetch(1, r[1]);
+                        for (int j = 0; j < 4; ++j) q_gload_f32x4(dst[j], rp + (long long)(f * 16 + j) * p.ldc);
+                    };
 #pragma unroll
-                for (int f = 0; f < FMW; ++f) {
+                    for (int f = 0; f < D; ++f) fetch(f, r[f]);
+                    auto row = [&](auto fc) {
+                        constexpr int f = decltype(fc)::value;
+                        f32x4 (&rr)[4] = r[f % D];
+                        q_wait_regs4<q_epi_younger(f, FMW, D, 4)>(rr[0], rr[1], rr[2], rr[3]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = mrow0 + f * 16 + j;
-                        f32x4 v = f32x4{acc[0][f][j], acc[1][f][j], acc[2][f][j], acc[3][f][j]} + b4;
-                        if (p.drop_t) {       // nn.Dropout on the Linear output, before the residual add (vit.py:24,48 + :80-81)
-                            const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+                        for (int j = 0; j < 4; ++j) {
+                            const int m = mrow0 + f * 16 + j;
+                            f32x4 v = f32x4{acc[0][f][j], acc[1][f][j], acc[2][f][j], acc[3][f][j]} + b4;
+                            if (p.drop_t) {       // nn.Dropout on the Linear output, before the residual add (vit.py:24,48 + :80-81)
+                                const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = drop_keep(hrow, (unsigned)(ncol4 + e), p.drop_t) ? v[e] * p.inv_keep : 0.f;
+                                for (int e = 0; e < 4; ++e) v[e] = drop_keep(hrow, (unsigned)(ncol4 + e), p.drop_t) ? v[e] * p.inv_keep : 0.f;
+                            }
+                            v += rr[j];
+                            *reinterpret_cast<f32x4*>(Cf + (long long)m * p.ldc + ncol4) = v;
                         }
-                        v += r[f & 1][j];
-                        if (INT || (m < p.M && colok)) *reinterpret_cast<f32x4*>(Cf + (long long)m * p.ldc + ncol4) = v;
+                        if constexpr (f + D < FMW) fetch(f + D, rr);
+                    };
+                    row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
+                    row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+                    if constexpr (FMW == 8) {
+                        row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{});
+                        row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
                     }
-                    if (f + 2 < FMW) fetch(f + 2, r[f & 1]);
+                } else {
+                    f32x4 r[2][4];
+                    auto fetch = [&](int f, f32x4 (&dst)[4]) {
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int m = mrow0 + f * 16 + j;
+                            if (!INT) m = m < p.M ? m : p.M - 1;
+                            dst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (colok) dst[j] = *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldc + ncol4);
+                        }
+                    };
+                    fetch(0, r[0]);
+                    fetch(1, r[1]);
+    #pragma unroll
+                    for (int f = 0; f < FMW; ++f) {
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int m = mrow0 + f * 16 + j;
+                            f32x4 v = f32x4{acc[0][f][j], acc[1][f][j], acc[2][f][j], acc[3][f][j]} + b4;
+                            if (p.drop_t) {       // nn.Dropout on the Linear output, before the residual add (vit.py:24,48 + :80-81)
+                                const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+    #pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = drop_keep(hrow, (unsigned)(ncol4 + e), p.drop_t) ? v[e] * p.inv_keep : 0.f;
+                            }
+                            v += r[f & 1][j];
+                            if (INT || (m < p.M && colok)) *reinterpret_cast<f32x4*>(Cf + (long long)m * p.ldc + ncol4) = v;
+                        }
+                        if (f + 2 < FMW) fetch(f + 2, r[f & 1]);
+                    }
                 }
             } else {
                 // after the pair exchange: even lanes own row r = mrow0 + 16 f + 2 pr, odd lanes row r + 1, columns ncol8 .. + 7
@@ -479,25 +551,33 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                 const int ncol8 = n0 + wn * 64 + 8 * (fi >> 1);
                 const bool colok = INT || ncol8 < p.N;
                 __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
-                bf16x8 hpre[2][2];             // GELU_BWD: saved pre-activations, fetched two fragment rows ahead
+                // GELU_BWD: saved pre-activations, fetched DP fragment rows ahead.  Interior tiles: uncounted asm loads + exact-count
+                // waits (see q_gload_f32x4); per fragment row 2 loads and 2 stores
+                constexpr bool ASM_PRE = (EPI == VITK_EPI_GELU_BWD) && INT;
+                constexpr int DP = ASM_PRE ? Q_EPI_DEPTH_PRE : 2;
+                bf16x8 hpre[DP][2];
                 auto fetch_pre = [&](int f, bf16x8 (&dst)[2]) {
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         int m = mrow0 + f * 16 + 2 * pr + odd;
-                        if (!INT) m = m < p.M ? m : p.M - 1;
-                        dst[pr] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                        if (colok) dst[pr] = *reinterpret_cast<const bf16x8*>(p.aux + (long long)m * p.ldc + ncol8);
+                        if constexpr (ASM_PRE) q_gload_bf16x8(dst[pr], p.aux + (long long)m * p.ldc + ncol8);
+                        else {
+                            if (!INT) m = m < p.M ? m : p.M - 1;
+                            dst[pr] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                            if (colok) dst[pr] = *reinterpret_cast<const bf16x8*>(p.aux + (long long)m * p.ldc + ncol8);
+                        }
                     }
                 };
                 if constexpr (EPI == VITK_EPI_GELU_BWD) {
-                    fetch_pre(0, hpre[0]);
-                    fetch_pre(1, hpre[1]);
+#pragma unroll
+                    for (int f = 0; f < DP; ++f) fetch_pre(f, hpre[f]);
                 }
                 float cs[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) cs[e] = 0.f;
-#pragma unroll
-                for (int f = 0; f < FMW; ++f) {
+                auto frow = [&](auto fc) {
+                    constexpr int f = decltype(fc)::value;
+                    if constexpr (ASM_PRE) q_wait_regs2<q_epi_younger(f, FMW, DP, 2)>(hpre[f % DP][0], hpre[f % DP][1]);
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         // rows j0 = 2 pr and j0 + 1 of this lane's 4 columns, rounded to the 16-bit type
@@ -527,7 +607,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                             }
                             if (ok) *reinterpret_cast<bf16x8*>(Cb + o) = g8;
                         } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
-                            const bf16x8 h8 = hpre[f & 1][pr];
+                            const bf16x8 h8 = hpre[f % DP][pr];
                             q_f32x8 g = q_widen8(v) * q_gelu_grad8(q_widen8(h8));
                             if (p.drop_t) {     // factor of the forward's dropout(gelu(pre)) at (m, n): same decision, same 1 / (1 - p)
                                 const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
@@ -543,8 +623,14 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                         }
                     }
                     if constexpr (EPI == VITK_EPI_GELU_BWD) {
-                        if (f + 2 < FMW) fetch_pre(f + 2, hpre[f & 1]);
+                        if constexpr (f + DP < FMW) fetch_pre(f + DP, hpre[f % DP]);
                     }
+                };
+                frow(std::integral_constant<int, 0>{}); frow(std::integral_constant<int, 1>{});
+                frow(std::integral_constant<int, 2>{}); frow(std::integral_constant<int, 3>{});
+                if constexpr (FMW == 8) {
+                    frow(std::integral_constant<int, 4>{}); frow(std::integral_constant<int, 5>{});
+                    frow(std::integral_constant<int, 6>{}); frow(std::integral_constant<int, 7>{});
                 }
                 if constexpr (EPI == VITK_EPI_GELU_BWD) {
                     if (p.csum) {

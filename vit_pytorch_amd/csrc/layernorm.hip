@@ -6,6 +6,7 @@
 // Algorithmic bytes per row: D*(sizeof(x)+sizeof(y)) forward; backward reads dy and x and
 // writes dx (f32 and/or T).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -16,7 +17,14 @@ constexpr int LNB_THREADS = 512;
 constexpr int LNB_WAVES = LNB_THREADS / WAVE;
 constexpr int LNB_MAX_BLOCKS = 512;   // two 8-wave blocks per CU: all resident at once; 1024 measured the same kernel time and doubles the partial rows the finalize reads
 
-template <typename XT, typename YT, typename WT, int MAXC>
+// streamed-once row loads (the LayerNorm backward gained 123 -> 99 us from the same hint)
+template <typename T> __device__ __forceinline__ f32x4 load4_nt(const T* p);
+template <> __device__ __forceinline__ f32x4 load4_nt<float>(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+template <> __device__ __forceinline__ f32x4 load4_nt<__bf16>(const __bf16* p) {
+    const bf16x4 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p));
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename XT, typename YT, typename WT, int MAXC, bool NT>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     const XT* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b,
     YT* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
         for (int t = 0; t < MAXC; ++t) {
             const int c = lane + 64 * t;
             if (c < nchunk) {
-                v[t] = load4<XT>(xr + 4 * c);
+                if constexpr (NT) v[t] = load4_nt<XT>(xr + 4 * c); else v[t] = load4<XT>(xr + 4 * c);
                 s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
             }
         }
@@ -538,8 +546,14 @@ int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* m
         VITK_CHECK_LAUNCH("layernorm_fwd");
         return 0;
     }
-#define LN_FWD_CASE(MC) hipLaunchKernelGGL((ln_fwd_kernel<XT, YT, WT, MC>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, \
-        (const XT*)x, (const WT*)w, (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao, f8)
+    // nontemporal row loads (VITK_LN_FWD_NT=1): [measured, round 3] no gain here, unlike the backward -- two interleaved bench runs
+    // 39.2-39.5 ms with the hint vs 39.2-39.3 without (the forward's rows are re-read soon, by the residual epilogue); left opt-in
+    const char* nt_env = getenv("VITK_LN_FWD_NT");
+    const bool nt = rows >= 4096 && nt_env && nt_env[0] == '1';
+#define LN_FWD_CASE(MC) do { if (nt) hipLaunchKernelGGL((ln_fwd_kernel<XT, YT, WT, MC, true>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, \
+        (const XT*)x, (const WT*)w, (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao, f8); \
+    else hipLaunchKernelGGL((ln_fwd_kernel<XT, YT, WT, MC, false>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, \
+        (const XT*)x, (const WT*)w, (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao, f8); } while (0)
     if (maxc <= 1) LN_FWD_CASE(1);
     else if (maxc <= 3) LN_FWD_CASE(3);
     else if (maxc <= 4) LN_FWD_CASE(4);

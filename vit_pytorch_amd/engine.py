@@ -35,6 +35,7 @@ from . import kernels as K
 from . import ops
 from . import _lib as L
 from ._lib import RowMap, VitkError
+from ._epoch import caller_grad_mode
 
 Tensor = torch.Tensor
 F32 = torch.float32
@@ -207,7 +208,8 @@ class TransformerFn(torch.autograd.Function):
             xs = ops.empty((B, N, D), F32, x)
             K.cast(x, xs)
         saved = []
-        keep = any(ctx.needs_input_grad)      # no_grad / eval: drop each layer's activations as soon as the layer is done
+        keep = any(ctx.needs_input_grad) and caller_grad_mode()      # no_grad / eval: drop each layer's activations as soon as the layer is done
+        # (needs_input_grad mirrors requires_grad even under torch.no_grad(): the module-level caller records the real mode, _epoch.py)
         esz = 4 if T == F32 else 2
         Fh0 = lp[7].shape[0] if depth else 0
         per_layer = M * (2 * D * 4 + (2 * D + 4 * I + 2 * Fh0) * esz)          # xs, x2 (f32) + a1, a2, qkv, o, pre, act
@@ -578,11 +580,33 @@ def pack_navit_layer_params(attn, ff) -> List[Tensor]:
             attn.to_out[0].weight, ff[0].gamma, ff[1].weight, ff[1].bias, ff[4].weight, ff[4].bias]
 
 
+_CAT_CACHE = {}     # (id(a), id(b)) -> (weakref a, weakref b, weight_key a, weight_key b, concatenated Parameter)
+
+
 def _cat_rows(a: Tensor, b: Tensor) -> Tensor:
+    """to_q | to_kv as ONE (3I, D) weight (na_vit.py:125-126 keeps them apart; one GEMM serves both).  Cached per parameter VALUE and
+    returned as a (frozen) Parameter, so that ops.nt_weight gives it the K-blocked copies and the cached transpose every other
+    Linear weight gets -- it used to be rebuilt by two cast launches per layer per forward, and, not being a Parameter, fed the
+    QKV / dX GEMMs from the slower row-major layout and re-transposed every step.  Never cached during HIP-graph capture."""
+    import weakref
+    from ._epoch import weight_key
+    capturing = torch.cuda.is_current_stream_capturing()
+    cacheable = not capturing and isinstance(a, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter)
+    k = (id(a), id(b))
+    if cacheable:
+        ka, kb = weight_key(a), weight_key(b)
+        ent = _CAT_CACHE.get(k)
+        if ent is not None and ent[0]() is a and ent[1]() is b and ent[2] == ka and ent[3] == kb:
+            return ent[4]
     out = torch.empty((a.shape[0] + b.shape[0], a.shape[1]), dtype=a.dtype, device=a.device)
     K.cast(a, out[:a.shape[0]])
     K.cast(b, out[a.shape[0]:])
-    return out
+    if not cacheable:
+        return out
+    outp = torch.nn.Parameter(out, requires_grad=False)
+    drop = lambda _r, k=k: _CAT_CACHE.pop(k, None)
+    _CAT_CACHE[k] = (weakref.ref(a, drop), weakref.ref(b, drop), ka, kb, outp)
+    return outp
 
 
 class PackedTransformerFn(torch.autograd.Function):
@@ -604,7 +628,8 @@ class PackedTransformerFn(torch.autograd.Function):
             xs = ops.empty((Tn, D), F32, x)
             K.cast(x, xs)
         saved = []
-        keep = any(ctx.needs_input_grad)      # no_grad / eval: drop each layer's activations as soon as the layer is done
+        keep = any(ctx.needs_input_grad) and caller_grad_mode()      # no_grad / eval: drop each layer's activations as soon as the layer is done
+        # (needs_input_grad mirrors requires_grad even under torch.no_grad(): the module-level caller records the real mode, _epoch.py)
         for li in range(depth):
             ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
             a1 = ops.empty((Tn, D), T, xs)

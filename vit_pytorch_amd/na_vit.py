@@ -24,6 +24,7 @@ import numpy as np
 import torch
 from torch import nn, Tensor
 
+from ._epoch import note_grad_mode
 from . import functional as Fn
 from . import kernels as K
 from . import ops
@@ -81,7 +82,7 @@ class _QKNormAttnFn(torch.autograd.Function):
         d = I // heads
         T = q.dtype
         if d != 64:
-            raise VitkError(f"NaViT attention kernels need dim_head == 64 (got {d})")
+            raise VitkError(f"q / k RMSNorm attention (NaViT, simple_vit_with_qk_norm) needs dim_head == 64 in every dtype (got {d}): vitk_rmsnorm_heads_* are written for it")
         qn = torch.empty_like(q); kn = torch.empty((Tk, I), dtype=T, device=q.device)
         rq = torch.empty(Tq * heads, dtype=F32, device=q.device); rk = torch.empty(Tk * heads, dtype=F32, device=q.device)
         gqf, gkf = gq.reshape(heads, d).contiguous(), gk.reshape(heads, d).contiguous()
@@ -251,6 +252,27 @@ class Attention(nn.Module):
             Fn.Dropout(dropout),
         )
 
+    def _drop_state(self):
+        """(calls so far, per-instance salt) of the fused-dropout seed sequence.  Plain instance state: modules unpickled from an older
+        torch.save(model) lack it (defaults here), and copy.deepcopy re-salts (__deepcopy__) so that an EMA / teacher copy does not
+        draw the masks of its source."""
+        if "_drop_salt" not in self.__dict__:
+            self.__dict__["_drop_calls"] = 0
+            self.__dict__["_drop_salt"] = Attention._instances[0]
+            Attention._instances[0] += 1
+        return self.__dict__["_drop_calls"], self.__dict__["_drop_salt"]
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_drop_calls"] = 0
+        new.__dict__["_drop_salt"] = Attention._instances[0]
+        Attention._instances[0] += 1
+        return new
+
     def forward(self, x, segs: Segments, context=None):
         """x: (Tq, dim) packed query-side tokens; context: (Tk, dim) packed key-side tokens (default: x)."""
         x = self.norm(x)
@@ -260,8 +282,8 @@ class Attention(nn.Module):
         p, seed = 0.0, 0
         if self.training and self.dropout_p > 0.:       # F.scaled_dot_product_attention(dropout_p=...) of na_vit.py:163, in-kernel
             p = float(self.dropout_p)
-            seed = (int(torch.initial_seed()) + 0x9E3779B1 * self._drop_calls + 0x85EBCA6B * self._drop_salt + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
-            self._drop_calls += 1
+            seed = (int(torch.initial_seed()) + 0x9E3779B1 * self._drop_state()[0] + 0x85EBCA6B * self._drop_state()[1] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
+            self.__dict__["_drop_calls"] = self._drop_state()[0] + 1
         out = _QKNormAttnFn.apply(q, kv, self.q_norm.gamma, self.k_norm.gamma, segs, self.heads, p, seed)
         return self.to_out(out)
 
@@ -296,6 +318,7 @@ class Transformer(nn.Module):
             for attn, ff in self.layers:
                 params += E.pack_navit_layer_params(attn, ff)
             heads = self.layers[0][0].heads if len(self.layers) else 1
+            note_grad_mode(torch.is_grad_enabled())      # Function.forward cannot see no_grad(): it decides what to keep from this
             return E.PackedTransformerFn.apply(x, segs, heads, 64, self.norm.gamma, *params)
         for attn, ff in self.layers:
             x = Fn.AddFn.apply(attn(x, segs), x)

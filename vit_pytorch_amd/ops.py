@@ -22,7 +22,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from ._lib import IDENT, RowMap
-from ._epoch import weight_key
+from ._epoch import caller_grad_mode, weight_key
 from .segments import uniform_segments
 
 Tensor = torch.Tensor
@@ -216,7 +216,8 @@ def nt_weight(W: Tensor, M: int, transposed: bool):
     `transposed=True` -- dX = dY W (rows K, reduction N).  For shapes the persistent kernel serves, a K-blocked copy
     (vitk_pack_w_nt, ldw = 0) cached per parameter VALUE like the transposed copies (weight_key): the kernel's LDS-DMA then
     reads whole 128-byte lines of W (the 8 GEMM shapes of a ViT-B/16 layer: 1.70 -> 1.59 ms).  Both copies are made by one
-    call on the first forward use while gradients are enabled; never cached during HIP-graph capture."""
+    call on the first forward use while the CALLER has gradients enabled (_epoch.caller_grad_mode); never cached during HIP-graph
+    capture.  Raw `.data` writes to a parameter need `vit_pytorch_amd.invalidate_weight_caches()` (they do not bump `_version`)."""
     N, Kd = W.shape
     rows, red = (Kd, N) if transposed else (N, Kd)
     if (W.dtype in HALF and isinstance(W, torch.nn.Parameter) and W.is_contiguous() and red % 32 == 0 and packed_weights_on()
@@ -232,7 +233,8 @@ def nt_weight(W: Tensor, M: int, transposed: bool):
         idx = 3 if transposed else 2
         if ent[idx] is None:
             want_f = not transposed and Kd % 32 == 0
-            want_t = (transposed or (torch.is_grad_enabled() and W.requires_grad and ent[3] is None)) and N % 32 == 0
+            # (the caller's grad mode: torch.is_grad_enabled() is always False inside autograd.Function.forward, where this runs)
+            want_t = (transposed or (caller_grad_mode() and W.requires_grad and ent[3] is None)) and N % 32 == 0
             pf = empty((K.pack_w_nt_bytes(N, Kd) // 2,), W.dtype, W) if want_f else None
             pt = empty((K.pack_w_nt_bytes(Kd, N) // 2,), W.dtype, W) if want_t else None
             K.pack_w_nt(W, Kd, N, Kd, pf, pt)

@@ -260,6 +260,8 @@ class DataParallel(torch.nn.Module):
         if broadcast and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             for p in model.parameters():
                 dist.broadcast(p.data, src=0, group=process_group)
+            from ._epoch import invalidate_weight_caches
+            invalidate_weight_caches()      # `.data` writes do not bump p._version: K-blocked / transposed copies made by an earlier forward are stale
 
     def forward(self, *a, **kw):
         return self.module(*a, **kw)

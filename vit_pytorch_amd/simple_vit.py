@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from ._epoch import note_grad_mode
 from . import engine as E
 from . import functional as Fn
 from .vit import _has_fwd_hooks, pair
@@ -87,6 +88,7 @@ class Transformer(nn.Module):
                 x = Fn.AddFn.apply(ff(x), x)
             return self.norm(x)
         flat = [t for attn, ff in self.layers for t in E.pack_layer_params(attn, ff)]
+        note_grad_mode(torch.is_grad_enabled())      # Function.forward cannot see no_grad(): it decides what to keep from this
         return E.TransformerFn.apply(x, self._heads, self._dim_head, 0.0, 0, getattr(self, "_fp8", None),
                                      self.norm.weight, self.norm.bias, *flat)
 

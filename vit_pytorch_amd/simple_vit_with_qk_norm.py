@@ -7,7 +7,7 @@ and the 1 / sqrt(dim_head) score scale is dropped.  The reference's `linear_head
 `state_dict` keys and outputs are the contract.
 
 Kernels: the per-head RMSNorm (`vitk_rmsnorm_heads_*`) and the scale-1 attention are the ones NaViT uses (na_vit._QKNormAttnFn,
-chunked flash kernels over one segment per image; dim_head must be 64 in the 16-bit modes); LayerNorm / Linear / GELU / residual
+chunked flash kernels over one segment per image; dim_head must be 64 in every mode: the per-head RMSNorm kernels are written for it); LayerNorm / Linear / GELU / residual
 adds are the op-level Functions of functional.py.
 """
 from __future__ import annotations

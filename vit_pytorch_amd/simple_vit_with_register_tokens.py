@@ -33,11 +33,22 @@ class SimpleViT(nn.Module):
         self.to_latent = nn.Identity()
         self.linear_head = Fn.Linear(dim, num_classes)
 
+    def _pos_on(self, device, dtype):
+        """The sincos table with R zero rows in front (it is added to the patch tokens only), built ONCE per (device, dtype) -- the
+        reference converts / concatenates on every forward (simple_vit_with_register_tokens.py:139-142); no torch op on the data path."""
+        slot = self.__dict__.setdefault("_pos_cache", {})
+        key = (str(device), dtype)
+        if key not in slot:
+            slot.clear()
+            pos = self.pos_embedding.to(device, dtype=dtype)
+            R = self.register_tokens.shape[0]
+            slot[key] = torch.cat([pos.new_zeros(R, pos.shape[1]), pos], dim=0).contiguous()
+        return slot[key]
+
     def forward(self, img):
         x = self.to_patch_embedding(img)
         R = self.register_tokens.shape[0]
-        pos = self.pos_embedding.to(x.device, dtype=x.dtype)
-        pos = torch.cat([pos.new_zeros(R, pos.shape[1]), pos], dim=0)           # the table is added to the patch tokens only
+        pos = self._pos_on(x.device, x.dtype)
         x = Fn.ConcatTokensFn.apply(x, self.register_tokens, pos)               # (B, R + patches, dim)
         x = self.transformer(x)
         x = Fn.TokenSliceFn.apply(x, R) if R else x                             # unpack: the patch tokens

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 from torch.nn import Module, ModuleList
 
+from ._epoch import note_grad_mode
 from . import engine as E
 from . import functional as Fn
 
@@ -86,6 +87,27 @@ class Transformer(Module):
     # index (instance state: two models in one process neither interleave their sequences nor share masks); not in state_dict
     _instances = [0]
 
+    def _drop_state(self):
+        """(calls so far, per-instance salt) of the fused-dropout seed sequence.  Plain instance state: modules unpickled from an older
+        torch.save(model) lack it (defaults here), and copy.deepcopy re-salts (__deepcopy__) so that an EMA / teacher copy does not
+        draw the masks of its source."""
+        if "_drop_salt" not in self.__dict__:
+            self.__dict__["_drop_calls"] = 0
+            self.__dict__["_drop_salt"] = Transformer._instances[0]
+            Transformer._instances[0] += 1
+        return self.__dict__["_drop_calls"], self.__dict__["_drop_salt"]
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_drop_calls"] = 0
+        new.__dict__["_drop_salt"] = Transformer._instances[0]
+        Transformer._instances[0] += 1
+        return new
+
     def _dropout_p(self):
         """The common p of the block's active dropouts (0.0 if inactive); None if the modules disagree (a user edited them)."""
         if not self.training:
@@ -128,8 +150,9 @@ class Transformer(Module):
             p = self._dropout_p()
             seed = 0
             if p > 0.:
-                seed = (int(torch.initial_seed()) + 0x9E3779B1 * self._drop_calls + 0x85EBCA6B * self._drop_salt + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
-                self._drop_calls += 1
+                seed = (int(torch.initial_seed()) + 0x9E3779B1 * self._drop_state()[0] + 0x85EBCA6B * self._drop_state()[1] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
+                self.__dict__["_drop_calls"] = self._drop_state()[0] + 1
+            note_grad_mode(torch.is_grad_enabled())      # Function.forward cannot see no_grad(): it decides what to keep from this
             return E.TransformerFn.apply(x, self._heads, self._dim_head, float(p), seed, getattr(self, "_fp8", None), self.norm.weight, self.norm.bias, *params)
         x = Fn.cast(x, self.norm.weight.dtype)       # in the graph: the embedding stage may have produced an f32 stream
         for attn, ff in self.layers:
