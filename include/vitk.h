@@ -188,6 +188,12 @@ int vitk_fp8_update_scales(uint32_t* amax64, float* scales2, int64_t nslots, voi
  * the strided one).  Split over M into `splits` slabs of f32 partials (ws: splits*N*K floats),
  * then reduced into dW (dtype odt, ld = ldo; accumulate: dW += ...).  N % 8 == 0, K % 8 == 0.  */
 int64_t vitk_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
+/* CUs the weight-gradient GEMMs leave to other kernels (train_vit_decorr.py:74-78,109: the gradient all-reduce that overlaps the
+ * backward): vitk_gemm_tn_splits plans for 256 - cus workgroups.  Process-wide; 0 (default) = the whole chip.               */
+int vitk_set_cu_reserve(int cus);
+int vitk_get_cu_reserve(void);
+/* Test hook: hold `ncus` CUs for `ms` milliseconds on `stream` (a stand-in for a collective's resident kernel).            */
+int vitk_test_occupy_cus(int ncus, float ms, void* stream);
 int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int64_t ldx,
                       void* dW, int odt, int64_t ldo, int accumulate,
                       int64_t M, int64_t N, int64_t K, float* ws, int64_t splits, void* stream);

@@ -169,3 +169,28 @@ def test_k_blocked_weight_refused_where_the_persistent_kernel_does_not_run():
     C = torch.empty(M, N, dtype=BF, device=DEV)
     with pytest.raises(L.VitkError):
         K.gemm_nt_bf16(A, Kd, pf, 0, C, N, M, N, Kd)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(12608, 768, 768), (12608, 3072, 768), (12608, 768, 3072), (33000, 520, 256)])
+def test_dynamic_tickets_equal_static_lists(M, N, Kd, monkeypatch):
+    """Dynamic tile tickets (K >= 256; the default) and the static lists (VITK_NTP_STATIC=1) compute every tile the same way: all
+    epilogues bit-identical -- also while another kernel holds 40 CUs (vitk_test_occupy_cus), when the late workgroups of a
+    dynamic launch find the queues dry and the resident ones draw the other XCDs' tiles."""
+    A = rnd(M, Kd, dtype=BF, seed=41); W = (rnd(N, Kd, seed=42) * Kd ** -0.5).to(BF)
+    bias = rnd(N, dtype=BF, seed=43); resid = rnd(M, N, seed=44); h = rnd(M, N, dtype=BF, seed=45)
+    monkeypatch.setenv("VITK_NTP_STATIC", "1")
+    ref = _all_epilogues(M, N, Kd, A, W, bias, resid, h)
+    monkeypatch.delenv("VITK_NTP_STATIC")
+    got = _all_epilogues(M, N, Kd, A, W, bias, resid, h)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
+    hog = torch.cuda.Stream(priority=-1)
+    for _ in range(2):
+        L.check(L.load().vitk_test_occupy_cus(40, 3.0, hog.cuda_stream), "occupy")
+        torch.cuda._sleep(100000)
+        got = _all_epilogues(M, N, Kd, A, W, bias, resid, h)
+        torch.cuda.synchronize()
+        for k in ref:
+            if k != "part":                     # (the column-sum partial rows are per m-tile: same values, checked via their sum)
+                assert torch.equal(ref[k], got[k]), k
+        assert rel(got["part"].double().sum(0), ref["part"].double().sum(0)) < 1e-6

@@ -74,6 +74,9 @@ SIGNATURES = {
     "vitk_pack_w_nt": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_nt_bf16_gelu_bwd_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_tn_splits": (_i64, [_i64, _i64, _i64]),
+    "vitk_set_cu_reserve": (_i, [_i]),
+    "vitk_get_cu_reserve": (_i, []),
+    "vitk_test_occupy_cus": (_i, [_i, _f, _vp]),
     "vitk_gemm_tn_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _i64, _i64, _i64, _vp, _i64, _vp]),
     "vitk_gemm_generic": (_i, [Mat, Mat, Mat, _vp, _i, _i64, _i64, _i64, _i64, _i64, _f, _f, _vp]),
     "vitk_attn_fwd_bf16": (_i, [BHND, BHND, BHND, BHND, _vp, _i64, _i64, _i64, _i64, _f, _vp]),

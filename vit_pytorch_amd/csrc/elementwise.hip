@@ -590,6 +590,25 @@ extern "C" int vitk_quantize_fp8(const void* x, int dt, void* out, int64_t n, co
     return 0;
 }
 
+// ---- test hook: hold `ncus` CUs for `ms` milliseconds (one 1024-thread, 160 KiB-LDS workgroup per CU, sleeping on the 100 MHz
+// real-time counter) -- stands in for a collective's resident kernel when co-scheduling is measured on ONE GPU (tools/cu_contention.py)
+namespace {
+__global__ __launch_bounds__(1024) void occupy_kernel(long long ticks) {
+    extern __shared__ char hold[];
+    if (threadIdx.x == 0) hold[0] = 1;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+}  // namespace
+extern "C" int vitk_test_occupy_cus(int ncus, float ms, void* stream) {
+    if (ncus < 1 || ncus > 256 || !(ms > 0.f) || ms > 1000.f) VITK_FAIL(VITK_E_ARG, "test_occupy_cus: 1..256 CUs, 0 < ms <= 1000");
+    static const int rc__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (rc__ != 0) VITK_FAIL(rc__, "test_occupy_cus: cannot enable 160 KiB of LDS");
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)ncus), dim3(1024), 160 * 1024, (hipStream_t)stream, (long long)(ms * 1e5f));
+    VITK_CHECK_LAUNCH("test_occupy_cus");
+    return 0;
+}
+
 extern "C" int vitk_dropout_keep(uint8_t* keep, int64_t rows, int64_t cols, float p, uint32_t seed, void* stream) {
     if (!keep) VITK_FAIL(VITK_E_ARG, "dropout_keep: null pointer");
     if (rows <= 0 || cols <= 0 || rows > 0xffffffffLL || cols > 0x7fffffffLL) VITK_FAIL(VITK_E_SHAPE, "dropout_keep: bad extents");

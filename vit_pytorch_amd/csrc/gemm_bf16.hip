@@ -24,6 +24,7 @@
 //  * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs walks a contiguous run of tiles, so the activation panel
 //    a tile row shares is fetched into one L2, not eight.
 #include "common.h"
+#include <atomic>
 #include "gemm_nt_plan.h"
 #include <stdlib.h>
 
@@ -945,10 +946,22 @@ int gemm_tn_dma_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, 
 
 static bool tn_large(int64_t M, int64_t N, int64_t K) { return M >= 4096 && N >= 256 && K >= 256 && !getenv("VITK_NO_256"); }
 
+// CUs to leave to OTHER kernels (an RCCL collective overlapping the backward): the weight-gradient GEMM launches one (tile, M-split)
+// job per workgroup and every job needs a whole CU -- with c CUs taken, c of ~250 jobs of a full-chip launch run as a second
+// round (2x the launch time); planned for 256 - c CUs all jobs run at once beside the collective (1 / (1 - c / 256) x).
+static std::atomic<int> g_cu_reserve{0};
+extern "C" int vitk_set_cu_reserve(int cus) {
+    if (cus < 0 || cus > 192) VITK_FAIL(VITK_E_ARG, "set_cu_reserve: 0 .. 192 (got %d)", cus);
+    g_cu_reserve.store(cus);
+    return 0;
+}
+extern "C" int vitk_get_cu_reserve(void) { return g_cu_reserve.load(); }
+
 extern "C" int64_t vitk_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
     if (tn_large(M, N, K)) {
         const int64_t tiles = ((N + 255) / 256) * ((K + 255) / 256);
-        int64_t s = (256 + tiles / 2) / tiles;            // ~one workgroup per CU
+        const int reserve = g_cu_reserve.load();
+        int64_t s = reserve ? (256 - reserve) / tiles : (256 + tiles / 2) / tiles;            // ~one workgroup per (available) CU
         const int64_t max_by_rows = (M + 511) / 512;      // at least 8 steps of 64 rows per split
         if (s > max_by_rows) s = max_by_rows;
         if (s > 64) s = 64;

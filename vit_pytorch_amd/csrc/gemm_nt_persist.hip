@@ -36,6 +36,7 @@
 #include "common.h"
 #include "gemm_nt_plan.h"
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <type_traits>
@@ -70,6 +71,7 @@ struct NtpArgs {
     int tiles_n, group_n, tm_main, tail_tm, n_main, n_tail, nt;
     unsigned drop_t, drop_seed; float inv_keep;     // fused nn.Dropout (vit.py:22,24,48): threshold 0 = off
     int tail_first;
+    unsigned* tickets;  // DYNAMIC tile tickets: 8 per-XCD counters zeroed before the launch (null: static tile lists) -- see the kernel
     int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone)
     long long* stamps;  // experiments: s_memtime after the phases of K-steps 8..39 of one workgroup (VITK_NTP_STAMPS)
 };
@@ -171,8 +173,9 @@ __device__ __forceinline__ unsigned q_pack2(float a, float b) {
 }
 typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI, bool PIPE>
+template <int EPI, bool PIPE, bool DYN>
 __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
+    static_assert(PIPE || !DYN, "dynamic tickets exist in the software-pipelined flavour only");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
     const int tid = threadIdx.x;
@@ -187,27 +190,63 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     //      tail_first: the 128-row tiles lead, which leaves the workgroups that own one half a tile out of phase with the
     //      others for the rest of the launch (their store bursts then fall into the others' main loops).
     const int xcd = blockIdx.x & 7, l0 = blockIdx.x >> 3, L = gridDim.x >> 3;
-    const int ms = (int)(((long long)xcd * p.n_main) >> 3), cm = (int)(((long long)(xcd + 1) * p.n_main) >> 3) - ms;
-    const int ts = (int)(((long long)xcd * p.n_tail) >> 3), ct = (int)(((long long)(xcd + 1) * p.n_tail) >> 3) - ts;
+    // queue q = XCD q's share of the main list and of the tail list
+    auto q_geom = [&](int q, int& ms_, int& cm_, int& ts_, int& ct_) {
+        ms_ = (int)(((long long)q * p.n_main) >> 3); cm_ = (int)(((long long)(q + 1) * p.n_main) >> 3) - ms_;
+        ts_ = (int)(((long long)q * p.n_tail) >> 3); ct_ = (int)(((long long)(q + 1) * p.n_tail) >> 3) - ts_;
+    };
+    int ms, cm, ts, ct;
+    q_geom(xcd, ms, cm, ts, ct);
     const int count = cm + ct;
-    if (l0 >= count) return;
-    const int ntiles = (count - l0 + L - 1) / L;
+    // DYNAMIC TICKETS (PIPE flavour, K >= 256): instead of the static list l0, l0 + L, ... every workgroup draws its next tile from
+    // its XCD's counter (and, once that queue is dry, from the other XCDs').  Why: each workgroup needs a whole CU (128+ KiB of
+    // LDS, 512 x 256 registers).  If another kernel -- an RCCL collective of the data-parallel step -- holds c CUs, c workgroups
+    // of a static launch start only when others have FINISHED their whole lists: a second round, up to 2x the launch time.  With
+    // tickets the resident workgroups simply draw more tiles and latecomers find the queues dry: ~256 / (256 - c).  The order
+    // within a queue is the grouped order of the static lists, so the tiles an XCD works on at one time still share panels in
+    // its L2.  A ticket is drawn TWO tiles ahead (the LDS-DMA stream crosses tile boundaries, so the producer needs tile n + 1
+    // three K-steps before tile n ends), by wave 0 at the end of its epilogue -- after its stores, whose completion the next
+    // tile's first counted wait has to wait for anyway -- and handed to the other waves through an LDS word.
+    constexpr bool dyn = DYN;
+    if (!dyn && l0 >= count) return;
+    const int ntiles = dyn ? 0 : (count - l0 + L - 1) / L;
     const int total_steps = ntiles * p.nt;
-    const int c_first = p.tail_first ? ct : cm;          // length of the leading run
+    const int c_first = p.tail_first ? ct : cm;          // length of the leading run (static lists)
+    int* const tk_slots = reinterpret_cast<int*>(lds + Q_LDS_BYTES + p.tiles_n * 512);     // 4 words above the bias image
+    int my_q = xcd;
+    // ticket = (queue << 24) | index within the queue, or -1 when every queue is dry.  Uniform across the wave.
+    auto pop_ticket = [&]() -> int {
+        int q = my_q;
+        for (int tries = 0; tries < 8; ++tries) {
+            int a, b, c, d;
+            q_geom(q, a, b, c, d);
+            unsigned v = 0;
+            if (lane == 0) v = atomicAdd(&p.tickets[q], 1u);
+            v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            if ((int)v < b + d) { my_q = q; return (q << 24) | (int)v; }
+            q = (q + 1) & 7;
+        }
+        return -1;
+    };
 
-    auto decode = [&](int idx, int& m0, int& half, int& n0, int& mt) {
+    // tile of a ticket (dynamic) or of a list position of this XCD (static: queue = xcd)
+    auto decode = [&](int tk, int& m0, int& half, int& n0, int& mt) {
+        int qms = ms, qcm = cm, qts = ts, qct = ct, idx = tk;
+        if (dyn) { q_geom(tk >> 24, qms, qcm, qts, qct); idx = tk & 0xffffff; }
+        const int first = p.tail_first ? qct : qcm;
         int tm, tn;
-        const bool lead = idx < c_first;
-        const int k = lead ? idx : idx - c_first;
+        const bool lead = idx < first;
+        const int k = lead ? idx : idx - first;
         if (lead != (p.tail_first != 0)) {
-            q_grouped_tile(ms + k, p.tm_main, p.tiles_n, p.group_n, tm, tn);
+            q_grouped_tile(qms + k, p.tm_main, p.tiles_n, p.group_n, tm, tn);
             m0 = tm * 256; half = 0; mt = tm;
         } else {
-            q_grouped_tile(ts + k, p.tail_tm, p.tiles_n, p.group_n, tm, tn);
+            q_grouped_tile(qts + k, p.tail_tm, p.tiles_n, p.group_n, tm, tn);
             m0 = p.tm_main * 256 + tm * 128; half = 1; mt = p.tm_main + tm;
         }
         n0 = tn * 256;
     };
+    (void)c_first;
 
     // ---- producer: the LDS-DMA stream runs three K-steps ahead of the consumer, across tile boundaries ----
     // 64-byte rows, a wave instruction fills 16 rows; wave w owns LDS row groups 2w, 2w+1 of each operand tile.  The LDS image
@@ -218,8 +257,12 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     const int schunk = spos ^ q_swz(lane >> 4);
     const char* a_src[2];
     const char* w_src[2];
-    int p_idx = l0, p_kt = 0, p_g = 0;
+    int p_idx = l0, p_kt = 0, p_g = 0;      // p_idx: list position (static) or ticket (dynamic)
+    int p_n = 0;                            // tiles the producer has started (dynamic: slot index of the next ticket)
     bool p_more = true;
+    auto next_ticket = [&](int n) -> int {  // written by wave 0 at least one barrier earlier
+        return __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(tk_slots + (n & 3)));
+    };
     auto setup_src = [&](int idx) {
         int m0, half, n0, mt;
         decode(idx, m0, half, n0, mt);
@@ -278,8 +321,10 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
         ++p_g;
         if (!p_more) return;
         if (++p_kt == p.nt) {
-            p_idx += L;
-            if (p_idx < count) { p_kt = 0; setup_src(p_idx); }
+            bool more;
+            if (dyn) { p_idx = next_ticket(++p_n); more = p_idx >= 0; }
+            else { p_idx += L; more = p_idx < count; }
+            if (more) { p_kt = 0; setup_src(p_idx); }
             else { p_more = false; p_kt = p.nt - 1; }
         }
     };
@@ -660,6 +705,17 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
         else body(std::integral_constant<bool, false>{});
     };
 
+    // ---- dynamic tickets: the first two, drawn by wave 0 ----
+    if (dyn) {
+        if (wave == 0) {
+            const int t0 = pop_ticket();
+            const int t1 = t0 >= 0 ? pop_ticket() : -1;
+            if (lane == 0) { tk_slots[0] = t0; tk_slots[1] = t1; }
+        }
+        __syncthreads();           // nothing is in flight yet
+        p_idx = next_ticket(0);
+        if (p_idx < 0) return;     // every queue was dry before this workgroup started (a latecomer beside another kernel)
+    }
     // ---- prologue: K-steps 0..2 in flight, K-step 0 landed ----
     setup_src(p_idx);
     if constexpr (PIPE) {
@@ -677,14 +733,43 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     QQ_BARRIER();              // also publishes the bias image
     if (!PIPE && grp_b) QQ_BARRIER();   // group B runs one slot behind group A
 
-    for (int idx = l0; idx < count; idx += L) {
-        int m0, half, n0, mt;
-        decode(idx, m0, half, n0, mt);
-        if (half) run_tile(std::integral_constant<int, 4>{}, m0, n0, mt);
-        else run_tile(std::integral_constant<int, 8>{}, m0, n0, mt);
+    if (dyn) {
+        int n = 0;
+        for (int cur = next_ticket(0); cur >= 0; cur = next_ticket(++n)) {
+            int m0, half, n0, mt;
+            decode(cur, m0, half, n0, mt);
+            if (half) run_tile(std::integral_constant<int, 4>{}, m0, n0, mt);
+            else run_tile(std::integral_constant<int, 8>{}, m0, n0, mt);
+            if (wave == 0) {       // the ticket of tile n + 2, after this wave's stores (see the top of the kernel)
+                const int t = pop_ticket();
+                if (lane == 0) tk_slots[(n + 2) & 3] = t;
+            }
+        }
+    } else {
+        for (int idx = l0; idx < count; idx += L) {
+            int m0, half, n0, mt;
+            decode(idx, m0, half, n0, mt);
+            if (half) run_tile(std::integral_constant<int, 4>{}, m0, n0, mt);
+            else run_tile(std::integral_constant<int, 8>{}, m0, n0, mt);
+        }
     }
     if (!PIPE && !grp_b) QQ_BARRIER();  // pairs with group B's extra barrier
     if constexpr (PIPE) q_wait_vm<0>();  // the surplus DMAs of the last K-steps must not outlive the workgroup's LDS allocation
+}
+
+// ---- dynamic tile tickets: 64 launch slots x 8 per-XCD counters (64-byte slots), zeroed by a memset node ahead of each launch ----
+__device__ unsigned q_ticket_pool[64 * 16];
+unsigned* q_ticket_slot(hipStream_t st) {
+    static unsigned* base = [] {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(q_ticket_pool)) != hipSuccess) return (unsigned*)nullptr;
+        return (unsigned*)ptr;
+    }();
+    static std::atomic<unsigned> seq{0};
+    if (!base) return nullptr;
+    unsigned* slot = base + (seq.fetch_add(1) & 63) * 16;
+    if (hipMemsetAsync(slot, 0, 64, st) != hipSuccess) return nullptr;
+    return slot;
 }
 
 template <typename Kern>
@@ -725,7 +810,7 @@ long long q_makespan(int n_main, int n_tail, int L, long long c_full, long long 
 NtpPlan ntp_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
     NtpPlan pl{};
     pl.ok = (K % 32 == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux)) &&
-            M < (1 << 30) && N <= 16384 /* bias image: 32 KiB of LDS above the ring */ && !getenv("VITK_NO_256") && !getenv("VITK_NO_PERSIST");
+            M < (1 << 30) && N <= 16128 /* bias image + ticket words: 32 KiB of LDS above the ring */ && !getenv("VITK_NO_256") && !getenv("VITK_NO_PERSIST");
     if (!pl.ok) return pl;
     struct Key { int64_t m, n, k; bool operator==(const Key& o) const { return m == o.m && n == o.n && k == o.k; } };
     struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.m * 1000003 + k.n * 10007 + k.k); } };
@@ -793,24 +878,27 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     a.n_main = pl.n_main; a.n_tail = pl.n_tail; a.nt = pl.nt;
     static const int tail_first = getenv("VITK_NTP_TAIL_LAST") ? 0 : 1;
     a.tail_first = tail_first;
-    a.dbg = getenv("VITK_NTP_DBG") ? atoi(getenv("VITK_NTP_DBG")) : 0;
-    a.stamps = getenv("VITK_NTP_STAMPS") ? (long long*)strtoull(getenv("VITK_NTP_STAMPS"), nullptr, 0) : nullptr;
-    const int lds_bytes = Q_LDS_BYTES + pl.tiles_n * 512;      // ring + bias image (tiles_n * 256 columns of 2 bytes)
-    hipStream_t st = (hipStream_t)stream;
     // main-loop flavour: software-pipelined (default) or the R/M slot ping-pong (VITK_NTP_PIPE=0).  [measured] kernel by kernel the
     // pipelined loop is ~5 % ahead (8-shape sum 1.688 vs 1.783 ms), inside the training step the two are level (42.7-43.1 vs
     // 43.0-43.2 ms on the same box).
     static const bool pipe = !(getenv("VITK_NTP_PIPE") && atoi(getenv("VITK_NTP_PIPE")) == 0);
+    // dynamic tile tickets (see the kernel): K >= 256 so that a ticket drawn two tiles ahead is always there in time;
+    // VITK_NTP_STATIC=1 keeps the static lists
+    const char* st_env = getenv("VITK_NTP_STATIC");
+    a.tickets = (pipe && pl.nt >= 8 && !(st_env && st_env[0] == '1')) ? q_ticket_slot((hipStream_t)stream) : nullptr;
+    a.dbg = getenv("VITK_NTP_DBG") ? atoi(getenv("VITK_NTP_DBG")) : 0;
+    a.stamps = getenv("VITK_NTP_STAMPS") ? (long long*)strtoull(getenv("VITK_NTP_STAMPS"), nullptr, 0) : nullptr;
+    const int lds_bytes = Q_LDS_BYTES + pl.tiles_n * 512 + 16;      // ring + bias image (tiles_n * 256 columns of 2 bytes) + 4 ticket words
+    hipStream_t st = (hipStream_t)stream;
+#define NTP_LAUNCH1(E, P, Dn) do { \
+            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, P, Dn>, Q_LDS_MAX); \
+            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
+            hipLaunchKernelGGL((gemm_ntp_kernel<E, P, Dn>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+        } while (0)
 #define NTP_LAUNCH(E) do { \
-        if (pipe) { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, true>, Q_LDS_MAX); \
-            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, true>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
-        } else { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, false>, Q_LDS_MAX); \
-            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, false>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
-        } \
+        if (pipe && a.tickets) NTP_LAUNCH1(E, true, true); \
+        else if (pipe) NTP_LAUNCH1(E, true, false); \
+        else NTP_LAUNCH1(E, false, false); \
     } while (0)
     switch (epilogue) {
         case VITK_EPI_NONE: NTP_LAUNCH(VITK_EPI_NONE); break;
@@ -821,6 +909,7 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
         default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: bad epilogue %d", epilogue);
     }
 #undef NTP_LAUNCH
+#undef NTP_LAUNCH1
     VITK_CHECK_LAUNCH("gemm_nt_bf16 (persistent)");
     return 0;
 }

@@ -383,6 +383,10 @@ class TransformerFn(torch.autograd.Function):
             g, gb = g1, g1b
             del g2, g2b, da1
             sk = _sink()
+            if sk is not None:
+                tick = getattr(sk, "layer_tick", None)
+                if tick is not None:
+                    tick()                       # counts down the CU reserve a collective's launch opened (parallel.FlatGradSink)
             if sk is not None and sk.wants_layer(li):
                 fork.join()                      # this layer's weight gradients (side stream) are part of the chunk
                 sk.stage_done("layer", li)

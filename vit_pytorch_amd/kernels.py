@@ -154,6 +154,12 @@ def gemm_nt_bf16_gelu_bwd_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Te
                                                      _stream()), "gemm_nt_bf16_gelu_bwd_colsum")
 
 
+def set_cu_reserve(cus: int, dtype=None):
+    """CUs the weight-gradient GEMMs leave to other kernels (vitk_set_cu_reserve; process-wide per library flavour)."""
+    lib = L.load_f16() if dtype == torch.float16 else L.load()
+    check(lib.vitk_set_cu_reserve(int(cus)), "set_cu_reserve")
+
+
 def gemm_tn_splits(M: int, N: int, K: int) -> int:
     return int(L.load().vitk_gemm_tn_splits(M, N, K))
 

@@ -65,8 +65,14 @@ class FlatGradSink:
     """Owns the flat gradient buffer; handed to the engine as the gradient sink."""
 
     def __init__(self, model: torch.nn.Module, process_group=None, average: bool = True, layers_per_chunk: Optional[int] = None,
-                 comm_priority: Optional[int] = None):
-        """layers_per_chunk: transformer layers per in-backward all-reduce (0 = one message for the whole stack when its backward
+                 comm_priority: Optional[int] = None, cu_reserve: Optional[int] = None, reserve_layers: Optional[int] = None):
+        """cu_reserve / reserve_layers: while a chunk's all-reduce is (probably) in flight -- from its launch until `reserve_layers`
+        more transformer layers have been enqueued -- the weight-gradient GEMMs are planned for 256 - cu_reserve CUs
+        (vitk_set_cu_reserve), so that their workgroups fit BESIDE the collective's resident kernel instead of queueing behind it
+        as a second round ([measured on one GPU with a stand-in kernel, tools/cu_contention.py] 32 CUs held: 1.62x -> 1.02-1.10x per
+        layer; the persistent NT GEMMs adapt by themselves through their tile tickets).  Defaults 32 / 1, env VITK_DP_CU_RESERVE /
+        VITK_DP_RESERVE_LAYERS; 0 turns it off.
+        layers_per_chunk: transformer layers per in-backward all-reduce (0 = one message for the whole stack when its backward
         ends); default 3, env VITK_DP_LAYERS_PER_CHUNK.  comm_priority: HIP stream priority of the side stream that carries the
         collectives (lower = more urgent; default -1 so that RCCL's kernels are scheduled ahead of the GEMM workgroups that
         would otherwise hold every CU), env VITK_DP_COMM_PRIORITY."""
@@ -81,6 +87,9 @@ class FlatGradSink:
             comm_priority = int(os.environ.get("VITK_DP_COMM_PRIORITY", "-1"))
         self.layers_per_chunk = layers_per_chunk
         self.comm_priority = comm_priority
+        self.cu_reserve = int(os.environ.get("VITK_DP_CU_RESERVE", "32")) if cu_reserve is None else cu_reserve
+        self.reserve_layers = int(os.environ.get("VITK_DP_RESERVE_LAYERS", "1")) if reserve_layers is None else reserve_layers
+        self._reserve_left = 0
         p0 = self.params[0]
         self.dtype, self.device = p0.dtype, p0.device
         assert all(p.dtype == self.dtype and p.device == self.device for p in self.params), \
@@ -154,6 +163,13 @@ class FlatGradSink:
     def wants_layer(self, layer: int) -> bool:
         return self.world > 1 and self.layers_per_chunk > 0 and layer % self.layers_per_chunk == 0 and layer in self.layer_end_off
 
+    def layer_tick(self):
+        """Called by the engine after every transformer layer's backward has been enqueued."""
+        if self._reserve_left > 0:
+            self._reserve_left -= 1
+            if self._reserve_left == 0:
+                self._set_reserve(0)
+
     def owns(self, t: torch.Tensor) -> bool:
         return t.data_ptr() in self._view_ptrs
 
@@ -181,7 +197,15 @@ class FlatGradSink:
             self._launch(self.flat[self.boundary:])
             self._late_launched = True
 
+    def _set_reserve(self, cus: int):
+        if self.device.type == "cuda":
+            from . import kernels as K
+            K.set_cu_reserve(cus, self.dtype)
+
     def _launch(self, seg: torch.Tensor):
+        if self.cu_reserve > 0 and self.reserve_layers > 0:
+            self._set_reserve(self.cu_reserve)
+            self._reserve_left = self.reserve_layers
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
@@ -213,6 +237,9 @@ class FlatGradSink:
     def finish_step(self):
         """After loss.backward(): make every p.grad the (reduced) flat view."""
         E.set_grad_sink(None)
+        if self._reserve_left > 0:
+            self._reserve_left = 0
+            self._set_reserve(0)
         # gradients autograd produced outside the sink (foreign modules / non-fused paths): copy them in
         missing = [i for i in range(len(self.params)) if i not in self._filled]
         if missing and self.world > 1 and self.side is not None:
