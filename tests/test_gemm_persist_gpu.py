@@ -173,7 +173,7 @@ def test_k_blocked_weight_refused_where_the_persistent_kernel_does_not_run():
 
 @pytest.mark.parametrize("M,N,Kd", [(12608, 768, 768), (12608, 3072, 768), (12608, 768, 3072), (33000, 520, 256)])
 def test_dynamic_tickets_equal_static_lists(M, N, Kd, monkeypatch):
-    """Dynamic tile tickets (K >= 256; the default) and the static lists (VITK_NTP_STATIC=1) compute every tile the same way: all
+    """Dynamic tile tickets (K >= 256; on while vitk_set_cu_reserve > 0 or with VITK_NTP_DYNAMIC=1) and the static lists compute every tile the same way: all
     epilogues bit-identical -- also while another kernel holds 40 CUs (vitk_test_occupy_cus), when the late workgroups of a
     dynamic launch find the queues dry and the resident ones draw the other XCDs' tiles."""
     A = rnd(M, Kd, dtype=BF, seed=41); W = (rnd(N, Kd, seed=42) * Kd ** -0.5).to(BF)
@@ -181,6 +181,7 @@ def test_dynamic_tickets_equal_static_lists(M, N, Kd, monkeypatch):
     monkeypatch.setenv("VITK_NTP_STATIC", "1")
     ref = _all_epilogues(M, N, Kd, A, W, bias, resid, h)
     monkeypatch.delenv("VITK_NTP_STATIC")
+    monkeypatch.setenv("VITK_NTP_DYNAMIC", "1")
     got = _all_epilogues(M, N, Kd, A, W, bias, resid, h)
     for k in ref:
         assert torch.equal(ref[k], got[k]), k

@@ -58,7 +58,8 @@ def layer_nt():
 print(f"device={torch.cuda.get_device_name(0)}  eight NT GEMMs of a ViT-B/16 layer (batch 256), us per layer")
 for c in (0, 16, 32, 64):
     os.environ["VITK_NTP_STATIC"] = "1"; t_s = timed(layer_nt, c)
-    os.environ.pop("VITK_NTP_STATIC"); t_d = timed(layer_nt, c)
+    os.environ.pop("VITK_NTP_STATIC"); os.environ["VITK_NTP_DYNAMIC"] = "1"; t_d = timed(layer_nt, c)
+    os.environ.pop("VITK_NTP_DYNAMIC")
     print(f"  {c:3d} CUs held: static lists {t_s:8.1f}   dynamic tickets {t_d:8.1f}   (ideal x{256 / (256 - c):.3f})")
 
 tn_shapes = {"dWqkv": (3 * D, D), "dWout": (D, D), "dW1": (F, D), "dW2": (D, F)}

@@ -727,7 +727,11 @@ bool attn_pipe_supported(int64_t N, int64_t d) { return d == 64 && N > 32 && N <
 // one whose per-wave rows are prefetched a whole item ahead -- gains, so only it is on.  VITK_ATTN_PIPE=<mask> overrides (tests: 7).
 int attn_pipe_mask() {
     const char* e = getenv("VITK_ATTN_PIPE");
-    return e ? atoi(e) : 2;
+    if (e) return atoi(e);
+    // the pipelined kernels are resident workgroups with STATIC item lists and a CU each: while another kernel is expected on the chip
+    // (vitk_set_cu_reserve > 0: a collective overlapping the backward) the per-head kernels run instead -- their 3,072 independent
+    // workgroups simply use the CUs that are there
+    return vitk_get_cu_reserve() > 0 ? 0 : 2;
 }
 int attn_pipe_fwd(const AttnPipeFwd& a, void* stream) {
     return a.ns == 2 ? launch_fwd<2>(a, (hipStream_t)stream) : launch_fwd<1>(a, (hipStream_t)stream);

@@ -47,6 +47,8 @@ constexpr int Q_TILE_BYTES = 256 * 64;              // one operand, one K-step: 
 constexpr int Q_STAGE_BYTES = 2 * Q_TILE_BYTES;     // 32 KiB
 constexpr int Q_LDS_BYTES = 4 * Q_STAGE_BYTES;      // 128 KiB ring
 constexpr int Q_LDS_MAX = Q_LDS_BYTES + 32768;      // + bias image
+constexpr int Q_TK_LINE = 32;                       // words per 128-byte line: one counter per line
+constexpr int Q_TK_SLOT_WORDS = 32 * Q_TK_LINE;     // 17 lines used: tickets [0, 8), per-XCD exits [8, 16), chip exit 16
 
 #define QQ_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -75,6 +77,14 @@ struct NtpArgs {
     int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone)
     long long* stamps;  // experiments: s_memtime after the phases of K-steps 8..39 of one workgroup (VITK_NTP_STAMPS)
 };
+
+// returning add on a device word through the SCALAR memory path: the old value lands in an SGPR (wave-uniform by construction) and is
+// tracked by lgkmcnt -- unlike a vector atomic it neither enters the in-order vmcnt queue of the LDS-DMA ring nor makes hipcc wait
+// vmcnt(0).  [tools/probe_satomic.hip: gfx950 executes it; 1024 concurrent adds return 0..1023 exactly once.]
+__device__ __forceinline__ unsigned q_satomic_add(unsigned* p, unsigned v) {
+    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(p) : "memory");
+    return v;
+}
 
 template <int N_> __device__ __forceinline__ void q_wait_vm() {
     if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -205,8 +215,9 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     // tickets the resident workgroups simply draw more tiles and latecomers find the queues dry: ~256 / (256 - c).  The order
     // within a queue is the grouped order of the static lists, so the tiles an XCD works on at one time still share panels in
     // its L2.  A ticket is drawn TWO tiles ahead (the LDS-DMA stream crosses tile boundaries, so the producer needs tile n + 1
-    // three K-steps before tile n ends), by wave 0 at the end of its epilogue -- after its stores, whose completion the next
-    // tile's first counted wait has to wait for anyway -- and handed to the other waves through an LDS word.
+    // three K-steps before tile n ends), by wave 0 right after its epilogue with a SCALAR atomic (q_satomic_add: a vector atomic
+    // would wait vmcnt(0), i.e. for the wave's own store drain, before the next tile's first K-step: measured +1 ms per step),
+    // and handed to the other waves through an LDS word.
     constexpr bool dyn = DYN;
     if (!dyn && l0 >= count) return;
     const int ntiles = dyn ? 0 : (count - l0 + L - 1) / L;
@@ -214,30 +225,53 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     const int c_first = p.tail_first ? ct : cm;          // length of the leading run (static lists)
     int* const tk_slots = reinterpret_cast<int*>(lds + Q_LDS_BYTES + p.tiles_n * 512);     // 4 words above the bias image
     int my_q = xcd;
-    // ticket = (queue << 24) | index within the queue, or -1 when every queue is dry.  Uniform across the wave.
+    // ticket = (queue << 24) | index within the queue, or -1 when every queue is dry.  Wave-uniform (scalar atomics).  `dry` stops a
+    // workgroup from hammering empty queues again; tk_done counts the workgroups that are through with the counters (see the end).
+    bool dry = false;
     auto pop_ticket = [&]() -> int {
+        if (dry) return -1;
         int q = my_q;
         for (int tries = 0; tries < 8; ++tries) {
             int a, b, c, d;
             q_geom(q, a, b, c, d);
-            unsigned v = 0;
-            if (lane == 0) v = atomicAdd(&p.tickets[q], 1u);
-            v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            const unsigned v = q_satomic_add(p.tickets + q * Q_TK_LINE, 1u);
             if ((int)v < b + d) { my_q = q; return (q << 24) | (int)v; }
             q = (q + 1) & 7;
         }
+        dry = true;
         return -1;
+    };
+    // the LAST workgroup to leave resets the slot for its next user (64 launches later): no memset node in front of every launch.
+    // Two levels (32 workgroups per XCD counter, then 8): 256 exits on one word would serialise for ~7 us at the end of the launch.
+    auto leave = [&]() {
+        if (wave == 0) {
+            const unsigned per_xcd = (gridDim.x >> 3) + (((int)gridDim.x & 7) > xcd ? 1u : 0u);
+            if (q_satomic_add(p.tickets + (8 + xcd) * Q_TK_LINE, 1u) == per_xcd - 1) {
+                if (q_satomic_add(p.tickets + 16 * Q_TK_LINE, 1u) == 7u && lane < 17) p.tickets[lane * Q_TK_LINE] = 0;
+            }
+        }
     };
 
     // tile of a ticket (dynamic) or of a list position of this XCD (static: queue = xcd)
     auto decode = [&](int tk, int& m0, int& half, int& n0, int& mt) {
         int qms = ms, qcm = cm, qts = ts, qct = ct, idx = tk;
         if (dyn) { q_geom(tk >> 24, qms, qcm, qts, qct); idx = tk & 0xffffff; }
-        const int first = p.tail_first ? qct : qcm;
+        // order within a queue: tail_first = 1: the 128-row tiles, then the 256-row tiles (static lists); 0: the other way round;
+        // 2 (experiments): HALF of the 128-row tiles, the 256-row tiles, the other half
         int tm, tn;
-        const bool lead = idx < first;
-        const int k = lead ? idx : idx - first;
-        if (lead != (p.tail_first != 0)) {
+        bool is_tail; int k;
+        if (p.tail_first == 2) {
+            const int h1 = (qct + 1) >> 1;
+            if (idx < h1) { is_tail = true; k = idx; }
+            else if (idx < h1 + qcm) { is_tail = false; k = idx - h1; }
+            else { is_tail = true; k = idx - qcm; }
+        } else {
+            const int first = p.tail_first ? qct : qcm;
+            const bool lead = idx < first;
+            k = lead ? idx : idx - first;
+            is_tail = lead == (p.tail_first != 0);
+        }
+        if (!is_tail) {
             q_grouped_tile(qms + k, p.tm_main, p.tiles_n, p.group_n, tm, tn);
             m0 = tm * 256; half = 0; mt = tm;
         } else {
@@ -708,13 +742,17 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     // ---- dynamic tickets: the first two, drawn by wave 0 ----
     if (dyn) {
         if (wave == 0) {
-            const int t0 = pop_ticket();
-            const int t1 = t0 >= 0 ? pop_ticket() : -1;
+            // the first two tickets with ONE add on the own queue where both exist (the common case)
+            int t0, t1;
+            const unsigned v = q_satomic_add(p.tickets + xcd * Q_TK_LINE, 2u);
+            if ((int)v + 1 < count) { t0 = (xcd << 24) | (int)v; t1 = t0 + 1; }
+            else if ((int)v < count) { t0 = (xcd << 24) | (int)v; t1 = pop_ticket(); }
+            else { t0 = pop_ticket(); t1 = t0 >= 0 ? pop_ticket() : -1; }
             if (lane == 0) { tk_slots[0] = t0; tk_slots[1] = t1; }
         }
         __syncthreads();           // nothing is in flight yet
         p_idx = next_ticket(0);
-        if (p_idx < 0) return;     // every queue was dry before this workgroup started (a latecomer beside another kernel)
+        if (p_idx < 0) { leave(); return; }     // every queue was dry before this workgroup started (a latecomer beside another kernel)
     }
     // ---- prologue: K-steps 0..2 in flight, K-step 0 landed ----
     setup_src(p_idx);
@@ -740,11 +778,12 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
             decode(cur, m0, half, n0, mt);
             if (half) run_tile(std::integral_constant<int, 4>{}, m0, n0, mt);
             else run_tile(std::integral_constant<int, 8>{}, m0, n0, mt);
-            if (wave == 0) {       // the ticket of tile n + 2, after this wave's stores (see the top of the kernel)
-                const int t = pop_ticket();
+            if (wave == 0) {       // the ticket of tile n + 2: ~1 us of scalar atomic that falls into the store drain every wave is
+                const int t = pop_ticket();      // about to sit out at its first counted wait of the next tile
                 if (lane == 0) tk_slots[(n + 2) & 3] = t;
             }
         }
+        leave();
     } else {
         for (int idx = l0; idx < count; idx += L) {
             int m0, half, n0, mt;
@@ -757,8 +796,10 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     if constexpr (PIPE) q_wait_vm<0>();  // the surplus DMAs of the last K-steps must not outlive the workgroup's LDS allocation
 }
 
-// ---- dynamic tile tickets: 64 launch slots x 8 per-XCD counters (64-byte slots), zeroed by a memset node ahead of each launch ----
-__device__ unsigned q_ticket_pool[64 * 16];
+// ---- dynamic tile tickets: 64 launch slots; a slot = 8 per-XCD ticket counters + 8 per-XCD exit counters + 1 chip exit counter,
+// EACH ON ITS OWN 128-byte line ([measured] with the nine words in one 64-byte line every launch cost a fixed +14 us: atomics on
+// one line serialise at ~27 ns each and 256 workgroups draw two tickets at once in the prologue); a launch leaves its slot zeroed
+__device__ unsigned q_ticket_pool[64 * Q_TK_SLOT_WORDS];
 unsigned* q_ticket_slot(hipStream_t st) {
     static unsigned* base = [] {
         void* ptr = nullptr;
@@ -767,9 +808,8 @@ unsigned* q_ticket_slot(hipStream_t st) {
     }();
     static std::atomic<unsigned> seq{0};
     if (!base) return nullptr;
-    unsigned* slot = base + (seq.fetch_add(1) & 63) * 16;
-    if (hipMemsetAsync(slot, 0, 64, st) != hipSuccess) return nullptr;
-    return slot;
+    (void)st;
+    return base + (seq.fetch_add(1) & 63) * Q_TK_SLOT_WORDS;      // zero-initialised; every launch's last workgroup leaves its slot zeroed again
 }
 
 template <typename Kern>
@@ -877,15 +917,24 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     a.tiles_n = pl.tiles_n; a.group_n = pl.group_n; a.tm_main = pl.tm_main; a.tail_tm = pl.tail_tm;
     a.n_main = pl.n_main; a.n_tail = pl.n_tail; a.nt = pl.nt;
     static const int tail_first = getenv("VITK_NTP_TAIL_LAST") ? 0 : 1;
-    a.tail_first = tail_first;
+    a.tail_first = tail_first;      // (static lists; with tickets the 128-row tiles go LAST, see below)
     // main-loop flavour: software-pipelined (default) or the R/M slot ping-pong (VITK_NTP_PIPE=0).  [measured] kernel by kernel the
     // pipelined loop is ~5 % ahead (8-shape sum 1.688 vs 1.783 ms), inside the training step the two are level (42.7-43.1 vs
     // 43.0-43.2 ms on the same box).
     static const bool pipe = !(getenv("VITK_NTP_PIPE") && atoi(getenv("VITK_NTP_PIPE")) == 0);
-    // dynamic tile tickets (see the kernel): K >= 256 so that a ticket drawn two tiles ahead is always there in time;
-    // VITK_NTP_STATIC=1 keeps the static lists
+    // dynamic tile tickets (see the kernel): K >= 256 so that a ticket drawn two tiles ahead is always there in time.  WHEN: while
+    // other kernels are expected on the chip -- vitk_set_cu_reserve(c > 0), which parallel.FlatGradSink opens around every
+    // in-backward all-reduce -- or VITK_NTP_DYNAMIC=1.  Not by default: [measured, ViT-B/16 batch 256, no other kernel on the
+    // chip] tickets cost the eight NT GEMMs of a layer 1.632 -> 1.664 ms (the N = 768 shapes, 2.6 tiles per workgroup, lose 6-18 us
+    // each to the static plan's makespan-optimal lists; FF1 gains 14 us) and the training step 0.8 ms; with 16-64 CUs held by
+    // another kernel they save 19-25 % (tools/cu_contention.py).  VITK_NTP_STATIC=1 forces the static lists.
     const char* st_env = getenv("VITK_NTP_STATIC");
-    a.tickets = (pipe && pl.nt >= 8 && !(st_env && st_env[0] == '1')) ? q_ticket_slot((hipStream_t)stream) : nullptr;
+    const char* dy_env = getenv("VITK_NTP_DYNAMIC");
+    const bool want_dyn = (dy_env && dy_env[0] == '1') || vitk_get_cu_reserve() > 0;
+    a.tickets = (pipe && pl.nt >= 8 && want_dyn && !(st_env && st_env[0] == '1')) ? q_ticket_slot((hipStream_t)stream) : nullptr;
+    // queue order under tickets: the 256-row tiles first, the 128-row tiles last (longest-processing-time rule; [measured] sums of the
+    // eight shapes: 1.664 ms vs 1.73 ms with the static lists' tail-first order or a half-and-half split).  VITK_NTP_DYN_ORDER = 0 / 1 / 2
+    if (a.tickets) a.tail_first = getenv("VITK_NTP_DYN_ORDER") ? atoi(getenv("VITK_NTP_DYN_ORDER")) : 0;
     a.dbg = getenv("VITK_NTP_DBG") ? atoi(getenv("VITK_NTP_DBG")) : 0;
     a.stamps = getenv("VITK_NTP_STAMPS") ? (long long*)strtoull(getenv("VITK_NTP_STAMPS"), nullptr, 0) : nullptr;
     const int lds_bytes = Q_LDS_BYTES + pl.tiles_n * 512 + 16;      // ring + bias image (tiles_n * 256 columns of 2 bytes) + 4 ticket words
