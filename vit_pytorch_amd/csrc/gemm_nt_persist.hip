@@ -103,6 +103,12 @@ template <int N_> __device__ __forceinline__ void q_wait_vm() {
 // and waited for by an EXACT count: D fragment rows are in flight, and the stores issued after a row's loads may stay in flight.
 // (Form (ii) of the guide's 5.7: "=v" loads, then a wait statement naming every destination "+v"; the epilogue is straight-line
 // code, so no destination is loop-carried; tools/asm_inflight_audit.py checks the .s for compiler accesses in between.)
+#ifndef Q_EPI_ASM_RESID
+#define Q_EPI_ASM_RESID 1        // 0: compiler-counted residual loads (A/B builds)
+#endif
+#ifndef Q_EPI_ASM_PRE
+#define Q_EPI_ASM_PRE 1          // 0: compiler-counted pre-activation loads (A/B builds)
+#endif
 #ifndef Q_EPI_DEPTH_RESID
 #define Q_EPI_DEPTH_RESID 3      // fragment rows of the residual in flight (16 VGPRs each)
 #endif
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                 // lane: rows mrow0 + 16 f + j, 4 consecutive f32 columns: 16 lanes = 256 contiguous bytes of a row
                 const bool colok = INT || ncol4 < p.N;
                 float* Cf = reinterpret_cast<float*>(p.C);
-                if constexpr (INT) {
+                if constexpr (INT && Q_EPI_ASM_RESID) {
                     // interior tile: residual rows by uncounted asm loads, D fragment rows ahead, exact-count waits (see q_gload_f32x4)
                     constexpr int D = Q_EPI_DEPTH_RESID;
                     f32x4 r[D][4];
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                 __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
                 // GELU_BWD: saved pre-activations, fetched DP fragment rows ahead.  Interior tiles: uncounted asm loads + exact-count
                 // waits (see q_gload_f32x4); per fragment row 2 loads and 2 stores
-                constexpr bool ASM_PRE = (EPI == VITK_EPI_GELU_BWD) && INT;
+                constexpr bool ASM_PRE = (EPI == VITK_EPI_GELU_BWD) && INT && Q_EPI_ASM_PRE;
                 constexpr int DP = ASM_PRE ? Q_EPI_DEPTH_PRE : 2;
                 bf16x8 hpre[DP][2];
                 auto fetch_pre = [&](int f, bf16x8 (&dst)[2]) {
