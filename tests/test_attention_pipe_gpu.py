@@ -150,3 +150,31 @@ def test_rescale_branch_in_the_second_half():
     assert torch.isfinite(o.float()).all()
     assert rel(o, oref) < 6e-3 and rel(dqkv, gref) < 1.5e-2
     assert (lse.double() - lref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (70, 12, 197), (9, 12, 196), (1, 1, 197), (3, 2, 208), (2, 2, 193), (300, 1, 197)])
+@pytest.mark.parametrize("dtype", [BF, torch.float16])
+def test_fused_backward_against_float64(B, H, N, dtype, monkeypatch):
+    """The single-kernel backward (VITK_ATTN_PIPE bit 3: dQ, dK, dV in one pass over the scores, every operand through LDS-DMA rings)
+    at the sequence lengths it serves (192 < N <= 208), from one item per workgroup to several, against float64; bit-identical run to
+    run; the delta scratch output is written as the two-kernel path writes it."""
+    monkeypatch.setenv("VITK_ATTN_PIPE", "8")
+    d = 64
+    scale = d ** -0.5
+    qkv = rnd(B, N, 3 * H * d, dtype=dtype, seed=11, scale=1.5)
+    do = rnd(B, N, H * d, dtype=dtype, seed=12)
+    o, lse, dqkv = run16(qkv, do, H, d, scale, dtype)
+    assert torch.isfinite(dqkv.float()).all()
+    eg = 0.0
+    for b0 in range(0, B, 16):
+        oref, lref, gref = attn_ref(qkv[b0:b0 + 16], do[b0:b0 + 16], H, d, scale)
+        eg = max(eg, rel(dqkv[b0:b0 + 16], gref))
+        for name, sl in (("dq", slice(0, H * d)), ("dk", slice(H * d, 2 * H * d)), ("dv", slice(2 * H * d, 3 * H * d))):
+            r = rel(dqkv[b0:b0 + 16, :, sl], gref[..., sl])
+            assert r < (1.2e-2 if dtype == BF else 2e-3), (name, r)
+    for _ in range(2):
+        o2, lse2, dqkv2 = run16(qkv, do, H, d, scale, dtype)
+        assert torch.equal(dqkv, dqkv2)
+    monkeypatch.setenv("VITK_ATTN_PIPE", "0")
+    o0, lse0, dqkv0 = run16(qkv, do, H, d, scale, dtype)
+    assert rel(dqkv, dqkv0) < 4e-3

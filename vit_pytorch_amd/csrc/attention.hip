@@ -1001,12 +1001,15 @@ extern "C" int vitk_attn_bwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vi
         !lse || !delta)
         VITK_FAIL(VITK_E_ALIGN, "attn_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     // per kernel: the pipelined flavour (attention_pipe.hip) where it is the faster one -- by default the dQ kernel only
-    const int pipe = attn_pipe_supported(N, d) ? (attn_pipe_mask() >> 1) & 3 : 0;
+    const int pmask = attn_pipe_mask();
+    const bool fused = (pmask & 8) && attn_fused_bwd_supported(N, d, drop_p);
+    const int pipe = attn_pipe_supported(N, d) ? (pmask >> 1) & 3 : 0;
     AttnPipeBwd pa{};
-    if (pipe) {
+    if (pipe || fused) {
         pa.ns = 1; pa.q[0] = q; pa.k[0] = k; pa.v[0] = v; pa.dout[0] = dout; pa.o = o; pa.dq = dq; pa.dk = dk; pa.dv = dv;
         pa.lse = lse; pa.delta = delta; pa.B = B; pa.H = H; pa.N = N; pa.scale = scale; pa.drop_p = drop_p; pa.drop_seed = drop_seed;
     }
+    if (fused) return attn_pipe_bwd_fused(pa, stream);
     const int rows_pad = (int)((N + 31) / 32 * 32);
     const size_t lds1 = (size_t)2 * rows_pad * AT_LD;
     const size_t lds2 = lds1 + (size_t)3 * rows_pad * sizeof(float);

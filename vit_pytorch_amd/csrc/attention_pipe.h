@@ -29,5 +29,8 @@ struct AttnPipeBwd {
 int attn_pipe_fwd(const AttnPipeFwd& a, void* stream);
 // which: bit 0 = dQ (+ delta), bit 1 = dK / dV (needs the delta a dQ kernel wrote before)
 int attn_pipe_bwd(const AttnPipeBwd& a, void* stream, int which);
+// the single-kernel backward (dQ, dK, dV in one pass over the scores): 16-bit, 192 < N <= 208, no dropout; mask bit 3
+bool attn_fused_bwd_supported(int64_t N, int64_t d, float drop_p);
+int attn_pipe_bwd_fused(const AttnPipeBwd& a, void* stream);
 // default selection of the 16-bit kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV (VITK_ATTN_PIPE overrides)
 int attn_pipe_mask();

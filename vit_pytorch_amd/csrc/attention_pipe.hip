@@ -619,6 +619,293 @@ __global__ __launch_bounds__(1024) void attn_dkv_pipe_kernel(const DkvArgs<NS> a
     }
 }
 
+// ==========================================================================================================================
+// backward, FUSED: dQ, dK, dV of one (batch, head) item in ONE pass over the scores (16-bit operands, 192 < N <= 208: the ViT-B/L
+// sequence lengths at 224^2 / patch 16).  Why: the two-kernel backward computes S and exp twice (7 matmul units instead of 5), reads
+// q, k, v, dO twice (927 MB instead of 618 MB at ViT-B/16 batch 256), and -- measured, see DESIGN section 4, round 3 -- spends half
+// its time on the rows every wave fetches for itself at the start of an item.  Here NO compute wave loads from global memory:
+//
+//   waves 0-12   "KV waves": wave w owns key tile w (16 keys): K / V fragments from LDS at the start of the item, then per 32-query
+//                step  S = Q K^T, dP = dO V^T, P = exp2(S c - lse), dS = P (dP - delta)  ->  dV += P^T dO, dK += dS^T Q  (accumulated in
+//                registers over the 7 steps) and dS^T (16 bit) -> LDS;
+//   waves 13-14  "dQ waves": one step behind, dQ[32 queries] = dS K over ALL keys from the LDS copy of dS^T and the resident K
+//                (transpose reads; wave 13 the first 32 columns of d, wave 14 the rest), handed through LDS to ONE of the KV waves
+//                (step g: wave g mod 13), which stores it as whole 128-byte rows -- the dQ waves never store, so their only global
+//                accesses, the O rows for delta = rowsum(dO * O) of the step AHEAD (dO from the ring), are counted exactly by hipcc
+//                (with stores in the same wave it waited for the stores' completion at every step);
+//   wave 15      producer: Q | dO | lse of every 32-query step through a 4-stage LDS ring (global_load_lds; continuous across
+//                items, three steps ahead), K of the NEXT item into the second K buffer and V of the next item into the single V
+//                buffer (its fragments are read once, at the start of an item) during steps 1-4 of the current one; exact-count
+//                vmcnt waits (9 ring pieces per step, + 14 K / V pieces in steps 1-4: only the current step's pieces may fly).
+//   One workgroup barrier per step.  LDS: K 2 x 28 KB, V 28 KB, dS^T 2 x 14 KB, ring 4 x 8.25 KB, dQ 2 x 4 KB, delta 256 B = 153 KB.
+// ==========================================================================================================================
+struct FusedArgs {
+    TND q, k, v, dout, o;
+    const float* lse;
+    float* delta;            // NOT written (the two-kernel path's scratch): delta lives in LDS here
+    OND dq, dk, dv;
+    int H, N, nitems;
+    float scale;
+};
+constexpr int FB_NKS = 7;                       // 32-row steps (192 < N <= 224 rows staged; key tiles limited to 13 -> N <= 208)
+constexpr int FB_ROWS = FB_NKS * 32;            // 224
+constexpr int FB_TILE = FB_ROWS * 128;          // one staged tensor
+constexpr int FB_DS = FB_ROWS * 64;             // dS^T of one step: 224 key rows x 32 queries
+constexpr int FB_NST = 4;
+constexpr int FB_STAGE = 4096 + 4096 + 256;     // Q | dO | lse of a 32-query step
+constexpr int FB_DQ = 32 * 128;                 // dQ of one step on its way from the dQ waves to the wave that stores it
+constexpr int FB_OFF_K = 0, FB_OFF_V = 2 * FB_TILE, FB_OFF_DS = 3 * FB_TILE, FB_OFF_RING = FB_OFF_DS + 2 * FB_DS,
+              FB_OFF_DQ = FB_OFF_RING + FB_NST * FB_STAGE, FB_OFF_DEL = FB_OFF_DQ + 2 * FB_DQ, FB_LDS = FB_OFF_DEL + 256;
+static_assert(FB_LDS <= 160 * 1024, "fused attention backward: LDS image");
+
+// dS^T image: row = key, 64 bytes = 32 queries; 16-byte chunk c of row r sits at position c ^ (((r >> 2) & 1) << 1), which keeps
+// the 8 rows x 32 bytes of a transpose read on 64 distinct banks
+__device__ __forceinline__ int ds_off(int row, int qbyte) { return row * 64 + ((((qbyte >> 4) ^ (((row >> 2) & 1) << 1)) << 4) | (qbyte & 15)); }
+// lane (i, g) gets dS^T[key0 + {4g..4g+3, 16+4g..16+4g+3}][q0 + i]  (q0 = 0 or 16)
+__device__ __forceinline__ bf16x8 ds_tr(const char* buf, int key0, int q0, int fi, int fg) {
+    const int row = key0 + 4 * fg + (fi >> 2);
+    const char* p = buf + ds_off(row, (q0 + (fi & 3) * 4) * 2);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * 64));   // row + 16: same swizzle
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, H = a.H;
+    const int first = blockIdx.x, stride = gridDim.x;
+    const int nit = first < a.nitems ? (a.nitems - first + stride - 1) / stride : 0;      // items of this workgroup
+    const int G = nit * FB_NKS;                                                           // steps of this workgroup
+    if (nit == 0) return;
+    char* const ring = smem + FB_OFF_RING;
+    float* const del = reinterpret_cast<float*>(smem + FB_OFF_DEL);
+    auto item_of = [&](int it) { return first + it * stride; };
+
+    if (wave == 15) {
+        // ------------------------------------------------------------------ producer ------------------------------------------------
+        const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+        auto issue_stage = [&](int g) {              // 9 pieces: Q 4, dO 4, lse 1 (steps past the end re-load the last one: uniform counts)
+            const int gg = g < G ? g : G - 1;
+            const int it = gg / FB_NKS, s = gg - it * FB_NKS;
+            const int item = item_of(it), b = item / H, h = item - b * H;
+            char* st = ring + (g % FB_NST) * FB_STAGE;
+            const __bf16* qb = a.q.p + b * a.q.s_b + h * a.q.s_h;
+            const __bf16* db = a.dout.p + b * a.dout.s_b + h * a.dout.s_h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = s * 32 + 8 * j + lrow; row = row < N ? row : N - 1;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(qb + (long long)row * a.q.s_n + lchunk * 8),
+                                                 (void __attribute__((address_space(3)))*)(st + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(db + (long long)row * a.dout.s_n + lchunk * 8),
+                                                 (void __attribute__((address_space(3)))*)(st + 4096 + j * 1024), 16, 0, 0);
+            }
+            int qi = s * 32 + (lane & 31); qi = qi < N ? qi : N - 1;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.lse + (long long)item * N + qi),
+                                             (void __attribute__((address_space(3)))*)(st + 8192), 4, 0, 0);
+        };
+        auto issue_kv = [&](int it, int part) {      // 14 pieces: part 0..3 of the 56 row groups of K (28) and V (28) of item `it` (clamped)
+            const int itc = it < nit ? it : nit - 1;
+            const int item = item_of(itc), b = item / H, h = item - b * H;
+            const __bf16* kb = a.k.p + b * a.k.s_b + h * a.k.s_h;
+            const __bf16* vb = a.v.p + b * a.v.s_b + h * a.v.s_h;
+            char* Kd = smem + FB_OFF_K + (it & 1) * FB_TILE;
+            char* Vd = smem + FB_OFF_V;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int g = part * 7 + j;
+                int row = 8 * g + lrow; row = row < N ? row : N - 1;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(kb + (long long)row * a.k.s_n + lchunk * 8),
+                                                 (void __attribute__((address_space(3)))*)(Kd + g * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(vb + (long long)row * a.v.s_n + lchunk * 8),
+                                                 (void __attribute__((address_space(3)))*)(Vd + g * 1024), 16, 0, 0);
+            }
+        };
+        // prologue: K / V of the first item, ring stages 0..2; everything landed before the first barrier
+        for (int part = 0; part < 4; ++part) issue_kv(0, part);
+        for (int g = 0; g < 3; ++g) issue_stage(g);
+        AP_WAIT_DMA();
+        AP_BARRIER();          // P: stage 0 (and 1) visible -> the dQ waves form delta(0)
+        AP_BARRIER();          // b_0
+        for (int g = 0; g <= G + 1; ++g) {
+            const int s = g % FB_NKS, it = g / FB_NKS;
+            issue_stage(g + 3);                                    // into the slot of step g - 1
+            const bool kv = s >= 1 && s <= 4;
+            if (kv) issue_kv(it + 1, s - 1);
+            // before b_{g+1}: stage g + 2 (issued in step g - 1) and everything older has landed; this step's pieces may fly
+            if (kv) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            AP_BARRIER();                                          // b_{g+1}
+        }
+        AP_WAIT_DMA();         // the surplus pieces must not outlive the workgroup's LDS
+        return;
+    }
+
+    const int fi = lane & 15, fg = lane >> 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const float c = a.scale * LOG2E;
+
+    if (wave >= 13) {
+        // ------------------------------------------------------------------ dQ waves ------------------------------------------------
+        const int qt = wave - 13;                                   // delta: which 16 of the step's 32 queries; dQ: which 32 columns of d
+        struct ORow { bf16x8 o[2]; };
+        auto o_rows = [&](int g) {                                  // the forward's output rows of step g (clamped), this lane's 16 columns
+            const int gg = g < G ? g : G - 1;
+            const int it = gg / FB_NKS, s = gg - it * FB_NKS;
+            const int item = item_of(it), b = item / H, h = item - b * H;
+            int qi = s * 32 + qt * 16 + fi; qi = qi < N ? qi : N - 1;
+            const __bf16* op = a.o.p + b * a.o.s_b + h * a.o.s_h + (long long)qi * a.o.s_n;
+            ORow r;
+            r.o[0] = *reinterpret_cast<const bf16x8*>(op + 8 * fg);
+            r.o[1] = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * fg);
+            return r;
+        };
+        auto make_delta = [&](int g, const ORow& r) {               // delta of step g from its ring stage (dO) and the O rows
+            const char* dst = ring + (g % FB_NST) * FB_STAGE + 4096;
+            float sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 d8 = sw_row(dst, qt * 16, ks, fi, fg);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum = fmaf((float)d8[e], (float)r.o[ks][e], sum);
+            }
+            sum = groups_sum(sum);
+            if (fg == 0) del[(g & 1) * 32 + qt * 16 + fi] = sum;
+        };
+        ORow cur = o_rows(0);
+        ORow nxt = o_rows(1);
+        AP_BARRIER();                                              // P
+        make_delta(0, cur);
+        cur = nxt;                                                 // rows of step 1
+        nxt = o_rows(2);
+        AP_BARRIER();                                              // b_0
+        for (int g = 0; g <= G + 1; ++g) {
+            const ORow req = o_rows(g + 3);                        // requested now, used two steps from now
+            if (g >= 1 && g <= G) {                                // dQ of step g - 1: dS K over all keys, columns 32 qt .. 32 qt + 31 of d
+                const int gp = g - 1, itp = gp / FB_NKS;
+                const char* Ks = smem + FB_OFF_K + (itp & 1) * FB_TILE;
+                const char* dsb = smem + FB_OFF_DS + (gp & 1) * FB_DS;
+                f32x4 acc[2][2];
+                acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = z4;
+#pragma unroll
+                for (int ks = 0; ks < FB_NKS; ++ks) {
+                    const bf16x8 ds0 = ds_tr(dsb, ks * 32, 0, fi, fg), ds1 = ds_tr(dsb, ks * 32, 16, fi, fg);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const bf16x8 kt = sw_tr(Ks, ks * 32, (2 * qt + f) * 16, fi, fg);
+                        acc[0][f] = MFMA(kt, ds0, acc[0][f]);
+                        acc[1][f] = MFMA(kt, ds1, acc[1][f]);
+                    }
+                }
+                // -> LDS (128-byte rows, chunk c of row r at position c ^ (r & 7)): lane (i, g) holds 4 consecutive d of query 16 t + i
+                char* stg = smem + FB_OFF_DQ + (g & 1) * FB_DQ;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const int row = t * 16 + fi, chunk = 2 * (2 * qt + f) + (fg >> 1);
+                        const f32x4 v = acc[t][f] * a.scale;
+                        const bf16x4 o4 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4) + ((fg & 1) << 3)) = o4;
+                    }
+            }
+            if (g + 1 < G) make_delta(g + 1, cur);                 // for the step ahead: its ring stage landed before b_g
+            cur = nxt; nxt = req;
+            AP_BARRIER();                                          // b_{g+1}
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- KV waves ------------------------------------------------
+    const int nkt = (N + 15) >> 4;
+    const bool active = wave < nkt;
+    const int ki = wave * 16 + fi;
+    // rows 16 nkt .. 223 of both dS^T buffers belong to no wave: zero them once (the dQ waves sum over all 224 rows)
+    for (int i = tid; i < 2 * FB_DS / 16; i += 13 * 64) {
+        const int bufi = i / (FB_DS / 16), r = (i % (FB_DS / 16)) >> 2;
+        if (r >= nkt * 16) *reinterpret_cast<f32x4*>(smem + FB_OFF_DS + bufi * FB_DS + (i % (FB_DS / 16)) * 16) = z4;
+    }
+    AP_BARRIER();                                                  // P
+    AP_BARRIER();                                                  // b_0
+    bf16x8 kf[2], vf[2];
+    f32x4 accK[4], accV[4];
+    for (int g = 0; g <= G + 1; ++g) {
+        const int it = g / FB_NKS, s = g - it * FB_NKS;
+        if (g >= 2 && wave == g % 13) {
+            // this step's storer: dQ of step g - 2 (left in LDS by the dQ waves during step g - 1), whole 128-byte rows
+            const int gp = g - 2, itp = gp / FB_NKS, sp = gp - itp * FB_NKS;
+            const int item = item_of(itp), b = item / H, h = item - b * H;
+            const char* stg = smem + FB_OFF_DQ + ((g - 1) & 1) * FB_DQ;
+            __bf16* dqb = reinterpret_cast<__bf16*>(a.dq.p) + b * a.dq.s_b + h * a.dq.s_h;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int row = 8 * j4 + (lane >> 3), qi = sp * 32 + row;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((lane & 7) << 4));
+                if (qi < N) *reinterpret_cast<bf16x8*>(dqb + (long long)qi * a.dq.s_n + (((lane & 7) ^ (row & 7)) << 3)) = v;
+            }
+        }
+        if (active && g < G) {
+            const char* Ks = smem + FB_OFF_K + (it & 1) * FB_TILE;
+            const char* Vs = smem + FB_OFF_V;
+            if (s == 0) {
+                kf[0] = sw_row(Ks, wave * 16, 0, fi, fg); kf[1] = sw_row(Ks, wave * 16, 1, fi, fg);
+                vf[0] = sw_row(Vs, wave * 16, 0, fi, fg); vf[1] = sw_row(Vs, wave * 16, 1, fi, fg);
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) { accK[fd] = z4; accV[fd] = z4; }
+            }
+            const char* Qs = ring + (g % FB_NST) * FB_STAGE;
+            const char* Ds = Qs + 4096;
+            const float* lse_s = reinterpret_cast<const float*>(Qs + 8192);
+            const float* del_s = del + (g & 1) * 32;
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int row0 = hh * 16;
+                const bf16x8 q0 = sw_row(Qs, row0, 0, fi, fg), q1 = sw_row(Qs, row0, 1, fi, fg);
+                const bf16x8 d0 = sw_row(Ds, row0, 0, fi, fg), d1 = sw_row(Ds, row0, 1, fi, fg);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
+                f32x4 st = MFMA(q0, kf[0], z4);            // S[q = row0 + 4g + e][key]
+                st = MFMA(q1, kf[1], st);
+                f32x4 dp = MFMA(d0, vf[0], z4);            // dP[q][key]
+                dp = MFMA(d1, vf[1], dp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], c, -LOG2E * l4[e]));
+                    ds[hh][e] = p[hh][e] * (dp[e] - d4[e]);                  // `scale` is applied once, to dK and dQ
+                }
+                if (s == FB_NKS - 1) {                     // padding query rows only exist in the last step
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (s * 32 + row0 + 4 * fg + e >= N) { p[hh][e] = 0.f; ds[hh][e] = 0.f; }
+                }
+            }
+            if (ki >= N) { ds[0] = z4; ds[1] = z4; p[0] = z4; p[1] = z4; }      // padding keys of the last key tile: nothing for dQ (their dK / dV rows are not stored)
+            const bf16x8 pb = pack8(p[0], p[1]), dsb = pack8(ds[0], ds[1]);
+            {   // dS^T -> LDS: this lane's key row, queries {4g..4g+3} and {16+4g..+3} of the step
+                char* dsw = smem + FB_OFF_DS + (g & 1) * FB_DS;
+                const s16x8 w = __builtin_bit_cast(s16x8, dsb);
+                *reinterpret_cast<s16x4*>(dsw + ds_off(ki, 8 * fg)) = s16x4{w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<s16x4*>(dsw + ds_off(ki, 32 + 8 * fg)) = s16x4{w[4], w[5], w[6], w[7]};
+            }
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                accV[fd] = MFMA(sw_tr(Ds, 0, fd * 16, fi, fg), pb, accV[fd]);     // dV^T[d][key]
+                accK[fd] = MFMA(sw_tr(Qs, 0, fd * 16, fi, fg), dsb, accK[fd]);    // dK^T[d][key]
+            }
+            if (s == FB_NKS - 1 && ki < N) {
+                const int item = item_of(it), b = item / H, h = item - b * H;
+                __bf16* dkp = reinterpret_cast<__bf16*>(a.dk.p) + b * a.dk.s_b + h * a.dk.s_h + (long long)ki * a.dk.s_n + 4 * fg;
+                __bf16* dvp = reinterpret_cast<__bf16*>(a.dv.p) + b * a.dv.s_b + h * a.dv.s_h + (long long)ki * a.dv.s_n + 4 * fg;
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd] * a.scale); store4<__bf16>(dvp + fd * 16, accV[fd]); }
+            }
+        }
+        AP_BARRIER();                                              // b_{g+1}
+    }
+}
+
 // ---- elementwise split of an f32 tensor into hi + lo 16-bit terms ----
 __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, __bf16* __restrict__ hi, __bf16* __restrict__ lo, long long n4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -643,7 +930,7 @@ int num_cus() {
 template <typename K> int set_lds(K kernel, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
-constexpr int AP_MAX_LDS = 2 * (2 * 224 * 128 + 2048);      // the largest image any of the kernels asks for (two buffers of Q | dO + lse, delta)
+constexpr int AP_MAX_LDS = 160 * 1024;      // the fused backward's image is 153.5 KB; the others ask for at most 119 KB
 #define AP_SET_LDS(kernel, name) do { static const int rc__ = set_lds(kernel, AP_MAX_LDS); \
     if (rc__ != 0) VITK_FAIL(rc__, "%s: hipFuncSetAttribute(max dynamic LDS) failed: %d", name, rc__); } while (0)
 
@@ -719,9 +1006,24 @@ template <int NS> int launch_bwd(const AttnPipeBwd& p, hipStream_t st, int which
     return 0;
 }
 
+int launch_fused(const AttnPipeBwd& p, hipStream_t st) {
+    FusedArgs a;
+    a.q = tnd(p.q[0]); a.k = tnd(p.k[0]); a.v = tnd(p.v[0]); a.dout = tnd(p.dout[0]); a.o = tnd(p.o);
+    a.lse = p.lse; a.delta = p.delta; a.dq = ond(p.dq); a.dk = ond(p.dk); a.dv = ond(p.dv);
+    a.H = (int)p.H; a.N = (int)p.N; a.nitems = (int)(p.B * p.H); a.scale = p.scale;
+    int grid = num_cus();
+    if (grid > a.nitems) grid = a.nitems;
+    AP_SET_LDS(attn_bwd_fused_kernel, "attn_bwd (fused)");
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)grid), dim3(1024), (size_t)FB_LDS, st, a);
+    VITK_CHECK_LAUNCH("attn_bwd (fused)");
+    return 0;
+}
+
 }  // namespace
 
 bool attn_pipe_supported(int64_t N, int64_t d) { return d == 64 && N > 32 && N <= 224; }
+bool attn_fused_bwd_supported(int64_t N, int64_t d, float drop_p) { return d == 64 && N > 192 && N <= 208 && drop_p == 0.f; }
+int attn_pipe_bwd_fused(const AttnPipeBwd& a, void* stream) { return launch_fused(a, (hipStream_t)stream); }
 // Which 16-bit kernels run pipelined by default: bit 0 forward, bit 1 dQ, bit 2 dK/dV.  [measured, ViT-B/16 batch 256, rocprofv3
 // averages, pipelined vs one-workgroup-per-head] forward 89 vs 81 us, dQ 110 vs 118 us, dK/dV 150 vs 143 us: only the dQ kernel -- the
 // one whose per-wave rows are prefetched a whole item ahead -- gains, so only it is on.  VITK_ATTN_PIPE=<mask> overrides (tests: 7).
