@@ -32,5 +32,6 @@ int attn_pipe_bwd(const AttnPipeBwd& a, void* stream, int which);
 // the single-kernel backward (dQ, dK, dV in one pass over the scores): 16-bit, 192 < N <= 208, no dropout; mask bit 3
 bool attn_fused_bwd_supported(int64_t N, int64_t d, float drop_p);
 int attn_pipe_bwd_fused(const AttnPipeBwd& a, void* stream);
-// default selection of the 16-bit kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV (VITK_ATTN_PIPE overrides)
+// selection of the 16-bit kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV, bit 3 the single-kernel backward where it applies
+// (default 2 | 8; 0 while vitk_set_cu_reserve > 0; VITK_ATTN_PIPE overrides)
 int attn_pipe_mask();

@@ -633,11 +633,11 @@ __global__ __launch_bounds__(1024) void attn_dkv_pipe_kernel(const DkvArgs<NS> a
 //                (step g: wave g mod 13), which stores it as whole 128-byte rows -- the dQ waves never store, so their only global
 //                accesses, the O rows for delta = rowsum(dO * O) of the step AHEAD (dO from the ring), are counted exactly by hipcc
 //                (with stores in the same wave it waited for the stores' completion at every step);
-//   wave 15      producer: Q | dO | lse of every 32-query step through a 4-stage LDS ring (global_load_lds; continuous across
-//                items, three steps ahead), K of the NEXT item into the second K buffer and V of the next item into the single V
+//   wave 15      producer: Q | dO | lse of every 32-query step through a 5-stage LDS ring (global_load_lds; continuous across
+//                items, four steps ahead), K of the NEXT item into the second K buffer and V of the next item into the single V
 //                buffer (its fragments are read once, at the start of an item) during steps 1-4 of the current one; exact-count
-//                vmcnt waits (9 ring pieces per step, + 14 K / V pieces in steps 1-4: only the current step's pieces may fly).
-//   One workgroup barrier per step.  LDS: K 2 x 28 KB, V 28 KB, dS^T 2 x 14 KB, ring 4 x 8.25 KB, dQ 2 x 4 KB, delta 256 B = 153 KB.
+//                vmcnt waits (9 ring pieces per step, + 13 K / V pieces in steps 1-4: the pieces of the last two steps may fly).
+//   One workgroup barrier per step.  LDS: K 2 x 26 KB, V 26 KB, dS^T 2 x 14 KB, ring 5 x 8.25 KB, dQ 2 x 4 KB, delta + lse 512 B = 155.8 KB.
 // ==========================================================================================================================
 struct FusedArgs {
     TND q, k, v, dout, o;
@@ -646,16 +646,19 @@ struct FusedArgs {
     OND dq, dk, dv;
     int H, N, nitems;
     float scale;
+    int dbg;                 // experiments (VITK_ATTN_DBG): 1 = no DMA, 2 = KV waves skip their arithmetic, 4 = dQ waves skip theirs
 };
 constexpr int FB_NKS = 7;                       // 32-row steps (192 < N <= 224 rows staged; key tiles limited to 13 -> N <= 208)
 constexpr int FB_ROWS = FB_NKS * 32;            // 224
-constexpr int FB_TILE = FB_ROWS * 128;          // one staged tensor
-constexpr int FB_DS = FB_ROWS * 64;             // dS^T of one step: 224 key rows x 32 queries
-constexpr int FB_NST = 4;
+constexpr int FB_KROWS = 13 * 16;               // K / V rows staged (the key tiles): reads of rows 208..223 (the second half of the
+                                                // 7th 32-key step) fall into the NEXT LDS region -- finite data -- and meet zero dS^T rows
+constexpr int FB_TILE = FB_KROWS * 128;         // one staged K or V
+constexpr int FB_DS = FB_ROWS * 64;             // dS^T of one step: 224 key rows x 32 queries (rows >= 16 nkt stay zero)
+constexpr int FB_NST = 5;
 constexpr int FB_STAGE = 4096 + 4096 + 256;     // Q | dO | lse of a 32-query step
 constexpr int FB_DQ = 32 * 128;                 // dQ of one step on its way from the dQ waves to the wave that stores it
 constexpr int FB_OFF_K = 0, FB_OFF_V = 2 * FB_TILE, FB_OFF_DS = 3 * FB_TILE, FB_OFF_RING = FB_OFF_DS + 2 * FB_DS,
-              FB_OFF_DQ = FB_OFF_RING + FB_NST * FB_STAGE, FB_OFF_DEL = FB_OFF_DQ + 2 * FB_DQ, FB_LDS = FB_OFF_DEL + 256;
+              FB_OFF_DQ = FB_OFF_RING + FB_NST * FB_STAGE, FB_OFF_DEL = FB_OFF_DQ + 2 * FB_DQ, FB_LDS = FB_OFF_DEL + 512;      // delta [2][32] | -log2(e) lse [2][32]
 static_assert(FB_LDS <= 160 * 1024, "fused attention backward: LDS image");
 
 // dS^T image: row = key, 64 bytes = 32 queries; 16-byte chunk c of row r sits at position c ^ (((r >> 2) & 1) << 1), which keeps
@@ -687,6 +690,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
         // ------------------------------------------------------------------ producer ------------------------------------------------
         const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
         auto issue_stage = [&](int g) {              // 9 pieces: Q 4, dO 4, lse 1 (steps past the end re-load the last one: uniform counts)
+            if (a.dbg & 1) return;
             const int gg = g < G ? g : G - 1;
             const int it = gg / FB_NKS, s = gg - it * FB_NKS;
             const int item = item_of(it), b = item / H, h = item - b * H;
@@ -705,37 +709,42 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.lse + (long long)item * N + qi),
                                              (void __attribute__((address_space(3)))*)(st + 8192), 4, 0, 0);
         };
-        auto issue_kv = [&](int it, int part) {      // 14 pieces: part 0..3 of the 56 row groups of K (28) and V (28) of item `it` (clamped)
+        auto issue_kv = [&](int it, int part) {      // 13 pieces: part 0..3 of the 52 row groups of K (26) and V (26) of item `it` (clamped)
+            if (a.dbg & 1) return;
             const int itc = it < nit ? it : nit - 1;
             const int item = item_of(itc), b = item / H, h = item - b * H;
             const __bf16* kb = a.k.p + b * a.k.s_b + h * a.k.s_h;
             const __bf16* vb = a.v.p + b * a.v.s_b + h * a.v.s_h;
             char* Kd = smem + FB_OFF_K + (it & 1) * FB_TILE;
             char* Vd = smem + FB_OFF_V;
+            // 52 pieces = K groups 0..25 then V groups 0..25; part p issues pieces 13 p .. 13 p + 12
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int g = part * 7 + j;
+            for (int j = 0; j < 13; ++j) {
+                const int pc = part * 13 + j;
+                const bool isv = pc >= 26;
+                const int g = isv ? pc - 26 : pc;
                 int row = 8 * g + lrow; row = row < N ? row : N - 1;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(kb + (long long)row * a.k.s_n + lchunk * 8),
-                                                 (void __attribute__((address_space(3)))*)(Kd + g * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(vb + (long long)row * a.v.s_n + lchunk * 8),
-                                                 (void __attribute__((address_space(3)))*)(Vd + g * 1024), 16, 0, 0);
+                const __bf16* src = isv ? vb + (long long)row * a.v.s_n : kb + (long long)row * a.k.s_n;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + lchunk * 8),
+                                                 (void __attribute__((address_space(3)))*)((isv ? Vd : Kd) + g * 1024), 16, 0, 0);
             }
         };
-        // prologue: K / V of the first item, ring stages 0..2; everything landed before the first barrier
+        // prologue: K / V of the first item, ring stages 0..3; everything landed before the first barrier
         for (int part = 0; part < 4; ++part) issue_kv(0, part);
-        for (int g = 0; g < 3; ++g) issue_stage(g);
+        for (int g = 0; g < 4; ++g) issue_stage(g);
         AP_WAIT_DMA();
         AP_BARRIER();          // P: stage 0 (and 1) visible -> the dQ waves form delta(0)
         AP_BARRIER();          // b_0
         for (int g = 0; g <= G + 1; ++g) {
             const int s = g % FB_NKS, it = g / FB_NKS;
-            issue_stage(g + 3);                                    // into the slot of step g - 1
+            issue_stage(g + 4);                                    // into the slot of step g - 1
             const bool kv = s >= 1 && s <= 4;
             if (kv) issue_kv(it + 1, s - 1);
-            // before b_{g+1}: stage g + 2 (issued in step g - 1) and everything older has landed; this step's pieces may fly
-            if (kv) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            // before b_{g+1}: stage g + 2 (issued in step g - 2) and everything older has landed; the pieces of steps g - 1 and g may fly
+            const bool kv_prev = s >= 2 && s <= 5;
+            if (kv && kv_prev) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+            else if (kv || kv_prev) asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
             AP_BARRIER();                                          // b_{g+1}
         }
         AP_WAIT_DMA();         // the surplus pieces must not outlive the workgroup's LDS
@@ -771,7 +780,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
                 for (int e = 0; e < 8; ++e) sum = fmaf((float)d8[e], (float)r.o[ks][e], sum);
             }
             sum = groups_sum(sum);
-            if (fg == 0) del[(g & 1) * 32 + qt * 16 + fi] = sum;
+            if (fg == 0) {
+                del[(g & 1) * 32 + qt * 16 + fi] = sum;
+                // the exp2 argument's constant term for the KV waves (one FMA there instead of a multiply and an FMA)
+                del[64 + (g & 1) * 32 + qt * 16 + fi] = -LOG2E * reinterpret_cast<const float*>(dst + 4096)[qt * 16 + fi];
+            }
         };
         ORow cur = o_rows(0);
         ORow nxt = o_rows(1);
@@ -780,12 +793,21 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
         cur = nxt;                                                 // rows of step 1
         nxt = o_rows(2);
         AP_BARRIER();                                              // b_0
+        constexpr int KREG = 5;                                    // K^T key steps held in registers per item (the same fragments serve all 7 query
+                                                                   // steps); the rest is re-read from LDS each step: 128 registers a lane
+        bf16x8 ktf[KREG][2];
         for (int g = 0; g <= G + 1; ++g) {
             const ORow req = o_rows(g + 3);                        // requested now, used two steps from now
-            if (g >= 1 && g <= G) {                                // dQ of step g - 1: dS K over all keys, columns 32 qt .. 32 qt + 31 of d
+            if (g >= 1 && g <= G && !(a.dbg & 4)) {                // dQ of step g - 1: dS K over all keys, columns 32 qt .. 32 qt + 31 of d
                 const int gp = g - 1, itp = gp / FB_NKS;
-                const char* Ks = smem + FB_OFF_K + (itp & 1) * FB_TILE;
                 const char* dsb = smem + FB_OFF_DS + (gp & 1) * FB_DS;
+                const char* Ks = smem + FB_OFF_K + (itp & 1) * FB_TILE;
+                if (gp - itp * FB_NKS == 0) {
+#pragma unroll
+                    for (int ks = 0; ks < KREG; ++ks)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) ktf[ks][f] = sw_tr(Ks, ks * 32, (2 * qt + f) * 16, fi, fg);
+                }
                 f32x4 acc[2][2];
                 acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = z4;
 #pragma unroll
@@ -793,7 +815,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
                     const bf16x8 ds0 = ds_tr(dsb, ks * 32, 0, fi, fg), ds1 = ds_tr(dsb, ks * 32, 16, fi, fg);
 #pragma unroll
                     for (int f = 0; f < 2; ++f) {
-                        const bf16x8 kt = sw_tr(Ks, ks * 32, (2 * qt + f) * 16, fi, fg);
+                        const bf16x8 kt = ks < KREG ? ktf[ks][f] : sw_tr(Ks, ks * 32, (2 * qt + f) * 16, fi, fg);
                         acc[0][f] = MFMA(kt, ds0, acc[0][f]);
                         acc[1][f] = MFMA(kt, ds1, acc[1][f]);
                     }
@@ -826,6 +848,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
         const int bufi = i / (FB_DS / 16), r = (i % (FB_DS / 16)) >> 2;
         if (r >= nkt * 16) *reinterpret_cast<f32x4*>(smem + FB_OFF_DS + bufi * FB_DS + (i % (FB_DS / 16)) * 16) = z4;
     }
+    // K[1] is empty during the first item and the dQ waves' reads of K[0] rows 208..223 fall into its first 16 rows: finite data there
+    if (tid < 128) *reinterpret_cast<f32x4*>(smem + FB_OFF_K + FB_TILE + tid * 16) = z4;
     AP_BARRIER();                                                  // P
     AP_BARRIER();                                                  // b_0
     bf16x8 kf[2], vf[2];
@@ -845,7 +869,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
                 if (qi < N) *reinterpret_cast<bf16x8*>(dqb + (long long)qi * a.dq.s_n + (((lane & 7) ^ (row & 7)) << 3)) = v;
             }
         }
-        if (active && g < G) {
+        if (active && g < G && !(a.dbg & 2)) {
             const char* Ks = smem + FB_OFF_K + (it & 1) * FB_TILE;
             const char* Vs = smem + FB_OFF_V;
             if (s == 0) {
@@ -856,15 +880,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
             }
             const char* Qs = ring + (g % FB_NST) * FB_STAGE;
             const char* Ds = Qs + 4096;
-            const float* lse_s = reinterpret_cast<const float*>(Qs + 8192);
             const float* del_s = del + (g & 1) * 32;
+            const float* nl_s = del_s + 64;                    // -log2(e) lse, written by the dQ waves with delta
             f32x4 p[2], ds[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int row0 = hh * 16;
                 const bf16x8 q0 = sw_row(Qs, row0, 0, fi, fg), q1 = sw_row(Qs, row0, 1, fi, fg);
                 const bf16x8 d0 = sw_row(Ds, row0, 0, fi, fg), d1 = sw_row(Ds, row0, 1, fi, fg);
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(nl_s + row0 + 4 * fg);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
                 f32x4 st = MFMA(q0, kf[0], z4);            // S[q = row0 + 4g + e][key]
                 st = MFMA(q1, kf[1], st);
@@ -872,7 +896,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
                 dp = MFMA(d1, vf[1], dp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    p[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], c, -LOG2E * l4[e]));
+                    p[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], c, l4[e]));
                     ds[hh][e] = p[hh][e] * (dp[e] - d4[e]);                  // `scale` is applied once, to dK and dQ
                 }
                 if (s == FB_NKS - 1) {                     // padding query rows only exist in the last step
@@ -881,7 +905,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
                         if (s * 32 + row0 + 4 * fg + e >= N) { p[hh][e] = 0.f; ds[hh][e] = 0.f; }
                 }
             }
-            if (ki >= N) { ds[0] = z4; ds[1] = z4; p[0] = z4; p[1] = z4; }      // padding keys of the last key tile: nothing for dQ (their dK / dV rows are not stored)
+            if (wave == nkt - 1 && ki >= N) { ds[0] = z4; ds[1] = z4; p[0] = z4; p[1] = z4; }      // padding keys (last key tile only: a wave-uniform test first): nothing for dQ; their dK / dV rows are not stored
             const bf16x8 pb = pack8(p[0], p[1]), dsb = pack8(ds[0], ds[1]);
             {   // dS^T -> LDS: this lane's key row, queries {4g..4g+3} and {16+4g..+3} of the step
                 char* dsw = smem + FB_OFF_DS + (g & 1) * FB_DS;
@@ -1011,6 +1035,7 @@ int launch_fused(const AttnPipeBwd& p, hipStream_t st) {
     a.q = tnd(p.q[0]); a.k = tnd(p.k[0]); a.v = tnd(p.v[0]); a.dout = tnd(p.dout[0]); a.o = tnd(p.o);
     a.lse = p.lse; a.delta = p.delta; a.dq = ond(p.dq); a.dk = ond(p.dk); a.dv = ond(p.dv);
     a.H = (int)p.H; a.N = (int)p.N; a.nitems = (int)(p.B * p.H); a.scale = p.scale;
+    a.dbg = getenv("VITK_ATTN_DBG") ? atoi(getenv("VITK_ATTN_DBG")) : 0;
     int grid = num_cus();
     if (grid > a.nitems) grid = a.nitems;
     AP_SET_LDS(attn_bwd_fused_kernel, "attn_bwd (fused)");
@@ -1033,7 +1058,9 @@ int attn_pipe_mask() {
     // the pipelined kernels are resident workgroups with STATIC item lists and a CU each: while another kernel is expected on the chip
     // (vitk_set_cu_reserve > 0: a collective overlapping the backward) the per-head kernels run instead -- their 3,072 independent
     // workgroups simply use the CUs that are there
-    return vitk_get_cu_reserve() > 0 ? 0 : 2;
+    // default: the single-kernel backward where it applies (16-bit, 192 < N <= 208, no dropout: 216 us against 280 us for the
+    // pair at ViT-B/16 batch 256), else the pipelined dQ kernel + the per-head dK / dV kernel; per-head forward
+    return vitk_get_cu_reserve() > 0 ? 0 : (2 | 8);
 }
 int attn_pipe_fwd(const AttnPipeFwd& a, void* stream) {
     return a.ns == 2 ? launch_fwd<2>(a, (hipStream_t)stream) : launch_fwd<1>(a, (hipStream_t)stream);
