@@ -35,3 +35,12 @@ tb = timeit(lambda: K.attn_bwd_bf16(q_, k_, v_, o_, K.bhnd(do, N * I, d, I), lse
                                     K.bhnd(dqkv, sb, sh, sn, offset=2 * I), B, H, N, d, d ** -0.5))
 import os
 print(f"VITK_ATTN_PIPE={os.environ.get('VITK_ATTN_PIPE', '(default)')} B={B}: fwd {tf:.1f} us  bwd {tb:.1f} us")
+if int(os.environ.get("VITK_ATTN_DBG", "0")) & 24:
+    # the fused backward's cycle stamps (workgroup 0): per-role totals in the (otherwise unused) delta buffer
+    torch.cuda.synchronize()
+    w = delta.view(-1)[:96].view(torch.int64).cpu().tolist()
+    G = max(w[4], 1)
+    print(f"  steps {G}; per step, cycles:  KV wave 2: loop head {w[0]/G:.0f}  first half {w[1]/G:.0f}  second half {w[2]/G:.0f}  barrier {w[3]/G:.0f}")
+    print(f"  dQ wave 0: dQ {w[8]/G:.0f}  delta {w[9]/G:.0f}  barrier {w[10]/G:.0f};   producer: issue {w[16]/G:.0f}  wait {w[17]/G:.0f}  barrier {w[18]/G:.0f}")
+    if int(os.environ.get("VITK_ATTN_DBG", "0")) & 16:
+        print("  barrier wait per step, waves 0..15 (the shortest wait is the wave the others wait for):", " ".join(f"{x / G:.0f}" for x in w[20:36]))

@@ -623,21 +623,34 @@ __global__ __launch_bounds__(1024) void attn_dkv_pipe_kernel(const DkvArgs<NS> a
 // backward, FUSED: dQ, dK, dV of one (batch, head) item in ONE pass over the scores (16-bit operands, 192 < N <= 208: the ViT-B/L
 // sequence lengths at 224^2 / patch 16).  Why: the two-kernel backward computes S and exp twice (7 matmul units instead of 5), reads
 // q, k, v, dO twice (927 MB instead of 618 MB at ViT-B/16 batch 256), and -- measured, see DESIGN section 4, round 3 -- spends half
-// its time on the rows every wave fetches for itself at the start of an item.  Here NO compute wave loads from global memory:
+// its time on the rows every wave fetches for itself at the start of an item.  Here NO compute wave loads from global memory
+// (KT = 1, the default, described; KT = 2 gives every KV wave two key tiles):
 //
 //   waves 0-12   "KV waves": wave w owns key tile w (16 keys): K / V fragments from LDS at the start of the item, then per 32-query
-//                step  S = Q K^T, dP = dO V^T, P = exp2(S c - lse), dS = P (dP - delta)  ->  dV += P^T dO, dK += dS^T Q  (accumulated in
-//                registers over the 7 steps) and dS^T (16 bit) -> LDS;
+//                step  S = Q K^T, dP = dO V^T - delta (delta enters as the accumulator's start), P = exp2(S c - lse log2 e),
+//                dS = P dP  ->  dV += P^T dO, dK += dS^T Q  (accumulated in registers over the 7 steps) and dS^T (16 bit) -> LDS;
 //   waves 13-14  "dQ waves": one step behind, dQ[32 queries] = dS K over ALL keys from the LDS copy of dS^T and the resident K
-//                (transpose reads; wave 13 the first 32 columns of d, wave 14 the rest), handed through LDS to ONE of the KV waves
-//                (step g: wave g mod 13), which stores it as whole 128-byte rows -- the dQ waves never store, so their only global
-//                accesses, the O rows for delta = rowsum(dO * O) of the step AHEAD (dO from the ring), are counted exactly by hipcc
-//                (with stores in the same wave it waited for the stores' completion at every step);
+//                (transpose reads, K^T of five key steps held in registers for the item; wave 13 the first 32 columns of d, wave 14
+//                the rest), left in LDS for the producer to store; their only global accesses are the O rows for
+//                delta = rowsum(dO * O) of the step AHEAD (dO from the ring), which hipcc counts exactly; -delta and -lse log2 e
+//                go to LDS for the KV waves;
 //   wave 15      producer: Q | dO | lse of every 32-query step through a 5-stage LDS ring (global_load_lds; continuous across
 //                items, four steps ahead), K of the NEXT item into the second K buffer and V of the next item into the single V
-//                buffer (its fragments are read once, at the start of an item) during steps 1-4 of the current one; exact-count
-//                vmcnt waits (9 ring pieces per step, + 13 K / V pieces in steps 1-4: the pieces of the last two steps may fly).
+//                buffer (its fragments are read once, at the start of an item) during steps 1-4 of the current one; and the dQ
+//                rows of step g - 2 from LDS to global memory as whole 128-byte rows, exactly four store instructions a step, so
+//                that its vmcnt waits stay exact counts (9 ring pieces + 4 stores per step, + 13 K / V pieces in steps 1-4: the
+//                operations of the last two steps may fly).
 //   One workgroup barrier per step.  LDS: K 2 x 26 KB, V 26 KB, dS^T 2 x 14 KB, ring 5 x 8.25 KB, dQ 2 x 4 KB, delta + lse 512 B = 155.8 KB.
+//
+//   [measured, ViT-B/16 batch 256, one box; VITK_ATTN_DBG = 8 / 16 cycle stamps, tools/attn_ab.py]  A step takes ~4,100 cycles; every
+//   wave waits >= 600 of them at the barrier and the waves with the highest ids on each SIMD arrive last: the four SIMDs are about
+//   equally loaded and the step is bound by what a SIMD can issue, not by one role.  What moved it (216 -> 203 us): the producer's
+//   addressing as uniform base + 32-bit lane offset (its issue phase 3,580 -> 1,390 cycles a step: it was the last to arrive), raised
+//   priority for the producer and the dQ waves, the dQ stores off the KV waves (a KV wave's turn as storer cost ~2,400 cycles: four
+//   serialized LDS-read -> store pairs right after the barrier), packed f32 math and one-instruction 16-bit packing in the KV waves,
+//   transpose reads with immediate offsets (inline asm + counted lgkmcnt waits: the builtin takes none).  What did not: running the
+//   dK / dV half of a step one step late in every second KV wave (-4 %, costs registers), 32 keys per KV wave (KT = 2: 7 KV waves,
+//   10 waves, 168 registers, half the LDS reads: 209 us -- its SIMDs are unevenly loaded, {2 KV} against {2 KV + dQ wave}).
 // ==========================================================================================================================
 struct FusedArgs {
     TND q, k, v, dout, o;
@@ -646,7 +659,8 @@ struct FusedArgs {
     OND dq, dk, dv;
     int H, N, nitems;
     float scale;
-    int dbg;                 // experiments (VITK_ATTN_DBG): 1 = no DMA, 2 = KV waves skip their arithmetic, 4 = dQ waves skip theirs
+    int dbg;                 // experiments (VITK_ATTN_DBG): 1 = no DMA, 2 = KV waves skip their arithmetic, 4 = dQ waves skip theirs,
+                             // 8 = cycle stamps of one wave per role, 16 = every wave's barrier wait (workgroup 0, into `delta`)
 };
 constexpr int FB_NKS = 7;                       // 32-row steps (192 < N <= 224 rows staged; key tiles limited to 13 -> N <= 208)
 constexpr int FB_ROWS = FB_NKS * 32;            // 224
@@ -655,6 +669,10 @@ constexpr int FB_KROWS = 13 * 16;               // K / V rows staged (the key ti
 constexpr int FB_TILE = FB_KROWS * 128;         // one staged K or V
 constexpr int FB_DS = FB_ROWS * 64;             // dS^T of one step: 224 key rows x 32 queries (rows >= 16 nkt stay zero)
 constexpr int FB_NST = 5;
+// KT = 16-key tiles per KV wave: 1 -> 13 KV waves (16 waves, 128 registers a lane), 2 -> 7 KV waves (10 waves, 168 registers); + two dQ
+// waves + the producer
+constexpr int fb_kvw(int KT) { return KT == 1 ? 13 : 7; }
+constexpr int fb_threads(int KT) { return (fb_kvw(KT) + 3) * 64; }
 constexpr int FB_STAGE = 4096 + 4096 + 256;     // Q | dO | lse of a 32-query step
 constexpr int FB_DQ = 32 * 128;                 // dQ of one step on its way from the dQ waves to the wave that stores it
 constexpr int FB_OFF_K = 0, FB_OFF_V = 2 * FB_TILE, FB_OFF_DS = 3 * FB_TILE, FB_OFF_RING = FB_OFF_DS + 2 * FB_DS,
@@ -674,7 +692,27 @@ __device__ __forceinline__ bf16x8 ds_tr(const char* buf, int key0, int q0, int f
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a) {
+// two f32 -> one register of two 16-bit values (round to nearest even), one instruction
+__device__ __forceinline__ unsigned fb_pk2(float lo, float hi) {
+#ifdef VITK_HALF_IS_F16
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 r = {(_Float16)lo, (_Float16)hi}; return __builtin_bit_cast(unsigned, r);
+#else
+    unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r;
+#endif
+}
+// cycle stamps (VITK_ATTN_DBG bit 3): ordered against the surrounding code, LDS results included
+__device__ __forceinline__ unsigned long long fb_now() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+template <int KT>
+__global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const FusedArgs a) {
+    constexpr int FB_KVW = fb_kvw(KT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, H = a.H;
@@ -686,35 +724,41 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
     float* const del = reinterpret_cast<float*>(smem + FB_OFF_DEL);
     auto item_of = [&](int it) { return first + it * stride; };
 
-    if (wave == 15) {
+    if (wave == FB_KVW + 2) {
         // ------------------------------------------------------------------ producer ------------------------------------------------
         const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+        // every piece: uniform item base (SGPR pair) + a 32-bit lane offset = min(first row + lrow, N - 1) * row stride + this lane's chunk
+        __builtin_amdgcn_s_setprio(3);                             // the other waves wait for what this one issues
+        const unsigned ch2 = lchunk * 16;
+        const int sq = (int)a.q.s_n * 2, sd = (int)a.dout.s_n * 2, sk = (int)a.k.s_n * 2, sv = (int)a.v.s_n * 2;      // row strides, bytes
+        auto piece = [&](const char* base, int row0, int stride, char* dst) {
+            int row = row0 + lrow; row = row < N ? row : N - 1;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + (unsigned)(row * stride + ch2)),
+                                             (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+        };
         auto issue_stage = [&](int g) {              // 9 pieces: Q 4, dO 4, lse 1 (steps past the end re-load the last one: uniform counts)
             if (a.dbg & 1) return;
             const int gg = g < G ? g : G - 1;
             const int it = gg / FB_NKS, s = gg - it * FB_NKS;
             const int item = item_of(it), b = item / H, h = item - b * H;
             char* st = ring + (g % FB_NST) * FB_STAGE;
-            const __bf16* qb = a.q.p + b * a.q.s_b + h * a.q.s_h;
-            const __bf16* db = a.dout.p + b * a.dout.s_b + h * a.dout.s_h;
+            const char* qb = reinterpret_cast<const char*>(a.q.p + b * a.q.s_b + h * a.q.s_h);
+            const char* db = reinterpret_cast<const char*>(a.dout.p + b * a.dout.s_b + h * a.dout.s_h);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int row = s * 32 + 8 * j + lrow; row = row < N ? row : N - 1;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(qb + (long long)row * a.q.s_n + lchunk * 8),
-                                                 (void __attribute__((address_space(3)))*)(st + j * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(db + (long long)row * a.dout.s_n + lchunk * 8),
-                                                 (void __attribute__((address_space(3)))*)(st + 4096 + j * 1024), 16, 0, 0);
+                piece(qb, s * 32 + 8 * j, sq, st + j * 1024);
+                piece(db, s * 32 + 8 * j, sd, st + 4096 + j * 1024);
             }
             int qi = s * 32 + (lane & 31); qi = qi < N ? qi : N - 1;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.lse + (long long)item * N + qi),
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(reinterpret_cast<const char*>(a.lse + (long long)item * N) + (unsigned)(qi * 4)),
                                              (void __attribute__((address_space(3)))*)(st + 8192), 4, 0, 0);
         };
         auto issue_kv = [&](int it, int part) {      // 13 pieces: part 0..3 of the 52 row groups of K (26) and V (26) of item `it` (clamped)
             if (a.dbg & 1) return;
             const int itc = it < nit ? it : nit - 1;
             const int item = item_of(itc), b = item / H, h = item - b * H;
-            const __bf16* kb = a.k.p + b * a.k.s_b + h * a.k.s_h;
-            const __bf16* vb = a.v.p + b * a.v.s_b + h * a.v.s_h;
+            const char* kb = reinterpret_cast<const char*>(a.k.p + b * a.k.s_b + h * a.k.s_h);
+            const char* vb = reinterpret_cast<const char*>(a.v.p + b * a.v.s_b + h * a.v.s_h);
             char* Kd = smem + FB_OFF_K + (it & 1) * FB_TILE;
             char* Vd = smem + FB_OFF_V;
             // 52 pieces = K groups 0..25 then V groups 0..25; part p issues pieces 13 p .. 13 p + 12
@@ -723,10 +767,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
                 const int pc = part * 13 + j;
                 const bool isv = pc >= 26;
                 const int g = isv ? pc - 26 : pc;
-                int row = 8 * g + lrow; row = row < N ? row : N - 1;
-                const __bf16* src = isv ? vb + (long long)row * a.v.s_n : kb + (long long)row * a.k.s_n;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + lchunk * 8),
-                                                 (void __attribute__((address_space(3)))*)((isv ? Vd : Kd) + g * 1024), 16, 0, 0);
+                piece(isv ? vb : kb, 8 * g, isv ? sv : sk, (isv ? Vd : Kd) + g * 1024);
             }
         };
         // prologue: K / V of the first item, ring stages 0..3; everything landed before the first barrier
@@ -735,18 +776,45 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
         AP_WAIT_DMA();
         AP_BARRIER();          // P: stage 0 (and 1) visible -> the dQ waves form delta(0)
         AP_BARRIER();          // b_0
+        const bool prof = (a.dbg & 24) && blockIdx.x == 0;
+        unsigned long long tp[3] = {0, 0, 0}, t0 = 0, t1 = 0, t2 = 0;
         for (int g = 0; g <= G + 1; ++g) {
             const int s = g % FB_NKS, it = g / FB_NKS;
+            if (prof) t0 = fb_now();
             issue_stage(g + 4);                                    // into the slot of step g - 1
             const bool kv = s >= 1 && s <= 4;
             if (kv) issue_kv(it + 1, s - 1);
-            // before b_{g+1}: stage g + 2 (issued in step g - 2) and everything older has landed; the pieces of steps g - 1 and g may fly
+            {   // dQ of step g - 2 (left in LDS by the dQ waves during step g - 1) out as whole 128-byte rows: exactly four store
+                // instructions every step -- rows that do not exist (and steps 0, 1) go to a dump slot in the unused delta buffer
+                const int gp = g >= 2 ? g - 2 : 0, itp = gp / FB_NKS, sp = gp - itp * FB_NKS;
+                const int item = item_of(itp), b = item / H, h = item - b * H;
+                const char* stg = smem + FB_OFF_DQ + ((g - 1) & 1) * FB_DQ;
+                char* dqb = reinterpret_cast<char*>(reinterpret_cast<__bf16*>(a.dq.p) + b * a.dq.s_b + h * a.dq.s_h);
+                char* dump = reinterpret_cast<char*>(a.delta) + (long long)blockIdx.x * N * 4 + 320 + (lane & 15) * 16;
+                const int sdq = (int)a.dq.s_n * 2;
+                bf16x8 v[4];
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) v[j4] = *reinterpret_cast<const bf16x8*>(stg + (8 * j4 + lrow) * 128 + ((lane & 7) << 4));
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    const int row = 8 * j4 + lrow, qi = sp * 32 + row;
+                    char* dst = (g >= 2 && qi < N) ? dqb + (unsigned)(qi * sdq + (((lane & 7) ^ (row & 7)) << 4)) : dump;
+                    *reinterpret_cast<bf16x8*>(dst) = v[j4];
+                }
+            }
+            if (prof) t1 = fb_now();
+            // before b_{g+1}: stage g + 2 and everything older has landed
+            // (a step = 9 ring pieces + 13 K / V pieces in steps 1-4 + 4 stores, in this order)
+            // stage g + 2 was issued in step g - 2: the operations of steps g - 1 and g may fly
             const bool kv_prev = s >= 2 && s <= 5;
-            if (kv && kv_prev) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
-            else if (kv || kv_prev) asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            if (kv && kv_prev) asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
+            else if (kv || kv_prev) asm volatile("s_waitcnt vmcnt(39)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+            if (prof) t2 = fb_now();
             AP_BARRIER();                                          // b_{g+1}
+            if (prof) { tp[0] += t1 - t0; tp[1] += t2 - t1; tp[2] += fb_now() - t2; }
         }
+        if (prof && lane == 0) { unsigned long long* o = reinterpret_cast<unsigned long long*>(a.delta); o[16] = tp[0]; o[17] = tp[1]; o[18] = tp[2]; o[20 + wave] = tp[2]; }
         AP_WAIT_DMA();         // the surplus pieces must not outlive the workgroup's LDS
         return;
     }
@@ -755,9 +823,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const float c = a.scale * LOG2E;
 
-    if (wave >= 13) {
+    if (wave >= FB_KVW) {
         // ------------------------------------------------------------------ dQ waves ------------------------------------------------
-        const int qt = wave - 13;                                   // delta: which 16 of the step's 32 queries; dQ: which 32 columns of d
+        const int qt = wave - FB_KVW;
+        __builtin_amdgcn_s_setprio(2);                             // the longest per-step chain of the workgroup                                   // delta: which 16 of the step's 32 queries; dQ: which 32 columns of d
         struct ORow { bf16x8 o[2]; };
         auto o_rows = [&](int g) {                                  // the forward's output rows of step g (clamped), this lane's 16 columns
             const int gg = g < G ? g : G - 1;
@@ -772,16 +841,16 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
         };
         auto make_delta = [&](int g, const ORow& r) {               // delta of step g from its ring stage (dO) and the O rows
             const char* dst = ring + (g % FB_NST) * FB_STAGE + 4096;
-            float sum = 0.f;
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 d8 = sw_row(dst, qt * 16, ks, fi, fg);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sum = fmaf((float)d8[e], (float)r.o[ks][e], sum);
+                for (int e = 0; e < 8; ++e) part[2 * ks + (e & 1)] = fmaf((float)d8[e], (float)r.o[ks][e], part[2 * ks + (e & 1)]);
             }
-            sum = groups_sum(sum);
+            float sum = groups_sum((part[0] + part[1]) + (part[2] + part[3]));
             if (fg == 0) {
-                del[(g & 1) * 32 + qt * 16 + fi] = sum;
+                del[(g & 1) * 32 + qt * 16 + fi] = -sum;            // negated: the KV waves start dP's accumulator from it
                 // the exp2 argument's constant term for the KV waves (one FMA there instead of a multiply and an FMA)
                 del[64 + (g & 1) * 32 + qt * 16 + fi] = -LOG2E * reinterpret_cast<const float*>(dst + 4096)[qt * 16 + fi];
             }
@@ -796,7 +865,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
         constexpr int KREG = 5;                                    // K^T key steps held in registers per item (the same fragments serve all 7 query
                                                                    // steps); the rest is re-read from LDS each step: 128 registers a lane
         bf16x8 ktf[KREG][2];
+        const bool prof = blockIdx.x == 0 && (((a.dbg & 8) && qt == 0) || (a.dbg & 16));
+        unsigned long long tp[3] = {0, 0, 0}, t0 = 0, t1 = 0, t2 = 0;
         for (int g = 0; g <= G + 1; ++g) {
+            if (prof) t0 = fb_now();
             const ORow req = o_rows(g + 3);                        // requested now, used two steps from now
             if (g >= 1 && g <= G && !(a.dbg & 4)) {                // dQ of step g - 1: dS K over all keys, columns 32 qt .. 32 qt + 31 of d
                 const int gp = g - 1, itp = gp / FB_NKS;
@@ -832,101 +904,204 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const FusedArgs a)
                         *reinterpret_cast<bf16x4*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4) + ((fg & 1) << 3)) = o4;
                     }
             }
+            if (prof) t1 = fb_now();
             if (g + 1 < G) make_delta(g + 1, cur);                 // for the step ahead: its ring stage landed before b_g
             cur = nxt; nxt = req;
+            if (prof) t2 = fb_now();
             AP_BARRIER();                                          // b_{g+1}
+            if (prof) { tp[0] += t1 - t0; tp[1] += t2 - t1; tp[2] += fb_now() - t2; }
+        }
+        if (prof && lane == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(a.delta);
+            if (a.dbg & 16) o[20 + wave] = tp[2];
+            if (qt == 0) { o[8] = tp[0]; o[9] = tp[1]; o[10] = tp[2]; }
         }
         return;
     }
 
     // ---------------------------------------------------------------------- KV waves ------------------------------------------------
+    // wave w: keys 16 KT w .. 16 KT w + 16 KT - 1 as KT 16-key tiles (KT = 2: every Q / dO fragment read from LDS feeds two MFMAs)
     const int nkt = (N + 15) >> 4;
-    const bool active = wave < nkt;
-    const int ki = wave * 16 + fi;
-    // rows 16 nkt .. 223 of both dS^T buffers belong to no wave: zero them once (the dQ waves sum over all 224 rows)
-    for (int i = tid; i < 2 * FB_DS / 16; i += 13 * 64) {
+    int ki[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) ki[t] = (wave * KT + t) * 16 + fi;
+    const bool pad_wave = (wave + 1) * KT * 16 > N;                // holds padding keys (wave-uniform)
+    // rows 16 nkt .. 223 of both dS^T buffers: zero them once (the dQ waves sum over all 224 rows)
+    for (int i = tid; i < 2 * FB_DS / 16; i += FB_KVW * 64) {
         const int bufi = i / (FB_DS / 16), r = (i % (FB_DS / 16)) >> 2;
         if (r >= nkt * 16) *reinterpret_cast<f32x4*>(smem + FB_OFF_DS + bufi * FB_DS + (i % (FB_DS / 16)) * 16) = z4;
     }
-    // K[1] is empty during the first item and the dQ waves' reads of K[0] rows 208..223 fall into its first 16 rows: finite data there
+    // K[1] is empty during the first item and reads of K[0] rows 208..223 fall into its first 16 rows: finite data there
     if (tid < 128) *reinterpret_cast<f32x4*>(smem + FB_OFF_K + FB_TILE + tid * 16) = z4;
     AP_BARRIER();                                                  // P
     AP_BARRIER();                                                  // b_0
-    bf16x8 kf[2], vf[2];
-    f32x4 accK[4], accV[4];
-    for (int g = 0; g <= G + 1; ++g) {
-        const int it = g / FB_NKS, s = g - it * FB_NKS;
-        if (g >= 2 && wave == g % 13) {
-            // this step's storer: dQ of step g - 2 (left in LDS by the dQ waves during step g - 1), whole 128-byte rows
-            const int gp = g - 2, itp = gp / FB_NKS, sp = gp - itp * FB_NKS;
-            const int item = item_of(itp), b = item / H, h = item - b * H;
-            const char* stg = smem + FB_OFF_DQ + ((g - 1) & 1) * FB_DQ;
-            __bf16* dqb = reinterpret_cast<__bf16*>(a.dq.p) + b * a.dq.s_b + h * a.dq.s_h;
+    bf16x8 kf[KT][2], vf[KT][2];
+    f32x4 accK[KT][4], accV[KT][4];
+    bf16x8 pb[KT], dsb[KT];                                        // P and dS of the step, 16-bit: from the first half to the second
+    // lane offsets into a ring stage (the 128-byte-row swizzle of sw_row / sw_tr, rows 0..15): one VGPR add per step each, everything
+    // else of an access is an immediate (query half + 2048, dO + 4096)
+    unsigned lrow_off[2], ltr_off[4];
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {
-                const int row = 8 * j4 + (lane >> 3), qi = sp * 32 + row;
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((lane & 7) << 4));
-                if (qi < N) *reinterpret_cast<bf16x8*>(dqb + (long long)qi * a.dq.s_n + (((lane & 7) ^ (row & 7)) << 3)) = v;
-            }
-        }
-        if (active && g < G && !(a.dbg & 2)) {
+    for (int ks = 0; ks < 2; ++ks) lrow_off[ks] = fi * 128 + (((ks * 4 + fg) ^ (fi & 7)) << 4);
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) {
+        const int row = 4 * fg + (fi >> 2);
+        ltr_off[fd] = row * 128 + ((((fd * 2) + ((fi & 3) >> 1)) ^ (row & 7)) << 4) + ((fi & 1) << 3);
+    }
+    const unsigned smem_lo = (unsigned)(size_t)smem;               // LDS address of the image (the low half of the flat address)
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const f32x2 c2 = {c, c};
+
+    // first half of step g: S, dP, P, dS for this wave's keys x the step's 32 queries; dS^T -> LDS for the dQ waves
+    auto front = [&](int g) {
+        const int it = g / FB_NKS, s = g - it * FB_NKS;
+        if (s == 0) {
             const char* Ks = smem + FB_OFF_K + (it & 1) * FB_TILE;
             const char* Vs = smem + FB_OFF_V;
-            if (s == 0) {
-                kf[0] = sw_row(Ks, wave * 16, 0, fi, fg); kf[1] = sw_row(Ks, wave * 16, 1, fi, fg);
-                vf[0] = sw_row(Vs, wave * 16, 0, fi, fg); vf[1] = sw_row(Vs, wave * 16, 1, fi, fg);
+            // (KT = 2: the last wave's second tile reads rows 208..223: past the staged tile, into the next LDS region -- its products are masked)
 #pragma unroll
-                for (int fd = 0; fd < 4; ++fd) { accK[fd] = z4; accV[fd] = z4; }
-            }
-            const char* Qs = ring + (g % FB_NST) * FB_STAGE;
-            const char* Ds = Qs + 4096;
-            const float* del_s = del + (g & 1) * 32;
-            const float* nl_s = del_s + 64;                    // -log2(e) lse, written by the dQ waves with delta
-            f32x4 p[2], ds[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int row0 = hh * 16;
-                const bf16x8 q0 = sw_row(Qs, row0, 0, fi, fg), q1 = sw_row(Qs, row0, 1, fi, fg);
-                const bf16x8 d0 = sw_row(Ds, row0, 0, fi, fg), d1 = sw_row(Ds, row0, 1, fi, fg);
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(nl_s + row0 + 4 * fg);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
-                f32x4 st = MFMA(q0, kf[0], z4);            // S[q = row0 + 4g + e][key]
-                st = MFMA(q1, kf[1], st);
-                f32x4 dp = MFMA(d0, vf[0], z4);            // dP[q][key]
-                dp = MFMA(d1, vf[1], dp);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], c, l4[e]));
-                    ds[hh][e] = p[hh][e] * (dp[e] - d4[e]);                  // `scale` is applied once, to dK and dQ
-                }
-                if (s == FB_NKS - 1) {                     // padding query rows only exist in the last step
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (s * 32 + row0 + 4 * fg + e >= N) { p[hh][e] = 0.f; ds[hh][e] = 0.f; }
-                }
-            }
-            if (wave == nkt - 1 && ki >= N) { ds[0] = z4; ds[1] = z4; p[0] = z4; p[1] = z4; }      // padding keys (last key tile only: a wave-uniform test first): nothing for dQ; their dK / dV rows are not stored
-            const bf16x8 pb = pack8(p[0], p[1]), dsb = pack8(ds[0], ds[1]);
-            {   // dS^T -> LDS: this lane's key row, queries {4g..4g+3} and {16+4g..+3} of the step
-                char* dsw = smem + FB_OFF_DS + (g & 1) * FB_DS;
-                const s16x8 w = __builtin_bit_cast(s16x8, dsb);
-                *reinterpret_cast<s16x4*>(dsw + ds_off(ki, 8 * fg)) = s16x4{w[0], w[1], w[2], w[3]};
-                *reinterpret_cast<s16x4*>(dsw + ds_off(ki, 32 + 8 * fg)) = s16x4{w[4], w[5], w[6], w[7]};
-            }
-#pragma unroll
-            for (int fd = 0; fd < 4; ++fd) {
-                accV[fd] = MFMA(sw_tr(Ds, 0, fd * 16, fi, fg), pb, accV[fd]);     // dV^T[d][key]
-                accK[fd] = MFMA(sw_tr(Qs, 0, fd * 16, fi, fg), dsb, accK[fd]);    // dK^T[d][key]
-            }
-            if (s == FB_NKS - 1 && ki < N) {
-                const int item = item_of(it), b = item / H, h = item - b * H;
-                __bf16* dkp = reinterpret_cast<__bf16*>(a.dk.p) + b * a.dk.s_b + h * a.dk.s_h + (long long)ki * a.dk.s_n + 4 * fg;
-                __bf16* dvp = reinterpret_cast<__bf16*>(a.dv.p) + b * a.dv.s_b + h * a.dv.s_h + (long long)ki * a.dv.s_n + 4 * fg;
-#pragma unroll
-                for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd] * a.scale); store4<__bf16>(dvp + fd * 16, accV[fd]); }
+            for (int t = 0; t < KT; ++t) {
+                const int r0 = (wave * KT + t) * 16;
+                kf[t][0] = sw_row(Ks, r0, 0, fi, fg); kf[t][1] = sw_row(Ks, r0, 1, fi, fg);
+                vf[t][0] = sw_row(Vs, r0, 0, fi, fg); vf[t][1] = sw_row(Vs, r0, 1, fi, fg);
             }
         }
+        const unsigned stage = FB_OFF_RING + (g % FB_NST) * FB_STAGE;
+        const char* rb0 = smem + (stage + lrow_off[0]);        // Q rows, d 0..31 (this lane's 16 bytes); + 2048: queries 16..31; + 4096: dO
+        const char* rb1 = smem + (stage + lrow_off[1]);        // d 32..63
+        const float* del_s = del + (g & 1) * 32;               // -delta
+        const float* nl_s = del_s + 64;                        // -log2(e) lse, written by the dQ waves with delta
+        u32x2 ph[KT][2], dh[KT][2];                            // [tile][query half]: this lane's 4 queries x 1 key, 16-bit
+        const bool last_step = s == FB_NKS - 1;                // padding query rows only exist in the last step
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int row0 = hh * 16;
+            const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(rb0 + hh * 2048), q1 = *reinterpret_cast<const bf16x8*>(rb1 + hh * 2048);
+            const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(rb0 + 4096 + hh * 2048), d1 = *reinterpret_cast<const bf16x8*>(rb1 + 4096 + hh * 2048);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(nl_s + row0 + 4 * fg);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                f32x4 st = MFMA(q0, kf[t][0], z4);             // S[q = row0 + 4g + e][key]
+                st = MFMA(q1, kf[t][1], st);
+                f32x4 dp = MFMA(d0, vf[t][0], d4);             // dP[q][key] - delta[q]
+                dp = MFMA(d1, vf[t][1], dp);
+                f32x4 pv, dv;
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {               // float pairs: v_pk_fma_f32 / v_pk_mul_f32
+                    const f32x2 x = __builtin_elementwise_fma(f32x2{st[2 * e2], st[2 * e2 + 1]}, c2, f32x2{l4[2 * e2], l4[2 * e2 + 1]});
+                    pv[2 * e2] = __builtin_amdgcn_exp2f(x[0]); pv[2 * e2 + 1] = __builtin_amdgcn_exp2f(x[1]);
+                    const f32x2 y = f32x2{pv[2 * e2], pv[2 * e2 + 1]} * f32x2{dp[2 * e2], dp[2 * e2 + 1]};      // `scale` is applied once, to dK and dQ
+                    dv[2 * e2] = y[0]; dv[2 * e2 + 1] = y[1];
+                }
+                if (last_step) {                               // (the empty asm keeps these wave-uniform tests branches: 24 selects a step otherwise)
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (s * 32 + row0 + 4 * fg + e >= N) { pv[e] = 0.f; dv[e] = 0.f; }
+                }
+                if (pad_wave) {                                // padding keys: nothing for dQ; their dK / dV rows are not stored
+                    asm volatile("" ::: "memory");
+                    if (ki[t] >= N) { pv = z4; dv = z4; }
+                }
+                ph[t][hh] = u32x2{fb_pk2(pv[0], pv[1]), fb_pk2(pv[2], pv[3])};
+                dh[t][hh] = u32x2{fb_pk2(dv[0], dv[1]), fb_pk2(dv[2], dv[3])};
+            }
+        }
+        char* dsw = smem + FB_OFF_DS + (g & 1) * FB_DS;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            pb[t] = __builtin_bit_cast(bf16x8, u32x4{ph[t][0][0], ph[t][0][1], ph[t][1][0], ph[t][1][1]});
+            dsb[t] = __builtin_bit_cast(bf16x8, u32x4{dh[t][0][0], dh[t][0][1], dh[t][1][0], dh[t][1][1]});
+            // dS^T -> LDS: this lane's key row, queries {4g..4g+3} and {16+4g..+3} of the step
+            *reinterpret_cast<u32x2*>(dsw + ds_off(ki[t], 8 * fg)) = dh[t][0];
+            *reinterpret_cast<u32x2*>(dsw + ds_off(ki[t], 32 + 8 * fg)) = dh[t][1];
+        }
+    };
+    // second half of step g: dV^T += dO^T P, dK^T += Q^T dS from the step's ring stage (transpose reads); the item's rows out after its last step
+    auto back = [&](int g) {
+        const int it = g / FB_NKS, s = g - it * FB_NKS;
+        const unsigned stage = FB_OFF_RING + (g % FB_NST) * FB_STAGE;
+        if (s == 0) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) { accK[t][fd] = z4; accV[t][fd] = z4; }
+        }
+        // The 16 transpose reads as inline asm: the builtin takes no immediate offset (one VALU add per read); here one add per 16-column
+        // block.  The compiler does not track them: each block's four results are released by a counted lgkmcnt wait they pass through
+        // (LDS operations return in order; anything the compiler issues in between only makes the counts conservative).
+        constexpr int NB = KT == 1 ? 4 : 2;                    // 16-column blocks read ahead at a time (registers: 8 a block)
+#pragma unroll
+        for (int f0 = 0; f0 < 4; f0 += NB) {
+            u32x2 r[NB][4];                                    // [block][dO lo, dO hi, Q lo, Q hi]: rows {4g..4g+3} / {16+4g..+3}, transposed
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const unsigned tb = smem_lo + stage + ltr_off[f0 + j];
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(r[j][0]) : "v"(tb));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(r[j][1]) : "v"(tb));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r[j][2]) : "v"(tb));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(r[j][3]) : "v"(tb));
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j) __builtin_amdgcn_sched_barrier(0);      // keep each wait behind the previous block's MFMAs
+                const int left = 4 * (NB - 1 - j);
+                if (left == 12) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(r[j][0]), "+v"(r[j][1]), "+v"(r[j][2]), "+v"(r[j][3]));
+                if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(r[j][0]), "+v"(r[j][1]), "+v"(r[j][2]), "+v"(r[j][3]));
+                if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r[j][0]), "+v"(r[j][1]), "+v"(r[j][2]), "+v"(r[j][3]));
+                if (left == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[j][0]), "+v"(r[j][1]), "+v"(r[j][2]), "+v"(r[j][3]));
+                const bf16x8 dot = __builtin_bit_cast(bf16x8, u32x4{r[j][0][0], r[j][0][1], r[j][1][0], r[j][1][1]});
+                const bf16x8 qt8 = __builtin_bit_cast(bf16x8, u32x4{r[j][2][0], r[j][2][1], r[j][3][0], r[j][3][1]});
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    accV[t][f0 + j] = MFMA(dot, pb[t], accV[t][f0 + j]);      // dV^T[d][key]
+                    accK[t][f0 + j] = MFMA(qt8, dsb[t], accK[t][f0 + j]);     // dK^T[d][key]
+                }
+            }
+        }
+        if (s == FB_NKS - 1) {
+            // the item's dK / dV rows: uniform item base + a 32-bit lane offset formed here (nothing of it lives through the steps)
+            const int item = item_of(it), b = item / H, h = item - b * H;
+            char* dkb = reinterpret_cast<char*>(reinterpret_cast<__bf16*>(a.dk.p) + b * a.dk.s_b + h * a.dk.s_h);
+            char* dvb = reinterpret_cast<char*>(reinterpret_cast<__bf16*>(a.dv.p) + b * a.dv.s_b + h * a.dv.s_h);
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));                   // opaque: keeps the offsets below out of the loop-invariant (spilled) set
+            const int fi_o = lane_o & 15, fg_o = lane_o >> 4;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const int key = (wave * KT + t) * 16 + fi_o;
+                if (key < N) {
+                    __bf16* dkp = reinterpret_cast<__bf16*>(dkb + (unsigned)(key * ((int)a.dk.s_n * 2) + 8 * fg_o));
+                    __bf16* dvp = reinterpret_cast<__bf16*>(dvb + (unsigned)(key * ((int)a.dv.s_n * 2) + 8 * fg_o));
+#pragma unroll
+                    for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[t][fd] * a.scale); store4<__bf16>(dvp + fd * 16, accV[t][fd]); }
+                }
+            }
+        }
+    };
+
+    const bool work = !(a.dbg & 2);
+    const bool prof = blockIdx.x == 0 && (((a.dbg & 8) && wave == 2) || (a.dbg & 16));
+    unsigned long long tp[4] = {0, 0, 0, 0}, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (int g = 0; g <= G + 1; ++g) {
+        if (prof) t0 = fb_now();
+        if (prof) t1 = fb_now();
+        if (work) {
+            if (g < G) front(g);
+            if (prof) t2 = fb_now();
+            if (g < G) back(g);
+        }
+        if (prof) t3 = fb_now();
         AP_BARRIER();                                              // b_{g+1}
+        if (prof) { tp[0] += t1 - t0; tp[1] += t2 - t1; tp[2] += t3 - t2; tp[3] += fb_now() - t3; }
+    }
+    if (prof && lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.delta);
+        if (a.dbg & 16) o[20 + wave] = tp[3];
+        if (wave == 2) { o[0] = tp[0]; o[1] = tp[1]; o[2] = tp[2]; o[3] = tp[3]; o[4] = (unsigned long long)G; }
     }
 }
 
@@ -1036,10 +1211,16 @@ int launch_fused(const AttnPipeBwd& p, hipStream_t st) {
     a.lse = p.lse; a.delta = p.delta; a.dq = ond(p.dq); a.dk = ond(p.dk); a.dv = ond(p.dv);
     a.H = (int)p.H; a.N = (int)p.N; a.nitems = (int)(p.B * p.H); a.scale = p.scale;
     a.dbg = getenv("VITK_ATTN_DBG") ? atoi(getenv("VITK_ATTN_DBG")) : 0;
+    const int kt = getenv("VITK_ATTN_KT") ? atoi(getenv("VITK_ATTN_KT")) : 1;
     int grid = num_cus();
     if (grid > a.nitems) grid = a.nitems;
-    AP_SET_LDS(attn_bwd_fused_kernel, "attn_bwd (fused)");
-    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)grid), dim3(1024), (size_t)FB_LDS, st, a);
+    if (kt == 2) {
+        AP_SET_LDS(attn_bwd_fused_kernel<2>, "attn_bwd (fused)");
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, dim3((unsigned)grid), dim3(fb_threads(2)), (size_t)FB_LDS, st, a);
+    } else {
+        AP_SET_LDS(attn_bwd_fused_kernel<1>, "attn_bwd (fused)");
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<1>, dim3((unsigned)grid), dim3(fb_threads(1)), (size_t)FB_LDS, st, a);
+    }
     VITK_CHECK_LAUNCH("attn_bwd (fused)");
     return 0;
 }
