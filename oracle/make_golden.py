@@ -31,7 +31,7 @@ sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from oracle.params import (CASES, NAVIT_CASES, VARIANT_CASES, WIDE_CASES, make_params_for, make_images, make_navit_images, make_navit_params, make_params,  # noqa: E402
+from oracle.params import (CASES, NAVIT_CASES, NAVIT_WIDE_CASES, VARIANT_CASES, WIDE_CASES, make_params_for, make_images, make_navit_images, make_navit_params, make_params,  # noqa: E402
                            sample_index)
 from oracle.vit_oracle import loss_fn  # noqa: E402
 
@@ -155,8 +155,42 @@ def main_navit():
         print(f"{name}: logits {tuple(out.shape)} loss {float(loss):.6f} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def main_navit_wide():
+    """NaViT at BASELINE config 4's width, one 4,096-token pack (oracle/params.py::NAVIT_WIDE_CASES): compact golden, f32 and the
+    reference's own bf16 run."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    mod = load_ref("na_vit")
+    for name, case in NAVIT_WIDE_CASES.items():
+        if ONLY and name not in ONLY:
+            continue
+        params = make_navit_params(case["cfg"], case["seed"])
+        images = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
+        assert sum((h // 16) * (w // 16) for (h, w) in case["sizes"][0]) == 4096
+        res = {}
+        for dtype in (torch.float32, torch.bfloat16):
+            model = mod.NaViT(**case["cfg"])
+            model.load_state_dict(params, strict=True)
+            model = model.to(dtype).eval()
+            out = model([[im.to(dtype) for im in pack] for pack in images])
+            loss_fn(out.float()).backward()
+            res[dtype] = (out.detach().float(), {k: p.grad.detach().float() for k, p in model.named_parameters()})
+        out, grads = res[torch.float32]
+        out16, grads16 = res[torch.bfloat16]
+        blob = {"logits": out.numpy(), "bf16::logits": out16.numpy()}
+        for k, g in grads.items():
+            idx = sample_index(g.numel(), case["sample"])
+            blob["gnorm::" + k] = np.float64(g.double().norm().item())
+            blob["gsample::" + k] = g.flatten().numpy()[idx]
+            blob["bf16::gsample::" + k] = grads16[k].flatten().numpy()[idx]
+        path = os.path.join(outdir, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(f"{name}: logits {tuple(out.shape)} {len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 if __name__ == "__main__":
     main()
     main_navit()
     main_wide()
     main_variants()
+    main_navit_wide()

@@ -270,3 +270,17 @@ NAVIT_CASES = {
         seed=5, sizes=[[(32, 48), (16, 16), (64, 24)], [(40, 40), (8, 56)]],
         cfg=dict(image_size=64, patch_size=8, num_classes=7, dim=64, depth=2, heads=2, mlp_dim=96)),
 }
+
+# BASELINE config 4 at its real width (dim 1024, 16 heads, mlp 4096, patch 16), depth 2: ONE pack of exactly 4,096 tokens from 32
+# images of mixed resolutions (256, 128, 64, 16 and 32 patches).  Compact golden (logits + norms and samples of every gradient),
+# reference in f32 and the reference's own bf16 run (make_golden.main_navit_wide).
+NAVIT_WIDE_CASES = {
+    "navit_cfg4_width": dict(
+        seed=41, sample=1024,
+        sizes=[[(256, 256), (128, 128), (256, 128), (64, 64), (256, 256), (128, 64), (256, 256), (64, 64), (256, 256), (128, 128),
+                (256, 256), (64, 64), (256, 128), (256, 256), (128, 64), (64, 64), (256, 256), (128, 128), (256, 256), (64, 64),
+                (256, 128), (256, 256), (128, 64), (64, 64), (256, 256), (128, 128), (256, 256), (64, 64), (256, 128), (256, 256),
+                (128, 64), (64, 64)]],
+        cfg=dict(image_size=256, patch_size=16, num_classes=1000, dim=1024, depth=2, heads=16, mlp_dim=4096)),
+}
+

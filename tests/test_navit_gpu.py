@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import navit_oracle as NO  # noqa: E402
-from oracle.params import NAVIT_CASES, make_navit_images, make_navit_params  # noqa: E402
+from oracle.params import NAVIT_CASES, NAVIT_WIDE_CASES, make_navit_images, make_navit_params, sample_index  # noqa: E402
 from vit_pytorch_amd import kernels as K  # noqa: E402
 from vit_pytorch_amd.na_vit import NaViT, Segments  # noqa: E402
 
@@ -121,6 +121,45 @@ def test_navit_f32_matches_reference_golden(name):
     assert rel(out, torch.from_numpy(gold["logits"])) <= 1e-3
     for k, g in grads.items():
         assert rel(g, torch.from_numpy(gold["grad::" + k])) <= 1e-3, k
+
+
+def _navit_wide_errors(name, dtype):
+    """(logits error, gradient-sample error, the reference's own bf16 errors, worst per-tensor sample error in units of the tensor's
+    share of its norm) of the drop-in at BASELINE config 4's width against the compact reference golden."""
+    case = NAVIT_WIDE_CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    out, grads, _, _ = _run_navit(case, dtype)
+    ref_logits = torch.from_numpy(gold["logits"])
+    mine, ref, ref16 = [], [], []
+    worst = 0.0
+    for k, gr in grads.items():
+        g = gr.detach().float().flatten().cpu()
+        idx = torch.from_numpy(sample_index(g.numel(), case["sample"]))
+        r = torch.from_numpy(gold["gsample::" + k]).float()
+        mine.append(g[idx]); ref.append(r); ref16.append(torch.from_numpy(gold["bf16::gsample::" + k]).float())
+        share = float(gold["gnorm::" + k]) * (r.numel() / g.numel()) ** 0.5
+        worst = max(worst, (g[idx].double() - r.double()).norm().item() / max(share, 1e-30))
+    cat = torch.cat
+    return (rel(out, ref_logits), rel(cat(mine), cat(ref)), rel(torch.from_numpy(gold["bf16::logits"]), ref_logits),
+            rel(cat(ref16), cat(ref)), worst)
+
+
+@pytest.mark.parametrize("name", list(NAVIT_WIDE_CASES))
+def test_navit_config4_width_f32_vs_reference_golden(name):
+    """dim 1024, 16 heads, ONE pack of 4,096 tokens (32 images of five resolutions), depth 2: f32 mode pinned to the reference (1e-3)."""
+    e, g, _, _, worst = _navit_wide_errors(name, torch.float32)
+    print(f"{name} f32: logits {e:.2e} grad samples {g:.2e} worst tensor {worst:.2e}")
+    assert e <= 1e-3 and g <= 1e-3 and worst <= 1e-2, (e, g, worst)
+
+
+@pytest.mark.parametrize("name", list(NAVIT_WIDE_CASES))
+def test_navit_config4_width_bf16_vs_reference_golden(name):
+    """The packed-token MFMA path (fused packed stack, varlen attention, persistent GEMMs at M = 4,096) against the reference's f32
+    outputs: held to 1.5x the error of the REFERENCE's own bf16 run on the same inputs (stored in the golden) + 1e-3."""
+    e, g, e16, g16, worst = _navit_wide_errors(name, BF)
+    print(f"{name} bf16: logits {e:.2e} (reference-bf16 {e16:.2e}) grad samples {g:.2e} (reference-bf16 {g16:.2e}) worst tensor {worst:.2e}")
+    assert e <= 1.5 * e16 + 1e-3 and g <= 1.5 * g16 + 1e-3, (e, e16, g, g16)
+    assert worst <= 0.15, worst
 
 
 @pytest.mark.parametrize("name", list(NAVIT_CASES))

@@ -126,7 +126,7 @@ def test_attention_core_bwd_formula():
 
 # ---- NaViT (config 4) ----------------------------------------------------------------------------------------
 from oracle import navit_oracle as NO  # noqa: E402
-from oracle.params import NAVIT_CASES, make_navit_images, make_navit_params  # noqa: E402
+from oracle.params import NAVIT_CASES, NAVIT_WIDE_CASES, make_navit_images, make_navit_params  # noqa: E402
 
 
 @pytest.mark.parametrize("name", list(NAVIT_CASES))
@@ -141,3 +141,23 @@ def test_navit_oracle_matches_reference_golden(name, dtype):
     assert rel_l2(out, torch.from_numpy(gold["logits"])) <= 2e-6
     for k, g in grads.items():
         assert rel_l2(g, torch.from_numpy(gold["grad::" + k])) <= 2e-5, k
+
+
+@pytest.mark.parametrize("name", list(NAVIT_WIDE_CASES))
+def test_navit_oracle_matches_compact_golden_at_config4_width(name):
+    """BASELINE config 4 at its real width (dim 1024, 16 heads, one pack of 4,096 tokens from 32 images, depth 2): the restatement
+    against the compact golden the reference produced (full logits; per gradient its norm and a fixed 1024-element sample)."""
+    case = NAVIT_WIDE_CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    params = make_navit_params(case["cfg"], case["seed"])
+    imgs = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
+    out, grads = NO.run_fwd_bwd(case["cfg"], params, imgs, torch.float32)
+    assert out.shape == gold["logits"].shape
+    assert rel_l2(out, torch.from_numpy(gold["logits"])) <= 1e-5
+    for k, g in grads.items():
+        g = g.flatten()
+        ref = torch.from_numpy(gold["gsample::" + k])
+        got = g[torch.from_numpy(sample_index(g.numel(), case["sample"]))]
+        norm = float(gold["gnorm::" + k])
+        assert abs(g.double().norm().item() - norm) <= 1e-4 * norm + 1e-12, k
+        assert (got.double() - ref.double()).norm().item() <= 1e-4 * norm * (ref.numel() / g.numel()) ** 0.5 + 1e-12, k
