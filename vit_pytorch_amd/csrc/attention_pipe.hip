@@ -624,7 +624,7 @@ __global__ __launch_bounds__(1024) void attn_dkv_pipe_kernel(const DkvArgs<NS> a
 // sequence lengths at 224^2 / patch 16).  Why: the two-kernel backward computes S and exp twice (7 matmul units instead of 5), reads
 // q, k, v, dO twice (927 MB instead of 618 MB at ViT-B/16 batch 256), and -- measured, see DESIGN section 4, round 3 -- spends half
 // its time on the rows every wave fetches for itself at the start of an item.  Here NO compute wave loads from global memory
-// (KT = 1, the default, described; KT = 2 gives every KV wave two key tiles):
+// (KT = 1 described, the flavour in use):
 //
 //   waves 0-12   "KV waves": wave w owns key tile w (16 keys): K / V fragments from LDS at the start of the item, then per 32-query
 //                step  S = Q K^T, dP = dO V^T - delta (delta enters as the accumulator's start), P = exp2(S c - lse log2 e),
@@ -650,7 +650,9 @@ __global__ __launch_bounds__(1024) void attn_dkv_pipe_kernel(const DkvArgs<NS> a
 //   serialized LDS-read -> store pairs right after the barrier), packed f32 math and one-instruction 16-bit packing in the KV waves,
 //   transpose reads with immediate offsets (inline asm + counted lgkmcnt waits: the builtin takes none).  What did not: running the
 //   dK / dV half of a step one step late in every second KV wave (-4 %, costs registers), 32 keys per KV wave (KT = 2: 7 KV waves,
-//   10 waves, 168 registers, half the LDS reads: 209 us -- its SIMDs are unevenly loaded, {2 KV} against {2 KV + dQ wave}).
+//   10 waves, 168 registers, half the LDS reads and 44 % of the KV cycles per key: 204-209 us, also with the roles spread over the SIMDs
+//   as {3 KV}, {2 KV + producer}, {KV + dQ}, {KV + dQ} in a 12-wave workgroup -- three of its KV waves on one SIMD take as long as
+//   four of the small ones; the instantiation was removed again, the loops stay written over KT).
 // ==========================================================================================================================
 struct FusedArgs {
     TND q, k, v, dout, o;
@@ -669,8 +671,8 @@ constexpr int FB_KROWS = 13 * 16;               // K / V rows staged (the key ti
 constexpr int FB_TILE = FB_KROWS * 128;         // one staged K or V
 constexpr int FB_DS = FB_ROWS * 64;             // dS^T of one step: 224 key rows x 32 queries (rows >= 16 nkt stay zero)
 constexpr int FB_NST = 5;
-// KT = 16-key tiles per KV wave: 1 -> 13 KV waves (16 waves, 128 registers a lane), 2 -> 7 KV waves (10 waves, 168 registers); + two dQ
-// waves + the producer
+// KT = 16-key tiles per KV wave: 1 -> 13 KV waves (16 waves, 128 registers a lane), the only flavour instantiated; 2 -> 7 KV waves (10
+// waves, 168 registers; measured level, see the header: the code below stays generic in KT); + two dQ waves + the producer
 constexpr int fb_kvw(int KT) { return KT == 1 ? 13 : 7; }
 constexpr int fb_threads(int KT) { return (fb_kvw(KT) + 3) * 64; }
 constexpr int FB_STAGE = 4096 + 4096 + 256;     // Q | dO | lse of a 32-query step
@@ -724,6 +726,7 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
     float* const del = reinterpret_cast<float*>(smem + FB_OFF_DEL);
     auto item_of = [&](int it) { return first + it * stride; };
 
+    const int kvw = wave;                                          // KV waves first, then the two dQ waves, then the producer
     if (wave == FB_KVW + 2) {
         // ------------------------------------------------------------------ producer ------------------------------------------------
         const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
@@ -924,15 +927,16 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
     const int nkt = (N + 15) >> 4;
     int ki[KT];
 #pragma unroll
-    for (int t = 0; t < KT; ++t) ki[t] = (wave * KT + t) * 16 + fi;
-    const bool pad_wave = (wave + 1) * KT * 16 > N;                // holds padding keys (wave-uniform)
+    for (int t = 0; t < KT; ++t) ki[t] = (kvw * KT + t) * 16 + fi;
+    const bool pad_wave = (kvw + 1) * KT * 16 > N;                 // holds padding keys (wave-uniform)
+    const int kvt = kvw * 64 + lane;                               // thread index among the KV waves
     // rows 16 nkt .. 223 of both dS^T buffers: zero them once (the dQ waves sum over all 224 rows)
-    for (int i = tid; i < 2 * FB_DS / 16; i += FB_KVW * 64) {
+    for (int i = kvt; i < 2 * FB_DS / 16; i += FB_KVW * 64) {
         const int bufi = i / (FB_DS / 16), r = (i % (FB_DS / 16)) >> 2;
         if (r >= nkt * 16) *reinterpret_cast<f32x4*>(smem + FB_OFF_DS + bufi * FB_DS + (i % (FB_DS / 16)) * 16) = z4;
     }
     // K[1] is empty during the first item and reads of K[0] rows 208..223 fall into its first 16 rows: finite data there
-    if (tid < 128) *reinterpret_cast<f32x4*>(smem + FB_OFF_K + FB_TILE + tid * 16) = z4;
+    if (kvt < 128) *reinterpret_cast<f32x4*>(smem + FB_OFF_K + FB_TILE + kvt * 16) = z4;
     AP_BARRIER();                                                  // P
     AP_BARRIER();                                                  // b_0
     bf16x8 kf[KT][2], vf[KT][2];
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
             // (KT = 2: the last wave's second tile reads rows 208..223: past the staged tile, into the next LDS region -- its products are masked)
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                const int r0 = (wave * KT + t) * 16;
+                const int r0 = (kvw * KT + t) * 16;
                 kf[t][0] = sw_row(Ks, r0, 0, fi, fg); kf[t][1] = sw_row(Ks, r0, 1, fi, fg);
                 vf[t][0] = sw_row(Vs, r0, 0, fi, fg); vf[t][1] = sw_row(Vs, r0, 1, fi, fg);
             }
@@ -1072,7 +1076,7 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
             const int fi_o = lane_o & 15, fg_o = lane_o >> 4;
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                const int key = (wave * KT + t) * 16 + fi_o;
+                const int key = (kvw * KT + t) * 16 + fi_o;
                 if (key < N) {
                     __bf16* dkp = reinterpret_cast<__bf16*>(dkb + (unsigned)(key * ((int)a.dk.s_n * 2) + 8 * fg_o));
                     __bf16* dvp = reinterpret_cast<__bf16*>(dvb + (unsigned)(key * ((int)a.dv.s_n * 2) + 8 * fg_o));
@@ -1211,16 +1215,10 @@ int launch_fused(const AttnPipeBwd& p, hipStream_t st) {
     a.lse = p.lse; a.delta = p.delta; a.dq = ond(p.dq); a.dk = ond(p.dk); a.dv = ond(p.dv);
     a.H = (int)p.H; a.N = (int)p.N; a.nitems = (int)(p.B * p.H); a.scale = p.scale;
     a.dbg = getenv("VITK_ATTN_DBG") ? atoi(getenv("VITK_ATTN_DBG")) : 0;
-    const int kt = getenv("VITK_ATTN_KT") ? atoi(getenv("VITK_ATTN_KT")) : 1;
     int grid = num_cus();
     if (grid > a.nitems) grid = a.nitems;
-    if (kt == 2) {
-        AP_SET_LDS(attn_bwd_fused_kernel<2>, "attn_bwd (fused)");
-        hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, dim3((unsigned)grid), dim3(fb_threads(2)), (size_t)FB_LDS, st, a);
-    } else {
-        AP_SET_LDS(attn_bwd_fused_kernel<1>, "attn_bwd (fused)");
-        hipLaunchKernelGGL(attn_bwd_fused_kernel<1>, dim3((unsigned)grid), dim3(fb_threads(1)), (size_t)FB_LDS, st, a);
-    }
+    AP_SET_LDS(attn_bwd_fused_kernel<1>, "attn_bwd (fused)");
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<1>, dim3((unsigned)grid), dim3(fb_threads(1)), (size_t)FB_LDS, st, a);
     VITK_CHECK_LAUNCH("attn_bwd (fused)");
     return 0;
 }
