@@ -269,3 +269,65 @@ def test_navit_trains_with_dropout():
     assert all(torch.isfinite(q.grad.float()).all() for q in m.parameters())
     m.eval()
     assert torch.equal(m(imgs), m(imgs))
+
+
+def test_packed_fused_dropout_layer_matches_masked_reference():
+    """Active dropout (na_vit.py:101,103,163,172 at p = 0.1, training mode) runs inside the fused packed engine; its keep decisions
+    are a counter hash, so a float64 reference that applies the very same masks (vitk_dropout_keep) must agree -- output and every
+    gradient.  Sites of layer li: 4 li + {0: attention matrix, 1: after to_out, 2: after the GELU, 3: after the second Linear}."""
+    from vit_pytorch_amd import engine as E
+    from vit_pytorch_amd.na_vit import Transformer
+    D, H, d, Fh, p = 256, 4, 64, 512, 0.1
+    lens = [300, 512, 129, 83, 476]
+    T, I = sum(lens), H * d
+    torch.manual_seed(11)
+    blk = Transformer(D, 1, H, d, Fh, dropout=p).to(DEV, dtype=BF).train()
+    for q_ in blk.parameters():                                  # non-trivial gains / biases
+        if q_.ndim == 1 or q_.shape[-2:] == (1, d):
+            q_.data.add_(0.1 * torch.randn_like(q_))
+    x = torch.randn(T, D, device=DEV).to(BF)
+    segs = Segments(lens, lens, torch.device(DEV))
+    assert blk._fusable(x) and blk._dropout_p() == p
+    calls, salt = blk._drop_state()
+    seed = (int(torch.initial_seed()) + 0x9E3779B1 * calls + 0x85EBCA6B * salt) & 0xffffffff
+    y = blk(x, segs)
+    assert blk._drop_state()[0] == calls + 1                    # the fused path drew its seeds
+    NO.O.loss_fn(y).backward()
+
+    def keep(rows, cols, k):
+        m = torch.empty(rows, cols, dtype=torch.uint8, device=DEV)
+        K.dropout_keep(m, rows, cols, p, E._hash32(seed + k))
+        return m.double() / (1 - p)
+
+    P = {k_: v.detach().double().requires_grad_(True) for k_, v in blk.named_parameters()}
+    ln = lambda t, g_: torch.nn.functional.layer_norm(t, (D,), g_, None, 1e-5)
+    rms = lambda t, g_: torch.nn.functional.normalize(t, dim=-1) * d ** 0.5 * g_.view(H, d)
+    xd = x.double()
+    a1 = ln(xd, P["layers.0.0.norm.gamma"])
+    q = rms((a1 @ P["layers.0.0.to_q.weight"].t()).view(T, H, d), P["layers.0.0.q_norm.gamma"])
+    kv = a1 @ P["layers.0.0.to_kv.weight"].t()
+    k = rms(kv[:, :I].view(T, H, d), P["layers.0.0.k_norm.gamma"])
+    v = kv[:, I:].view(T, H, d)
+    km = keep(H * T, max(lens), 0).view(H, T, max(lens))
+    outs, start = [], 0
+    for n in lens:
+        qs, ks, vs = (t[start:start + n].transpose(0, 1) for t in (q, k, v))
+        pm = torch.softmax(qs @ ks.transpose(-1, -2), -1) * km[:, start:start + n, :n]      # scale 1: q and k are normalised
+        outs.append((pm @ vs).transpose(0, 1).reshape(n, I))
+        start += n
+    o = torch.cat(outs)
+    x2 = xd + (o @ P["layers.0.0.to_out.0.weight"].t()) * keep(T, D, 1)
+    a2 = ln(x2, P["layers.0.1.0.gamma"])
+    act = torch.nn.functional.gelu(a2 @ P["layers.0.1.1.weight"].t() + P["layers.0.1.1.bias"]) * keep(T, Fh, 2)
+    x3 = x2 + (act @ P["layers.0.1.4.weight"].t() + P["layers.0.1.4.bias"]) * keep(T, D, 3)
+    yref = ln(x3, P["norm.gamma"])
+    NO.O.loss_fn(yref).backward()
+    e = rel(y, yref)
+    keys = list(P)
+    g = rel(torch.cat([blk.get_parameter(k_).grad.float().flatten() for k_ in keys]), torch.cat([P[k_].grad.flatten() for k_ in keys]))
+    worst = max(rel(blk.get_parameter(k_).grad, P[k_].grad) for k_ in keys)
+    print(f"packed fused dropout layer: out {e:.2e}, grads {g:.2e}, worst tensor {worst:.2e}")
+    assert e < 1e-2 and g < 2e-2 and worst < 6e-2
+    blk.eval()
+    assert blk._dropout_p() == 0.0 and blk._fusable(x)
+

@@ -613,9 +613,21 @@ def _cat_rows(a: Tensor, b: Tensor) -> Tensor:
     return outp
 
 
+def packed_dropout_fusable(T, Tn: int, D: int, heads: int, dim_head: int, F: int) -> bool:
+    """Active dropout (na_vit.py:100-103,163,171-175) runs inside the packed engine when the three Linear layers that carry one are
+    served by the 256-row GEMM kernel (its epilogues hold the fused dropout); the packed attention kernels always take theirs."""
+    I = heads * dim_head
+    return T in ops.HALF and ops.fused_dropout_ok(T, Tn, D, I) and ops.fused_dropout_ok(T, Tn, F, D) and ops.fused_dropout_ok(T, Tn, D, F)
+
+
 class PackedTransformerFn(torch.autograd.Function):
+    """na_vit.Transformer.forward (na_vit.py:196-214) on packed tokens.  drop_p > 0 (training): the four dropouts of a layer --
+    inside scaled_dot_product_attention (na_vit.py:163), after to_out (:172), after the GELU (:101), after the second FeedForward
+    Linear (:103) -- are taken inside the packed attention kernels and the GEMM epilogues, exactly as TransformerFn does (per-site
+    seeds from drop_seed, keep decisions regenerated by the backward kernels, no mask tensor)."""
+
     @staticmethod
-    def forward(ctx, x, segs, heads: int, dim_head: int, norm_g, *lp):
+    def forward(ctx, x, segs, heads: int, dim_head: int, drop_p: float, drop_seed: int, norm_g, *lp):
         K.require_device(x, norm_g)
         depth = len(lp) // NLP_NAVIT
         T = norm_g.dtype
@@ -634,6 +646,10 @@ class PackedTransformerFn(torch.autograd.Function):
         saved = []
         keep = any(ctx.needs_input_grad) and caller_grad_mode()      # no_grad / eval: drop each layer's activations as soon as the layer is done
         # (needs_input_grad mirrors requires_grad even under torch.no_grad(): the module-level caller records the real mode, _epoch.py)
+        if drop_p > 0.0 and depth and not packed_dropout_fusable(T, Tn, D, heads, dim_head, lp[7].shape[0]):
+            raise VitkError("PackedTransformerFn: this shape does not take the fused dropout path (caller must check packed_dropout_fusable)")
+        site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
+        att_drop = lambda li: site(li, 0) or (0.0, 0)
         for li in range(depth):
             ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
             a1 = ops.empty((Tn, D), T, xs)
@@ -648,12 +664,12 @@ class PackedTransformerFn(torch.autograd.Function):
             o = ops.empty((Tn, I), T, xs)
             lse = ops.empty((heads, Tn), F32, xs)
             K.attn_varlen_fwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(qkv, d, 3 * I, offset=2 * I), K.hnd(o, d, I), lse,
-                                   segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, Tn, heads, d, 1.0)
-            x2 = ops.linear_fwd(o, wout, None, Tn, resid=xs)
+                                   segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, Tn, heads, d, 1.0, *att_drop(li))
+            x2 = ops.linear_fwd(o, wout, None, Tn, resid=xs, drop=site(li, 1))
             a2 = ops.empty((Tn, D), T, xs)
             st2 = ops.ln_fwd(x2, ln2g, None, Tn, D, a2)
-            act, pre = ops.linear_fwd(a2, w1, b1, Tn, gelu=True)
-            x3 = ops.linear_fwd(act, w2, b2, Tn, resid=x2)
+            act, pre = ops.linear_fwd(a2, w1, b1, Tn, gelu=True, drop=site(li, 2))
+            x3 = ops.linear_fwd(act, w2, b2, Tn, resid=x2, drop=site(li, 3))
             if keep:
                 saved.append((xs, a1, st1, wcat, qkv, gqf, gkf, qn, kn, rq, rk, o, lse, x2, a2, st2, pre, act))
             xs = x3
@@ -662,12 +678,16 @@ class PackedTransformerFn(torch.autograd.Function):
         ctx.saved = saved
         ctx.x_last, ctx.stf = xs, stf
         ctx.meta = (segs, heads, dim_head, depth, Tn, D, x.dtype)
+        ctx.drop = (drop_p, drop_seed)
         ctx.save_for_backward(norm_g, *lp)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         segs, heads, d, depth, Tn, D, in_dtype = ctx.meta
+        drop_p, drop_seed = ctx.drop
+        site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
+        att_drop = lambda li: site(li, 0) or (0.0, 0)
         sv = list(ctx.saved_tensors)
         norm_g, lp = sv[0], sv[1:]
         T = norm_g.dtype
@@ -684,7 +704,9 @@ class PackedTransformerFn(torch.autograd.Function):
         g, gb = newg()
         dng = _grad_buf(norm_g)
         dcol = ops.empty((D,), F32, dy)
-        ops.ln_bwd(dy, ctx.x_last, norm_g, ctx.stf[0], ctx.stf[1], Tn, D, dx_f32=g, dx_t=gb, dw=dng, dcol=dcol)
+        # (with dropout: gb and dcol carry the keep decisions of the LAST layer's post-FF2 dropout; g, the stream gradient, does not)
+        ops.ln_bwd(dy, ctx.x_last, norm_g, ctx.stf[0], ctx.stf[1], Tn, D, dx_f32=g, dx_t=gb, dw=dng, dcol=dcol,
+                   drop=site(depth - 1, 3) if depth else None)
         ctx.x_last = None
         for li in reversed(range(depth)):
             ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
@@ -698,7 +720,7 @@ class PackedTransformerFn(torch.autograd.Function):
             K.cast(dcol, db2)
             grads[base + 9], grads[base + 10] = dw2, db2
             dw1, db1 = _grad_buf(w1), _grad_buf(b1)
-            dpre, db_done = ops.linear_dx(gb, w2, Tn, gelu_pre=pre, db=db1)
+            dpre, db_done = ops.linear_dx(gb, w2, Tn, gelu_pre=pre, db=db1, drop=site(li, 2))
             db_todo = None if db_done else db1
             fork.run(lambda: ops.linear_dw(dpre, a2, Tn, dw1, db_todo), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
@@ -706,7 +728,8 @@ class PackedTransformerFn(torch.autograd.Function):
             del dpre, pre, act
             g2, g2b = newg()
             dl2 = _grad_buf(ln2g)
-            ops.ln_bwd(da2, x2, ln2g, st2[0], st2[1], Tn, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2)
+            ops.ln_bwd(da2, x2, ln2g, st2[0], st2[1], Tn, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2,
+                       drop=site(li, 1))      # g2b: gradient at to_out's output, behind its dropout
             grads[base + 6] = dl2
             del da2, g, gb
             # ---- attention ----
@@ -720,7 +743,7 @@ class PackedTransformerFn(torch.autograd.Function):
             K.attn_varlen_bwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(qkv, d, 3 * I, offset=2 * I), K.hnd(o, d, I),
                                    K.hnd(do, d, I), lse, delta, K.hnd(dqn, d, I), K.hnd(dkn, d, I),
                                    K.hnd(dqkv, d, 3 * I, offset=2 * I), segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0,
-                                   segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, Tn, heads, d, 1.0)
+                                   segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, Tn, heads, d, 1.0, *att_drop(li))
             dgq = torch.empty_like(gqf); dgk = torch.empty_like(gkf)
             part = ops.empty((K.rmsnorm_heads_rows(Tn, heads) * 64,), F32, dy)
             K.rmsnorm_heads_bwd(dqn, I, qkv, 3 * I, gqf, rq, dqkv, 3 * I, dgq, part, Tn, heads, d)
@@ -735,10 +758,11 @@ class PackedTransformerFn(torch.autograd.Function):
             g1, g1b = newg()
             dl1 = _grad_buf(ln1g)
             dcol = ops.empty((D,), F32, dy)
-            ops.ln_bwd(da1, xs, ln1g, st1[0], st1[1], Tn, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1, dcol=dcol)
+            ops.ln_bwd(da1, xs, ln1g, st1[0], st1[1], Tn, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1, dcol=dcol,
+                       drop=site(li - 1, 3) if li > 0 else None)   # feeds the layer below: behind ITS post-FF2 dropout
             grads[base + 0] = dl1
             g, gb = g1, g1b
             del g2, g2b, da1
         fork.join()
         dx = g if in_dtype == F32 else gb
-        return (dx, None, None, None, _ret(dng), *[_ret(t) for t in grads])
+        return (dx, None, None, None, None, None, _ret(dng), *[_ret(t) for t in grads])

@@ -299,17 +299,57 @@ class Transformer(nn.Module):
             ]))
         self.norm = LayerNorm(dim)
 
+    # fused-dropout seed sequence: per instance, per training call (see vit.Transformer); not in state_dict
+    _instances = [0]
+
+    def _drop_state(self):
+        if "_drop_salt" not in self.__dict__:
+            self.__dict__["_drop_calls"] = 0
+            self.__dict__["_drop_salt"] = Transformer._instances[0]
+            Transformer._instances[0] += 1
+        return self.__dict__["_drop_calls"], self.__dict__["_drop_salt"]
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_drop_calls"] = 0
+        new.__dict__["_drop_salt"] = Transformer._instances[0]
+        Transformer._instances[0] += 1
+        return new
+
+    def _dropout_p(self):
+        """The common p of the block's active dropouts (0.0 if inactive); None if the modules disagree (a user edited them)."""
+        if not self.training:
+            return 0.0
+        ps = set()
+        for attn, ff in self.layers:
+            ps.add(float(attn.dropout_p))
+            ps.update(float(m.p) for m in list(ff) + list(attn.to_out) if isinstance(m, nn.Dropout))
+        return ps.pop() if len(ps) == 1 else (0.0 if not ps else None)
+
     def _fusable(self, x) -> bool:
+        """The fused packed engine covers the block in 16 bit with dim_head 64 when nothing observes its inside; active dropout is
+        fused too when the GEMM shapes are those the fused-dropout epilogues serve (engine.packed_dropout_fusable)."""
         if x.dtype not in (torch.bfloat16, torch.float16) or self.norm.gamma.dtype != x.dtype:
             return False
         for attn, ff in self.layers:
             if attn.q_norm.gamma.shape[-1] != 64:
                 return False
-            if self.training and (attn.dropout_p > 0. or any(isinstance(m, nn.Dropout) and m.p > 0. for m in list(ff) + list(attn.to_out))):
-                return False
             if any(bool(m._forward_hooks) or bool(m._forward_pre_hooks) for m in list(attn.modules()) + list(ff.modules())):
                 return False
-        return not (self.norm._forward_hooks or self.norm._forward_pre_hooks)
+        if self.norm._forward_hooks or self.norm._forward_pre_hooks:
+            return False
+        p = self._dropout_p()
+        if p is None:
+            return False
+        if p > 0. and len(self.layers):
+            from . import engine as E
+            attn, ff = self.layers[0]
+            return E.packed_dropout_fusable(x.dtype, x.shape[0], x.shape[1], attn.heads, 64, ff[1].weight.shape[0])
+        return True
 
     def forward(self, x, segs: Segments):
         if self._fusable(x):
@@ -318,8 +358,13 @@ class Transformer(nn.Module):
             for attn, ff in self.layers:
                 params += E.pack_navit_layer_params(attn, ff)
             heads = self.layers[0][0].heads if len(self.layers) else 1
+            p = self._dropout_p()
+            seed = 0
+            if p > 0.:
+                seed = (int(torch.initial_seed()) + 0x9E3779B1 * self._drop_state()[0] + 0x85EBCA6B * self._drop_state()[1] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
+                self.__dict__["_drop_calls"] = self._drop_state()[0] + 1
             note_grad_mode(torch.is_grad_enabled())      # Function.forward cannot see no_grad(): it decides what to keep from this
-            return E.PackedTransformerFn.apply(x, segs, heads, 64, self.norm.gamma, *params)
+            return E.PackedTransformerFn.apply(x, segs, heads, 64, float(p), seed, self.norm.gamma, *params)
         for attn, ff in self.layers:
             x = Fn.AddFn.apply(attn(x, segs), x)
             x = Fn.AddFn.apply(ff(x), x)
