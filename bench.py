@@ -119,7 +119,7 @@ def time_dominant_kernel(step_fn, nsteps: int = 3):
     return out
 
 
-TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def pmc_traffic_bytes():
