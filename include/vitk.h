@@ -219,7 +219,9 @@ int vitk_gemm_generic(vitk_mat A, vitk_mat B, vitk_mat C, const void* bias, int 
 typedef struct vitk_bhnd { void* p; int64_t s_b, s_h, s_n; } vitk_bhnd;
 int vitk_attn_fwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, float* lse,
                        int64_t B, int64_t H, int64_t N, int64_t d, float scale, void* stream);
-/* delta: f32 (B,H,N) scratch (rowsum(dO*O)), written by the call. */
+/* delta: f32 (B,H,N) SCRATCH of the call, contents unspecified afterwards: the two-kernel path keeps rowsum(dO*O) in it between its
+ * kernels; the single-kernel path (16-bit, 192 < N <= 208, no dropout, no CU reserve) keeps that in LDS and uses the buffer only as a
+ * target for the store slots of rows that do not exist. */
 int vitk_attn_bwd_bf16(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vitk_bhnd o, vitk_bhnd dout,
                        const float* lse, float* delta,
                        vitk_bhnd dq, vitk_bhnd dk, vitk_bhnd dv,
