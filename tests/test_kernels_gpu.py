@@ -98,6 +98,38 @@ def test_layernorm_bwd(dydt, xdt, wdt, rows, D):
     assert rel(dc, dx_ref.sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("xdt", [F32, BF])
+@pytest.mark.parametrize("rows,D", [(2100, 768), (40, 64), (3100, 1024), (2600, 1280), (900, 256)])
+def test_layernorm_bwd_16bit_stream(xdt, rows, D):
+    """vitk_layernorm_bwd_s16: the stream gradient comes in and leaves in the 16-bit type (dx_t = dx + gin, no float32 output) --
+    the specialised kernel at D = 768 / 1024 / 1280 and the general one; against float64 and against the float32-stream kernel
+    fed the same (widened) gin: the two may differ only by the final rounding."""
+    x = rnd(rows, D, dtype=xdt, seed=21) * 1.5 + 0.3
+    dy = rnd(rows, D, dtype=BF, seed=22)
+    w = (1 + 0.2 * rnd(D, seed=23)).to(BF)
+    gin = rnd(rows, D, dtype=BF, seed=25)
+    xd = x.double().requires_grad_(True); wd = w.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (D,), wd, None, 1e-5).backward(dy.double())
+    mean = x.double().mean(-1).float(); rstd = (1 / torch.sqrt(x.double().var(-1, unbiased=False) + 1e-5)).float()
+    nblk = K.layernorm_bwd_blocks(rows, D)
+    partials = torch.empty(3 * nblk * D, device=DEV)
+    dxt = torch.empty(rows, D, dtype=BF, device=DEV)
+    K.layernorm_bwd_s16(dy, x, w, mean, rstd, gin, dxt, partials, True, rows, D)
+    dw = torch.empty(D, dtype=BF, device=DEV); db = torch.empty(D, dtype=BF, device=DEV); dc = torch.empty(D, device=DEV)
+    K.layernorm_bwd_finalize(partials, nblk, D, dw, db, dc, K.dt(w))
+    dx_ref = xd.grad + gin.double()
+    assert rel(dxt, dx_ref) < 4e-3
+    assert rel(dw, wd.grad) < 5e-3 and rel(db, dy.double().sum(0)) < 5e-3
+    assert rel(dc, dx_ref.sum(0)) < 1e-4
+    # the float32-stream kernel on the same inputs: same values before the last rounding
+    p2 = torch.empty(3 * nblk * D, device=DEV); dxf = torch.empty(rows, D, device=DEV); dxt2 = torch.empty(rows, D, dtype=BF, device=DEV)
+    K.layernorm_bwd(dy, x, w, mean, rstd, gin.float(), dxf, dxt2, p2, True, rows, D)
+    assert torch.equal(dxt, dxt2)
+    # without an incoming gradient (the last LayerNorm of the stack)
+    K.layernorm_bwd_s16(dy, x, w, mean, rstd, None, dxt, partials, True, rows, D)
+    assert rel(dxt, xd.grad) < 4e-3
+
+
 def test_layernorm_bwd_maps():
     # dy rows are the cls rows result (B rows), x rows are strided in (B,N,D), dx scattered to row 0 of each image
     B, N, D = 4, 5, 64

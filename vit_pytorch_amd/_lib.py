@@ -16,7 +16,7 @@ LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit t
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3, 4
-VITK_VERSION = 130
+VITK_VERSION = 131
 
 
 class RowMap(C.Structure):
@@ -58,6 +58,7 @@ SIGNATURES = {
     "vitk_adam_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i64, _f, _vp]),
     "vitk_gemm_nt_bf16_drop": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, C.c_uint32, _vp]),
     "vitk_layernorm_bwd_drop": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i64, RowMap, RowMap, RowMap, _f, C.c_uint32, _vp]),
+    "vitk_layernorm_bwd_s16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i64, RowMap, RowMap, RowMap, _vp]),
     "vitk_gemm_nt_fp8": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _f, _vp]),
     "vitk_fp8_amax_scale": (_i, [_vp, _i, _i64, _vp, _vp]),
     "vitk_quantize_fp8": (_i, [_vp, _i, _vp, _i64, _vp, _f, _vp]),

@@ -7,6 +7,7 @@
 // writes dx (f32 and/or T).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -119,11 +120,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 // NW waves per block: 8 for rows up to 768 columns (<= 128 VGPRs: two blocks per CU), 4 for wider rows, whose three
 // column accumulators push the kernel to ~155-170 VGPRs -- three 4-wave blocks then fit a CU (12 waves) where a single
 // 8-wave block would (8 waves).
-template <typename DYT, typename XT, typename WT, typename DXT, int MAXC, int NW>
+// GT: type of the incoming stream gradient `gin` -- float (f32 stream: dx_f32 is its update, dx_t the 16-bit copy the GEMMs read) or
+// DXT (16-bit stream: dx_t IS the updated stream, dx_f32 is null).
+template <typename DYT, typename XT, typename WT, typename DXT, typename GT, int MAXC, int NW>
 __global__ __launch_bounds__(NW * WAVE, (MAXC <= 3 ? 4 : 1)) void ln_bwd_kernel(
     const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-    const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
+    const GT* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
     float* __restrict__ partials, int colsum_dx,
     long long rows, int D, RowMap dymap, RowMap xmap, RowMap dxmap, unsigned drop_t, unsigned drop_seed, float inv_keep) {
     const int lane = threadIdx.x & 63;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(NW * WAVE, (MAXC <= 3 ? 4 : 1)) void ln_bwd_kernel(
         for (int t = 0; t < MAXC; ++t) {
             const int c = lane + 64 * t;
             gi[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EARLY_GIN && gin && want_dx && c < nchunk) gi[t] = *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
+            if (EARLY_GIN && gin && want_dx && c < nchunk) gi[t] = load4<GT>(gin + orow * D + 4 * c);
         }
 #pragma unroll
         for (int t = 0; t < MAXC; ++t) {
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(NW * WAVE, (MAXC <= 3 ? 4 : 1)) void ln_bwd_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rstd * (g[t][e] - c1 - xh[t][e] * c2);
                     if (EARLY_GIN) o += gi[t];
-                    else if (gin) o += *reinterpret_cast<const f32x4*>(gin + orow * D + 4 * c);
+                    else if (gin) o += load4<GT>(gin + orow * D + 4 * c);
                     if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow * D + 4 * c) = o;
                     if (drop_t) {           // dx_t / its column sums are the gradient at the OUTPUT of the preceding Linear, whose
                                             // dropout (vit.py:24,48) kept element (row, col) by the same hash; the f32 stream is not masked
@@ -252,11 +255,11 @@ __device__ __forceinline__ void opaque(bf16x4& v) {
 __device__ __forceinline__ void opaque(f32x4&) {}
 __device__ __forceinline__ f32x2 widen2(const f32x4& v, int p) { return f32x2{v[2 * p], v[2 * p + 1]}; }
 __device__ __forceinline__ f32x2 widen2(const bf16x4& v, int p) { return f32x2{(float)v[2 * p], (float)v[2 * p + 1]}; }
-template <typename DYT, typename XT, typename WT, typename DXT, int MAXC, int NW, int WPE, bool NT, bool PIPE, bool DROP>
+template <typename DYT, typename XT, typename WT, typename DXT, typename GT, int MAXC, int NW, int WPE, bool NT, bool PIPE, bool DROP>
 __global__ __launch_bounds__(NW * WAVE, WPE) void ln_bwd_fast_kernel(
     const DYT* __restrict__ dy, const XT* __restrict__ x, const WT* __restrict__ w,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-    const float* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
+    const GT* __restrict__ gin, float* __restrict__ dx_f32, DXT* __restrict__ dx_t,
     float* __restrict__ partials, long long rows, unsigned drop_t, unsigned drop_seed, float inv_keep) {
     constexpr int D = 256 * MAXC;
     constexpr float invD = 1.0f / (float)D;
@@ -275,14 +278,15 @@ __global__ __launch_bounds__(NW * WAVE, WPE) void ln_bwd_fast_kernel(
     long long row = (long long)blockIdx.x * NW + wave;
     // software pipeline: the loads of row i+1 are issued as soon as row i has left the registers they land in (dy and x after
     // the first pass, the stream gradient after the second), so they fly under row i's reductions, second pass and stores
-    f32x4 gi[MAXC];
+    constexpr bool F32_STREAM = std::is_same<GT, float>::value;       // else: 16-bit stream, dx_t is its update, no f32 output
+    typename Raw4<GT>::type gi[MAXC];
     typename Raw4<DYT>::type dv[MAXC];
     typename Raw4<XT>::type xv[MAXC];
     float mean = 0.f, rstd = 0.f;
     if (PIPE && row < rows) {
         const long long ro = row * D + 4 * lane;
 #pragma unroll
-        for (int t = 0; t < MAXC; ++t) gi[t] = ld16<NT>(gin + ro + 256 * t);
+        for (int t = 0; t < MAXC; ++t) gi[t] = ldraw<NT>(gin + ro + 256 * t);
 #pragma unroll
         for (int t = 0; t < MAXC; ++t) { dv[t] = ldraw<NT>(dy + ro + 256 * t); xv[t] = ldraw<NT>(x + ro + 256 * t); }
         mean = mean_in[row]; rstd = rstd_in[row];
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(NW * WAVE, WPE) void ln_bwd_fast_kernel(
         const long long nro = nrow * D + 4 * lane;
         if (!PIPE) {
 #pragma unroll
-            for (int t = 0; t < MAXC; ++t) gi[t] = ld16<NT>(gin + ro + 256 * t);
+            for (int t = 0; t < MAXC; ++t) gi[t] = ldraw<NT>(gin + ro + 256 * t);
 #pragma unroll
             for (int t = 0; t < MAXC; ++t) { dv[t] = ldraw<NT>(dy + ro + 256 * t); xv[t] = ldraw<NT>(x + ro + 256 * t); }
             mean = mean_in[row]; rstd = rstd_in[row];
@@ -336,12 +340,12 @@ __global__ __launch_bounds__(NW * WAVE, WPE) void ln_bwd_fast_kernel(
             for (int p = 0; p < 2; ++p) {
                 o[p] = g[t][p] * rs2 - c1;
                 o[p] = o[p] - h[t][p] * c2;
-                o[p] += f32x2{gi[t][2 * p], gi[t][2 * p + 1]};
+                o[p] += widen2(gi[t], p);
                 if (!DROP) ax[t][p] += o[p];
             }
             const f32x4 ov = {o[0][0], o[0][1], o[1][0], o[1][1]};
-            if (PIPE) gi[t] = ld16<NT>(gin + nro + 256 * t);
-            *reinterpret_cast<f32x4*>(of + 256 * t) = ov;
+            if (PIPE) gi[t] = ldraw<NT>(gin + nro + 256 * t);
+            if constexpr (F32_STREAM) *reinterpret_cast<f32x4*>(of + 256 * t) = ov;
             if (DROP) {     // dx_t and its column sums are the gradient at the OUTPUT of the preceding Linear, whose dropout
                             // (vit.py:24,48) kept element (row, col) by the same hash; the f32 stream is not masked
                 const unsigned hrow = drop_row((unsigned)row, drop_seed);
@@ -589,14 +593,18 @@ int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* m
     return 0;
 }
 
-template <typename DYT, typename XT, typename WT, typename DXT>
-int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const float* gin,
+template <typename DYT, typename XT, typename WT, typename DXT, typename GT = float>
+int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* gin_,
                   float* dxf, void* dxt, float* partials, int colsum_dx, long long rows, int D, RowMap dm, RowMap xm,
                   RowMap om, hipStream_t st, unsigned drop_t, unsigned drop_seed, float inv_keep) {
+    const GT* gin = (const GT*)gin_;
+    constexpr bool F32_STREAM = std::is_same<GT, float>::value;
     const int nchunk = D / 4;
     const int maxc = (nchunk + 63) / 64;
     const long long blocks = vitk_layernorm_bwd_blocks(rows, D);
     if (D & 3) {
+        if constexpr (!F32_STREAM) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd_s16: the 16-bit stream needs D %% 4 == 0 (got %d)", D);
+        else {
         const bool wide = (D / 4 + 63) / 64 >= 4;          // the block shape vitk_layernorm_bwd_blocks assumed
         const size_t lds = (size_t)(wide ? 4 : 8) * 3 * D * sizeof(float);
         if (lds > 150 * 1024) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd: widths that are not multiples of 4 are served up to D = 3200 (got %d)", D);
@@ -611,12 +619,13 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
 #undef LN_BWD_ANY
         VITK_CHECK_LAUNCH("layernorm_bwd");
         return 0;
+        }
     }
     static const int no_fast = getenv("VITK_LNB_FAST") ? !atoi(getenv("VITK_LNB_FAST")) : 0;
-    if (!no_fast && gin && dxf && dxt && colsum_dx && dm.group <= 0 && xm.group <= 0 && om.group <= 0 && (D == 768 || D == 1024 || D == 1280)) {
+    if (!no_fast && gin && (dxf || !F32_STREAM) && dxt && colsum_dx && dm.group <= 0 && xm.group <= 0 && om.group <= 0 && (D == 768 || D == 1024 || D == 1280)) {
         // nontemporal loads of the three row streams: 123 -> 99 us at 50432 x 768 (6.3 TB/s); prefetching the next row (PIPE) on
         // top of them costs 10 us, so it stays a switch
-#define LN_BWD_FAST(MC, NWV, WPE, NTL, PIPE, DROP) hipLaunchKernelGGL((ln_bwd_fast_kernel<DYT, XT, WT, DXT, MC, NWV, WPE, NTL, PIPE, DROP>), \
+#define LN_BWD_FAST(MC, NWV, WPE, NTL, PIPE, DROP) hipLaunchKernelGGL((ln_bwd_fast_kernel<DYT, XT, WT, DXT, GT, MC, NWV, WPE, NTL, PIPE, DROP>), \
         dim3((unsigned)blocks), dim3(NWV * WAVE), 0, st, \
         (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, rows, drop_t, drop_seed, inv_keep)
         static const int fnt = getenv("VITK_LNB_NT") ? atoi(getenv("VITK_LNB_NT")) : 1;
@@ -635,7 +644,7 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
         VITK_CHECK_LAUNCH("layernorm_bwd");
         return 0;
     }
-#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, MC, (MC >= 4 ? 4 : 8)>), dim3((unsigned)blocks), dim3((MC >= 4 ? 4 : 8) * WAVE), 0, st, \
+#define LN_BWD_CASE(MC) hipLaunchKernelGGL((ln_bwd_kernel<DYT, XT, WT, DXT, GT, MC, (MC >= 4 ? 4 : 8)>), dim3((unsigned)blocks), dim3((MC >= 4 ? 4 : 8) * WAVE), 0, st, \
         (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, colsum_dx, rows, D, dm, xm, om, drop_t, drop_seed, inv_keep)
     if (maxc <= 1) LN_BWD_CASE(1);
     else if (maxc <= 3) LN_BWD_CASE(3);
@@ -726,6 +735,20 @@ extern "C" int vitk_layernorm_bwd_drop(const void* dy, int dydt, const void* x, 
     if (dydt == VITK_F32 && xdt == VITK_F32) return launch_ln_bwd<float, float, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, drop_t, drop_seed, inv_keep);
     if (dydt == VITK_F32 && xdt == VITK_BF16) return launch_ln_bwd<float, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, drop_t, drop_seed, inv_keep);
     VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd: bad dtype combination");
+}
+
+extern "C" int vitk_layernorm_bwd_s16(const void* dy, int dydt, const void* x, int xdt, const void* w, int wdt, const float* mean,
+                                      const float* rstd, const void* gin, void* dx_t, int dxtdt, float* partials, int colsum_dx,
+                                      int64_t rows, int64_t D, vitk_rowmap dymap, vitk_rowmap xmap, vitk_rowmap dxmap, void* stream) {
+    if (!dy || !x || !w || !mean || !rstd || !partials || !dx_t) VITK_FAIL(VITK_E_ARG, "layernorm_bwd_s16: null pointer");
+    if (rows <= 0 || D <= 0 || D > 4096 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "layernorm_bwd_s16: need rows > 0, 0 < D <= 4096, D %% 4 == 0");
+    if (!aligned16(dy) || !aligned16(x) || (gin && !aligned16(gin)) || !aligned16(dx_t)) VITK_FAIL(VITK_E_ALIGN, "layernorm_bwd_s16: pointers must be 16-byte aligned");
+    if (wdt != VITK_BF16 || dxtdt != VITK_BF16) VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd_s16: the 16-bit stream comes with 16-bit parameters");
+    hipStream_t st = (hipStream_t)stream;
+    const RowMap dm = to_map(dymap), xm = to_map(xmap), om = to_map(dxmap);
+    if (dydt == VITK_BF16 && xdt == VITK_F32) return launch_ln_bwd<__bf16, float, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, nullptr, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, 0u, 0u, 1.0f);
+    if (dydt == VITK_BF16 && xdt == VITK_BF16) return launch_ln_bwd<__bf16, __bf16, __bf16, __bf16, __bf16>(dy, x, w, mean, rstd, gin, nullptr, dx_t, partials, colsum_dx, rows, (int)D, dm, xm, om, st, 0u, 0u, 1.0f);
+    VITK_FAIL(VITK_E_DTYPE, "layernorm_bwd_s16: dy must be 16-bit, x float32 or 16-bit");
 }
 
 extern "C" int vitk_layernorm_bwd_finalize(const float* partials, int64_t nblk, int64_t D, void* dw, void* db, int odt,

@@ -303,8 +303,12 @@ class TransformerFn(torch.autograd.Function):
         dy = dy.contiguous()
         grads: List[Optional[Tensor]] = [None] * len(lp)
 
+        # the residual stream of the backward: float32, or (16-bit parameters, no active dropout: ops.grad_stream_16) the parameter
+        # dtype -- then the LayerNorm backward's 16-bit output IS the stream and the f32 tensors below do not exist
+        s16 = bf and drop_p == 0.0 and D % 4 == 0 and ops.grad_stream_16()
+
         def newg():
-            g32 = ops.empty((M, D), F32, dy)
+            g32 = None if s16 else ops.empty((M, D), F32, dy)
             return g32, (ops.empty((M, D), T, dy) if bf else None)
 
         fork = _Fork(dy.device)
@@ -353,7 +357,7 @@ class TransformerFn(torch.autograd.Function):
             g2, g2b = newg()
             dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
             dcol2 = bias_target(bout if wout is not None else None)
-            ops.ln_bwd(da2, x2, ln2w, st2[0], st2[1], M, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2w, db=dl2b, dcol=dcol2,
+            ops.ln_bwd(da2, x2, ln2w, st2[0], st2[1], M, D, gin=gb if s16 else g, dx_f32=g2, dx_t=g2b, dw=dl2w, db=dl2b, dcol=dcol2,
                        drop=site(li, 1))      # g2b / dcol2: gradient at to_out's output, behind its dropout
             grads[base + 5], grads[base + 6] = dl2w, dl2b
             del da2, g, gb
@@ -377,7 +381,7 @@ class TransformerFn(torch.autograd.Function):
             g1, g1b = newg()
             dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
             dcol = bias_target(lp[(li - 1) * NLP + 10] if li > 0 else None)
-            ops.ln_bwd(da1, xs, ln1w, st1[0], st1[1], M, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1w, db=dl1b, dcol=dcol,
+            ops.ln_bwd(da1, xs, ln1w, st1[0], st1[1], M, D, gin=g2b if s16 else g2, dx_f32=g1, dx_t=g1b, dw=dl1w, db=dl1b, dcol=dcol,
                        drop=site(li - 1, 3) if li > 0 else None)   # feeds the layer below: behind ITS post-FF2 dropout
             grads[base + 0], grads[base + 1] = dl1w, dl1b
             g, gb = g1, g1b
@@ -395,6 +399,9 @@ class TransformerFn(torch.autograd.Function):
         if s is not None:
             s.stage_done("transformer")
         if in_dtype == F32:
+            if g is None:                        # 16-bit stream, float32 input (the embedding stage's f32 stream): widen once
+                g = ops.empty((M, D), F32, dy)
+                K.cast(gb, g)
             dx = g.view(B, N, D)
         else:
             dx = (gb if gb is not None else g).view(B, N, D)
@@ -698,8 +705,10 @@ class PackedTransformerFn(torch.autograd.Function):
         grads: List[Optional[Tensor]] = [None] * len(lp)
         fork = _Fork(dy.device)
 
+        s16 = drop_p == 0.0 and ops.grad_stream_16()        # the backward's residual stream in the parameter dtype (see TransformerFn.backward)
+
         def newg():
-            return ops.empty((Tn, D), F32, dy), ops.empty((Tn, D), T, dy)
+            return (None if s16 else ops.empty((Tn, D), F32, dy)), ops.empty((Tn, D), T, dy)
 
         g, gb = newg()
         dng = _grad_buf(norm_g)
@@ -728,7 +737,7 @@ class PackedTransformerFn(torch.autograd.Function):
             del dpre, pre, act
             g2, g2b = newg()
             dl2 = _grad_buf(ln2g)
-            ops.ln_bwd(da2, x2, ln2g, st2[0], st2[1], Tn, D, gin=g, dx_f32=g2, dx_t=g2b, dw=dl2,
+            ops.ln_bwd(da2, x2, ln2g, st2[0], st2[1], Tn, D, gin=gb if s16 else g, dx_f32=g2, dx_t=g2b, dw=dl2,
                        drop=site(li, 1))      # g2b: gradient at to_out's output, behind its dropout
             grads[base + 6] = dl2
             del da2, g, gb
@@ -758,11 +767,14 @@ class PackedTransformerFn(torch.autograd.Function):
             g1, g1b = newg()
             dl1 = _grad_buf(ln1g)
             dcol = ops.empty((D,), F32, dy)
-            ops.ln_bwd(da1, xs, ln1g, st1[0], st1[1], Tn, D, gin=g2, dx_f32=g1, dx_t=g1b, dw=dl1, dcol=dcol,
+            ops.ln_bwd(da1, xs, ln1g, st1[0], st1[1], Tn, D, gin=g2b if s16 else g2, dx_f32=g1, dx_t=g1b, dw=dl1, dcol=dcol,
                        drop=site(li - 1, 3) if li > 0 else None)   # feeds the layer below: behind ITS post-FF2 dropout
             grads[base + 0] = dl1
             g, gb = g1, g1b
             del g2, g2b, da1
         fork.join()
+        if in_dtype == F32 and g is None:        # 16-bit stream, float32 input: widen once
+            g = ops.empty((Tn, D), F32, dy)
+            K.cast(gb, g)
         dx = g if in_dtype == F32 else gb
         return (dx, None, None, None, None, None, _ret(dng), *[_ret(t) for t in grads])

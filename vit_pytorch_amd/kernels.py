@@ -89,6 +89,15 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
           "layernorm_bwd")
 
 
+def layernorm_bwd_s16(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, gin: Optional[Tensor], dx_t: Tensor,
+                      partials: Tensor, colsum_dx: bool, rows: int, D: int, dymap: RowMap = IDENT, xmap: RowMap = IDENT,
+                      dxmap: RowMap = IDENT):
+    """LayerNorm backward with the stream gradient in the 16-bit type: dx_t = dx + gin, no float32 output."""
+    lib = _lib_for(dy, x, w, mean, rstd, partials, dx_t, gin)
+    check(lib.vitk_layernorm_bwd_s16(_p(dy), dt(dy), _p(x), dt(x), _p(w), dt(w), _p(mean), _p(rstd), _p(gin), _p(dx_t), dt(dx_t),
+                                     _p(partials), 1 if colsum_dx else 0, rows, D, dymap, xmap, dxmap, _stream()), "layernorm_bwd_s16")
+
+
 def layernorm_bwd_finalize(partials: Tensor, nblk: int, D: int, dw: Optional[Tensor], db: Optional[Tensor],
                            dcol: Optional[Tensor], odt: int):
     """dcol: float32, or the parameter dtype (then it is written as the bias gradient it is: vitk_layernorm_bwd_finalize_ex)."""

@@ -58,10 +58,23 @@ def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, rows: i
     nblk = K.layernorm_bwd_blocks(rows, D)
     nslab = 3 if dcol is not None else 2
     partials = empty((nslab * nblk * D,), F32, x)
-    K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap,
-                    *(drop if drop else (0.0, 0)))
+    if gin is not None and gin.dtype in HALF:          # 16-bit gradient stream (grad_stream_16): dx_t = dx + gin is the new stream
+        if dx_f32 is not None or dx_t is None or dx_t.dtype != gin.dtype or drop or D % 4:
+            raise L.VitkError("ln_bwd: a 16-bit stream gradient comes with a 16-bit dx_t of the same dtype, no float32 output, no dropout, D % 4 == 0")
+        K.layernorm_bwd_s16(dy, x, w, mean, rstd, gin, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap)
+    else:
+        K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap,
+                        *(drop if drop else (0.0, 0)))
     assert dcol is None or dcol.dtype in (F32, w.dtype)
     K.layernorm_bwd_finalize(partials, nblk, D, dw, db, dcol, K.dt(w))
+
+
+def grad_stream_16() -> bool:
+    """The backward's residual stream (the gradient that flows through the `+ x` of vit.py:80-81) in the parameter dtype -- what
+    torch autograd does when the reference runs in bfloat16 -- instead of float32: the LayerNorm backward, an HBM-bound kernel,
+    moves 386 instead of 619 MB per launch.  On by default for 16-bit parameters without active
+    dropout; VITK_GRAD_STREAM=f32 keeps the float32 stream (the forward stream is float32 either way)."""
+    return os.environ.get("VITK_GRAD_STREAM", "16") != "f32"
 
 
 # ---- column sums (bias / pos / cls gradients) -----------------------------------------------------
