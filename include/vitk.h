@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 131
+#define VITK_VERSION 132
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -190,6 +190,26 @@ int vitk_gemm_nt_fp8_ex(const void* A, int64_t lda, int a_is_fp8, const void* W,
                         const float* alpha_a, const float* alpha_w, void* c8, const float* c8_scale, uint32_t* c8_amax64,
                         void* stream);
 int vitk_fp8_update_scales(uint32_t* amax64, float* scales2, int64_t nslots, void* stream);
+/* fp8 for the BACKWARD and the out-projection (round 3; vit.py:20,23,44,47 -- the autograd of nn.Linear -- and vit.py:46-49):
+ * vitk_gemm_nt_fp8_v2: vitk_gemm_nt_fp8_ex with (a) a_kind = 0 (A in the 16-bit type), 1 (e4m3) or 2 (OCP e5m2: gradients;
+ *   W stays e4m3, v_mfma_f32_16x16x32_fp8_bf8; NONE and GELU_BWD epilogues -- dX = dY . W of the four Linear layers),
+ *   (b) colsum_partials for the GELU_BWD epilogue (vitk_gemm_nt_fp8_colsum_rows(M, N, K, ldc) rows of N floats; fold with
+ *   vitk_colsum_partials), (c) flags bit 0: the K = 128 instruction (v_mfma_f32_16x16x128_f8f6f4 with unit block scales, the
+ *   only fp8 form above the bf16 matrix rate on gfx950; K %% 128 == 0, 1-byte A).
+ * vitk_quantize_fp8_delayed: ONE pass over a 16-bit / f32 tensor that (out8 != null) writes out8 = fp8(clamp(x * scale2[0]))
+ *   -- fmt 0 = e4m3 (+-448), 1 = e5m2 (+-57344), round to nearest even -- under the scale decided BEFORE this step and
+ *   (amax64 != null) records max|x| of THIS step into 64 words (float bit patterns, atomicMax), as the producers of
+ *   vitk_layernorm_fwd_fp8 do.  n %% 4 == 0.
+ * vitk_fp8_update_scales_fmt: vitk_fp8_update_scales with a per-slot format maximum fmax[s] (null = 448 everywhere):
+ *   scales2[2 s] = fmax[s] / m, scales2[2 s + 1] = m / fmax[s].                                                        */
+int vitk_gemm_nt_fp8_v2(const void* A, int64_t lda, int a_kind, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                        int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux,
+                        float* colsum_partials, float alpha, const float* alpha_a, const float* alpha_w, void* c8,
+                        const float* c8_scale, uint32_t* c8_amax64, int flags, void* stream);
+int64_t vitk_gemm_nt_fp8_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc);
+int vitk_quantize_fp8_delayed(const void* x, int dt, void* out8, int64_t n, const float* scale2, uint32_t* amax64, int fmt,
+                              void* stream);
+int vitk_fp8_update_scales_fmt(uint32_t* amax64, float* scales2, int64_t nslots, const float* fmax, void* stream);
 
 /* dW[N,K] = sum_m dY[m,N]^T X[m,K]  ("TN": both operands are read with the reduction index as
  * the strided one).  Split over M into `splits` slabs of f32 partials (ws: splits*N*K floats),

@@ -1,0 +1,273 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU doubles of the libvitk entry points the fused Transformer stage calls.
+
+`installed()` swaps a few dozen functions of `vit_pytorch_amd.kernels` / `vit_pytorch_amd.ops` for torch-CPU stand-ins built from the
+oracle's per-op restatements (oracle/vit_oracle.py), so that the HOST LOGIC of `engine.TransformerFn` -- which tensor goes into
+which launch, the saved-activation bookkeeping, the fp8 slot / scale / recording state machine, the weight caches -- can be run
+and checked in the CPU suite, where no kernel can launch.  Nothing here is importable from the product package, the product has
+no CPU path (`kernels.require_device` raises on CPU tensors), and no parity claim rests on these doubles: the kernels themselves
+are tested against float64 / the oracle / the reference's goldens in the `-m gpu` tests.
+
+Each double states the contract of the entry point it stands in for (include/vitk.h) in torch: compute in float32, round to the
+output dtype.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+
+from oracle import vit_oracle as O
+from vit_pytorch_amd import _lib as L
+from vit_pytorch_amd import kernels as K
+from vit_pytorch_amd import ops
+
+F32 = torch.float32
+E4M3, E5M2 = torch.float8_e4m3fn, torch.float8_e5m2
+CALLS = []          # (name, info) log of the launches a test wants to assert on
+
+
+def _rec_amax(amax64, v):
+    """atomicMax of the float bit pattern into word 0 of the slot's 64."""
+    cur = amax64.view(torch.int32)[0:1].view(F32)
+    amax64.view(torch.int32)[0:1] = torch.maximum(cur, v.abs().max().to(F32).reshape(1)).view(torch.int32)
+
+
+def _q8(v, scale, fmt):
+    fmax = 448.0 if fmt == E4M3 else 57344.0
+    return (v.float() * scale).clamp(-fmax, fmax).to(fmt).view(torch.uint8)
+
+
+def _deq(t8, fmt):
+    return t8.view(fmt).float()
+
+
+def _w_plain(W, ldw, N, Kd):
+    """The W operand of an NT GEMM as (N, Kd) float32: row-major (ldw == Kd) or a K-blocked copy (ldw == 0: the double of
+    vitk_pack_w_nt keeps the plain rows at the start of the buffer)."""
+    if ldw == 0:
+        return W.flatten()[:N * Kd].view(N, Kd).float()
+    assert ldw == Kd
+    return W.reshape(N, Kd).float()
+
+
+def _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials=None):
+    if epilogue in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_RESID) and bias is not None:
+        acc = acc + bias.float()
+    if epilogue == L.EPI_BIAS_GELU:
+        aux.view(M, N).copy_(acc)                                   # pre-activation, rounded to T
+        C.view(M, N).copy_(O.gelu_fwd(aux.view(M, N).float()))
+    elif epilogue == L.EPI_RESID:
+        assert C.dtype == F32 and resid.dtype == F32
+        C.view(M, N).copy_(acc + resid.view(M, N))
+    elif epilogue == L.EPI_GELU_BWD:
+        C.view(M, N).copy_(O.gelu_bwd(acc, aux.view(M, N).float()))
+        if partials is not None:
+            partials.zero_()
+            partials[:N] = C.view(M, N).float().sum(0)              # of the ROUNDED values, like the kernel
+    else:
+        C.view(M, N).copy_(acc)
+
+
+def gemm_nt_bf16(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue=L.EPI_NONE, bias=None, resid=None, aux=None):
+    assert lda == Kd and ldc == N
+    CALLS.append(("gemm_nt_bf16", (M, N, Kd, epilogue)))
+    _epilogue(A.reshape(M, Kd).float() @ _w_plain(W, ldw, N, Kd).t(), C, M, N, epilogue, bias, resid, aux)
+
+
+def gemm_nt_bf16_gelu_bwd_colsum(A, lda, W, ldw, C, ldc, M, N, Kd, aux, partials):
+    CALLS.append(("gemm_nt_bf16_gelu_bwd_colsum", (M, N, Kd)))
+    _epilogue(A.reshape(M, Kd).float() @ _w_plain(W, ldw, N, Kd).t(), C, M, N, L.EPI_GELU_BWD, None, None, aux, partials)
+
+
+def gemm_nt_fp8_v2(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue, *, a_kind, bias=None, resid=None, aux=None, partials=None, alpha=1.0,
+                   alpha_a=None, alpha_w=None, c8=None, c8_scale=None, c8_amax64=None, k128=False):
+    assert lda == Kd and ldw == Kd and ldc == N and Kd % 64 == 0 and (not k128 or Kd % 128 == 0)
+    assert W.dtype == torch.uint8 and W.shape == (N, Kd)
+    CALLS.append(("gemm_nt_fp8_v2", (M, N, Kd, epilogue, a_kind, bool(k128))))
+    if a_kind == K.A_16BIT:
+        raise AssertionError("the doubles expect the recording pass through gemm_nt_fp8_ex")
+    a = _deq(A.reshape(M, Kd), E4M3 if a_kind == K.A_E4M3 else E5M2)
+    al = alpha * (float(alpha_a[0]) if alpha_a is not None else 1.0) * (float(alpha_w[0]) if alpha_w is not None else 1.0)
+    acc = (a @ _deq(W, E4M3).t()) * al
+    _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials)
+    if epilogue == L.EPI_BIAS_GELU:
+        if c8_amax64 is not None:
+            _rec_amax(c8_amax64, C.view(M, N).float())
+        if c8 is not None:
+            c8.view(M, N).copy_(_q8(C.view(M, N), float(c8_scale[0]), E4M3))
+
+
+def gemm_nt_fp8_ex(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue, *, a_is_fp8, bias=None, resid=None, aux=None, alpha=1.0, alpha_a=None,
+                   alpha_w=None, c8=None, c8_scale=None, c8_amax64=None):
+    if a_is_fp8:
+        return gemm_nt_fp8_v2(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue, a_kind=K.A_E4M3, bias=bias, resid=resid, aux=aux, alpha=alpha,
+                              alpha_a=alpha_a, alpha_w=alpha_w, c8=c8, c8_scale=c8_scale, c8_amax64=c8_amax64)
+    CALLS.append(("gemm_nt_fp8_ex/16bit", (M, N, Kd, epilogue)))
+    _epilogue(A.reshape(M, Kd).float() @ W.reshape(N, Kd).float().t(), C, M, N, epilogue, bias, resid, aux)
+    if epilogue == L.EPI_BIAS_GELU and c8_amax64 is not None:
+        _rec_amax(c8_amax64, C.view(M, N).float())
+
+
+def pack_w_nt(W, ldw, N, Kd, out, out_t):
+    if out is not None:
+        out[:N * Kd] = W.reshape(N, Kd).flatten()
+    if out_t is not None:
+        out_t[:N * Kd] = W.reshape(N, Kd).t().contiguous().flatten()
+
+
+def gemm_tn_bf16(dY, ldy, X, ldx, dW, ldo, M, N, Kd, ws, splits, accumulate=False):
+    assert ldy == N and ldx == Kd and ldo == Kd
+    CALLS.append(("gemm_tn_bf16", (M, N, Kd)))
+    r = dY.reshape(M, N).float().t() @ X.reshape(M, Kd).float()
+    dW.view(N, Kd).copy_(r + (dW.view(N, Kd).float() if accumulate else 0))
+
+
+def layernorm_fwd(x, w, b, y, mean, rstd, rows, D, eps=1e-5, imap=L.IDENT, omap=L.IDENT, add=None, add_group=0, add_off=0, y8=None,
+                  scale8=None, amax64=None):
+    assert imap.group == 0 and omap.group == 0 and add is None, "the doubles cover the Transformer stage (identity row maps)"
+    yy, m, r = O.layer_norm_fwd(x.reshape(rows, D).float(), w.float(), None if b is None else b.float(), eps)
+    y.view(rows, D).copy_(yy); mean.copy_(m); rstd.copy_(r)
+    if amax64 is not None:
+        _rec_amax(amax64, yy)
+    if y8 is not None:
+        y8.view(rows, D).copy_(_q8(yy, float(scale8[0]), E4M3))
+
+
+def ln_bwd(dy, x, w, mean, rstd, rows, D, *, gin=None, dx_f32=None, dx_t=None, dw=None, db=None, dcol=None, dymap=L.IDENT,
+           xmap=L.IDENT, dxmap=L.IDENT, drop=None):
+    assert drop is None and dymap.group == 0 and xmap.group == 0 and dxmap.group == 0
+    dx, gw, gb = O.layer_norm_bwd(dy.reshape(rows, D).float(), x.reshape(rows, D).float(), w.float(), mean, rstd)
+    if gin is not None:
+        dx = dx + gin.reshape(rows, D).float()
+    if dx_f32 is not None:
+        dx_f32.view(rows, D).copy_(dx)
+    if dx_t is not None:
+        dx_t.view(rows, D).copy_(dx)
+    if dw is not None:
+        dw.copy_(gw)
+    if db is not None:
+        db.copy_(gb)
+    if dcol is not None:
+        dcol.copy_((dx_t.view(rows, D).float() if dx_t is not None else dx).sum(0))
+
+
+def _heads(qkv, B, N, H, d):
+    I = H * d
+    t = qkv.reshape(B, N, 3, H, d).float()
+    return (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))         # (B, H, N, d) each
+
+
+def attn_fwd(qkv, B, N, H, d, scale, drop=None):
+    assert drop is None
+    q, k, v = _heads(qkv, B, N, H, d)
+    out, _ = O.attention_core_fwd(q, k, v, scale)
+    o = torch.empty((B * N, H * d), dtype=qkv.dtype)
+    o.copy_(out.permute(0, 2, 1, 3).reshape(B * N, H * d))
+    return o, torch.zeros((B, H, N), dtype=F32)                       # (the doubles recompute P; lse is a placeholder)
+
+
+def attn_bwd(qkv, o, do, saved, B, N, H, d, scale, drop=None):
+    q, k, v = _heads(qkv, B, N, H, d)
+    dq, dk, dv = O.attention_core_bwd(do.reshape(B, N, H, d).float().permute(0, 2, 1, 3), q, k, v, scale)
+    dqkv = torch.empty((B * N, 3 * H * d), dtype=qkv.dtype)
+    dqkv.view(B, N, 3, H, d).copy_(torch.stack([t.permute(0, 2, 1, 3) for t in (dq, dk, dv)], dim=2))
+    return dqkv
+
+
+def fp8_amax_scale(x, scale2):
+    a = x.float().abs().max().clamp_min(1e-12)
+    scale2[0] = 448.0 / a; scale2[1] = a / 448.0
+
+
+def quantize_fp8(x, out, scale_dev=None, scale=1.0):
+    out.view(x.shape).copy_(_q8(x, float(scale_dev[0]) if scale_dev is not None else scale, E4M3))
+
+
+def quantize_fp8_delayed(x, out8, scale2, amax64, fmt):
+    CALLS.append(("quantize_fp8_delayed", (tuple(x.shape), out8 is not None, amax64 is not None, fmt)))
+    assert out8 is not None or amax64 is not None
+    if out8 is not None:
+        assert float(scale2[0]) > 0.0, "quantising under a scale that was never decided"
+        out8.view(x.shape).copy_(_q8(x, float(scale2[0]), E4M3 if fmt == K.FMT_E4M3 else E5M2))
+    if amax64 is not None:
+        _rec_amax(amax64, x.float())
+
+
+def fp8_update_scales_fmt(amax64, scales2, nslots, fmax):
+    for s in range(nslots):
+        m = float(amax64[s].view(F32).max())
+        amax64[s].zero_()
+        if m > 0.0:
+            fm = float(fmax[s]) if fmax is not None else 448.0
+            scales2[s, 0] = fm / m; scales2[s, 1] = m / fm
+
+
+def fp8_update_scales(amax64, scales2, nslots):
+    fp8_update_scales_fmt(amax64, scales2, nslots, None)
+
+
+def colsum_partials(partials, nparts, ld, cols, out, accumulate=False):
+    r = partials[:nparts * ld].view(nparts, ld)[:, :cols].sum(0)
+    out.copy_(r + (out.float() if accumulate else 0))
+
+
+def colsum(x, rows, cols, ld, out, ws, accumulate=False):
+    r = x.reshape(rows, ld)[:, :cols].float().sum(0)
+    out.copy_(r + (out.float() if accumulate else 0))
+
+
+def transpose(x, out, rows, cols):
+    out.view(cols, rows).copy_(x.reshape(rows, cols).t())
+
+
+def add_rows(a, b, bias, out, rows, cols):
+    r = a.reshape(rows, cols).float() + b.reshape(rows, cols).float()
+    out.view(rows, cols).copy_(r + (bias.float() if bias is not None else 0))
+
+
+def cast(x, y):
+    y.copy_(x)
+
+
+def gelu_fwd(x, y):
+    y.copy_(O.gelu_fwd(x.float()))
+
+
+def gelu_bwd(dy, x, dx):
+    dx.copy_(O.gelu_bwd(dy.float(), x.float()))
+
+
+def require_device(*ts):
+    return None
+
+
+_K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_nt_bf16_gelu_bwd_colsum, gemm_nt_fp8_v2=gemm_nt_fp8_v2,
+                  gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, layernorm_fwd=layernorm_fwd,
+                  fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
+                  fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,
+                  colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd,
+                  require_device=require_device)
+_OPS_DOUBLES = dict(attn_fwd=attn_fwd, attn_bwd=attn_bwd, ln_bwd=ln_bwd)
+
+
+@contextlib.contextmanager
+def installed():
+    """Swap the doubles in (and torch.cuda.is_current_stream_capturing, which raises without a device), restore on exit."""
+    saved_k = {n: getattr(K, n) for n in _K_DOUBLES}
+    saved_o = {n: getattr(ops, n) for n in _OPS_DOUBLES}
+    saved_cap = torch.cuda.is_current_stream_capturing
+    del CALLS[:]
+    try:
+        for n, f in _K_DOUBLES.items():
+            setattr(K, n, f)
+        for n, f in _OPS_DOUBLES.items():
+            setattr(ops, n, f)
+        torch.cuda.is_current_stream_capturing = lambda: False
+        yield CALLS
+    finally:
+        for n, f in saved_k.items():
+            setattr(K, n, f)
+        for n, f in saved_o.items():
+            setattr(ops, n, f)
+        torch.cuda.is_current_stream_capturing = saved_cap
+        ops._WT_CACHE.clear(); ops._WP_CACHE.clear()

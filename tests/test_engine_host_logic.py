@@ -1,0 +1,168 @@
+"""CPU: the host logic of the fused Transformer stage (engine.TransformerFn) with the kernels replaced by test doubles
+(tests/_kernel_doubles.py -- the oracle's per-op restatements in the kernels' calling conventions).  What is checked here is
+the PLUMBING: operand routing, saved activations, the 16-bit gradient stream, the activation-recompute policy and the fp8
+state machine (recording passes, delayed scales, which GEMM runs in which format).  The kernels themselves are checked on the GPU."""
+import os
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from oracle import vit_oracle as O
+from oracle.params import make_params_for
+from vit_pytorch_amd import _lib as L
+from vit_pytorch_amd import kernels as K
+from vit_pytorch_amd.fp8 import SLOTS_PER_LAYER, enable_fp8, enable_fp8_forward
+from vit_pytorch_amd.vit import Transformer
+
+import _kernel_doubles as KD
+
+DIM, DEPTH, HEADS, DH, MLP = 256, 2, 4, 64, 512
+B, N = 8, 128                     # M = 1024: the smallest extent the 256-row GEMM kernels (and with them the fp8 path) serve
+
+
+def rel(a, b):
+    a = a.detach().double().flatten(); b = b.detach().double().flatten()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def build(dtype):
+    m = Transformer(DIM, DEPTH, HEADS, DH, MLP)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in m.state_dict().items())
+    params = make_params_for(shapes, 11)
+    m.load_state_dict(params)
+    return m.to(dtype), params
+
+
+def reference(params, x):
+    """The oracle's Transformer.forward (vit.py:78-83) in float32 under torch autograd."""
+    p = {"transformer." + k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xr = x.clone().requires_grad_(True)
+    y = O.transformer_fwd(xr, p, DEPTH, HEADS, DH, simple=False)
+    O.loss_fn(y).backward()
+    return y.detach(), xr.grad, {k[len("transformer."):]: v.grad for k, v in p.items()}
+
+
+def run(m, x):
+    m.zero_grad(set_to_none=True)
+    xi = x.clone().requires_grad_(True)
+    y = m(xi)
+    O.loss_fn(y).backward()
+    return y.detach().float(), xi.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}
+
+
+@pytest.fixture()
+def x():
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(B, N, DIM, generator=g)
+
+
+def worst_grad(g, gref):
+    return max(rel(g[k], gref[k]) for k in gref)
+
+
+def test_16bit_stage_against_the_oracle(x):
+    m, params = build(torch.bfloat16)
+    y_ref, dx_ref, g_ref = reference(params, x)
+    with KD.installed() as calls:
+        y, dx, g = run(m, x)
+    assert rel(y, y_ref) < 2e-2 and rel(dx, dx_ref) < 4e-2 and worst_grad(g, g_ref) < 6e-2, (rel(y, y_ref), rel(dx, dx_ref), worst_grad(g, g_ref))
+    names = [c[0] for c in calls]
+    assert names.count("gemm_tn_bf16") == 4 * DEPTH                     # dW of QKV, out, FF1, FF2
+    assert "gemm_nt_fp8_v2" not in names and "quantize_fp8_delayed" not in names
+
+
+def fp8_calls(calls):
+    return [c[1] for c in calls if c[0] == "gemm_nt_fp8_v2"]
+
+
+@pytest.mark.parametrize("backward", [True, False])
+def test_fp8_state_machine_and_formats(x, backward, monkeypatch):
+    monkeypatch.delenv("VITK_FP8_K128", raising=False)
+    m16, params = build(torch.bfloat16)
+    y_ref, dx_ref, g_ref = reference(params, x)
+    m8, _ = build(torch.bfloat16)
+    (enable_fp8 if backward else enable_fp8_forward)(m8)
+    st = m8._fp8
+    assert st.backward is backward and not st.ready and not st.bwd_ready and not st.k128
+    M, I = B * N, HEADS * DH
+    with KD.installed() as calls:
+        y16, dx16, g16 = run(m16, x)
+        del calls[:]
+        # step 1: every GEMM in 16 bit, amax of the four activation tensors (forward) and the four gradient tensors (backward) recorded
+        y1, dx1, g1 = run(m8, x)
+        assert torch.equal(y1, y16) and torch.equal(dx1, dx16) and all(torch.equal(g1[k], g16[k]) for k in g16)
+        assert not fp8_calls(calls)
+        rec = [c[1] for c in calls if c[0] == "quantize_fp8_delayed"]
+        assert all(not r[1] and r[2] for r in rec)                       # record only, nothing written
+        assert len(rec) == DEPTH * (1 + (4 if backward else 0))          # attention output + four gradients per layer
+        assert st.ready and not st.bwd_ready
+        sc = st.scales.view(DEPTH, SLOTS_PER_LAYER, 2)
+        assert (sc[:, :4, 0] > 0).all() and float(sc[:, 4:].abs().sum()) == 0.0          # activation scales decided, gradient scales not yet
+        assert torch.allclose(sc[:, :4, 0] * sc[:, :4, 1], torch.ones(DEPTH, 4), rtol=1e-5)
+        am = st.amax.view(DEPTH, SLOTS_PER_LAYER, 64)
+        assert int(am[:, :4].abs().sum()) == 0                           # forward records folded and reset
+        assert (int(am[:, 4:].abs().sum()) > 0) is backward              # backward records wait for the next fold
+        del calls[:]
+        # step 2: forward on e4m3 operands; the fold after it decides the gradient scales, so this backward runs on e5m2 gradients
+        y2, dx2, g2 = run(m8, x)
+        f = fp8_calls(calls)
+        fwd = [c for c in f if c[4] == K.A_E4M3]
+        bwd = [c for c in f if c[4] == K.A_E5M2]
+        assert len(fwd) == 4 * DEPTH and len(bwd) == (4 * DEPTH if backward else 0)
+        per_layer_fwd = {(M, 3 * I, DIM, L.EPI_NONE), (M, DIM, I, L.EPI_RESID), (M, MLP, DIM, L.EPI_BIAS_GELU), (M, DIM, MLP, L.EPI_RESID)}
+        assert {c[:4] for c in fwd} == per_layer_fwd
+        if backward:
+            per_layer_bwd = {(M, MLP, DIM, L.EPI_GELU_BWD), (M, DIM, MLP, L.EPI_NONE), (M, I, DIM, L.EPI_NONE), (M, DIM, 3 * I, L.EPI_NONE)}
+            assert {c[:4] for c in bwd} == per_layer_bwd
+            assert st.bwd_ready and (st.scales.view(DEPTH, SLOTS_PER_LAYER, 2)[:, 4:, 0] > 0).all()
+            # what is left in 16 bit: the weight-gradient GEMMs and nothing else GEMM-shaped
+            assert [c[0] for c in calls].count("gemm_tn_bf16") == 4 * DEPTH
+            assert not [c for c in calls if c[0] in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum")]
+        assert not any(c[5] for c in f)                                  # K = 128 flavour is opt-in
+        # numerics of the plumbing: fp8-sized distance from the 16-bit run and from the f32 oracle
+        e_y, e_dx, e_g = rel(y2, y16), rel(dx2, dx16), worst_grad(g2, g16)
+        print(f"fp8 ({'fwd+bwd' if backward else 'fwd'}) vs 16-bit: out {e_y:.2e} dx {e_dx:.2e} worst grad {e_g:.2e}; vs f32 oracle: out {rel(y2, y_ref):.2e}")
+        assert 1e-4 < e_y < 6e-2 and e_dx < 1.2e-1 and e_g < 1.5e-1 and rel(y2, y_ref) < 6e-2
+        # unchanged weights are not re-quantised; an in-place update is
+        n_w, n_wt = len(st._w), len(st._wt)
+        assert n_w == 4 * DEPTH and n_wt == (4 * DEPTH if backward else 0)
+        key0 = st._w[id(m8.layers[0][1].net[1].weight)][0]
+        run(m8, x)
+        assert st._w[id(m8.layers[0][1].net[1].weight)][0] == key0 and len(st._w) == n_w
+        with torch.no_grad():
+            m8.layers[0][1].net[1].weight.mul_(1.0)
+        run(m8, x)
+        assert st._w[id(m8.layers[0][1].net[1].weight)][0] != key0
+
+
+def test_fp8_k128_switch_and_recompute(x, monkeypatch):
+    monkeypatch.setenv("VITK_FP8_K128", "1")
+    m8, _ = build(torch.bfloat16)
+    enable_fp8(m8)
+    assert m8._fp8.k128
+    with KD.installed() as calls:
+        run(m8, x); run(m8, x)
+        del calls[:]
+        y_a, dx_a, g_a = run(m8, x)
+        f = fp8_calls(calls)
+        assert len(f) == 8 * DEPTH and all(c[5] == (c[2] % 128 == 0) for c in f) and any(c[5] for c in f)
+        # the activation-recompute policy (engine._recompute_policy, what lets ViT-H/14 batch 256 fit) composes with fp8: the backward
+        # rebuilds the LayerNorm / GELU outputs it no longer finds saved (the delayed scales moved by one step in between, so the
+        # two runs agree to quantisation noise, not bit for bit)
+        monkeypatch.setenv("VITK_RECOMPUTE", "1")
+        y_b, dx_b, g_b = run(m8, x)
+        assert rel(y_b, y_a) < 2e-2 and rel(dx_b, dx_a) < 6e-2 and worst_grad(g_b, g_a) < 1e-1     # a routing error shows as O(1)
+
+
+def test_fp8_needs_16bit_parameters_and_a_transformer():
+    m, _ = build(torch.float32)
+    with pytest.raises(L.VitkError):
+        enable_fp8(m)
+    with pytest.raises(L.VitkError):
+        enable_fp8(torch.nn.Linear(4, 4).to(torch.bfloat16))
+    m16, _ = build(torch.bfloat16)
+    enable_fp8(m16)
+    assert m16._fp8 is not None
+    enable_fp8(m16, enabled=False)
+    assert m16._fp8 is None

@@ -219,6 +219,53 @@ __global__ __launch_bounds__(64) void fp8_update_scales_kernel(unsigned* __restr
     if (threadIdx.x == 0 && m > 0.f) { scales[2 * s] = 448.f / m; scales[2 * s + 1] = m / 448.f; }
 }
 
+// vitk_fp8_update_scales_fmt: the same fold with a per-slot format maximum (e4m3 448, e5m2 57344 or less for headroom)
+__global__ __launch_bounds__(64) void fp8_update_scales_fmt_kernel(unsigned* __restrict__ amax, float* __restrict__ scales, int nslots,
+                                                                   const float* __restrict__ fmax) {
+    const int s = blockIdx.x;
+    if (s >= nslots) return;
+    float m = __builtin_bit_cast(float, amax[s * 64 + threadIdx.x]);
+    amax[s * 64 + threadIdx.x] = 0u;
+    m = wave_max(m);
+    const float fm = fmax ? fmax[s] : 448.f;
+    if (threadIdx.x == 0 && m > 0.f) { scales[2 * s] = fm / m; scales[2 * s + 1] = m / fm; }
+}
+
+// One pass: out8 = fp8(clamp(x * scale2[0])) under the scale decided before this step (out8 null: record only) and this step's
+// max|x| into amax64[blockIdx & 63] (null: no record).  BF8: OCP e5m2 (v_cvt_pk_bf8_f32, +-57344) instead of e4m3 (+-448).
+template <typename T, bool BF8>
+__global__ __launch_bounds__(256) void quantize_fp8_delayed_kernel(const T* __restrict__ x, unsigned* __restrict__ out, long long n4,
+                                                                    const float* __restrict__ scale2, unsigned* __restrict__ amax64) {
+    const float sc = out ? scale2[0] : 0.f;
+    constexpr float FMAX = BF8 ? 57344.f : 448.f;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v0 = load4<T>(x + 4 * i);
+        m = fmaxf(m, absmax4(v0));
+        if (out) {
+            f32x4 v = v0 * sc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -FMAX, FMAX);
+            int w = 0;
+            if constexpr (BF8) {
+                w = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], w, false);
+                w = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w, true);
+            } else {
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+            }
+            out[i] = (unsigned)w;
+        }
+    }
+    if (amax64) {       // uniform branch; one atomic per block, spread over the slot's 64 words (same-address atomics serialise)
+        m = wave_max(m);
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(amax64 + (blockIdx.x & 63), __builtin_bit_cast(unsigned, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    }
+}
+
 template <typename XT, typename PT>
 __global__ __launch_bounds__(256) void write_cls_kernel(XT* __restrict__ x, const PT* __restrict__ cls, const PT* __restrict__ pos,
                                                          long long B, long long N, int D, int ncls) {
@@ -623,6 +670,35 @@ extern "C" int vitk_fp8_update_scales(uint32_t* amax64, float* scales2, int64_t 
     if (nslots <= 0) return 0;
     hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((unsigned)nslots), dim3(64), 0, (hipStream_t)stream, (unsigned*)amax64, scales2, (int)nslots);
     VITK_CHECK_LAUNCH("fp8_update_scales");
+    return 0;
+}
+
+extern "C" int vitk_fp8_update_scales_fmt(uint32_t* amax64, float* scales2, int64_t nslots, const float* fmax, void* stream) {
+    if (!amax64 || !scales2) VITK_FAIL(VITK_E_ARG, "fp8_update_scales_fmt: null pointer");
+    if (nslots <= 0) return 0;
+    hipLaunchKernelGGL(fp8_update_scales_fmt_kernel, dim3((unsigned)nslots), dim3(64), 0, (hipStream_t)stream, (unsigned*)amax64, scales2,
+                       (int)nslots, fmax);
+    VITK_CHECK_LAUNCH("fp8_update_scales_fmt");
+    return 0;
+}
+
+extern "C" int vitk_quantize_fp8_delayed(const void* x, int dt, void* out8, int64_t n, const float* scale2, uint32_t* amax64, int fmt,
+                                         void* stream) {
+    if (!x || (!out8 && !amax64)) VITK_FAIL(VITK_E_ARG, "quantize_fp8_delayed: null input, or neither an output nor an amax record");
+    if (out8 && !scale2) VITK_FAIL(VITK_E_ARG, "quantize_fp8_delayed: an fp8 output needs its scale");
+    if (fmt != 0 && fmt != 1) VITK_FAIL(VITK_E_ARG, "quantize_fp8_delayed: fmt is 0 (e4m3) or 1 (e5m2), got %d", fmt);
+    if (n <= 0 || (n & 3)) VITK_FAIL(VITK_E_SHAPE, "quantize_fp8_delayed: n must be a positive multiple of 4");
+    if (!aligned16(x) || (out8 && !aligned16(out8))) VITK_FAIL(VITK_E_ALIGN, "quantize_fp8_delayed: 16-byte aligned pointers required");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned blocks = ew_blocks(n / 4); if (blocks > 4096) blocks = 4096;
+    if (fmt == 1) {
+        VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((quantize_fp8_delayed_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)x,
+                                                    (unsigned*)out8, (long long)(n / 4), scale2, (unsigned*)amax64));
+    } else {
+        VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((quantize_fp8_delayed_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x,
+                                                    (unsigned*)out8, (long long)(n / 4), scale2, (unsigned*)amax64));
+    }
+    VITK_CHECK_LAUNCH("quantize_fp8_delayed");
     return 0;
 }
 

@@ -325,7 +325,13 @@ constexpr int P_LDS_BYTES = P_STAGES * P_STAGE_BYTES; // 128 KiB
 // 16-byte fragment read feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes: any split of the k index is legal
 // as long as both operands use the same one), so a K-step covers 64 k with the same DMA / LDS traffic and barrier count as
 // 32 k of bf16 -- the main loop is paced by exactly those.  `alpha` (fp8: 1 / (scale_a * scale_w)) multiplies the sums.
-template <int EPI, int FM, int EB = 2>
+// F8 (EB == 1 only) -- bit 0: the A operand (activations / gradients) is OCP e5m2 ("bf8"), W stays e4m3: the backward's
+// dX = dY . W with e5m2 gradients runs on v_mfma_f32_16x16x32_fp8_bf8.  Bit 1: the K = 128 instruction
+// (v_mfma_f32_16x16x128_f8f6f4, unit block scales: twice the matrix rate of the K = 32 forms on gfx950): the fragments of
+// an EVEN K-step are held in registers and multiplied together with those of the following odd K-step -- a lane then
+// feeds 32 bytes per operand, and since both operands pair the same two K-steps in the same order the k permutation
+// is a legal one.  DMA ring, LDS layout, barrier slots and epilogues are those of the K = 32 loop; needs K %% 128 == 0.
+template <int EPI, int FM, int EB = 2, int F8 = 0>
 __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     const void* __restrict__ Av, long long lda, const void* __restrict__ Wv, long long ldw,
     void* __restrict__ Cv, long long ldc, int M, int N, int K,
@@ -378,10 +384,24 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
         } else {
             typedef long l2 __attribute__((ext_vector_type(2)));
             const l2 w2 = __builtin_bit_cast(l2, wfr), x2 = __builtin_bit_cast(l2, xfr);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], x2[0], c, 0, 0, 0);
-            return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], x2[1], c, 0, 0, 0);
+            if constexpr (F8 & 1) {     // W (MFMA operand A) e4m3, activations / gradients (operand B) e5m2
+                c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(w2[0], x2[0], c, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(w2[1], x2[1], c, 0, 0, 0);
+            } else {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], x2[0], c, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], x2[1], c, 0, 0, 0);
+            }
         }
     };
+    // K = 128: (w0 | w1) . (x0 | x1) over two K-steps; zero scale operands select the unscaled instruction (scale 1.0)
+    auto mma128 = [&](const bf16x8& w0, const bf16x8& w1, const bf16x8& x0, const bf16x8& x1, f32x4 c) -> f32x4 {
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        typedef int i8 __attribute__((ext_vector_type(8)));
+        const i8 a = __builtin_shufflevector(__builtin_bit_cast(i4, w0), __builtin_bit_cast(i4, w1), 0, 1, 2, 3, 4, 5, 6, 7);
+        const i8 b = __builtin_shufflevector(__builtin_bit_cast(i4, x0), __builtin_bit_cast(i4, x1), 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /* A: e4m3 */, (F8 & 1) ? 1 : 0 /* B: e5m2 / e4m3 */, 0, 0, 0, 0);
+    };
+    static_assert(F8 == 0 || EB == 1, "the e5m2 / K = 128 flavours are fp8 flavours");
 
     const int fi = lane & 15, fg = lane >> 4;
     const int fpos = fg ^ swz_f(fi >> 2);
@@ -405,6 +425,62 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     PP_BARRIER();
     if (grp_b) PP_BARRIER();   // group B runs one slot behind group A
 
+    if constexpr ((F8 & 2) != 0) {
+        // K = 128 flavour: the slots of the loop below, K-steps taken in pairs -- even: fragments into hw / hx, no MFMA;
+        // odd: 16 MFMAs of K = 128 per M slot (the cycles of the 32 K = 32 ones they replace, covering two K-steps)
+        bf16x8 hw[4], hx[FM];
+        for (int j = 0; j < nt; ++j) {
+            const char* base = lds + (j & 3) * P_STAGE_BYTES;
+            const bool more = j + 3 < nt;
+            const bool odd = (j & 1) != 0;          // wave-uniform
+            bf16x8 wf[4], xf[4];
+            // ---- R0 ----
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(base + w_off + f * 1024);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + f * 1024);
+            if (more) stage_a(j + 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            // ---- M0 ----
+            if (odd) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[fn][f] = mma128(hw[fn], wf[fn], hx[f], xf[f], acc[fn][f]);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) { hw[f] = wf[f]; hx[f] = xf[f]; }
+            }
+            PP_BARRIER();
+            // ---- R1 ----
+#pragma unroll
+            for (int f = 0; f < FM - 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
+            if (more) stage_w(j + 3);
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BARRIER();
+            // ---- M1 ----
+            if (odd) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                    for (int f = 0; f < FM - 4; ++f)
+                        acc[fn][4 + f] = mma128(hw[fn], wf[fn], hx[4 + f], xf[f], acc[fn][4 + f]);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+#pragma unroll
+                for (int f = 0; f < FM - 4; ++f) hx[4 + f] = xf[f];
+            }
+            PP_BARRIER();
+        }
+    } else
     for (int j = 0; j < nt; ++j) {
         const char* base = lds + (j & 3) * P_STAGE_BYTES;
         const bool more = j + 3 < nt;
@@ -782,7 +858,7 @@ NtPlan nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                  int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8 = false,
                  float alpha = 1.0f, float drop_p = 0.f, unsigned drop_seed = 0u, const float* alpha_a = nullptr,
-                 const float* alpha_w = nullptr, F8Out f8 = F8Out{nullptr, nullptr, nullptr});
+                 const float* alpha_w = nullptr, F8Out f8 = F8Out{nullptr, nullptr, nullptr}, int f8kind = 0);
 }  // namespace
 
 extern "C" int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
@@ -811,6 +887,30 @@ extern "C" int vitk_gemm_nt_fp8_ex(const void* A, int64_t lda, int a_is_fp8, con
 extern "C" int vitk_gemm_nt_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
                                int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float alpha, void* stream) {
     return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, nullptr, stream, true, alpha);
+}
+
+// a_kind: 0 = A in the 16-bit type (recording pass), 1 = e4m3, 2 = e5m2 (gradients; W stays e4m3).  flags bit 0: the K = 128 MFMA.
+extern "C" int vitk_gemm_nt_fp8_v2(const void* A, int64_t lda, int a_kind, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                   int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux,
+                                   float* colsum_partials, float alpha, const float* alpha_a, const float* alpha_w, void* c8,
+                                   const float* c8_scale, uint32_t* c8_amax64, int flags, void* stream) {
+    if (a_kind < 0 || a_kind > 2) VITK_FAIL(VITK_E_ARG, "gemm_nt_fp8_v2: a_kind is 0 (16-bit), 1 (e4m3) or 2 (e5m2), got %d", a_kind);
+    if (flags & ~1) VITK_FAIL(VITK_E_ARG, "gemm_nt_fp8_v2: unknown flags 0x%x", (unsigned)flags);
+    if (a_kind == 0 && (flags & 1)) VITK_FAIL(VITK_E_ARG, "gemm_nt_fp8_v2: the K = 128 instruction takes 1-byte operands");
+    if ((flags & 1) && (K % 128)) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_fp8_v2: the K = 128 flavour needs K %% 128 == 0 (K = %lld)", (long long)K);
+    if (colsum_partials && (epilogue != VITK_EPI_GELU_BWD || vitk_gemm_nt_fp8_colsum_rows(M, N, K, ldc) == 0))
+        VITK_FAIL(VITK_E_SHAPE, "gemm_nt_fp8_v2: column sums come with the GELU_BWD epilogue of the 256-row kernel only");
+    const F8Out f8{(unsigned char*)c8, c8_scale, (unsigned*)c8_amax64};
+    return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, colsum_partials, stream, a_kind != 0, alpha, 0.f, 0u,
+                        alpha_a, alpha_w, f8, (a_kind == 2 ? 1 : 0) | ((flags & 1) ? 2 : 0));
+}
+
+// Partial rows the GELU_BWD epilogue of the fp8 (per-tile 256-row) kernel writes: two per row tile; 0 = shape not served.
+extern "C" int64_t vitk_gemm_nt_fp8_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 64)) return 0;
+    const NtPlan pl = nt_plan(M, N, K, ldc, nullptr);
+    if (!pl.large) return 0;
+    return 2 * ((M + 32 * pl.fm - 1) / (32 * pl.fm));
 }
 
 extern "C" int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc) {
@@ -842,7 +942,10 @@ extern "C" int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, con
 namespace {
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                  int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8, float alpha,
-                 float drop_p, unsigned drop_seed, const float* alpha_a, const float* alpha_w, F8Out f8) {
+                 float drop_p, unsigned drop_seed, const float* alpha_a, const float* alpha_w, F8Out f8, int f8kind) {
+    if (f8kind && !fp8) VITK_FAIL(VITK_E_ARG, "gemm_nt: e5m2 / K = 128 flavours need 1-byte operands");
+    if ((f8kind & 1) && epilogue != VITK_EPI_NONE && epilogue != VITK_EPI_GELU_BWD)
+        VITK_FAIL(VITK_E_ARG, "gemm_nt_fp8: e5m2 operands (gradients) come with the NONE and GELU_BWD epilogues only (got %d)", epilogue);
     if ((f8.p || f8.amax) && epilogue != VITK_EPI_BIAS_GELU) VITK_FAIL(VITK_E_ARG, "gemm_nt: the fp8 side output exists in the BIAS_GELU epilogue only");
     if (f8.p && (!f8.scale || (ldc & 7))) VITK_FAIL(VITK_E_ARG, "gemm_nt: fp8 side output needs a scale and ldc %% 8 == 0");
     if (!A || !W || !C) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: null pointer");
@@ -897,12 +1000,21 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     if (large && tiles_n > 8) group_n = (tiles_n + (tiles_n + 5) / 6 - 1) / ((tiles_n + 5) / 6);
     if (getenv("VITK_GROUP_N")) group_n = atoi(getenv("VITK_GROUP_N")) > 0 ? atoi(getenv("VITK_GROUP_N")) : tiles_n;
     if (group_n > tiles_n) group_n = tiles_n;
+#define NT_LAUNCH_F8(E, F, FK) do { \
+            static const int rc8__ = set_max_lds(gemm_nt256pp_kernel<E, F, 1, FK>, P_LDS_BYTES); \
+            if (rc8__ != 0) VITK_FAIL(rc8__, "gemm_nt_fp8: cannot enable %d B of LDS", P_LDS_BYTES); \
+            hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F, 1, FK>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, A, (long long)lda, \
+                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, alpha, drop_t, drop_seed, inv_keep, alpha_a, alpha_w, f8); \
+        } while (0)
+    // e5m2 flavours (f8kind bit 0) are instantiated for the two epilogues the backward uses (checked above)
 #define NT_LAUNCH_PP(E, F) do { \
         if (fp8) { \
-            static const int rc8__ = set_max_lds(gemm_nt256pp_kernel<E, F, 1>, P_LDS_BYTES); \
-            if (rc8__ != 0) VITK_FAIL(rc8__, "gemm_nt_fp8: cannot enable %d B of LDS", P_LDS_BYTES); \
-            hipLaunchKernelGGL((gemm_nt256pp_kernel<E, F, 1>), dim3((unsigned)nwg), dim3(512), P_LDS_BYTES, st, A, (long long)lda, \
-                W, (long long)ldw, C, (long long)ldc, (int)M, (int)N, (int)K, (const __bf16*)bias, resid, (__bf16*)aux, tiles_n, (int)nwg, group_n, csum, alpha, drop_t, drop_seed, inv_keep, alpha_a, alpha_w, f8); \
+            if constexpr (E == VITK_EPI_NONE || E == VITK_EPI_GELU_BWD) { \
+                if (f8kind == 1) NT_LAUNCH_F8(E, F, 1); else if (f8kind == 3) NT_LAUNCH_F8(E, F, 3); \
+                else if (f8kind == 2) NT_LAUNCH_F8(E, F, 2); else NT_LAUNCH_F8(E, F, 0); \
+            } else { \
+                if (f8kind == 2) NT_LAUNCH_F8(E, F, 2); else NT_LAUNCH_F8(E, F, 0); \
+            } \
         } else { \
             static const int rc__ = set_max_lds(gemm_nt256pp_kernel<E, F, 2>, P_LDS_BYTES); \
             if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", P_LDS_BYTES); \
@@ -935,6 +1047,7 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     }
 #undef NT_LAUNCH
 #undef NT_LAUNCH_PP
+#undef NT_LAUNCH_F8
     VITK_CHECK_LAUNCH("gemm_nt_bf16");
     return 0;
 }

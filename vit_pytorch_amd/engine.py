@@ -213,13 +213,19 @@ class TransformerFn(torch.autograd.Function):
         esz = 4 if T == F32 else 2
         Fh0 = lp[7].shape[0] if depth else 0
         per_layer = M * (2 * D * 4 + (2 * D + 4 * I + 2 * Fh0) * esz)          # xs, x2 (f32) + a1, a2, qkv, o, pre, act
-        recompute = bool(keep and depth and drop_p == 0.0 and fp8 is None and _recompute_policy(per_layer * depth, xs.device))
+        recompute = bool(keep and depth and drop_p == 0.0 and _recompute_policy(per_layer * depth, xs.device))
         if drop_p > 0.0 and (lp[3] is None or lp[8] is None or not dropout_fusable(T, B, N, D, heads, dim_head, lp[7].shape[0])):
             raise VitkError("TransformerFn: this shape does not take the fused dropout path (caller must check dropout_fusable)")
         site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
-        # fp8 forward (fp8.py): e4m3 operands for QKV / FF1 / FF2 once the delayed scales exist; the first call only records amax
+        # fp8 (fp8.py): e4m3 operands for QKV / out-projection / FF1 / FF2 once the delayed scales exist; the first call only records amax
         use8 = fp8 is not None and T in ops.HALF and drop_p == 0.0 and depth > 0 and lp[8] is not None and ops.fp8_gemm_ok(M, D, I, lp[7].shape[0])
         go8 = use8 and fp8.ready
+        out8 = use8 and lp[3] is not None and ops.fp8_out_ok(M, D, I)       # the out-projection takes an e4m3 copy of the attention output
+
+        def gemm8(a8, sc_a, w, out, Nn, Kd, epi, **kw):       # out (M, Nn) = a8 (M, Kd) e4m3 . e4m3(w)^T under the two per-tensor scales
+            w8, wsc = fp8.weight(w)
+            K.gemm_nt_fp8_v2(a8, Kd, w8, Kd, out, Nn, M, Nn, Kd, epi, a_kind=K.A_E4M3, alpha_a=sc_a[1:], alpha_w=wsc[1:],
+                             k128=fp8.k128 and Kd % 128 == 0, **kw)
         for li in range(depth):
             ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
             a1 = ops.empty((M, D), T, xs)
@@ -230,14 +236,24 @@ class TransformerFn(torch.autograd.Function):
             else:
                 st1 = ops.ln_fwd(xs, ln1w, ln1b, M, D, a1)
             if go8:
-                w8, wsc = fp8.weight(wqkv)
                 qkv = ops.empty((M, 3 * I), T, xs)
-                K.gemm_nt_fp8_ex(a1_8, D, w8, D, qkv, 3 * I, M, 3 * I, D, L.EPI_NONE, a_is_fp8=True, alpha_a=sc1[1:], alpha_w=wsc[1:])
+                gemm8(a1_8, sc1, wqkv, qkv, 3 * I, D, L.EPI_NONE)
                 del a1_8
             else:
                 qkv = ops.linear_fwd(a1, wqkv, None, M)
             o, att_saved = ops.attn_fwd(qkv, B, N, heads, dim_head, scale, drop=site(li, 0))
-            if wout is not None:
+            if out8:
+                sc4, am4 = fp8.slot(li, 3)
+                if go8:         # one pass over o: its e4m3 copy under last step's scale + this step's amax
+                    o_8 = torch.empty((M, I), dtype=torch.uint8, device=xs.device)
+                    K.quantize_fp8_delayed(o, o_8, sc4, am4, K.FMT_E4M3)
+                    x2 = ops.empty((M, D), F32, xs)
+                    gemm8(o_8, sc4, wout, x2, D, I, L.EPI_RESID, bias=bout, resid=xs)
+                    del o_8
+                else:
+                    K.quantize_fp8_delayed(o, None, None, am4, K.FMT_E4M3)
+                    x2 = ops.linear_fwd(o, wout, bout, M, resid=xs)
+            elif wout is not None:
                 x2 = ops.linear_fwd(o, wout, bout, M, resid=xs, drop=site(li, 1))
             else:  # to_out = Identity (heads == 1 and dim_head == dim, vit.py:34,49)
                 x2 = ops.empty((M, D), F32, xs)
@@ -251,15 +267,11 @@ class TransformerFn(torch.autograd.Function):
                 st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2, f8=(a2_8, sc2, am2))
                 act = ops.empty((M, Fh), T, xs); pre = ops.empty((M, Fh), T, xs)
                 if go8:
-                    w8, wsc = fp8.weight(w1)
                     act_8 = torch.empty((M, Fh), dtype=torch.uint8, device=xs.device)
-                    K.gemm_nt_fp8_ex(a2_8, D, w8, D, act, Fh, M, Fh, D, L.EPI_BIAS_GELU, a_is_fp8=True, bias=b1, aux=pre,
-                                     alpha_a=sc2[1:], alpha_w=wsc[1:], c8=act_8, c8_scale=sc3, c8_amax64=am3)
+                    gemm8(a2_8, sc2, w1, act, Fh, D, L.EPI_BIAS_GELU, bias=b1, aux=pre, c8=act_8, c8_scale=sc3, c8_amax64=am3)
                     del a2_8
-                    w8, wsc = fp8.weight(w2)
                     x3 = ops.empty((M, D), F32, xs)
-                    K.gemm_nt_fp8_ex(act_8, Fh, w8, Fh, x3, D, M, D, Fh, L.EPI_RESID, a_is_fp8=True, bias=b2, resid=x2,
-                                     alpha_a=sc3[1:], alpha_w=wsc[1:])
+                    gemm8(act_8, sc3, w2, x3, D, Fh, L.EPI_RESID, bias=b2, resid=x2)
                     del act_8
                 else:       # recording pass: 16-bit operands, amax of the GELU output collected by the same epilogue
                     K.gemm_nt_fp8_ex(a2, D, w1, D, act, Fh, M, Fh, D, L.EPI_BIAS_GELU, a_is_fp8=False, bias=b1, aux=pre, c8_amax64=am3)
@@ -281,6 +293,7 @@ class TransformerFn(torch.autograd.Function):
         ctx.stf = stf
         ctx.meta = (heads, dim_head, depth, B, N, D, x.dtype)
         ctx.drop = (drop_p, drop_seed)
+        ctx.fp8 = fp8 if (use8 and fp8.backward and lp[3] is not None and ops.fp8_bwd_ok(M, D, I, lp[7].shape[0])) else None
         ctx.save_for_backward(norm_w, norm_b, *[t for t in lp if t is not None])
         ctx.lp_mask = [t is not None for t in lp]
         return y
@@ -310,6 +323,32 @@ class TransformerFn(torch.autograd.Function):
         def newg():
             g32 = None if s16 else ops.empty((M, D), F32, dy)
             return g32, (ops.empty((M, D), T, dy) if bf else None)
+
+        # fp8 backward (fp8.py): dX = dY . W of the four Linear layers on e5m2 gradients x e4m3 weights; dY takes one pass
+        # (vitk_quantize_fp8_delayed: e5m2 copy under last step's scale + this step's amax).  The first backward only records.
+        f8 = ctx.fp8
+        I = heads * dim_head
+
+        def dx8(li, slot, dyT, W, epi=L.EPI_NONE, pre=None, db=None):
+            """dX (M, Kd) = dY (M, Nw) . W (Nw, Kd) [* gelu'(pre), column sums -> db]; None while the scales do not exist yet."""
+            Nw, Kd = W.shape
+            sc, am = f8.slot(li, slot)
+            if not f8.bwd_ready:
+                K.quantize_fp8_delayed(dyT, None, None, am, K.FMT_E5M2)
+                return None
+            dy8 = torch.empty((M, Nw), dtype=torch.uint8, device=dyT.device)
+            K.quantize_fp8_delayed(dyT, dy8, sc, am, K.FMT_E5M2)
+            w8t, wsc = f8.weight_t(W)
+            dx = ops.empty((M, Kd), T, dyT)
+            part = None
+            if db is not None:
+                R = K.gemm_nt_fp8_colsum_rows(M, Kd, Nw, Kd)
+                part = ops.empty((R * Kd,), F32, dyT)
+            K.gemm_nt_fp8_v2(dy8, Nw, w8t, Nw, dx, Kd, M, Kd, Nw, epi, a_kind=K.A_E5M2, aux=pre, partials=part,
+                             alpha_a=sc[1:], alpha_w=wsc[1:], k128=f8.k128 and Nw % 128 == 0)
+            if db is not None:
+                K.colsum_partials(part, R, Kd, Kd, db)
+            return dx
 
         fork = _Fork(dy.device)
         # final LayerNorm (vit.py:83)
@@ -345,14 +384,19 @@ class TransformerFn(torch.autograd.Function):
                 grads[base + 10] = dcol          # written by the LayerNorm backward above this layer (bias_target)
             dw1 = _grad_buf(w1)
             db1 = _grad_buf(b1) if b1 is not None else None
-            if db1 is not None:
+            dpre = dx8(li, 4, gT, w2, L.EPI_GELU_BWD, pre, db1) if f8 is not None else None
+            if dpre is not None:
+                db_done = True
+            elif db1 is not None:
                 dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, db=db1, drop=site(li, 2))   # b1's gradient out of the GEMM epilogue
             else:
                 dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, drop=site(li, 2)), True
             db_todo = None if db_done else db1
             fork.run(lambda: ops.linear_dw(dpre, a2, M, dw1, db_todo), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
-            da2 = ops.linear_dx(dpre, w1, M)
+            da2 = dx8(li, 5, dpre, w1) if f8 is not None else None
+            if da2 is None:
+                da2 = ops.linear_dx(dpre, w1, M)
             del dpre, pre, act
             g2, g2b = newg()
             dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
@@ -369,14 +413,18 @@ class TransformerFn(torch.autograd.Function):
                 grads[base + 3] = dwo
                 if bout is not None:
                     grads[base + 4] = dcol2
-                do = ops.linear_dx(g2T, wout, M)
+                do = dx8(li, 6, g2T, wout) if f8 is not None else None
+                if do is None:
+                    do = ops.linear_dx(g2T, wout, M)
             else:
                 do = g2T
             dqkv = ops.attn_bwd(qkv, o, do, att_saved, B, N, heads, dim_head, scale, drop=site(li, 0))
             dwq = _grad_buf(wqkv)
             fork.run(lambda: ops.linear_dw(dqkv, a1, M, dwq), dqkv, a1, dwq)
             grads[base + 2] = dwq
-            da1 = ops.linear_dx(dqkv, wqkv, M)
+            da1 = dx8(li, 7, dqkv, wqkv) if f8 is not None else None
+            if da1 is None:
+                da1 = ops.linear_dx(dqkv, wqkv, M)
             del dqkv, do, qkv, o
             g1, g1b = newg()
             dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
@@ -395,6 +443,8 @@ class TransformerFn(torch.autograd.Function):
                 fork.join()                      # this layer's weight gradients (side stream) are part of the chunk
                 sk.stage_done("layer", li)
         fork.join()
+        if f8 is not None:
+            f8.end_of_backward()
         s = _sink()
         if s is not None:
             s.stage_done("transformer")

@@ -390,3 +390,34 @@ def gemm_nt_fp8_ex(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int
 
 def fp8_update_scales(amax64: Tensor, scales2: Tensor, nslots: int):
     check(L.load().vitk_fp8_update_scales(_p(amax64), _p(scales2), nslots, _stream()), "fp8_update_scales")
+
+
+# ---- fp8 for the backward / out-projection (fp8.py, round 3) ---------------------------------------------------------------
+A_16BIT, A_E4M3, A_E5M2 = 0, 1, 2       # a_kind of gemm_nt_fp8_v2
+FMT_E4M3, FMT_E5M2 = 0, 1               # fmt of quantize_fp8_delayed
+
+
+def gemm_nt_fp8_v2(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int, epilogue: int, *,
+                   a_kind: int, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, aux: Optional[Tensor] = None,
+                   partials: Optional[Tensor] = None, alpha: float = 1.0, alpha_a: Optional[Tensor] = None,
+                   alpha_w: Optional[Tensor] = None, c8: Optional[Tensor] = None, c8_scale: Optional[Tensor] = None,
+                   c8_amax64: Optional[Tensor] = None, k128: bool = False):
+    """vitk_gemm_nt_fp8_v2: e4m3 / e5m2 / 16-bit A against an e4m3 W, every epilogue of the 16-bit GEMM (e5m2: NONE, GELU_BWD),
+    optional bias-gradient column sums (GELU_BWD), optional K = 128 MFMA."""
+    check(_lib_for(C, bias, aux, A if a_kind == A_16BIT else None).vitk_gemm_nt_fp8_v2(
+        _p(A), lda, int(a_kind), _p(W), ldw, _p(C), ldc, M, N, K, epilogue, _p(bias), _p(resid), _p(aux), _p(partials), alpha,
+        _p(alpha_a), _p(alpha_w), _p(c8), _p(c8_scale), _p(c8_amax64), 1 if k128 else 0, _stream()), "gemm_nt_fp8_v2")
+
+
+def gemm_nt_fp8_colsum_rows(M: int, N: int, K: int, ldc: int) -> int:
+    return int(L.load().vitk_gemm_nt_fp8_colsum_rows(M, N, K, ldc))
+
+
+def quantize_fp8_delayed(x: Tensor, out8: Optional[Tensor], scale2: Optional[Tensor], amax64: Optional[Tensor], fmt: int):
+    """One pass over x: fp8 copy under the PREVIOUS step's scale (out8 None: none) + this step's amax record (amax64 None: none)."""
+    check(_lib_for(x).vitk_quantize_fp8_delayed(_p(x), dt(x), _p(out8), x.numel(), _p(scale2), _p(amax64), int(fmt), _stream()),
+          "quantize_fp8_delayed")
+
+
+def fp8_update_scales_fmt(amax64: Tensor, scales2: Tensor, nslots: int, fmax: Optional[Tensor]):
+    check(L.load().vitk_fp8_update_scales_fmt(_p(amax64), _p(scales2), nslots, _p(fmax), _stream()), "fp8_update_scales_fmt")

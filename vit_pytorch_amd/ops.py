@@ -99,6 +99,20 @@ def fp8_gemm_ok(M: int, D: int, I: int, Fh: int) -> bool:
             and K.gemm_nt_colsum_rows(M, D, Fh, D) > 0)
 
 
+def _fp8_shape_ok(M: int, N: int, Kd: int) -> bool:
+    return Kd % 64 == 0 and N % 16 == 0 and K.gemm_nt_fp8_colsum_rows(M, N, Kd, N) > 0
+
+
+def fp8_out_ok(M: int, D: int, I: int) -> bool:
+    """The out-projection (M, D) = o (M, I) . Wout^T on e4m3 operands (256-row kernel)."""
+    return _fp8_shape_ok(M, D, I)
+
+
+def fp8_bwd_ok(M: int, D: int, I: int, Fh: int) -> bool:
+    """The four dX GEMMs of a layer on e5m2 x e4m3 operands: (M, Fh) = g . W2, (M, D) = dpre . W1, (M, I) = g2 . Wout, (M, D) = dqkv . Wqkv."""
+    return (_fp8_shape_ok(M, Fh, D) and _fp8_shape_ok(M, D, Fh) and _fp8_shape_ok(M, I, D) and _fp8_shape_ok(M, D, 3 * I))
+
+
 # ---- f32 validation mode on the production MFMA kernels ------------------------------------------------------------------------
 # The float32 mode (params float32: the mode that proves the host logic and the kernels' arithmetic to round-off) used to run every
 # Linear on the VALU coverage kernel, i.e. it validated different kernels than the ones production runs.  For shapes the production
