@@ -30,6 +30,11 @@ Extra objects in the line:
   model         whole-step algorithmic TFLOP/s (105.383 GF/img for ViT-B/16) and its fraction of peak.
   cpu_baseline  the CPU oracle (oracle/vit_oracle.py, kind "port") timed on this host's cores on a bounded
                 sample of the same workload (same model, f32, batch 32, best of a thread sweep), rank 0 at N = 1 only.
+
+`--config vit_h14 --fp8` is BASELINE config 5's line: `dtype: "fp8"` with `dtype_detail` saying which GEMMs run in which format
+(forward and dX GEMMs on fp8 operands; the weight-gradient GEMMs, attention and LayerNorm in bf16) and `roof` naming the peak the
+timed fp8 kernel is priced against: 2,516.6 TFLOP/s for the non-scaled K = 32 fp8 forms, 5,033.2 for the K = 128 form
+(VITK_FP8_K128=1).  The default line (no flags) is the bf16 headline and is unchanged by any of this.
 """
 from __future__ import annotations
 
@@ -78,7 +83,7 @@ def time_dominant_kernel(step_fn, nsteps: int = 3):
     stream it is enqueued on.  Done in `nsteps` extra steps after the timed region, so the events do not sit inside it;
     rocprofv3's per-kernel average of the same command sees exactly these launches plus the timed ones."""
     from vit_pytorch_amd import _lib as L, kernels as K
-    orig_nt, orig_bwd = K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum
+    orig_nt, orig_bwd, orig_f8 = K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2
     taps = {"ff1": [], "dff1": []}
 
     def bracket(key, flops, fn, a, kw):
@@ -99,7 +104,13 @@ def time_dominant_kernel(step_fn, nsteps: int = 3):
     def tapped_bwd(*a, **kw):
         return bracket("dff1", 2.0 * a[6] * a[7] * a[8], orig_bwd, a, kw)
 
-    K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum = tapped_nt, tapped_bwd
+    def tapped_f8(*a, **kw):        # --fp8: the same two GEMMs go through the fp8 entry point (a[9] = epilogue)
+        key = {L.EPI_BIAS_GELU: "ff1", L.EPI_GELU_BWD: "dff1"}.get(a[9])
+        if key is None:
+            return orig_f8(*a, **kw)
+        return bracket(key, 2.0 * a[6] * a[7] * a[8], orig_f8, a, kw)
+
+    K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2 = tapped_nt, tapped_bwd, tapped_f8
     prev = os.environ.get("VITK_DW_STREAM")
     os.environ["VITK_DW_STREAM"] = "0"          # serialized: engine._Fork reads it per backward
     try:
@@ -107,7 +118,7 @@ def time_dominant_kernel(step_fn, nsteps: int = 3):
             step_fn()
         torch.cuda.synchronize()
     finally:
-        K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum = orig_nt, orig_bwd
+        K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2 = orig_nt, orig_bwd, orig_f8
         if prev is None:
             os.environ.pop("VITK_DW_STREAM", None)
         else:
@@ -239,6 +250,10 @@ def main():
     ap.add_argument("--config", default="vit_b16", choices=list(CONFIGS) + ["navit"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (invalidates the headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE config 5's precision (vit_pytorch_amd.fp8.enable_fp8): e4m3 operands for the four forward GEMMs of a "
+                         "layer, e5m2 gradients x e4m3 weights for its four dX GEMMs; weight-gradient GEMMs, attention and LayerNorm stay "
+                         "bf16.  VITK_FP8_K128=1 selects the K = 128 MFMA.  Not the headline metric (that one is bf16).")
     ap.add_argument("--repeats", type=int, default=3,
                     help="time the K-step region this many times and report the MEDIAN window (every repeat is exactly K steps "
                          "between barrier + synchronize; all of them are listed in ms_per_step_all)")
@@ -269,6 +284,10 @@ def main():
         batch = args.batch
     torch.manual_seed(0)  # identical init on every rank (DataParallel also broadcasts rank 0's)
     model = ViT(**cfg).to(dev, dtype=torch.bfloat16)
+    if args.fp8:
+        from vit_pytorch_amd.fp8 import enable_fp8
+        enable_fp8(model)
+        args.warmup = max(args.warmup, 3)       # steps 1-2 decide the delayed scales (16-bit recording passes); timed steps are steady state
     dp = DataParallel(model)
     g = torch.Generator(device=dev)
     g.manual_seed(1 + rank)
@@ -333,18 +352,31 @@ def main():
         kms, kflops, klaunches = taps["ff1"]
         ach = kflops / (kms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic_bytes()
+        if args.fp8:
+            traffic, traffic_src = None, "not collected for the fp8 flavour (profiles/*_pmc_traffic.json is the bf16 kernel)"
         others = []
         if "dff1" in taps:
             dms, dfl, dn = taps["dff1"]
-            others.append({"kernel": "gemm_ntp_kernel<EPI_GELU_BWD> (dFF1: GELU' + bias-gradient column sums)", "achieved": round(dfl / (dms * 1e-3) / 1e12, 2),
-                           "frac": round(dfl / (dms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(dms, 4), "launches_timed": dn})
+            others.append({"kernel": ("gemm_nt256pp_kernel<EPI_GELU_BWD, e5m2 x e4m3>" if args.fp8 else "gemm_ntp_kernel<EPI_GELU_BWD>") + " (dFF1: GELU' + bias-gradient column sums)", "achieved": round(dfl / (dms * 1e-3) / 1e12, 2),
+                           "frac": round(dfl / (dms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * (2.0 if (args.fp8 and model.transformer._fp8.k128) else 1.0)), 4), "avg_launch_ms": round(dms, 4), "launches_timed": dn})
         isz = cfg["image_size"]
+        k128 = bool(args.fp8 and model.transformer._fp8.k128)
+        prec = "fp8" if args.fp8 else "bf16"
+        # the roof a number is priced against: bf16 MFMA dense for the headline; with --fp8 the fp8 forms the GEMMs actually issue --
+        # K = 32 (v_mfma_f32_16x16x32_fp8_fp8 / _fp8_bf8) run at the bf16 rate, K = 128 (v_mfma_f32_16x16x128_f8f6f4) at twice that
+        peak = PEAK_BF16_TFLOPS * (2.0 if k128 else 1.0)
+        roof_name = ("fp8 MFMA dense, K = 128 f8f6f4 form: 2 x 2516.6 = 5033.2 TFLOP/s" if k128 else
+                     "fp8 MFMA dense, non-scaled K = 32 forms: 2516.6 TFLOP/s (= the bf16 rate)" if args.fp8 else "bf16 MFMA dense: 2516.6 TFLOP/s")
         line = {
-            "metric": "images/sec (fwd+bwd) ViT-B/16 224^2 bf16" if args.config == "vit_b16" else f"images/sec (fwd+bwd) {args.config} bf16",
+            "metric": "images/sec (fwd+bwd) ViT-B/16 224^2 bf16" if (args.config == "vit_b16" and not args.fp8) else f"images/sec (fwd+bwd) {args.config} {prec}",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "ms_per_step_all": [round(d / args.steps * 1e3, 3) for d in dts],
             "weight_cache_rebuild_ms": round(weight_cache_rebuild_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (randn images, randint labels, random-init weights)",
+            "dtype": prec, "data": "synthetic (randn images, randint labels, random-init weights)",
+            **({"dtype_detail": "e4m3 x e4m3 forward GEMMs (QKV, out-projection, FF1, FF2), e5m2 gradients x e4m3 weights for the four dX GEMMs, "
+                                "per-tensor delayed scaling, f32 accumulation; weight-gradient GEMMs, attention, LayerNorm and the residual "
+                                "streams in bf16 / f32" + ("; K = 128 MFMA" if k128 else "; K = 32 MFMA forms"),
+                "roof": roof_name} if args.fp8 else {}),
             "memory": {"peak_allocated_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                        "peak_reserved_gib": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
                        "allocator_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0))},
@@ -353,10 +385,12 @@ def main():
                        "global_batch": batch * world, "per_gpu_batch": batch, "seq_len": N, "parallelism": f"dp{world}"},
             "per_gpu_images_per_s": round(value / world, 2),
             "model": {"gflop_per_image_fwd_bwd": round(gf, 3), "tflops_per_gpu": round(value / world * gf / 1e3, 2),
-                      "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_ntp_kernel<EPI_BIAS_GELU> (persistent NT GEMM, FF1: tokens x mlp_dim x dim at this batch)",
-                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(kms, 4), "launches_timed": klaunches,
+                      "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
+                      **({"frac_note": "whole-step fraction is of the bf16 peak (a third of the GEMM work and the attention run in bf16)"} if args.fp8 else {})},
+            "roofline": {"bound": "mfma", "kernel": ("gemm_nt256pp_kernel<EPI_BIAS_GELU, fp8> (FF1 on e4m3 operands)" if args.fp8 else
+                                                     "gemm_ntp_kernel<EPI_BIAS_GELU> (persistent NT GEMM, FF1: tokens x mlp_dim x dim at this batch)"),
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "roof": roof_name,
+                         "frac": round(ach / peak, 4), "avg_launch_ms": round(kms, 4), "launches_timed": klaunches,
                          "timed_in": "3 extra steps after the timed region, weight-gradient side stream off (serialized launches)",
                          "traffic": traffic, "traffic_source": traffic_src, "other_kernels": others},
         }

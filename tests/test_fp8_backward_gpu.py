@@ -1,0 +1,200 @@
+"""GPU: fp8 for the backward and the out-projection (vit_pytorch_amd/fp8.py, BASELINE config 5 / SURVEY §8f item 2).
+
+Kernel level: the one-pass delayed quantiser against torch's float8 casts (bit exact, e4m3 and e5m2), the e5m2 x e4m3 GEMM
+(dX = dY . W, plain and with the GELU' + bias-gradient epilogue) and the K = 128 MFMA flavour against float64 products of the
+DEQUANTISED operands (products of fp8 values are exact in f32, so only f32 accumulation order and the 16-bit output rounding
+remain: 4e-3).  Model level: ViT at BASELINE config 5's width (ViT-H/14: dim 1280, 16 heads of 80, mlp 5120, N = 577) and
+config 2's, with `enable_fp8`, against the goldens the REFERENCE produced in float32 (tests/golden/vit_h14_width.npz,
+vit_b16_width.npz).  Stated fp8 tolerance: logits within 6e-2, the gradient sample within 1.5e-1 relative L2 of the
+reference's f32 values (3-bit / 2-bit mantissa operands in 8 of the 12 GEMMs of a layer; measured values are printed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vit_oracle as O  # noqa: E402
+from oracle.params import WIDE_CASES, make_images, make_params, sample_index  # noqa: E402
+from vit_pytorch_amd import ViT, _lib as L, kernels as K  # noqa: E402
+from vit_pytorch_amd.fp8 import SLOTS_PER_LAYER, enable_fp8  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+E4M3, E5M2 = torch.float8_e4m3fn, torch.float8_e5m2
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def gelu_grad(x):
+    x = x.double()
+    return 0.5 * (1.0 + torch.erf(x * 2 ** -0.5)) + x * torch.exp(-0.5 * x * x) * (2 * torch.pi) ** -0.5
+
+
+@pytest.mark.parametrize("fmt", [K.FMT_E4M3, K.FMT_E5M2])
+def test_delayed_quantiser_matches_torch(fmt):
+    tdt, fmax = (E4M3, 448.0) if fmt == K.FMT_E4M3 else (E5M2, 57344.0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = (torch.randn(1154, 1280, device=DEV, generator=g) * torch.logspace(-6, 1, 1280, device=DEV)).to(BF)    # subnormals .. saturation
+    amax_true = x.float().abs().max()
+    scale = torch.tensor([fmax / 4.0 / float(amax_true), 0.0], device=DEV)          # a stale scale: the top quarter saturates
+    scale[1] = 1.0 / scale[0]
+    out = torch.zeros(x.shape, dtype=torch.uint8, device=DEV)
+    am = torch.zeros(64, dtype=torch.int32, device=DEV)
+    K.quantize_fp8_delayed(x, out, scale, am, fmt)
+    ref = (x.float() * scale[0]).clamp(-fmax, fmax).to(tdt)
+    assert torch.equal(out.view(tdt).float(), ref.float())                  # same values: round to nearest even, saturating
+    assert float(am.view(torch.float32).max()) == float(amax_true)          # this step's amax, exact
+    # record only: nothing written, amax accumulates by max
+    am.zero_(); out.zero_()
+    K.quantize_fp8_delayed(x * 0.5, None, None, am, fmt)
+    K.quantize_fp8_delayed(x, None, None, am, fmt)
+    assert float(am.view(torch.float32).max()) == float(amax_true) and int(out.sum()) == 0
+    # f32 input, quantise only
+    K.quantize_fp8_delayed(x.float(), out, scale, None, fmt)
+    assert torch.equal(out.view(tdt).float(), ref.float())
+    with pytest.raises(L.VitkError):
+        K.quantize_fp8_delayed(x, None, None, None, fmt)
+    with pytest.raises(L.VitkError):
+        K.quantize_fp8_delayed(x, out, None, am, fmt)
+
+
+def test_update_scales_with_per_slot_format_maximum():
+    amax = torch.zeros(3, 64, dtype=torch.int32, device=DEV)
+    amax.view(torch.float32)[0, 5] = 2.0
+    amax.view(torch.float32)[0, 63] = 7.0
+    amax.view(torch.float32)[2, 0] = 0.5
+    scales = torch.full((3, 2), -1.0, device=DEV)
+    fmax = torch.tensor([448.0, 448.0, 28672.0], device=DEV)
+    K.fp8_update_scales_fmt(amax, scales, 3, fmax)
+    assert torch.allclose(scales[0], torch.tensor([64.0, 1 / 64.0], device=DEV))
+    assert torch.equal(scales[1], torch.tensor([-1.0, -1.0], device=DEV))           # nothing recorded: the old scale stays
+    assert torch.allclose(scales[2], torch.tensor([57344.0, 1 / 57344.0], device=DEV))
+    assert int(amax.abs().sum()) == 0
+    K.fp8_update_scales_fmt(amax, scales, 3, None)
+    assert torch.allclose(scales[0], torch.tensor([64.0, 1 / 64.0], device=DEV))
+
+
+def _quantised(x, fmt, gen_scale=None):
+    tdt, fmax = (E4M3, 448.0) if fmt == K.FMT_E4M3 else (E5M2, 57344.0)
+    sc = torch.empty(2, device=DEV)
+    a = x.float().abs().max()
+    sc[0] = fmax / a; sc[1] = a / fmax
+    x8 = torch.empty(x.shape, dtype=torch.uint8, device=DEV)
+    K.quantize_fp8_delayed(x, x8, sc, None, fmt)
+    return x8, sc, x8.view(tdt).double() * sc[1].double()
+
+
+# dX shapes of ViT-H/14 (M = 4 x 577) and ViT-B/16 (M = 32 x 197; the last one at the full batch-256 extent, where the plan picks 224-row tiles)
+@pytest.mark.parametrize("k128", [False, True])
+@pytest.mark.parametrize("M,Kd,Nw", [(2308, 5120, 1280), (2308, 1280, 5120), (2308, 1280, 3840), (6304, 3072, 768), (50432, 768, 3072)])
+def test_gemm_e5m2_gradients_against_dequantised_product(M, Kd, Nw, k128):
+    """dX (M, Kd) = dY (M, Nw) . W (Nw, Kd): A = e5m2 dY, "W" operand = e4m3 W^T (Kd, Nw)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    dY = (torch.randn(M, Nw, device=DEV, generator=g) * 1e-4 * torch.logspace(0, 1.5, Nw, device=DEV)).to(BF)      # gradient-sized, wide spread
+    Wt = (torch.randn(Kd, Nw, device=DEV, generator=g) * Nw ** -0.5).to(BF)
+    pre = torch.randn(M, Kd, device=DEV, generator=g).to(BF)
+    dY8, sa, dYq = _quantised(dY, K.FMT_E5M2)
+    W8, sw, Wq = _quantised(Wt, K.FMT_E4M3)
+    ref = dYq @ Wq.t()
+    C = torch.empty(M, Kd, dtype=BF, device=DEV)
+    K.gemm_nt_fp8_v2(dY8, Nw, W8, Nw, C, Kd, M, Kd, Nw, L.EPI_NONE, a_kind=K.A_E5M2, alpha_a=sa[1:], alpha_w=sw[1:], k128=k128)
+    assert rel(C, ref) < 4e-3, rel(C, ref)
+    assert rel(C, dY.double() @ Wt.double().t()) < 8e-2                     # what the two quantisations cost
+    # GELU' epilogue + bias-gradient column sums
+    R = K.gemm_nt_fp8_colsum_rows(M, Kd, Nw, Kd)
+    assert R > 0
+    part = torch.full((R * Kd,), float("nan"), device=DEV)
+    K.gemm_nt_fp8_v2(dY8, Nw, W8, Nw, C, Kd, M, Kd, Nw, L.EPI_GELU_BWD, a_kind=K.A_E5M2, aux=pre, partials=part, alpha_a=sa[1:],
+                     alpha_w=sw[1:], k128=k128)
+    refg = ref * gelu_grad(pre)
+    assert rel(C, refg) < 4e-3, rel(C, refg)
+    db = torch.empty(Kd, dtype=BF, device=DEV)
+    K.colsum_partials(part, R, Kd, Kd, db)
+    assert rel(db, C.double().sum(0)) < 4e-3                                # column sums of the rounded output, as the 16-bit kernel's
+    with pytest.raises(L.VitkError):                                        # e5m2 operands are a backward thing: no bias / residual epilogues
+        K.gemm_nt_fp8_v2(dY8, Nw, W8, Nw, C, Kd, M, Kd, Nw, L.EPI_BIAS, a_kind=K.A_E5M2, bias=db)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(2308, 3840, 1280), (2308, 1280, 5120), (6304, 768, 768)])
+def test_k128_flavour_forward_epilogues(M, N, Kd):
+    """e4m3 x e4m3 on v_mfma_f32_16x16x128_f8f6f4: the four forward epilogues, and the K = 32 flavour beside it."""
+    g = torch.Generator(device=DEV).manual_seed(4)
+    A = torch.randn(M, Kd, device=DEV, generator=g).to(BF)
+    W = (torch.randn(N, Kd, device=DEV, generator=g) * Kd ** -0.5).to(BF)
+    bias = torch.randn(N, device=DEV, generator=g).to(BF)
+    resid = torch.randn(M, N, device=DEV, generator=g)
+    A8, sa, Aq = _quantised(A, K.FMT_E4M3)
+    W8, sw, Wq = _quantised(W, K.FMT_E4M3)
+    ref = Aq @ Wq.t()
+    kw = dict(a_kind=K.A_E4M3, alpha_a=sa[1:], alpha_w=sw[1:])
+    C = torch.empty(M, N, dtype=BF, device=DEV); C32 = torch.empty(M, N, dtype=BF, device=DEV)
+    K.gemm_nt_fp8_v2(A8, Kd, W8, Kd, C, N, M, N, Kd, L.EPI_NONE, k128=True, **kw)
+    K.gemm_nt_fp8_v2(A8, Kd, W8, Kd, C32, N, M, N, Kd, L.EPI_NONE, k128=False, **kw)
+    assert rel(C, ref) < 4e-3 and rel(C32, ref) < 4e-3 and rel(C, C32) < 4e-3
+    K.gemm_nt_fp8_v2(A8, Kd, W8, Kd, C, N, M, N, Kd, L.EPI_BIAS, bias=bias, k128=True, **kw)
+    assert rel(C, ref + bias.double()) < 4e-3
+    aux = torch.empty(M, N, dtype=BF, device=DEV)
+    c8 = torch.empty(M, N, dtype=torch.uint8, device=DEV)
+    c8s = torch.tensor([8.0, 0.125], device=DEV)
+    am = torch.zeros(64, dtype=torch.int32, device=DEV)
+    K.gemm_nt_fp8_v2(A8, Kd, W8, Kd, C, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=aux, c8=c8, c8_scale=c8s, c8_amax64=am, k128=True, **kw)
+    pre = ref + bias.double()
+    assert rel(aux, pre) < 4e-3 and rel(C, torch.nn.functional.gelu(pre)) < 4e-3
+    assert torch.equal(c8.view(E4M3).float(), (C.float() * 8.0).clamp(-448, 448).to(E4M3).float())
+    assert float(am.view(torch.float32).max()) == float(C.float().abs().max())
+    out = torch.empty(M, N, device=DEV)
+    K.gemm_nt_fp8_v2(A8, Kd, W8, Kd, out, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid, k128=True, **kw)
+    assert rel(out, resid.double() + pre) < 1e-5
+    with pytest.raises(L.VitkError):                                        # K % 128 != 0
+        K.gemm_nt_fp8_v2(A8[:, :64].contiguous(), 64, W8[:, :64].contiguous(), 64, C, N, M, N, 64, L.EPI_NONE, k128=True, **kw)
+
+
+def _golden_errors(name, model, img, params, case):
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    model.zero_grad(set_to_none=True)
+    out = model(img)
+    O.loss_fn(out).backward()
+    keys = [k for k in params if params[k].numel()]
+    named = dict(model.named_parameters())
+    mine, ref = [], []
+    for k in keys:
+        gk = named[k].grad.detach().float().flatten().cpu()
+        idx = torch.from_numpy(sample_index(gk.numel(), case.get("sample", 4096)))
+        mine.append(gk[idx]); ref.append(torch.from_numpy(gold["gsample::" + k]).float())
+    ref_logits = torch.from_numpy(gold["logits"])
+    e16 = rel(torch.from_numpy(gold["bf16::logits"]), ref_logits)
+    return rel(out, ref_logits), rel(torch.cat(mine), torch.cat(ref)), e16, out.detach().clone()
+
+
+@pytest.mark.parametrize("k128", ["0", "1"])
+@pytest.mark.parametrize("name", ["vit_h14_width", "vit_b16_width"])
+def test_fp8_training_step_against_reference_golden(name, k128, monkeypatch):
+    monkeypatch.setenv("VITK_FP8_K128", k128)
+    case = WIDE_CASES[name]
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000).to(DEV, dtype=BF)
+    m = ViT(**case["cfg"]); m.load_state_dict(params, strict=True)
+    m = m.to(DEV, dtype=BF)
+    e16r, g16r, e_ref16, out16 = _golden_errors(name, m, img, params, case)          # the 16-bit run of the same model
+    enable_fp8(m)
+    st = m.transformer._fp8
+    depth = case["cfg"]["depth"]
+    assert st.k128 == (k128 == "1")
+    e1, g1, _, out1 = _golden_errors(name, m, img, params, case)                      # step 1: 16-bit GEMMs, records only
+    assert torch.equal(out1, out16) and st.ready and not st.bwd_ready
+    e2, g2, _, out2 = _golden_errors(name, m, img, params, case)                      # step 2: fp8 forward AND backward
+    assert st.bwd_ready and not torch.equal(out2, out16)
+    sc = st.scales.view(depth, SLOTS_PER_LAYER, 2)
+    assert (sc[..., 0] > 0).all() and torch.allclose(sc[..., 0] * sc[..., 1], torch.ones_like(sc[..., 0]), rtol=1e-5)
+    e3, g3, _, _ = _golden_errors(name, m, img, params, case)                         # step 3: steady state of the delayed scales
+    print(f"{name} K128={k128}: vs reference f32 -- fp8 logits {e3:.2e} grad sample {g3:.2e} (step 2: {e2:.2e} / {g2:.2e}); "
+          f"16-bit run {e16r:.2e} / {g16r:.2e}; reference's own bf16 logits {e_ref16:.2e}")
+    for e, g in ((e2, g2), (e3, g3)):
+        assert e < 6e-2 and g < 1.5e-1, (e, g)
+    assert e3 > e16r                                                                   # fp8 did run (it cannot be as close as 16 bit)

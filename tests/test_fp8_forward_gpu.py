@@ -42,9 +42,12 @@ def test_fp8_forward_against_16bit_and_oracle(kind):
     assert not st.ready and float(st.scales.abs().sum()) == 0.0
     o_rec, g_rec = run(m8)                               # first call: 16-bit GEMMs, amax recorded
     assert torch.equal(o_rec, o16) and st.ready
-    assert (st.scales[:, 0] > 0).all() and torch.allclose(st.scales[:, 0] * st.scales[:, 1], torch.ones_like(st.scales[:, 0]), rtol=1e-5)
+    from vit_pytorch_amd.fp8 import SLOTS_PER_LAYER
+    act = st.scales.view(CFG["depth"], SLOTS_PER_LAYER, 2)[:, :4]        # the four activation slots of a layer (gradient slots: enable_fp8)
+    assert (act[..., 0] > 0).all() and torch.allclose(act[..., 0] * act[..., 1], torch.ones_like(act[..., 0]), rtol=1e-5)
+    assert float(st.scales.view(CFG["depth"], SLOTS_PER_LAYER, 2)[:, 4:].abs().sum()) == 0.0 and not st.backward
     assert int(st.amax.abs().sum()) == 0                 # records folded and reset
-    o8, g8 = run(m8)                                     # second call: e4m3 operands for QKV / FF1 / FF2
+    o8, g8 = run(m8)                                     # second call: e4m3 operands for QKV / out-projection / FF1 / FF2
     assert not torch.equal(o8, o16)
     e, g = rel(o8, o16), rel(g8, g16)
     ref_out, _ = O.run_fwd_bwd(kind, CFG, params, img, torch.float32)
