@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 132
+#define VITK_VERSION 133
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -210,6 +210,16 @@ int64_t vitk_gemm_nt_fp8_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ld
 int vitk_quantize_fp8_delayed(const void* x, int dt, void* out8, int64_t n, const float* scale2, uint32_t* amax64, int fmt,
                               void* stream);
 int vitk_fp8_update_scales_fmt(uint32_t* amax64, float* scales2, int64_t nslots, const float* fmax, void* stream);
+/* Weight gradient on fp8 operands: dW[N,K] = alpha_y * alpha_x * sum_m dY8[m,N]^T X8[m,K] (autograd of nn.Linear, vit.py:20,23,44,47).
+ * dY8: OCP e5m2 bytes (the copy vitk_quantize_fp8_delayed made for the dX GEMM), X8: OCP e4m3 bytes, both row-major with the
+ * token index as the slow one (ldy, ldx %% 16 == 0); fragments by ds_read_b64_tr_b8, v_mfma_f32_16x16x32_bf8_fp8 or (flags bit 0)
+ * v_mfma_f32_16x16x128_f8f6f4.  Split over M into `splits` f32 slabs (ws: splits * N * K floats; vitk_gemm_tn_fp8_splits, 0 =
+ * shape not served: M >= 1024, N, K >= 256 and multiples of 16), folded into dW (dtype odt, ld = ldo; accumulate: dW += ...)
+ * with the two device-resident inverse scales (null = 1).                                                              */
+int64_t vitk_gemm_tn_fp8_splits(int64_t M, int64_t N, int64_t K, int flags);
+int vitk_gemm_tn_fp8(const void* dY8, int64_t ldy, const void* X8, int64_t ldx, void* dW, int odt, int64_t ldo, int accumulate,
+                     int64_t M, int64_t N, int64_t K, float* ws, int64_t splits, const float* alpha_y, const float* alpha_x,
+                     int flags, void* stream);
 
 /* dW[N,K] = sum_m dY[m,N]^T X[m,K]  ("TN": both operands are read with the reduction index as
  * the strided one).  Split over M into `splits` slabs of f32 partials (ws: splits*N*K floats),

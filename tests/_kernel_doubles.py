@@ -122,6 +122,15 @@ def gemm_tn_bf16(dY, ldy, X, ldx, dW, ldo, M, N, Kd, ws, splits, accumulate=Fals
     dW.view(N, Kd).copy_(r + (dW.view(N, Kd).float() if accumulate else 0))
 
 
+def gemm_tn_fp8(dY8, ldy, X8, ldx, dW, ldo, M, N, Kd, ws, splits, *, alpha_y=None, alpha_x=None, k128=False, accumulate=False):
+    assert ldy == N and ldx == Kd and ldo == Kd and dY8.dtype == torch.uint8 and X8.dtype == torch.uint8 and splits >= 1
+    assert ws.numel() >= splits * N * Kd
+    CALLS.append(("gemm_tn_fp8", (M, N, Kd, bool(k128))))
+    al = (float(alpha_y[0]) if alpha_y is not None else 1.0) * (float(alpha_x[0]) if alpha_x is not None else 1.0)
+    r = (_deq(dY8.reshape(M, N), E5M2).t() @ _deq(X8.reshape(M, Kd), E4M3)) * al
+    dW.view(N, Kd).copy_(r + (dW.view(N, Kd).float() if accumulate else 0))
+
+
 def layernorm_fwd(x, w, b, y, mean, rstd, rows, D, eps=1e-5, imap=L.IDENT, omap=L.IDENT, add=None, add_group=0, add_off=0, y8=None,
                   scale8=None, amax64=None):
     assert imap.group == 0 and omap.group == 0 and add is None, "the doubles cover the Transformer stage (identity row maps)"
@@ -242,7 +251,7 @@ def require_device(*ts):
 
 
 _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_nt_bf16_gelu_bwd_colsum, gemm_nt_fp8_v2=gemm_nt_fp8_v2,
-                  gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, layernorm_fwd=layernorm_fwd,
+                  gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,
                   colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd,

@@ -76,15 +76,19 @@ def fp8_calls(calls):
     return [c[1] for c in calls if c[0] == "gemm_nt_fp8_v2"]
 
 
-@pytest.mark.parametrize("backward", [True, False])
-def test_fp8_state_machine_and_formats(x, backward, monkeypatch):
+@pytest.mark.parametrize("mode", ["fwd+dx+dw", "fwd+dx", "fwd"])
+def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
     monkeypatch.delenv("VITK_FP8_K128", raising=False)
+    backward, wgrad = mode != "fwd", mode == "fwd+dx+dw"
     m16, params = build(torch.bfloat16)
     y_ref, dx_ref, g_ref = reference(params, x)
     m8, _ = build(torch.bfloat16)
-    (enable_fp8 if backward else enable_fp8_forward)(m8)
+    if backward:
+        enable_fp8(m8, wgrad=wgrad)
+    else:
+        enable_fp8_forward(m8)
     st = m8._fp8
-    assert st.backward is backward and not st.ready and not st.bwd_ready and not st.k128
+    assert st.backward is backward and st.wgrad is wgrad and not st.ready and not st.bwd_ready and not st.k128
     M, I = B * N, HEADS * DH
     with KD.installed() as calls:
         y16, dx16, g16 = run(m16, x)
@@ -116,13 +120,19 @@ def test_fp8_state_machine_and_formats(x, backward, monkeypatch):
             per_layer_bwd = {(M, MLP, DIM, L.EPI_GELU_BWD), (M, DIM, MLP, L.EPI_NONE), (M, I, DIM, L.EPI_NONE), (M, DIM, 3 * I, L.EPI_NONE)}
             assert {c[:4] for c in bwd} == per_layer_bwd
             assert st.bwd_ready and (st.scales.view(DEPTH, SLOTS_PER_LAYER, 2)[:, 4:, 0] > 0).all()
-            # what is left in 16 bit: the weight-gradient GEMMs and nothing else GEMM-shaped
-            assert [c[0] for c in calls].count("gemm_tn_bf16") == 4 * DEPTH
+            # the weight-gradient GEMMs: on the e5m2 copies the dX GEMMs already made + e4m3 copies of the saved activations, or 16 bit
+            names = [c[0] for c in calls]
+            assert names.count("gemm_tn_fp8") == (4 * DEPTH if wgrad else 0) and names.count("gemm_tn_bf16") == (0 if wgrad else 4 * DEPTH)
+            if wgrad:
+                assert {c[1][:3] for c in calls if c[0] == "gemm_tn_fp8"} == {(M, DIM, MLP), (M, MLP, DIM), (M, DIM, I), (M, 3 * I, DIM)}
+                qs = [c[1] for c in calls if c[0] == "quantize_fp8_delayed"]
+                # per layer: o (fwd, e4m3, recorded), 4 gradients (e5m2, recorded), 4 saved activations re-quantised (e4m3, not recorded)
+                assert len(qs) == 9 * DEPTH and sum(1 for q in qs if q[3] == K.FMT_E4M3 and not q[2]) == 4 * DEPTH
             assert not [c for c in calls if c[0] in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum")]
         assert not any(c[5] for c in f)                                  # K = 128 flavour is opt-in
         # numerics of the plumbing: fp8-sized distance from the 16-bit run and from the f32 oracle
         e_y, e_dx, e_g = rel(y2, y16), rel(dx2, dx16), worst_grad(g2, g16)
-        print(f"fp8 ({'fwd+bwd' if backward else 'fwd'}) vs 16-bit: out {e_y:.2e} dx {e_dx:.2e} worst grad {e_g:.2e}; vs f32 oracle: out {rel(y2, y_ref):.2e}")
+        print(f"fp8 ({mode}) vs 16-bit: out {e_y:.2e} dx {e_dx:.2e} worst grad {e_g:.2e}; vs f32 oracle: out {rel(y2, y_ref):.2e}")
         assert 1e-4 < e_y < 6e-2 and e_dx < 1.2e-1 and e_g < 1.5e-1 and rel(y2, y_ref) < 6e-2
         # unchanged weights are not re-quantised; an in-place update is
         n_w, n_wt = len(st._w), len(st._wt)
@@ -147,6 +157,8 @@ def test_fp8_k128_switch_and_recompute(x, monkeypatch):
         y_a, dx_a, g_a = run(m8, x)
         f = fp8_calls(calls)
         assert len(f) == 8 * DEPTH and all(c[5] == (c[2] % 128 == 0) for c in f) and any(c[5] for c in f)
+        tn = [c[1] for c in calls if c[0] == "gemm_tn_fp8"]
+        assert len(tn) == 4 * DEPTH and all(c[3] for c in tn)             # every weight-gradient GEMM takes the K = 128 form (tokens are zero-padded)
         # the activation-recompute policy (engine._recompute_policy, what lets ViT-H/14 batch 256 fit) composes with fp8: the backward
         # rebuilds the LayerNorm / GELU outputs it no longer finds saved (the delayed scales moved by one step in between, so the
         # two runs agree to quantisation noise, not bit for bit)

@@ -6,7 +6,8 @@ DEQUANTISED operands (products of fp8 values are exact in f32, so only f32 accum
 remain: 4e-3).  Model level: ViT at BASELINE config 5's width (ViT-H/14: dim 1280, 16 heads of 80, mlp 5120, N = 577) and
 config 2's, with `enable_fp8`, against the goldens the REFERENCE produced in float32 (tests/golden/vit_h14_width.npz,
 vit_b16_width.npz).  Stated fp8 tolerance: logits within 6e-2, the gradient sample within 1.5e-1 relative L2 of the
-reference's f32 values (3-bit / 2-bit mantissa operands in 8 of the 12 GEMMs of a layer; measured values are printed)."""
+reference's f32 values (3-bit / 2-bit mantissa operands in 8 or all 12 of the GEMMs of a layer; measured values are printed).
+The weight-gradient GEMM (gemm_tn_fp8.hip, ds_read_b64_tr_b8 fragments) has its own test against the dequantised product."""
 import os
 
 import numpy as np
@@ -155,6 +156,38 @@ def test_k128_flavour_forward_epilogues(M, N, Kd):
         K.gemm_nt_fp8_v2(A8[:, :64].contiguous(), 64, W8[:, :64].contiguous(), 64, C, N, M, N, 64, L.EPI_NONE, k128=True, **kw)
 
 
+# dW shapes of ViT-H/14 (M = 4 x 577) and ViT-B/16; a ragged tile (N = 272); M that is no multiple of the 64- / 128-row LDS step
+@pytest.mark.parametrize("k128", [False, True])
+@pytest.mark.parametrize("M,N,Kd", [(2308, 1280, 5120), (2308, 3840, 1280), (6304, 768, 3072), (1154, 272, 256), (50432, 768, 768)])
+def test_gemm_tn_fp8_against_dequantised_product(M, N, Kd, k128):
+    """dW (N, Kd) = dY (M, N)^T X (M, Kd): e5m2 dY, e4m3 X, fragments by ds_read_b64_tr_b8."""
+    g = torch.Generator(device=DEV).manual_seed(6)
+    dY = (torch.randn(M, N, device=DEV, generator=g) * 1e-4 * torch.logspace(0, 1.5, N, device=DEV)).to(BF)
+    X = (torch.randn(M, Kd, device=DEV, generator=g) * torch.linspace(0.5, 2.0, Kd, device=DEV)).to(BF)       # asymmetric in both index directions
+    dY8, sy, dYq = _quantised(dY, K.FMT_E5M2)
+    X8, sx, Xq = _quantised(X, K.FMT_E4M3)
+    ref = dYq.t() @ Xq
+    splits = K.gemm_tn_fp8_splits(M, N, Kd, k128)
+    assert splits >= 1
+    ws = torch.empty(splits * N * Kd, device=DEV)
+    dW = torch.empty(N, Kd, dtype=BF, device=DEV)
+    K.gemm_tn_fp8(dY8, N, X8, Kd, dW, Kd, M, N, Kd, ws, splits, alpha_y=sy[1:], alpha_x=sx[1:], k128=k128)
+    assert rel(dW, ref) < 4e-3, rel(dW, ref)                                # bf16 output rounding
+    assert rel(dW, dY.double().t() @ X.double()) < 8e-2                     # what the two quantisations cost
+    dW32 = torch.empty(N, Kd, device=DEV)
+    K.gemm_tn_fp8(dY8, N, X8, Kd, dW32, Kd, M, N, Kd, ws, splits, alpha_y=sy[1:], alpha_x=sx[1:], k128=k128)
+    assert rel(dW32, ref) < 2e-5, rel(dW32, ref)                            # f32 accumulation of exact products
+    K.gemm_tn_fp8(dY8, N, X8, Kd, dW32, Kd, M, N, Kd, ws, splits, alpha_y=sy[1:], alpha_x=sx[1:], k128=k128, accumulate=True)
+    assert rel(dW32, 2 * ref) < 2e-5
+    # one split and many splits agree (the fold is a plain sum of slabs)
+    ws2 = torch.empty(3 * N * Kd, device=DEV)
+    K.gemm_tn_fp8(dY8, N, X8, Kd, dW, Kd, M, N, Kd, ws2, 3, alpha_y=sy[1:], alpha_x=sx[1:], k128=k128)
+    assert rel(dW, ref) < 4e-3
+    with pytest.raises(L.VitkError):
+        K.gemm_tn_fp8(dY8, N, X8, Kd, dW, Kd, 512, N, Kd, ws, 1)            # M < 1024: not served
+    assert K.gemm_tn_fp8_splits(512, N, Kd) == 0 and K.gemm_tn_fp8_splits(M, 264, Kd) == 0      # N % 16 != 0
+
+
 def _golden_errors(name, model, img, params, case):
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     model.zero_grad(set_to_none=True)
@@ -172,9 +205,11 @@ def _golden_errors(name, model, img, params, case):
     return rel(out, ref_logits), rel(torch.cat(mine), torch.cat(ref)), e16, out.detach().clone()
 
 
+@pytest.mark.parametrize("wgrad", [False, True])
 @pytest.mark.parametrize("k128", ["0", "1"])
 @pytest.mark.parametrize("name", ["vit_h14_width", "vit_b16_width"])
-def test_fp8_training_step_against_reference_golden(name, k128, monkeypatch):
+def test_fp8_training_step_against_reference_golden(name, k128, wgrad, monkeypatch):
+    """wgrad=False: forward + dX GEMMs on fp8 (8 of a layer's 12 GEMMs); wgrad=True: the weight-gradient GEMMs too (all 12)."""
     monkeypatch.setenv("VITK_FP8_K128", k128)
     case = WIDE_CASES[name]
     params = make_params(case["kind"], case["cfg"], case["seed"])
@@ -182,10 +217,10 @@ def test_fp8_training_step_against_reference_golden(name, k128, monkeypatch):
     m = ViT(**case["cfg"]); m.load_state_dict(params, strict=True)
     m = m.to(DEV, dtype=BF)
     e16r, g16r, e_ref16, out16 = _golden_errors(name, m, img, params, case)          # the 16-bit run of the same model
-    enable_fp8(m)
+    enable_fp8(m, wgrad=wgrad)
     st = m.transformer._fp8
     depth = case["cfg"]["depth"]
-    assert st.k128 == (k128 == "1")
+    assert st.k128 == (k128 == "1") and st.wgrad is wgrad
     e1, g1, _, out1 = _golden_errors(name, m, img, params, case)                      # step 1: 16-bit GEMMs, records only
     assert torch.equal(out1, out16) and st.ready and not st.bwd_ready
     e2, g2, _, out2 = _golden_errors(name, m, img, params, case)                      # step 2: fp8 forward AND backward
@@ -193,7 +228,7 @@ def test_fp8_training_step_against_reference_golden(name, k128, monkeypatch):
     sc = st.scales.view(depth, SLOTS_PER_LAYER, 2)
     assert (sc[..., 0] > 0).all() and torch.allclose(sc[..., 0] * sc[..., 1], torch.ones_like(sc[..., 0]), rtol=1e-5)
     e3, g3, _, _ = _golden_errors(name, m, img, params, case)                         # step 3: steady state of the delayed scales
-    print(f"{name} K128={k128}: vs reference f32 -- fp8 logits {e3:.2e} grad sample {g3:.2e} (step 2: {e2:.2e} / {g2:.2e}); "
+    print(f"{name} K128={k128} wgrad={wgrad}: vs reference f32 -- fp8 logits {e3:.2e} grad sample {g3:.2e} (step 2: {e2:.2e} / {g2:.2e}); "
           f"16-bit run {e16r:.2e} / {g16r:.2e}; reference's own bf16 logits {e_ref16:.2e}")
     for e, g in ((e2, g2), (e3, g3)):
         assert e < 6e-2 and g < 1.5e-1, (e, g)

@@ -16,7 +16,7 @@ LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit t
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3, 4
-VITK_VERSION = 132
+VITK_VERSION = 133
 
 
 class RowMap(C.Structure):
@@ -69,6 +69,8 @@ SIGNATURES = {
     "vitk_gemm_nt_fp8_colsum_rows": (_i64, [_i64, _i64, _i64, _i64]),
     "vitk_quantize_fp8_delayed": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _i, _vp]),
     "vitk_fp8_update_scales_fmt": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "vitk_gemm_tn_fp8_splits": (_i64, [_i64, _i64, _i64, _i]),
+    "vitk_gemm_tn_fp8": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i, _vp]),
     "vitk_gemm_nt_colsum_rows": (_i64, [_i64, _i64, _i64, _i64]),
     "vitk_gemm_nt_plan": (_i, [_i64, _i64, _i64, _i64, _vp]),
     "vitk_comm_unique_id": (_i, [_vp]),

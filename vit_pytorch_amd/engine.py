@@ -293,7 +293,8 @@ class TransformerFn(torch.autograd.Function):
         ctx.stf = stf
         ctx.meta = (heads, dim_head, depth, B, N, D, x.dtype)
         ctx.drop = (drop_p, drop_seed)
-        ctx.fp8 = fp8 if (use8 and fp8.backward and lp[3] is not None and ops.fp8_bwd_ok(M, D, I, lp[7].shape[0])) else None
+        # (the backward re-quantises the saved activations under the FORWARD slots' scales: all four of them must be live -> out8)
+        ctx.fp8 = fp8 if (use8 and out8 and fp8.backward and ops.fp8_bwd_ok(M, D, I, lp[7].shape[0])) else None
         ctx.save_for_backward(norm_w, norm_b, *[t for t in lp if t is not None])
         ctx.lp_mask = [t is not None for t in lp]
         return y
@@ -329,26 +330,50 @@ class TransformerFn(torch.autograd.Function):
         f8 = ctx.fp8
         I = heads * dim_head
 
-        def dx8(li, slot, dyT, W, epi=L.EPI_NONE, pre=None, db=None):
-            """dX (M, Kd) = dY (M, Nw) . W (Nw, Kd) [* gelu'(pre), column sums -> db]; None while the scales do not exist yet."""
-            Nw, Kd = W.shape
+        def q5(li, slot, t):
+            """(e5m2 copy, scale pair) of a gradient tensor under last step's scale, this step's amax recorded on the way; None (record
+            only) while the gradient scales do not exist yet."""
             sc, am = f8.slot(li, slot)
             if not f8.bwd_ready:
-                K.quantize_fp8_delayed(dyT, None, None, am, K.FMT_E5M2)
+                K.quantize_fp8_delayed(t, None, None, am, K.FMT_E5M2)
                 return None
-            dy8 = torch.empty((M, Nw), dtype=torch.uint8, device=dyT.device)
-            K.quantize_fp8_delayed(dyT, dy8, sc, am, K.FMT_E5M2)
+            t8 = torch.empty(t.shape, dtype=torch.uint8, device=t.device)
+            K.quantize_fp8_delayed(t, t8, sc, am, K.FMT_E5M2)
+            return t8, sc
+
+        def dx8(q, W, epi=L.EPI_NONE, pre=None, db=None):
+            """dX (M, Kd) = dY (M, Nw) . W (Nw, Kd) [* gelu'(pre), column sums -> db] from q = q5(dY)."""
+            dy8, sc = q
+            Nw, Kd = W.shape
             w8t, wsc = f8.weight_t(W)
-            dx = ops.empty((M, Kd), T, dyT)
+            dx = ops.empty((M, Kd), T, dy8)
             part = None
             if db is not None:
                 R = K.gemm_nt_fp8_colsum_rows(M, Kd, Nw, Kd)
-                part = ops.empty((R * Kd,), F32, dyT)
+                part = ops.empty((R * Kd,), F32, dy8)
             K.gemm_nt_fp8_v2(dy8, Nw, w8t, Nw, dx, Kd, M, Kd, Nw, epi, a_kind=K.A_E5M2, aux=pre, partials=part,
                              alpha_a=sc[1:], alpha_w=wsc[1:], k128=f8.k128 and Nw % 128 == 0)
             if db is not None:
                 K.colsum_partials(part, R, Kd, Kd, db)
             return dx
+
+        def dw(li, q, dyT, x, xslot, dW, db=None):
+            """dW (Nw, Kd) = dY^T X (+ db = colsum dY): on fp8 operands -- the e5m2 copy q already holds, an e4m3 copy of the saved
+            activation under its forward scale -- when the state asks for it and the shape is served, else the 16-bit GEMM."""
+            Nw, Kd = dW.shape
+            if q is None or not f8.wgrad or not ops.fp8_tn_ok(M, Nw, Kd):
+                ops.linear_dw(dyT, x, M, dW, db)
+                return
+            dy8, sc = q
+            scx, _ = f8.slot(li, xslot)
+            x8 = torch.empty((M, Kd), dtype=torch.uint8, device=x.device)
+            K.quantize_fp8_delayed(x, x8, scx, None, K.FMT_E4M3)
+            k128 = f8.k128
+            splits = K.gemm_tn_fp8_splits(M, Nw, Kd, k128)
+            ws = ops.empty((splits * Nw * Kd,), F32, x)
+            K.gemm_tn_fp8(dy8, Nw, x8, Kd, dW, Kd, M, Nw, Kd, ws, splits, alpha_y=sc[1:], alpha_x=scx[1:], k128=k128)
+            if db is not None:
+                ops.colsum(dyT, M, Nw, db)
 
         fork = _Fork(dy.device)
         # final LayerNorm (vit.py:83)
@@ -377,27 +402,33 @@ class TransformerFn(torch.autograd.Function):
             gT = gb if bf else g
             base = li * NLP
             # ---- feed-forward branch (vit.py:18-25) ----
+            q3 = q5(li, 4, gT) if f8 is not None else None
             dw2 = _grad_buf(w2)
-            fork.run(lambda: ops.linear_dw(gT, act, M, dw2), gT, act, dw2)
+            if f8 is not None:
+                fork.run(lambda: dw(li, q3, gT, act, 2, dw2), gT, act, dw2, q3)
+            else:
+                fork.run(lambda: ops.linear_dw(gT, act, M, dw2), gT, act, dw2)
             grads[base + 9] = dw2
             if b2 is not None:
                 grads[base + 10] = dcol          # written by the LayerNorm backward above this layer (bias_target)
             dw1 = _grad_buf(w1)
             db1 = _grad_buf(b1) if b1 is not None else None
-            dpre = dx8(li, 4, gT, w2, L.EPI_GELU_BWD, pre, db1) if f8 is not None else None
-            if dpre is not None:
-                db_done = True
+            if q3 is not None:
+                dpre, db_done = dx8(q3, w2, L.EPI_GELU_BWD, pre, db1), True
             elif db1 is not None:
                 dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, db=db1, drop=site(li, 2))   # b1's gradient out of the GEMM epilogue
             else:
                 dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, drop=site(li, 2)), True
+            del q3
             db_todo = None if db_done else db1
-            fork.run(lambda: ops.linear_dw(dpre, a2, M, dw1, db_todo), dpre, a2, dw1, db1)
+            qd = q5(li, 5, dpre) if f8 is not None else None
+            if f8 is not None:
+                fork.run(lambda: dw(li, qd, dpre, a2, 1, dw1, db_todo), dpre, a2, dw1, db1, qd)
+            else:
+                fork.run(lambda: ops.linear_dw(dpre, a2, M, dw1, db_todo), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
-            da2 = dx8(li, 5, dpre, w1) if f8 is not None else None
-            if da2 is None:
-                da2 = ops.linear_dx(dpre, w1, M)
-            del dpre, pre, act
+            da2 = dx8(qd, w1) if qd is not None else ops.linear_dx(dpre, w1, M)
+            del dpre, pre, act, qd
             g2, g2b = newg()
             dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
             dcol2 = bias_target(bout if wout is not None else None)
@@ -408,24 +439,29 @@ class TransformerFn(torch.autograd.Function):
             g2T = g2b if bf else g2
             # ---- attention branch (vit.py:51-64) ----
             if wout is not None:
+                q2 = q5(li, 6, g2T) if f8 is not None else None
                 dwo = _grad_buf(wout)
-                fork.run(lambda: ops.linear_dw(g2T, o, M, dwo), g2T, o, dwo)
+                if f8 is not None:
+                    fork.run(lambda: dw(li, q2, g2T, o, 3, dwo), g2T, o, dwo, q2)
+                else:
+                    fork.run(lambda: ops.linear_dw(g2T, o, M, dwo), g2T, o, dwo)
                 grads[base + 3] = dwo
                 if bout is not None:
                     grads[base + 4] = dcol2
-                do = dx8(li, 6, g2T, wout) if f8 is not None else None
-                if do is None:
-                    do = ops.linear_dx(g2T, wout, M)
+                do = dx8(q2, wout) if q2 is not None else ops.linear_dx(g2T, wout, M)
+                del q2
             else:
                 do = g2T
             dqkv = ops.attn_bwd(qkv, o, do, att_saved, B, N, heads, dim_head, scale, drop=site(li, 0))
+            qq = q5(li, 7, dqkv) if f8 is not None else None
             dwq = _grad_buf(wqkv)
-            fork.run(lambda: ops.linear_dw(dqkv, a1, M, dwq), dqkv, a1, dwq)
+            if f8 is not None:
+                fork.run(lambda: dw(li, qq, dqkv, a1, 0, dwq), dqkv, a1, dwq, qq)
+            else:
+                fork.run(lambda: ops.linear_dw(dqkv, a1, M, dwq), dqkv, a1, dwq)
             grads[base + 2] = dwq
-            da1 = dx8(li, 7, dqkv, wqkv) if f8 is not None else None
-            if da1 is None:
-                da1 = ops.linear_dx(dqkv, wqkv, M)
-            del dqkv, do, qkv, o
+            da1 = dx8(qq, wqkv) if qq is not None else ops.linear_dx(dqkv, wqkv, M)
+            del dqkv, do, qkv, o, qq
             g1, g1b = newg()
             dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
             dcol = bias_target(lp[(li - 1) * NLP + 10] if li > 0 else None)

@@ -9,13 +9,16 @@ What runs on fp8 once the scales exist (the reference's four nn.Linear per layer
     forward   QKV, out-projection, FF1, FF2      e4m3 activations x e4m3 weights   (v_mfma_f32_16x16x32_fp8_fp8)
     backward  dX of FF2 (+ GELU'), FF1, out-projection, QKV
                                                  e5m2 gradients x e4m3 weights^T   (v_mfma_f32_16x16x32_fp8_bf8)
-    16-bit    the weight-gradient GEMMs dW = dY^T X (they read both operands with the token index as the strided one: an 8-bit
-              transposing LDS read, ds_read_b64_tr_b8, whose lane mapping could not be probed in the build container), attention,
-              LayerNorm, the residual stream -- and everything the backward reads (saved activations, weights).
+              dW of the same four layers         e5m2 gradients^T x e4m3 activations (gemm_tn_fp8.hip: ds_read_b64_tr_b8 fragments,
+                                                 v_mfma_f32_16x16x32_bf8_fp8; `wgrad=False` keeps them 16-bit)
+    16-bit    attention, LayerNorm, the residual streams -- and everything that is SAVED for the backward (activations, weights):
+              the e4m3 operands of the dW GEMMs are re-made from the saved 16-bit activations under their forward scales, one
+              pass each, instead of keeping 1 B / element / tensor alive across the step.
 
-`VITK_FP8_K128=1` switches every fp8 GEMM whose reduction extent is a multiple of 128 to v_mfma_f32_16x16x128_f8f6f4 with unit
-block scales -- the one fp8 form above the bf16 matrix rate on gfx950 (MI355X_MICROARCH.md: 2x) -- by pairing the fragments of
-two consecutive K-steps in registers (gemm_bf16.hip); per-tensor scales stay outside the instruction.
+`VITK_FP8_K128=1` switches every fp8 GEMM whose reduction extent is a multiple of 128 (every dW GEMM: tokens are zero-padded) to
+v_mfma_f32_16x16x128_f8f6f4 with unit block scales -- the one fp8 form above the bf16 matrix rate on gfx950
+(MI355X_MICROARCH.md: 2x) -- by pairing the fragments of two consecutive K-steps in registers (gemm_bf16.hip) / four
+transposing reads per operand (gemm_tn_fp8.hip); per-tensor scales stay outside the instruction.
 
 Scaling is per tensor and DELAYED by one step.  Producers that already hold an activation in registers -- LayerNorm forward for
 the QKV / FF1 inputs, the GELU epilogue of FF1 for the FF2 input -- write its e4m3 copy themselves under the scale decided from
@@ -54,9 +57,10 @@ E5M2_MAX_USED = 28672.0                   # 57344 / 2: one-step-old gradient sca
 class Fp8State:
     """Delayed-scaling state of one Transformer: scales / amax records per (layer, tensor) and the e4m3 weight caches."""
 
-    def __init__(self, depth: int, device, backward: bool = True):
+    def __init__(self, depth: int, device, backward: bool = True, wgrad: bool = True):
         self.depth = depth
         self.backward = bool(backward)
+        self.wgrad = bool(backward and wgrad)
         self.k128 = os.environ.get("VITK_FP8_K128", "0") not in ("0", "")
         n = depth * SLOTS_PER_LAYER
         self.scales = torch.zeros(n, 2, dtype=torch.float32, device=device)        # {scale, 1/scale}
@@ -111,9 +115,10 @@ class Fp8State:
         self._bwd_recorded = True
 
 
-def enable_fp8(model: torch.nn.Module, enabled: bool = True, backward: bool = True):
+def enable_fp8(model: torch.nn.Module, enabled: bool = True, backward: bool = True, wgrad: bool = True):
     """Switch the fused Transformer stack(s) inside `model` to fp8 GEMM operands (see module docstring).  `backward=False`: the
-    forward GEMMs only (QKV, out-projection, FF1, FF2); the backward then runs entirely on the saved 16-bit tensors."""
+    forward GEMMs only (QKV, out-projection, FF1, FF2); the backward then runs entirely on the saved 16-bit tensors.
+    `wgrad=False`: forward and dX GEMMs on fp8, the weight-gradient GEMMs in 16 bit."""
     from .simple_vit import Transformer as SimpleTransformer
     from .vit import Transformer
     found = False
@@ -122,7 +127,7 @@ def enable_fp8(model: torch.nn.Module, enabled: bool = True, backward: bool = Tr
             p = next(m.parameters())
             if enabled and p.dtype not in (torch.bfloat16, torch.float16):
                 raise VitkError("enable_fp8: the model must be bfloat16 or float16 (fp8 replaces the 16-bit GEMM operands)")
-            m._fp8 = Fp8State(len(m.layers), p.device, backward) if enabled else None
+            m._fp8 = Fp8State(len(m.layers), p.device, backward, wgrad) if enabled else None
             found = True
     if not found:
         raise VitkError("enable_fp8: no vit_pytorch_amd.vit.Transformer inside this model")

@@ -421,3 +421,14 @@ def quantize_fp8_delayed(x: Tensor, out8: Optional[Tensor], scale2: Optional[Ten
 
 def fp8_update_scales_fmt(amax64: Tensor, scales2: Tensor, nslots: int, fmax: Optional[Tensor]):
     check(L.load().vitk_fp8_update_scales_fmt(_p(amax64), _p(scales2), nslots, _p(fmax), _stream()), "fp8_update_scales_fmt")
+
+
+def gemm_tn_fp8_splits(M: int, N: int, K: int, k128: bool = False) -> int:
+    return int(L.load().vitk_gemm_tn_fp8_splits(M, N, K, 1 if k128 else 0))
+
+
+def gemm_tn_fp8(dY8: Tensor, ldy: int, X8: Tensor, ldx: int, dW: Tensor, ldo: int, M: int, N: int, K: int, ws: Tensor, splits: int, *,
+                alpha_y: Optional[Tensor] = None, alpha_x: Optional[Tensor] = None, k128: bool = False, accumulate: bool = False):
+    """dW (N, K) = alpha_y alpha_x dY8^T X8 with e5m2 gradients and e4m3 activations (uint8 storage); dW in the model dtype."""
+    check(_lib_for(dW).vitk_gemm_tn_fp8(_p(dY8), ldy, _p(X8), ldx, _p(dW), dt(dW), ldo, int(accumulate), M, N, K, _p(ws), splits,
+                                        _p(alpha_y), _p(alpha_x), 1 if k128 else 0, _stream()), "gemm_tn_fp8")

@@ -113,6 +113,11 @@ def fp8_bwd_ok(M: int, D: int, I: int, Fh: int) -> bool:
     return (_fp8_shape_ok(M, Fh, D) and _fp8_shape_ok(M, D, Fh) and _fp8_shape_ok(M, I, D) and _fp8_shape_ok(M, D, 3 * I))
 
 
+def fp8_tn_ok(M: int, N: int, Kd: int) -> bool:
+    """The fp8 weight-gradient GEMM (gemm_tn_fp8.hip) serves this (tokens, out features, in features) shape."""
+    return K.gemm_tn_fp8_splits(M, N, Kd) > 0
+
+
 # ---- f32 validation mode on the production MFMA kernels ------------------------------------------------------------------------
 # The float32 mode (params float32: the mode that proves the host logic and the kernels' arithmetic to round-off) used to run every
 # Linear on the VALU coverage kernel, i.e. it validated different kernels than the ones production runs.  For shapes the production
