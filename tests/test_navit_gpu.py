@@ -25,7 +25,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("lens", [[197], [16, 300, 1, 129, 64], [1600, 7], [128, 128, 256]])
-@pytest.mark.parametrize("H,d", [(1, 64), (3, 64), (2, 80)])
+@pytest.mark.parametrize("H,d", [(1, 64), (3, 64), (2, 80), (2, 32), (3, 48), (2, 96)])
 def test_varlen_attention_fwd_bwd(lens, H, d):
     I = H * d
     T = sum(lens)

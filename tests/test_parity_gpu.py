@@ -407,6 +407,26 @@ def test_long_sequence_dim_head_64_uses_chunked_attention():
     assert rel(cat(grads), cat(ref_g)) <= 1.5 * rel(cat(bf_g), cat(ref_g)) + 1e-3
 
 
+@pytest.mark.parametrize("dh", [32, 48, 96])
+def test_other_head_widths_run_on_the_flash_kernels(dh):
+    """vit.py:86 leaves dim_head free: 32 / 48 / 96 (beside 64 and 80) take the chunked flash kernels in 16 bit (round 3; they
+    used to fall to the kernels that materialise the attention matrix).  Oracle f32 vs bf16 run, depth 2, N = 65."""
+    from vit_pytorch_amd import ops
+    assert ops.attn_varlen_ok(torch.bfloat16, dh) and not ops.attn_fast_ok(torch.bfloat16, 65, dh)
+    cfg = dict(image_size=64, patch_size=8, num_classes=10, dim=128, depth=2, heads=2, dim_head=dh, mlp_dim=256)
+    params = make_params("vit", cfg, 23 + dh)
+    img = make_images(cfg, 3, 1023 + dh)
+    ref_out, ref_g = O.run_fwd_bwd("vit", cfg, params, img, torch.float32)
+    bf_out, bf_g = O.run_fwd_bwd("vit", cfg, params, img, torch.bfloat16)
+    out, grads = run_mine("vit", cfg, params, img, torch.bfloat16)
+    keys = list(params)
+    cat = lambda d: torch.cat([d[k].detach().float().flatten().cpu() for k in keys])
+    assert rel(out, ref_out) <= 1.5 * rel(bf_out, ref_out) + 1e-3
+    assert rel(cat(grads), cat(ref_g)) <= 1.5 * rel(cat(bf_g), cat(ref_g)) + 1e-3
+    for k in keys:
+        assert rel(grads[k], ref_g[k]) <= 0.15, (k, rel(grads[k], ref_g[k]))
+
+
 def test_fused_dropout_layer_matches_masked_reference():
     """Active dropout (vit.py:22,24,48,60 at p = 0.1, training mode) runs inside the fused engine; its keep decisions are
     a counter hash, so a float64 reference that applies the very same masks (vitk_dropout_keep) must agree."""

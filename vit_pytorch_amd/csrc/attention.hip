@@ -482,7 +482,10 @@ struct HND { __bf16* p; long long s_h, s_n; };   // element (n, h, d) at p + n*s
 template <int DH> struct HD {
     static constexpr int NKS = (DH + 31) / 32;      // MFMA K-steps over d
     static constexpr int NFD = DH / 16;             // 16-column output blocks
-    static constexpr int LD = DH == 64 ? 160 : 208; // bytes per LDS row
+    // bytes per LDS row: 64 NKS of data + 16 (an odd number of 16-byte slots: 16 consecutive rows start in distinct 4-bank windows);
+    // DH = 64 keeps the 160 it was measured with.  DH = 32 / 48 / 96 (round 3): 80 / 144 / 208.  Static LDS (2 chunks of 128 rows) caps
+    // the row at 256 bytes: DH <= 96.
+    static constexpr int LD = DH == 64 ? 160 : NKS * 64 + 16;
     static constexpr int NCH = NKS * 4;             // 16-byte chunks per LDS row that are read by fragments
 };
 
@@ -1094,17 +1097,22 @@ extern "C" int vitk_attn_varlen_fwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v
                                               void* stream) {
     if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_fwd_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
     if (H * tq_total > 0xffffffffLL) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: H * tokens exceeds the 32-bit dropout row index");
-    if (d != 64 && d != 80) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: needs dim_head 64 or 80 (got %lld)", (long long)d);
+    if (d != 32 && d != 48 && d != 64 && d != 80 && d != 96) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: needs dim_head 32, 48, 64, 80 or 96 (got %lld)", (long long)d);
     if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_fwd_bf16: scale must be positive (got %g)", (double)scale);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !lse || !cu_q || !cu_k || !blk_seg || !blk_r0)
         VITK_FAIL(VITK_E_ALIGN, "attn_varlen_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
     if (nblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: empty problem");
-    if (d == 64) hipLaunchKernelGGL(attn_varlen_fwd_kernel<64>, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q),
-                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E, drop_thresh(drop_p), drop_seed,
-                       1.0f / (1.0f - drop_p));
-    else hipLaunchKernelGGL(attn_varlen_fwd_kernel<80>, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q),
-                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E, drop_thresh(drop_p), drop_seed,
-                       1.0f / (1.0f - drop_p));
+#define VL_FWD(DHV) hipLaunchKernelGGL(attn_varlen_fwd_kernel<DHV>, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q), \
+                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E, drop_thresh(drop_p), drop_seed, \
+                       1.0f / (1.0f - drop_p))
+    switch ((int)d) {
+        case 32: VL_FWD(32); break;
+        case 48: VL_FWD(48); break;
+        case 64: VL_FWD(64); break;
+        case 80: VL_FWD(80); break;
+        default: VL_FWD(96); break;
+    }
+#undef VL_FWD
     VITK_CHECK_LAUNCH("attn_varlen_fwd_bf16");
     return 0;
 }
@@ -1127,7 +1135,7 @@ extern "C" int vitk_attn_varlen_bwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v
     if (H * tq_total > 0xffffffffLL) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: H * tokens exceeds the 32-bit dropout row index");
     const unsigned drop_t = drop_thresh(drop_p);
     const float inv_keep = 1.0f / (1.0f - drop_p);
-    if (d != 64 && d != 80) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: needs dim_head 64 or 80 (got %lld)", (long long)d);
+    if (d != 32 && d != 48 && d != 64 && d != 80 && d != 96) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: needs dim_head 32, 48, 64, 80 or 96 (got %lld)", (long long)d);
     if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_bwd_bf16: scale must be positive (got %g)", (double)scale);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !hnd_ok(dout) || !hnd_ok(dq) || !hnd_ok(dk) || !hnd_ok(dv) || !lse ||
         !delta || !cu_q || !cu_k || !qblk_seg || !qblk_r0 || !kblk_seg || !kblk_r0)
@@ -1139,7 +1147,13 @@ extern "C" int vitk_attn_varlen_bwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v
                        to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep); \
     hipLaunchKernelGGL(attn_varlen_bwd_dkv_kernel<DHV>, dim3((unsigned)nkblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k), \
                        to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep); } while (0)
-    if (d == 64) VL_BWD(64); else VL_BWD(80);
+    switch ((int)d) {
+        case 32: VL_BWD(32); break;
+        case 48: VL_BWD(48); break;
+        case 64: VL_BWD(64); break;
+        case 80: VL_BWD(80); break;
+        default: VL_BWD(96); break;
+    }
 #undef VL_BWD
     VITK_CHECK_LAUNCH("attn_varlen_bwd_dkv");
     return 0;

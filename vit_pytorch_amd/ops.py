@@ -404,8 +404,12 @@ def _split2(x: Tensor):
 
 
 def attn_varlen_ok(T, d: int) -> bool:
-    """chunked kernels (any N): bf16, dim_head 64 or 80 (ViT-H/14: dim_head 80, N = 577)"""
-    return T in HALF and d in (64, 80)
+    """chunked flash kernels (any N): 16-bit, dim_head 32 / 48 / 64 / 80 / 96 (ViT-H/14: dim_head 80, N = 577; vit.py:86 leaves dim_head
+    free -- the other widths a multiple of 16 up to 96 were instantiated in round 3).  VITK_ATTN_DH_EXT=0 keeps 32 / 48 / 96 on the
+    materialising path."""
+    if d in (32, 48, 96) and os.environ.get("VITK_ATTN_DH_EXT", "1") == "0":
+        return False
+    return T in HALF and d in (32, 48, 64, 80, 96)
 
 
 def attn_fwd(qkv: Tensor, B: int, N: int, H: int, d: int, scale: float, drop: Optional[Tuple[float, int]] = None):
