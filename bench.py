@@ -33,8 +33,8 @@ Extra objects in the line:
 
 `--config vit_h14 --fp8` is BASELINE config 5's line: `dtype: "fp8"` with `dtype_detail` saying which GEMMs run in which format
 (forward and dX GEMMs on fp8 operands; the weight-gradient GEMMs, attention and LayerNorm in bf16) and `roof` naming the peak the
-timed fp8 kernel is priced against: 2,516.6 TFLOP/s for the non-scaled K = 32 fp8 forms, 5,033.2 for the K = 128 form
-(VITK_FP8_K128=1).  The default line (no flags) is the bf16 headline and is unchanged by any of this.
+timed fp8 kernel is priced against: 5,033.2 TFLOP/s for the K = 128 form (the default), 2,516.6 for the non-scaled K = 32 fp8
+forms (VITK_FP8_K128=0).  The default line (no flags) is the bf16 headline and is unchanged by any of this.
 """
 from __future__ import annotations
 
@@ -253,7 +253,7 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5's precision (vit_pytorch_amd.fp8.enable_fp8): e4m3 operands for the four forward GEMMs of a "
                          "layer, e5m2 gradients x e4m3 weights for its four dX GEMMs; weight-gradient GEMMs, attention and LayerNorm stay "
-                         "bf16.  VITK_FP8_K128=1 selects the K = 128 MFMA.  Not the headline metric (that one is bf16).")
+                         "bf16.  VITK_FP8_K128=0 selects the K = 32 MFMA forms (default: K = 128).  Not the headline metric (that one is bf16).")
     ap.add_argument("--repeats", type=int, default=3,
                     help="time the K-step region this many times and report the MEDIAN window (every repeat is exactly K steps "
                          "between barrier + synchronize; all of them are listed in ms_per_step_all)")

@@ -78,7 +78,7 @@ def fp8_calls(calls):
 
 @pytest.mark.parametrize("mode", ["fwd+dx+dw", "fwd+dx", "fwd"])
 def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
-    monkeypatch.delenv("VITK_FP8_K128", raising=False)
+    monkeypatch.setenv("VITK_FP8_K128", "0")
     backward, wgrad = mode != "fwd", mode == "fwd+dx+dw"
     m16, params = build(torch.bfloat16)
     y_ref, dx_ref, g_ref = reference(params, x)
@@ -129,7 +129,7 @@ def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
                 # per layer: o (fwd, e4m3, recorded), 4 gradients (e5m2, recorded), 4 saved activations re-quantised (e4m3, not recorded)
                 assert len(qs) == 9 * DEPTH and sum(1 for q in qs if q[3] == K.FMT_E4M3 and not q[2]) == 4 * DEPTH
             assert not [c for c in calls if c[0] in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum")]
-        assert not any(c[5] for c in f)                                  # K = 128 flavour is opt-in
+        assert not any(c[5] for c in f)                                  # VITK_FP8_K128=0: the K = 32 forms
         # numerics of the plumbing: fp8-sized distance from the 16-bit run and from the f32 oracle
         e_y, e_dx, e_g = rel(y2, y16), rel(dx2, dx16), worst_grad(g2, g16)
         print(f"fp8 ({mode}) vs 16-bit: out {e_y:.2e} dx {e_dx:.2e} worst grad {e_g:.2e}; vs f32 oracle: out {rel(y2, y_ref):.2e}")
@@ -147,7 +147,7 @@ def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
 
 
 def test_fp8_k128_switch_and_recompute(x, monkeypatch):
-    monkeypatch.setenv("VITK_FP8_K128", "1")
+    monkeypatch.delenv("VITK_FP8_K128", raising=False)             # the default: K = 128 wherever the reduction extent allows
     m8, _ = build(torch.bfloat16)
     enable_fp8(m8)
     assert m8._fp8.k128
