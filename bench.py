@@ -31,8 +31,9 @@ Extra objects in the line:
   cpu_baseline  the CPU oracle (oracle/vit_oracle.py, kind "port") timed on this host's cores on a bounded
                 sample of the same workload (same model, f32, batch 32, best of a thread sweep), rank 0 at N = 1 only.
 
-`--config vit_h14 --fp8` is BASELINE config 5's line: `dtype: "fp8"` with `dtype_detail` saying which GEMMs run in which format
-(forward and dX GEMMs on fp8 operands; the weight-gradient GEMMs, attention and LayerNorm in bf16) and `roof` naming the peak the
+`--config vit_h14` is BASELINE config 5's line and runs in fp8 by default (`--precision bf16` for the 16-bit number): `dtype: "fp8"`
+with `dtype_detail` saying which GEMMs run in which format (all twelve GEMMs of a layer on fp8 operands; attention and LayerNorm in
+bf16) and `roof` naming the peak the
 timed fp8 kernel is priced against: 5,033.2 TFLOP/s for the K = 128 form (the default), 2,516.6 for the non-scaled K = 32 fp8
 forms (VITK_FP8_K128=0).  The default line (no flags) is the bf16 headline and is unchanged by any of this.
 """
@@ -57,8 +58,8 @@ CONFIGS = {
     # name: (ctor kwargs, per-GPU batch)
     "vit_b16": (dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072), 256),
     "vit_l16": (dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096), 128),
-    # config 5's architecture and per-GPU batch (2048 / 8) in bf16; fits through the engine's activation recompute policy
-    # (engine._recompute_policy).  fp8 operands exist for the forward GEMMs only (fp8.py), so this is NOT config 5's fp8 number.
+    # config 5's architecture and per-GPU batch (2048 / 8); runs in fp8 by default (vit_pytorch_amd.fp8.enable_fp8: all twelve GEMMs of a
+    # layer on fp8 operands), `--precision bf16` for the 16-bit number beside it (that one fits through engine._recompute_policy)
     "vit_h14": (dict(image_size=336, patch_size=14, num_classes=1000, dim=1280, depth=32, heads=16, dim_head=80, mlp_dim=5120), 256),
 }
 
@@ -250,10 +251,12 @@ def main():
     ap.add_argument("--config", default="vit_b16", choices=list(CONFIGS) + ["navit"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (invalidates the headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16", "fp8"], default=None,
+                    help="GEMM operand precision; default: the one BASELINE.json quotes the config in (vit_b16 / vit_l16: bf16, vit_h14 = config 5: fp8)")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5's precision (vit_pytorch_amd.fp8.enable_fp8): e4m3 operands for the four forward GEMMs of a "
-                         "layer, e5m2 gradients x e4m3 weights for its four dX GEMMs; weight-gradient GEMMs, attention and LayerNorm stay "
-                         "bf16.  VITK_FP8_K128=0 selects the K = 32 MFMA forms (default: K = 128).  Not the headline metric (that one is bf16).")
+                         "layer, e5m2 gradients for its four dX and four dW GEMMs; attention and LayerNorm stay bf16.  Same as "
+                         "--precision fp8.  VITK_FP8_K128=0 selects the K = 32 MFMA forms (default: K = 128).  Not the headline metric (that one is bf16).")
     ap.add_argument("--repeats", type=int, default=3,
                     help="time the K-step region this many times and report the MEDIAN window (every repeat is exactly K steps "
                          "between barrier + synchronize; all of them are listed in ms_per_step_all)")
@@ -280,6 +283,9 @@ def main():
     from vit_pytorch_amd.parallel import DataParallel
 
     cfg, batch = CONFIGS[args.config]
+    if args.precision is None:
+        args.precision = "fp8" if (args.fp8 or args.config == "vit_h14") else "bf16"
+    args.fp8 = args.precision == "fp8"
     if args.batch:
         batch = args.batch
     torch.manual_seed(0)  # identical init on every rank (DataParallel also broadcasts rank 0's)
@@ -373,9 +379,9 @@ def main():
             "ms_per_step": round(ms, 3), "ms_per_step_all": [round(d / args.steps * 1e3, 3) for d in dts],
             "weight_cache_rebuild_ms": round(weight_cache_rebuild_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": prec, "data": "synthetic (randn images, randint labels, random-init weights)",
-            **({"dtype_detail": "e4m3 x e4m3 forward GEMMs (QKV, out-projection, FF1, FF2), e5m2 gradients x e4m3 weights for the four dX GEMMs, "
-                                "per-tensor delayed scaling, f32 accumulation; weight-gradient GEMMs, attention, LayerNorm and the residual "
-                                "streams in bf16 / f32" + ("; K = 128 MFMA" if k128 else "; K = 32 MFMA forms"),
+            **({"dtype_detail": "e4m3 x e4m3 forward GEMMs (QKV, out-projection, FF1, FF2), e5m2 gradients x e4m3 weights^T for the four dX GEMMs, "
+                                "e5m2 gradients^T x e4m3 activations for the four dW GEMMs, per-tensor delayed scaling, f32 accumulation; attention, "
+                                "LayerNorm and the residual streams in bf16 / f32" + ("; K = 128 MFMA" if k128 else "; K = 32 MFMA forms"),
                 "roof": roof_name} if args.fp8 else {}),
             "memory": {"peak_allocated_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                        "peak_reserved_gib": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
@@ -386,7 +392,8 @@ def main():
             "per_gpu_images_per_s": round(value / world, 2),
             "model": {"gflop_per_image_fwd_bwd": round(gf, 3), "tflops_per_gpu": round(value / world * gf / 1e3, 2),
                       "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
-                      **({"frac_note": "whole-step fraction is of the bf16 peak (a third of the GEMM work and the attention run in bf16)"} if args.fp8 else {})},
+                      **({"frac_note": "whole-step fraction is of the bf16 peak 2516.6 TF/s (the number comparable with the bf16 line); of the fp8 roof named in `roof` it is "
+                                       + str(round(value / world * gf / 1e3 / peak, 4))} if args.fp8 else {})},
             "roofline": {"bound": "mfma", "kernel": ("gemm_nt256pp_kernel<EPI_BIAS_GELU, fp8> (FF1 on e4m3 operands)" if args.fp8 else
                                                      "gemm_ntp_kernel<EPI_BIAS_GELU> (persistent NT GEMM, FF1: tokens x mlp_dim x dim at this batch)"),
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "roof": roof_name,

@@ -76,10 +76,12 @@ def fp8_calls(calls):
     return [c[1] for c in calls if c[0] == "gemm_nt_fp8_v2"]
 
 
-@pytest.mark.parametrize("mode", ["fwd+dx+dw", "fwd+dx", "fwd"])
+@pytest.mark.parametrize("mode", ["fwd+dx+dw", "fwd+dx+dw/requantise", "fwd+dx", "fwd"])
 def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
     monkeypatch.setenv("VITK_FP8_K128", "0")
-    backward, wgrad = mode != "fwd", mode == "fwd+dx+dw"
+    lean = mode == "fwd+dx+dw"             # the forward's e4m3 copies are kept for the weight-gradient GEMMs (the default)
+    monkeypatch.setenv("VITK_FP8_LEAN", "1" if lean else "0")
+    backward, wgrad = mode != "fwd", mode.startswith("fwd+dx+dw")
     m16, params = build(torch.bfloat16)
     y_ref, dx_ref, g_ref = reference(params, x)
     m8, _ = build(torch.bfloat16)
@@ -126,8 +128,10 @@ def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
             if wgrad:
                 assert {c[1][:3] for c in calls if c[0] == "gemm_tn_fp8"} == {(M, DIM, MLP), (M, MLP, DIM), (M, DIM, I), (M, 3 * I, DIM)}
                 qs = [c[1] for c in calls if c[0] == "quantize_fp8_delayed"]
-                # per layer: o (fwd, e4m3, recorded), 4 gradients (e5m2, recorded), 4 saved activations re-quantised (e4m3, not recorded)
-                assert len(qs) == 9 * DEPTH and sum(1 for q in qs if q[3] == K.FMT_E4M3 and not q[2]) == 4 * DEPTH
+                # per layer: o (fwd, e4m3, recorded), 4 gradients (e5m2, recorded); the e4m3 activation operands are the copies the
+                # forward kept (lean) or the 4 saved 16-bit activations re-quantised (e4m3, not recorded)
+                requant = sum(1 for q in qs if q[3] == K.FMT_E4M3 and not q[2])
+                assert (len(qs), requant) == ((5 * DEPTH, 0) if lean else (9 * DEPTH, 4 * DEPTH))
             assert not [c for c in calls if c[0] in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum")]
         assert not any(c[5] for c in f)                                  # VITK_FP8_K128=0: the K = 32 forms
         # numerics of the plumbing: fp8-sized distance from the 16-bit run and from the f32 oracle
@@ -159,6 +163,7 @@ def test_fp8_k128_switch_and_recompute(x, monkeypatch):
         assert len(f) == 8 * DEPTH and all(c[5] == (c[2] % 128 == 0) for c in f) and any(c[5] for c in f)
         tn = [c[1] for c in calls if c[0] == "gemm_tn_fp8"]
         assert len(tn) == 4 * DEPTH and all(c[3] for c in tn)             # every weight-gradient GEMM takes the K = 128 form (tokens are zero-padded)
+        monkeypatch.setenv("VITK_FP8_LEAN", "0")                           # the recompute policy matters where 16-bit activations are saved
         # the activation-recompute policy (engine._recompute_policy, what lets ViT-H/14 batch 256 fit) composes with fp8: the backward
         # rebuilds the LayerNorm / GELU outputs it no longer finds saved (the delayed scales moved by one step in between, so the
         # two runs agree to quantisation noise, not bit for bit)

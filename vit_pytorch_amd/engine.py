@@ -41,6 +41,7 @@ Tensor = torch.Tensor
 F32 = torch.float32
 
 _sink_global = [None]
+_os_environ_get = __import__("os").environ.get
 
 
 def set_grad_sink(sink):
@@ -221,6 +222,14 @@ class TransformerFn(torch.autograd.Function):
         use8 = fp8 is not None and T in ops.HALF and drop_p == 0.0 and depth > 0 and lp[8] is not None and ops.fp8_gemm_ok(M, D, I, lp[7].shape[0])
         go8 = use8 and fp8.ready
         out8 = use8 and lp[3] is not None and ops.fp8_out_ok(M, D, I)       # the out-projection takes an e4m3 copy of the attention output
+        bwd8 = bool(use8 and out8 and fp8.backward and ops.fp8_bwd_ok(M, D, I, lp[7].shape[0]))
+        # "lean" saving: when THIS step's weight-gradient GEMMs will run on fp8 operands, the e4m3 copies the forward GEMMs just
+        # consumed ARE their activation operands -- they are kept (1 B / element) INSTEAD of the 16-bit LayerNorm / GELU outputs
+        # (2 B / element), which nothing else in the backward reads: no re-quantisation pass, no recompute pass, less memory.
+        # The scales they were made under are snapshotted (the fold at the end of this forward overwrites the live ones).
+        lean8 = bool(go8 and keep and bwd8 and fp8.wgrad and fp8.backward_will_be_fp8() and _os_environ_get("VITK_FP8_LEAN", "1") != "0"
+                     and all(ops.fp8_tn_ok(M, n_, k_) for n_, k_ in ((D, lp[7].shape[0]), (lp[7].shape[0], D), (D, I), (3 * I, D))))
+        scales_used = fp8.scales.clone() if lean8 else None
 
         def gemm8(a8, sc_a, w, out, Nn, Kd, epi, **kw):       # out (M, Nn) = a8 (M, Kd) e4m3 . e4m3(w)^T under the two per-tensor scales
             w8, wsc = fp8.weight(w)
@@ -238,10 +247,10 @@ class TransformerFn(torch.autograd.Function):
             if go8:
                 qkv = ops.empty((M, 3 * I), T, xs)
                 gemm8(a1_8, sc1, wqkv, qkv, 3 * I, D, L.EPI_NONE)
-                del a1_8
             else:
                 qkv = ops.linear_fwd(a1, wqkv, None, M)
             o, att_saved = ops.attn_fwd(qkv, B, N, heads, dim_head, scale, drop=site(li, 0))
+            o_8 = act_8 = None
             if out8:
                 sc4, am4 = fp8.slot(li, 3)
                 if go8:         # one pass over o: its e4m3 copy under last step's scale + this step's amax
@@ -249,7 +258,6 @@ class TransformerFn(torch.autograd.Function):
                     K.quantize_fp8_delayed(o, o_8, sc4, am4, K.FMT_E4M3)
                     x2 = ops.empty((M, D), F32, xs)
                     gemm8(o_8, sc4, wout, x2, D, I, L.EPI_RESID, bias=bout, resid=xs)
-                    del o_8
                 else:
                     K.quantize_fp8_delayed(o, None, None, am4, K.FMT_E4M3)
                     x2 = ops.linear_fwd(o, wout, bout, M, resid=xs)
@@ -269,10 +277,8 @@ class TransformerFn(torch.autograd.Function):
                 if go8:
                     act_8 = torch.empty((M, Fh), dtype=torch.uint8, device=xs.device)
                     gemm8(a2_8, sc2, w1, act, Fh, D, L.EPI_BIAS_GELU, bias=b1, aux=pre, c8=act_8, c8_scale=sc3, c8_amax64=am3)
-                    del a2_8
                     x3 = ops.empty((M, D), F32, xs)
                     gemm8(act_8, sc3, w2, x3, D, Fh, L.EPI_RESID, bias=b2, resid=x2)
-                    del act_8
                 else:       # recording pass: 16-bit operands, amax of the GELU output collected by the same epilogue
                     K.gemm_nt_fp8_ex(a2, D, w1, D, act, Fh, M, Fh, D, L.EPI_BIAS_GELU, a_is_fp8=False, bias=b1, aux=pre, c8_amax64=am3)
                     x3 = ops.linear_fwd(act, w2, b2, M, resid=x2)
@@ -281,8 +287,11 @@ class TransformerFn(torch.autograd.Function):
                 act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True, drop=site(li, 2))
                 x3 = ops.linear_fwd(act, w2, b2, M, resid=x2, drop=site(li, 3))
             if keep:
-                saved.append((xs, None, st1, qkv, o, att_saved, x2, None, st2, pre, None) if recompute
-                             else (xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act))
+                if lean8:
+                    saved.append((xs, None, st1, qkv, o, att_saved, x2, None, st2, pre, None, (a1_8, a2_8, act_8, o_8)))
+                else:
+                    saved.append((xs, None, st1, qkv, o, att_saved, x2, None, st2, pre, None, None) if recompute
+                                 else (xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act, None))
             xs = x3
         if use8:
             fp8.end_of_forward()
@@ -294,7 +303,8 @@ class TransformerFn(torch.autograd.Function):
         ctx.meta = (heads, dim_head, depth, B, N, D, x.dtype)
         ctx.drop = (drop_p, drop_seed)
         # (the backward re-quantises the saved activations under the FORWARD slots' scales: all four of them must be live -> out8)
-        ctx.fp8 = fp8 if (use8 and out8 and fp8.backward and ops.fp8_bwd_ok(M, D, I, lp[7].shape[0])) else None
+        ctx.fp8 = fp8 if bwd8 else None
+        ctx.f8_scales = scales_used
         ctx.save_for_backward(norm_w, norm_b, *[t for t in lp if t is not None])
         ctx.lp_mask = [t is not None for t in lp]
         return y
@@ -329,6 +339,7 @@ class TransformerFn(torch.autograd.Function):
         # (vitk_quantize_fp8_delayed: e5m2 copy under last step's scale + this step's amax).  The first backward only records.
         f8 = ctx.fp8
         I = heads * dim_head
+        ctx_scales = ctx.f8_scales.view(depth, -1, 2) if ctx.f8_scales is not None else None      # scales the kept e4m3 copies were made under
 
         def q5(li, slot, t):
             """(e5m2 copy, scale pair) of a gradient tensor under last step's scale, this step's amax recorded on the way; None (record
@@ -357,20 +368,26 @@ class TransformerFn(torch.autograd.Function):
                 K.colsum_partials(part, R, Kd, Kd, db)
             return dx
 
-        def dw(li, q, dyT, x, xslot, dW, db=None):
-            """dW (Nw, Kd) = dY^T X (+ db = colsum dY): on fp8 operands -- the e5m2 copy q already holds, an e4m3 copy of the saved
-            activation under its forward scale -- when the state asks for it and the shape is served, else the 16-bit GEMM."""
+        def dw(li, q, dyT, x, xslot, dW, db=None, x8=None):
+            """dW (Nw, Kd) = dY^T X (+ db = colsum dY): on fp8 operands -- the e5m2 copy q already holds and the e4m3 activation: the
+            copy the forward kept (x8, lean saving; its scale from the snapshot) or one re-made from the saved 16-bit tensor under
+            the live forward scale -- when the state asks for it and the shape is served, else the 16-bit GEMM."""
             Nw, Kd = dW.shape
             if q is None or not f8.wgrad or not ops.fp8_tn_ok(M, Nw, Kd):
+                if x is None:
+                    raise RuntimeError("vit_pytorch_amd: fp8 lean saving kept only the e4m3 activations, but this backward cannot run its weight-gradient GEMMs on fp8 (fp8 state changed between forward and backward?)")
                 ops.linear_dw(dyT, x, M, dW, db)
                 return
             dy8, sc = q
-            scx, _ = f8.slot(li, xslot)
-            x8 = torch.empty((M, Kd), dtype=torch.uint8, device=x.device)
-            K.quantize_fp8_delayed(x, x8, scx, None, K.FMT_E4M3)
+            if x8 is not None:
+                scx = ctx_scales[li, xslot]
+            else:
+                scx, _ = f8.slot(li, xslot)
+                x8 = torch.empty((M, Kd), dtype=torch.uint8, device=x.device)
+                K.quantize_fp8_delayed(x, x8, scx, None, K.FMT_E4M3)
             k128 = f8.k128
             splits = K.gemm_tn_fp8_splits(M, Nw, Kd, k128)
-            ws = ops.empty((splits * Nw * Kd,), F32, x)
+            ws = ops.empty((splits * Nw * Kd,), F32, x8)
             K.gemm_tn_fp8(dy8, Nw, x8, Kd, dW, Kd, M, Nw, Kd, ws, splits, alpha_y=sc[1:], alpha_x=scx[1:], k128=k128)
             if db is not None:
                 ops.colsum(dyT, M, Nw, db)
@@ -390,9 +407,11 @@ class TransformerFn(torch.autograd.Function):
         ctx.x_last = None
         for li in reversed(range(depth)):
             ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
-            xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act = ctx.saved[li]
+            xs, a1, st1, qkv, o, att_saved, x2, a2, st2, pre, act, kept8 = ctx.saved[li]
             ctx.saved[li] = None
-            if act is None:         # recompute mode (_recompute_policy): rebuild the GELU output and the LayerNorm outputs of this layer
+            a1_8, a2_8, act_8, o_8 = kept8 if kept8 is not None else (None, None, None, None)
+            del kept8
+            if act is None and act_8 is None:         # recompute mode (_recompute_policy): rebuild the GELU output and the LayerNorm outputs of this layer
                 act = ops.empty(pre.shape, T, pre)
                 K.gelu_fwd(pre, act)
                 a2 = ops.empty((M, D), T, x2)
@@ -405,7 +424,7 @@ class TransformerFn(torch.autograd.Function):
             q3 = q5(li, 4, gT) if f8 is not None else None
             dw2 = _grad_buf(w2)
             if f8 is not None:
-                fork.run(lambda: dw(li, q3, gT, act, 2, dw2), gT, act, dw2, q3)
+                fork.run(lambda: dw(li, q3, gT, act, 2, dw2, x8=act_8), gT, act, dw2, q3, act_8)
             else:
                 fork.run(lambda: ops.linear_dw(gT, act, M, dw2), gT, act, dw2)
             grads[base + 9] = dw2
@@ -423,12 +442,12 @@ class TransformerFn(torch.autograd.Function):
             db_todo = None if db_done else db1
             qd = q5(li, 5, dpre) if f8 is not None else None
             if f8 is not None:
-                fork.run(lambda: dw(li, qd, dpre, a2, 1, dw1, db_todo), dpre, a2, dw1, db1, qd)
+                fork.run(lambda: dw(li, qd, dpre, a2, 1, dw1, db_todo, x8=a2_8), dpre, a2, dw1, db1, qd, a2_8)
             else:
                 fork.run(lambda: ops.linear_dw(dpre, a2, M, dw1, db_todo), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
             da2 = dx8(qd, w1) if qd is not None else ops.linear_dx(dpre, w1, M)
-            del dpre, pre, act, qd
+            del dpre, pre, act, qd, act_8, a2_8
             g2, g2b = newg()
             dl2w, dl2b = _grad_buf(ln2w), _grad_buf(ln2b)
             dcol2 = bias_target(bout if wout is not None else None)
@@ -442,7 +461,7 @@ class TransformerFn(torch.autograd.Function):
                 q2 = q5(li, 6, g2T) if f8 is not None else None
                 dwo = _grad_buf(wout)
                 if f8 is not None:
-                    fork.run(lambda: dw(li, q2, g2T, o, 3, dwo), g2T, o, dwo, q2)
+                    fork.run(lambda: dw(li, q2, g2T, o, 3, dwo, x8=o_8), g2T, o, dwo, q2, o_8)
                 else:
                     fork.run(lambda: ops.linear_dw(g2T, o, M, dwo), g2T, o, dwo)
                 grads[base + 3] = dwo
@@ -456,12 +475,12 @@ class TransformerFn(torch.autograd.Function):
             qq = q5(li, 7, dqkv) if f8 is not None else None
             dwq = _grad_buf(wqkv)
             if f8 is not None:
-                fork.run(lambda: dw(li, qq, dqkv, a1, 0, dwq), dqkv, a1, dwq, qq)
+                fork.run(lambda: dw(li, qq, dqkv, a1, 0, dwq, x8=a1_8), dqkv, a1, dwq, qq, a1_8)
             else:
                 fork.run(lambda: ops.linear_dw(dqkv, a1, M, dwq), dqkv, a1, dwq)
             grads[base + 2] = dwq
             da1 = dx8(qq, wqkv) if qq is not None else ops.linear_dx(dqkv, wqkv, M)
-            del dqkv, do, qkv, o, qq
+            del dqkv, do, qkv, o, qq, o_8, a1_8
             g1, g1b = newg()
             dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
             dcol = bias_target(lp[(li - 1) * NLP + 10] if li > 0 else None)

@@ -105,6 +105,11 @@ class Fp8State:
             self._wt[id(w)] = ent
         return ent[1], sc
 
+    def backward_will_be_fp8(self) -> bool:
+        """Asked DURING a forward: will the backward of this step find gradient scales (a backward has recorded, and the fold at the
+        end of this forward turns the records into scales)?"""
+        return self.bwd_ready or self._bwd_recorded
+
     def end_of_forward(self):
         K.fp8_update_scales_fmt(self.amax, self.scales, self.depth * SLOTS_PER_LAYER, self.fmax)
         self.ready = True
