@@ -5,8 +5,10 @@ Kernel level: the one-pass delayed quantiser against torch's float8 casts (bit e
 DEQUANTISED operands (products of fp8 values are exact in f32, so only f32 accumulation order and the 16-bit output rounding
 remain: 4e-3).  Model level: ViT at BASELINE config 5's width (ViT-H/14: dim 1280, 16 heads of 80, mlp 5120, N = 577) and
 config 2's, with `enable_fp8`, against the goldens the REFERENCE produced in float32 (tests/golden/vit_h14_width.npz,
-vit_b16_width.npz).  Stated fp8 tolerance: logits within 6e-2, the gradient sample within 1.5e-1 relative L2 of the
-reference's f32 values (3-bit / 2-bit mantissa operands in 8 or all 12 of the GEMMs of a layer; measured values are printed).
+vit_b16_width.npz).  Stated fp8 tolerance: logits within 3e-2, the gradient sample within 5e-2 relative L2 of the
+reference's f32 values (3-bit / 2-bit mantissa operands in 8 or all 12 of the GEMMs of a layer).  Measured on the MI355X
+(profiles/r03_fp8_tests*.log): logits 8.1e-3 (ViT-H/14 width) / 1.1e-2 (ViT-B/16 width), gradient sample 1.3e-2 .. 1.8e-2 -- the
+16-bit run of the same model: 3.6e-3 / 4.8e-3, the reference's own bf16 run: 4.6e-3 .. 5.1e-3 on the logits.
 The weight-gradient GEMM (gemm_tn_fp8.hip, ds_read_b64_tr_b8 fragments) has its own test against the dequantised product."""
 import os
 
@@ -231,5 +233,5 @@ def test_fp8_training_step_against_reference_golden(name, k128, wgrad, monkeypat
     print(f"{name} K128={k128} wgrad={wgrad}: vs reference f32 -- fp8 logits {e3:.2e} grad sample {g3:.2e} (step 2: {e2:.2e} / {g2:.2e}); "
           f"16-bit run {e16r:.2e} / {g16r:.2e}; reference's own bf16 logits {e_ref16:.2e}")
     for e, g in ((e2, g2), (e3, g3)):
-        assert e < 6e-2 and g < 1.5e-1, (e, g)
+        assert e < 3e-2 and g < 5e-2, (e, g)
     assert e3 > e16r                                                                   # fp8 did run (it cannot be as close as 16 bit)
