@@ -216,3 +216,62 @@ def test_chunk_plan_world_size_8_depth_24(lpc, late_layer):
     a gradient that arrives outside the sink after its chunk has gone out (late_layer) is reduced again on its own, result = average."""
     port = _free_port()
     mp.spawn(_worker8, args=(8, port, lpc, late_layer), nprocs=8, join=True)
+
+
+# ---- the REAL fused Transformer stage under DataParallel, 2 ranks (kernels replaced by the CPU doubles) --------------------------------
+class _EngineModel(torch.nn.Module):
+    """Named like the drop-in ViT (to_patch_embedding / transformer / mlp_head) so that the sink orders its segments as it does there;
+    the transformer IS vit_pytorch_amd.vit.Transformer running engine.TransformerFn."""
+
+    def __init__(self):
+        super().__init__()
+        from vit_pytorch_amd.vit import Transformer
+        self.to_patch_embedding = torch.nn.Linear(24, 64)
+        self.transformer = Transformer(dim=64, depth=4, heads=2, dim_head=32, mlp_dim=128)
+        self.mlp_head = torch.nn.Linear(64, 5)
+
+    def forward(self, x):
+        return self.mlp_head(self.transformer(self.to_patch_embedding(x)).mean(dim=1))
+
+
+def _engine_worker(rank, world, port):
+    import _kernel_doubles as KD
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with KD.installed():
+            torch.manual_seed(7)
+            full = torch.randn(world * 3, 16, 24)                       # the global batch; rank r owns rows 3r .. 3r + 2
+            torch.manual_seed(50 + rank)                                # different init per rank: the broadcast must fix it
+            model = _EngineModel().to(torch.bfloat16)
+            dp = DataParallel(model, layers_per_chunk=3)
+            dp.sink.log = []
+            x = full[3 * rank:3 * rank + 3].to(torch.bfloat16)
+            dp.backward(dp(x).float().square().mean())
+            # the stack's gradients left in two in-backward chunks (after layers 3 and 0) + the rest: several collectives, not one
+            assert len(dp.sink.log) >= 3, dp.sink.log
+            # ... which tile the flat buffer exactly once; the head here is a plain nn.Linear (autograd hands its gradients over after the
+            # segment that holds its slots has gone out), so finish_step re-reduces exactly those two slots on their own
+            tiles = [seg for seg in dp.sink.log if seg[1] > 320]
+            assert [o for o, _ in tiles] == [0] + [o + n for o, n in tiles][:-1] and sum(n for _, n in tiles) == dp.sink.total, dp.sink.log
+            assert sorted(n for _, n in dp.sink.log if n <= 320) == [5, 320], dp.sink.log
+            got = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.sink.params, dp.sink.views))
+            # expected: the same model on the WHOLE batch in one process (mean loss over 2x the samples = average of the rank losses)
+            E.set_grad_sink(None)
+            model.zero_grad(set_to_none=True)
+            model(full.to(torch.bfloat16)).float().square().mean().backward()
+            for n, p in model.named_parameters():
+                ref = p.grad.detach().float()
+                err = (got[n] - ref).norm() / ref.norm().clamp_min(1e-12)
+                assert err < 3e-2, (n, float(err))                      # 16-bit gradients summed in a different order
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_engine_stage_under_data_parallel_two_ranks_gloo():
+    """engine.TransformerFn (host logic: gradient buffers from the sink, layer ticks, per-chunk stage announcements) with the kernels
+    replaced by tests/_kernel_doubles.py, wrapped in DataParallel on 2 gloo ranks: gradients equal the single-process full-batch run."""
+    port = _free_port()
+    mp.spawn(_engine_worker, args=(2, port), nprocs=2, join=True)
