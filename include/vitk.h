@@ -194,7 +194,9 @@ int vitk_fp8_update_scales(uint32_t* amax64, float* scales2, int64_t nslots, voi
  * vitk_gemm_nt_fp8_v2: vitk_gemm_nt_fp8_ex with (a) a_kind = 0 (A in the 16-bit type), 1 (e4m3) or 2 (OCP e5m2: gradients;
  *   W stays e4m3, v_mfma_f32_16x16x32_fp8_bf8; NONE and GELU_BWD epilogues -- dX = dY . W of the four Linear layers),
  *   (b) colsum_partials for the GELU_BWD epilogue (vitk_gemm_nt_fp8_colsum_rows(M, N, K, ldc) rows of N floats; fold with
- *   vitk_colsum_partials), (c) flags bit 0: the K = 128 instruction (v_mfma_f32_16x16x128_f8f6f4 with unit block scales, the
+ *   vitk_colsum_partials); with GELU_BWD c8 / c8_scale / c8_amax64 give the output an e5m2 copy and an amax record (the operand
+ *   of the next dX / dW GEMMs); with BIAS_GELU, fp8 operands and a c8 output, C may be null (only the e4m3 copy is wanted),
+ *   (c) flags bit 0: the K = 128 instruction (v_mfma_f32_16x16x128_f8f6f4 with unit block scales, the
  *   only fp8 form above the bf16 matrix rate on gfx950; K %% 128 == 0, 1-byte A).
  * vitk_quantize_fp8_delayed: ONE pass over a 16-bit / f32 tensor that (out8 != null) writes out8 = fp8(clamp(x * scale2[0]))
  *   -- fmt 0 = e4m3 (+-448), 1 = e5m2 (+-57344), round to nearest even -- under the scale decided BEFORE this step and

@@ -55,7 +55,8 @@ def _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials=None):
         acc = acc + bias.float()
     if epilogue == L.EPI_BIAS_GELU:
         aux.view(M, N).copy_(acc)                                   # pre-activation, rounded to T
-        C.view(M, N).copy_(O.gelu_fwd(aux.view(M, N).float()))
+        if C is not None:                                           # (fp8, lean saving: only the e4m3 copy is wanted)
+            C.view(M, N).copy_(O.gelu_fwd(aux.view(M, N).float()))
     elif epilogue == L.EPI_RESID:
         assert C.dtype == F32 and resid.dtype == F32
         C.view(M, N).copy_(acc + resid.view(M, N))
@@ -83,6 +84,7 @@ def gemm_nt_fp8_v2(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue, *, a_kind, bias=N
                    alpha_a=None, alpha_w=None, c8=None, c8_scale=None, c8_amax64=None, k128=False):
     assert lda == Kd and ldw == Kd and ldc == N and Kd % 64 == 0 and (not k128 or Kd % 128 == 0)
     assert W.dtype == torch.uint8 and W.shape == (N, Kd)
+    assert C is not None or (epilogue == L.EPI_BIAS_GELU and c8 is not None and a_kind != K.A_16BIT)
     CALLS.append(("gemm_nt_fp8_v2", (M, N, Kd, epilogue, a_kind, bool(k128))))
     if a_kind == K.A_16BIT:
         raise AssertionError("the doubles expect the recording pass through gemm_nt_fp8_ex")
@@ -91,10 +93,18 @@ def gemm_nt_fp8_v2(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue, *, a_kind, bias=N
     acc = (a @ _deq(W, E4M3).t()) * al
     _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials)
     if epilogue == L.EPI_BIAS_GELU:
+        g = O.gelu_fwd(aux.view(M, N).float()).to(aux.dtype) if C is None else C.view(M, N)
+        if c8_amax64 is not None:
+            _rec_amax(c8_amax64, g.float())
+        if c8 is not None:
+            c8.view(M, N).copy_(_q8(g, float(c8_scale[0]), E4M3))
+    elif epilogue == L.EPI_GELU_BWD:                                # e5m2 copy of the gradient the epilogue just formed
         if c8_amax64 is not None:
             _rec_amax(c8_amax64, C.view(M, N).float())
         if c8 is not None:
-            c8.view(M, N).copy_(_q8(C.view(M, N), float(c8_scale[0]), E4M3))
+            c8.view(M, N).copy_(_q8(C.view(M, N), float(c8_scale[0]), E5M2))
+    else:
+        assert c8 is None and c8_amax64 is None
 
 
 def gemm_nt_fp8_ex(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue, *, a_is_fp8, bias=None, resid=None, aux=None, alpha=1.0, alpha_a=None,

@@ -131,7 +131,8 @@ def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
                 # per layer: o (fwd, e4m3, recorded), 4 gradients (e5m2, recorded); the e4m3 activation operands are the copies the
                 # forward kept (lean) or the 4 saved 16-bit activations re-quantised (e4m3, not recorded)
                 requant = sum(1 for q in qs if q[3] == K.FMT_E4M3 and not q[2])
-                assert (len(qs), requant) == ((5 * DEPTH, 0) if lean else (9 * DEPTH, 4 * DEPTH))
+                # (the e5m2 copy of dpre comes out of the GELU' epilogue: 3 gradient passes a layer, not 4)
+                assert (len(qs), requant) == ((4 * DEPTH, 0) if lean else (8 * DEPTH, 4 * DEPTH))
             assert not [c for c in calls if c[0] in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum")]
         assert not any(c[5] for c in f)                                  # VITK_FP8_K128=0: the K = 32 forms
         # numerics of the plumbing: fp8-sized distance from the 16-bit run and from the f32 oracle

@@ -120,6 +120,16 @@ def test_gemm_e5m2_gradients_against_dequantised_product(M, Kd, Nw, k128):
     db = torch.empty(Kd, dtype=BF, device=DEV)
     K.colsum_partials(part, R, Kd, Kd, db)
     assert rel(db, C.double().sum(0)) < 4e-3                                # column sums of the rounded output, as the 16-bit kernel's
+    # the same epilogue also emits the e5m2 copy of its output (the operand of the next dX and dW GEMMs) and records its amax
+    c8 = torch.zeros(M, Kd, dtype=torch.uint8, device=DEV)
+    c8s = torch.tensor([3.0e4, 1 / 3.0e4], device=DEV)                      # C is ~1e-4-sized: the top of the range saturates
+    am = torch.zeros(64, dtype=torch.int32, device=DEV)
+    C2 = torch.empty_like(C)
+    K.gemm_nt_fp8_v2(dY8, Nw, W8, Nw, C2, Kd, M, Kd, Nw, L.EPI_GELU_BWD, a_kind=K.A_E5M2, aux=pre, partials=part, alpha_a=sa[1:],
+                     alpha_w=sw[1:], c8=c8, c8_scale=c8s, c8_amax64=am, k128=k128)
+    assert torch.equal(C2, C)
+    assert torch.equal(c8.view(E5M2).float(), (C.float() * c8s[0]).clamp(-57344, 57344).to(E5M2).float())
+    assert float(am.view(torch.float32).max()) == float(C.float().abs().max())
     with pytest.raises(L.VitkError):                                        # e5m2 operands are a backward thing: no bias / residual epilogues
         K.gemm_nt_fp8_v2(dY8, Nw, W8, Nw, C, Kd, M, Kd, Nw, L.EPI_BIAS, a_kind=K.A_E5M2, bias=db)
 
@@ -151,6 +161,12 @@ def test_k128_flavour_forward_epilogues(M, N, Kd):
     assert rel(aux, pre) < 4e-3 and rel(C, torch.nn.functional.gelu(pre)) < 4e-3
     assert torch.equal(c8.view(E4M3).float(), (C.float() * 8.0).clamp(-448, 448).to(E4M3).float())
     assert float(am.view(torch.float32).max()) == float(C.float().abs().max())
+    # lean saving: the 16-bit GELU output is not wanted (C = None) -- pre-activation and e4m3 copy unchanged
+    aux2 = torch.empty_like(aux); c82 = torch.zeros_like(c8)
+    K.gemm_nt_fp8_v2(A8, Kd, W8, Kd, None, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=aux2, c8=c82, c8_scale=c8s, k128=True, **kw)
+    assert torch.equal(aux2, aux) and torch.equal(c82, c8)
+    with pytest.raises(L.VitkError):
+        K.gemm_nt_fp8_v2(A8, Kd, W8, Kd, None, N, M, N, Kd, L.EPI_BIAS_GELU, bias=bias, aux=aux2, k128=True, **kw)      # nothing to produce
     out = torch.empty(M, N, device=DEV)
     K.gemm_nt_fp8_v2(A8, Kd, W8, Kd, out, N, M, N, Kd, L.EPI_RESID, bias=bias, resid=resid, k128=True, **kw)
     assert rel(out, resid.double() + pre) < 1e-5

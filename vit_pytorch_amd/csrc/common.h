@@ -156,6 +156,15 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v, float sc) {
     w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
     return (unsigned)w;
 }
+// the same for OCP e5m2 ("bf8"; gradients): clamp at +-57344, v_cvt_pk_bf8_f32
+__device__ __forceinline__ unsigned pack_bf8x4(f32x4 v, float sc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * sc, -57344.f, 57344.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w, true);
+    return (unsigned)w;
+}
 __device__ __forceinline__ float absmax4(f32x4 v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
 
 // ---- counter-based dropout decisions for the fused paths ------------------------------------------------------------

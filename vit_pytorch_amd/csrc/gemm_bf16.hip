@@ -652,7 +652,7 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                         for (int e = 0; e < 8; ++e)
                             g8[e] = drop_keep(hrow, (unsigned)(ncol + e), drop_t) ? (__bf16)((float)g8[e] * inv_keep) : (__bf16)0.f;
                     }
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
+                    if (Cv) *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;      // (null: only the e4m3 copy is wanted)
                     if (f8.p || f8.amax) {        // e4m3 copy of the activation for the next GEMM (+ this step's amax)
                         const f32x4 lo = {(float)g8[0], (float)g8[1], (float)g8[2], (float)g8[3]};
                         const f32x4 hi = {(float)g8[4], (float)g8[5], (float)g8[6], (float)g8[7]};
@@ -682,10 +682,20 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
                         cs[e] += (float)g8[e]; cs[e + 1] += (float)g8[e + 1];      // of the ROUNDED values: what a later colsum(C) would read
                     }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(Cv) + o) = g8;
+                    if (f8.p || f8.amax) {        // e5m2 copy of this gradient for the two GEMMs that read it (+ this step's amax)
+                        const f32x4 lo = {(float)g8[0], (float)g8[1], (float)g8[2], (float)g8[3]};
+                        const f32x4 hi = {(float)g8[4], (float)g8[5], (float)g8[6], (float)g8[7]};
+                        if (f8.p) {
+                            const float sc8 = *f8.scale;
+                            unsigned* d8 = reinterpret_cast<unsigned*>(f8.p + o);
+                            d8[0] = pack_bf8x4(lo, sc8); d8[1] = pack_bf8x4(hi, sc8);
+                        }
+                        if (f8.amax) f8max = fmaxf(f8max, fmaxf(absmax4(lo), absmax4(hi)));
+                    }
                 }
             }
         }
-        if constexpr (EPI == VITK_EPI_BIAS_GELU) {
+        if constexpr (EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_GELU_BWD) {
             if (f8.amax) {     // one atomic per workgroup, through the first words of its (idle) LDS
                 f8max = wave_max(f8max);
                 __syncthreads();
@@ -946,9 +956,12 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     if (f8kind && !fp8) VITK_FAIL(VITK_E_ARG, "gemm_nt: e5m2 / K = 128 flavours need 1-byte operands");
     if ((f8kind & 1) && epilogue != VITK_EPI_NONE && epilogue != VITK_EPI_GELU_BWD)
         VITK_FAIL(VITK_E_ARG, "gemm_nt_fp8: e5m2 operands (gradients) come with the NONE and GELU_BWD epilogues only (got %d)", epilogue);
-    if ((f8.p || f8.amax) && epilogue != VITK_EPI_BIAS_GELU) VITK_FAIL(VITK_E_ARG, "gemm_nt: the fp8 side output exists in the BIAS_GELU epilogue only");
+    if ((f8.p || f8.amax) && epilogue != VITK_EPI_BIAS_GELU && epilogue != VITK_EPI_GELU_BWD)
+        VITK_FAIL(VITK_E_ARG, "gemm_nt: the fp8 side output exists in the BIAS_GELU (e4m3) and GELU_BWD (e5m2) epilogues only");
     if (f8.p && (!f8.scale || (ldc & 7))) VITK_FAIL(VITK_E_ARG, "gemm_nt: fp8 side output needs a scale and ldc %% 8 == 0");
-    if (!A || !W || !C) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: null pointer");
+    // C may be null where the 16-bit output is not wanted: fp8 operands, BIAS_GELU, with the e4m3 copy as the product
+    const bool c_optional = fp8 && epilogue == VITK_EPI_BIAS_GELU && f8.p;
+    if (!A || !W || (!C && !c_optional)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: null pointer");
     if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
     const unsigned drop_t = drop_thresh(drop_p);
     const float inv_keep = 1.0f / (1.0f - drop_p);

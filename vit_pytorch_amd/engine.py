@@ -273,7 +273,8 @@ class TransformerFn(torch.autograd.Function):
                 Fh = w1.shape[0]
                 a2_8 = torch.empty((M, D), dtype=torch.uint8, device=xs.device) if go8 else None
                 st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2, f8=(a2_8, sc2, am2))
-                act = ops.empty((M, Fh), T, xs); pre = ops.empty((M, Fh), T, xs)
+                pre = ops.empty((M, Fh), T, xs)
+                act = None if lean8 else ops.empty((M, Fh), T, xs)      # lean saving: nothing reads the 16-bit GELU output -- FF2 and dW2 take the e4m3 copy
                 if go8:
                     act_8 = torch.empty((M, Fh), dtype=torch.uint8, device=xs.device)
                     gemm8(a2_8, sc2, w1, act, Fh, D, L.EPI_BIAS_GELU, bias=b1, aux=pre, c8=act_8, c8_scale=sc3, c8_amax64=am3)
@@ -352,8 +353,9 @@ class TransformerFn(torch.autograd.Function):
             K.quantize_fp8_delayed(t, t8, sc, am, K.FMT_E5M2)
             return t8, sc
 
-        def dx8(q, W, epi=L.EPI_NONE, pre=None, db=None):
-            """dX (M, Kd) = dY (M, Nw) . W (Nw, Kd) [* gelu'(pre), column sums -> db] from q = q5(dY)."""
+        def dx8(q, W, epi=L.EPI_NONE, pre=None, db=None, c8=None):
+            """dX (M, Kd) = dY (M, Nw) . W (Nw, Kd) [* gelu'(pre), column sums -> db] from q = q5(dY); c8 = (bytes, scale, amax words):
+            the GELU' epilogue also writes the e5m2 copy of dX (and records its amax) for the two GEMMs that read it next."""
             dy8, sc = q
             Nw, Kd = W.shape
             w8t, wsc = f8.weight_t(W)
@@ -362,8 +364,9 @@ class TransformerFn(torch.autograd.Function):
             if db is not None:
                 R = K.gemm_nt_fp8_colsum_rows(M, Kd, Nw, Kd)
                 part = ops.empty((R * Kd,), F32, dy8)
+            c8b, c8s, c8a = c8 if c8 is not None else (None, None, None)
             K.gemm_nt_fp8_v2(dy8, Nw, w8t, Nw, dx, Kd, M, Kd, Nw, epi, a_kind=K.A_E5M2, aux=pre, partials=part,
-                             alpha_a=sc[1:], alpha_w=wsc[1:], k128=f8.k128 and Nw % 128 == 0)
+                             alpha_a=sc[1:], alpha_w=wsc[1:], c8=c8b, c8_scale=c8s, c8_amax64=c8a, k128=f8.k128 and Nw % 128 == 0)
             if db is not None:
                 K.colsum_partials(part, R, Kd, Kd, db)
             return dx
@@ -432,15 +435,21 @@ class TransformerFn(torch.autograd.Function):
                 grads[base + 10] = dcol          # written by the LayerNorm backward above this layer (bias_target)
             dw1 = _grad_buf(w1)
             db1 = _grad_buf(b1) if b1 is not None else None
-            if q3 is not None:
-                dpre, db_done = dx8(q3, w2, L.EPI_GELU_BWD, pre, db1), True
+            qd = None
+            if q3 is not None:      # the GELU' epilogue emits the e5m2 copy of dpre itself (no quantisation pass over the widest gradient)
+                sc5, am5 = f8.slot(li, 5)
+                dpre_8 = torch.empty((M, w2.shape[1]), dtype=torch.uint8, device=gT.device)
+                dpre, db_done = dx8(q3, w2, L.EPI_GELU_BWD, pre, db1, c8=(dpre_8, sc5, am5)), True
+                qd = (dpre_8, sc5)
+                del dpre_8
             elif db1 is not None:
                 dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, db=db1, drop=site(li, 2))   # b1's gradient out of the GEMM epilogue
             else:
                 dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, drop=site(li, 2)), True
             del q3
             db_todo = None if db_done else db1
-            qd = q5(li, 5, dpre) if f8 is not None else None
+            if qd is None and f8 is not None:
+                qd = q5(li, 5, dpre)          # recording pass (no scales yet): amax only
             if f8 is not None:
                 fork.run(lambda: dw(li, qd, dpre, a2, 1, dw1, db_todo, x8=a2_8), dpre, a2, dw1, db1, qd, a2_8)
             else:
