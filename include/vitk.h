@@ -125,6 +125,8 @@ int vitk_colsum(const void* x, int xdt, int64_t rows, int64_t cols, int64_t ld,
 #define VITK_EPI_BIAS 1        /* C = acc + bias[n]                                             */
 #define VITK_EPI_BIAS_GELU 2   /* aux = acc + bias (pre-activation, bf16); C = gelu_erf(aux)    */
 #define VITK_EPI_RESID 3       /* Cf32 = resid_f32 + acc (+ bias[n] if bias)  (C: f32)          */
+#define VITK_EPI_RESID16 5     /* C16 = T(resid16 + acc (+ bias[n])): the `+ x` of vit.py:80-81 with the forward residual stream in the
+                                  16-bit type (opt-in, VITK_FWD_STREAM=16); `resid` then points at 16-bit data; persistent kernel only */
 #define VITK_EPI_GELU_BWD 4    /* C = acc * gelu'(aux[m][n])   (aux = saved pre-activation)     */
 
 /* C[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  A, W bf16, K-contiguous ("NT").

@@ -51,7 +51,7 @@ def _w_plain(W, ldw, N, Kd):
 
 
 def _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials=None):
-    if epilogue in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_RESID) and bias is not None:
+    if epilogue in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_RESID, L.EPI_RESID16) and bias is not None:
         acc = acc + bias.float()
     if epilogue == L.EPI_BIAS_GELU:
         aux.view(M, N).copy_(acc)                                   # pre-activation, rounded to T
@@ -60,6 +60,9 @@ def _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials=None):
     elif epilogue == L.EPI_RESID:
         assert C.dtype == F32 and resid.dtype == F32
         C.view(M, N).copy_(acc + resid.view(M, N))
+    elif epilogue == L.EPI_RESID16:
+        assert C.dtype == resid.dtype and C.dtype != F32
+        C.view(M, N).copy_(acc + resid.view(M, N).float())
     elif epilogue == L.EPI_GELU_BWD:
         C.view(M, N).copy_(O.gelu_bwd(acc, aux.view(M, N).float()))
         if partials is not None:

@@ -72,6 +72,25 @@ def test_16bit_stage_against_the_oracle(x):
     assert "gemm_nt_fp8_v2" not in names and "quantize_fp8_delayed" not in names
 
 
+def test_16bit_forward_stream_option(x, monkeypatch):
+    """VITK_FWD_STREAM=16: the residual stream of the forward in the parameter dtype -- both residual GEMMs of a layer take the RESID16
+    epilogue (16-bit residual in, 16-bit sum out), LayerNorm reads the 16-bit stream, no float32 (M, D) tensor is produced."""
+    m, params = build(torch.bfloat16)
+    y_ref, dx_ref, g_ref = reference(params, x)
+    with KD.installed() as calls:
+        y32, dx32, g32 = run(m, x)
+        n32 = [c[1][3] for c in calls if c[0] == "gemm_nt_bf16"]
+        assert n32.count(L.EPI_RESID) == 2 * DEPTH and n32.count(L.EPI_RESID16) == 0
+        del calls[:]
+        monkeypatch.setenv("VITK_FWD_STREAM", "16")
+        y, dx, g = run(m, x)
+        n16 = [c[1][3] for c in calls if c[0] == "gemm_nt_bf16"]
+        assert n16.count(L.EPI_RESID16) == 2 * DEPTH and n16.count(L.EPI_RESID) == 0
+    assert not torch.equal(y, y32)
+    assert rel(y, y_ref) < 3e-2 and rel(dx, dx_ref) < 6e-2 and worst_grad(g, g_ref) < 8e-2, (rel(y, y_ref), rel(dx, dx_ref), worst_grad(g, g_ref))
+    print(f"16-bit forward stream vs f32 oracle: out {rel(y, y_ref):.2e} (f32 stream {rel(y32, y_ref):.2e}), worst grad {worst_grad(g, g_ref):.2e} ({worst_grad(g32, g_ref):.2e})")
+
+
 def fp8_calls(calls):
     return [c[1] for c in calls if c[0] == "gemm_nt_fp8_v2"]
 

@@ -982,6 +982,11 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
         // VITK_NTP_EPIS = bit mask over VITK_EPI_* overrides (GELU_BWD always: its column-sum rows follow the persistent plan).
         const NtpPlan q = ntp_plan(M, N, K, ldc, aux);
         const unsigned epis = getenv("VITK_NTP_EPIS") ? (unsigned)atoi(getenv("VITK_NTP_EPIS")) : 0x1fu;
+        if (epilogue == VITK_EPI_RESID16) {       // 16-bit forward residual stream (opt-in): the persistent kernel only
+            if (!q.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: EPI_RESID16 is served by the persistent kernel only (vitk_gemm_nt_plan() says which shapes)");
+            if (!resid || !aligned8(resid) || drop_t) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_RESID16 needs an 8-byte aligned 16-bit resid and no dropout");
+            return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, 0u, 0u, 1.0f, stream);
+        }
         if (q.ok && epilogue >= 0 && epilogue <= 4 && (((epis >> epilogue) & 1u) || epilogue == VITK_EPI_GELU_BWD)) {
             switch (epilogue) {
                 case VITK_EPI_NONE: break;

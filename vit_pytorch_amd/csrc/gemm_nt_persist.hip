@@ -177,7 +177,7 @@ __device__ __forceinline__ bf16x8 q_narrow8(q_f32x8 v) {
 }
 
 template <int EPI> __host__ __device__ constexpr bool q_has_bias() {
-    return EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_RESID;
+    return EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_RESID || EPI == VITK_EPI_RESID16;
 }
 
 __device__ __forceinline__ unsigned q_dpp_xor1(unsigned v) {       // value of lane ^ 1 (quad_perm [1,0,3,2])
@@ -630,6 +630,36 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                         if (f + 2 < FMW) fetch(f + 2, r[f & 1]);
                     }
                 }
+            } else if constexpr (EPI == VITK_EPI_RESID16) {
+                // the f32-residual epilogue with the stream in the 16-bit type: same lane -> (row, 4 columns) map, 8-byte loads and
+                // stores (16 lanes = 128 contiguous bytes of a row); the sum is formed in f32 and rounded once
+                const bool colok = INT || ncol4 < p.N;
+                __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+                const __bf16* Rb = reinterpret_cast<const __bf16*>(p.resid);
+                bf16x4 r[2][4];
+                auto fetch = [&](int f, bf16x4 (&dst)[4]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int m = mrow0 + f * 16 + j;
+                        if (!INT) m = m < p.M ? m : p.M - 1;
+                        dst[j] = bf16x4{0, 0, 0, 0};
+                        if (colok) dst[j] = *reinterpret_cast<const bf16x4*>(Rb + (long long)m * p.ldc + ncol4);
+                    }
+                };
+                fetch(0, r[0]);
+                fetch(1, r[1]);
+#pragma unroll
+                for (int f = 0; f < FMW; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = mrow0 + f * 16 + j;
+                        f32x4 v = f32x4{acc[0][f][j], acc[1][f][j], acc[2][f][j], acc[3][f][j]} + b4;
+                        const bf16x4 rr = r[f & 1][j];
+                        v += f32x4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
+                        if (INT || (m < p.M && colok)) store4<__bf16>(Cb + (long long)m * p.ldc + ncol4, v);
+                    }
+                    if (f + 2 < FMW) fetch(f + 2, r[f & 1]);
+                }
             } else {
                 // after the pair exchange: even lanes own row r = mrow0 + 16 f + 2 pr, odd lanes row r + 1, columns ncol8 .. + 7
                 const int odd = fi & 1;
@@ -961,6 +991,7 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
         case VITK_EPI_BIAS_GELU: NTP_LAUNCH(VITK_EPI_BIAS_GELU); break;
         case VITK_EPI_RESID: NTP_LAUNCH(VITK_EPI_RESID); break;
         case VITK_EPI_GELU_BWD: NTP_LAUNCH(VITK_EPI_GELU_BWD); break;
+        case VITK_EPI_RESID16: NTP_LAUNCH(VITK_EPI_RESID16); break;
         default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: bad epilogue %d", epilogue);
     }
 #undef NTP_LAUNCH

@@ -77,6 +77,19 @@ def grad_stream_16() -> bool:
     return os.environ.get("VITK_GRAD_STREAM", "16") != "f32"
 
 
+def fwd_stream_16() -> bool:
+    """The FORWARD residual stream x (vit.py:80-81) in the parameter dtype instead of float32 -- what the reference itself does when it
+    runs in bfloat16.  Opt-in (VITK_FWD_STREAM=16): halves the bytes of the stream in the two residual GEMM epilogues and in the
+    LayerNorm forward / backward reads (~1 ms of the ViT-B/16 step by byte count; unmeasured when written), at the
+    reference-bf16's own accuracy instead of the f32 stream's."""
+    return os.environ.get("VITK_FWD_STREAM", "f32") == "16"
+
+
+def stream16_ok(M: int, D: int, I: int, Fh: int) -> bool:
+    """Both residual GEMMs of a layer -- (M, D) = o (M, I) . Wout^T and (M, D) = act (M, Fh) . W2^T -- on the persistent NT kernel."""
+    return I % 32 == 0 and Fh % 32 == 0 and D % 4 == 0 and _persistent_nt(M, D, I) and _persistent_nt(M, D, Fh)
+
+
 # ---- column sums (bias / pos / cls gradients) -----------------------------------------------------
 def colsum(x: Tensor, rows: int, cols: int, out: Tensor, accumulate: bool = False):
     ws = empty((K.colsum_ws_floats(rows, cols),), F32, x)
@@ -192,6 +205,13 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
             return act, y
         return y
     Wn, ldw = nt_weight(W, M, False) if _fast_nt(x, N, Kd) else (W, Kd)
+    if resid is not None and resid.dtype in HALF:
+        # 16-bit forward residual stream (fwd_stream_16): T(resid + y), the sum formed in f32 inside the epilogue
+        if drop is not None or not (_fast_nt(x, N, Kd) and _persistent_nt(M, N, Kd)):
+            raise L.VitkError("linear_fwd: a 16-bit residual needs a shape the persistent NT kernel serves and no fused dropout (caller must check stream16_ok)")
+        out = empty((M, N), T, x)
+        K.gemm_nt_bf16(x, Kd, Wn, ldw, out, N, M, N, Kd, L.EPI_RESID16, bias=bias, resid=resid)
+        return out
     if resid is not None:
         out = empty((M, N), F32, x)
         if drop is not None:
