@@ -275,3 +275,66 @@ def test_real_engine_stage_under_data_parallel_two_ranks_gloo():
     replaced by tests/_kernel_doubles.py, wrapped in DataParallel on 2 gloo ranks: gradients equal the single-process full-batch run."""
     port = _free_port()
     mp.spawn(_engine_worker, args=(2, port), nprocs=2, join=True)
+
+
+class _WideEngineModel(torch.nn.Module):
+    """As _EngineModel, at the smallest extents the fp8 GEMM kernels serve (dim 256, 1,024 token rows per rank)."""
+
+    def __init__(self):
+        super().__init__()
+        from vit_pytorch_amd.vit import Transformer
+        self.to_patch_embedding = torch.nn.Linear(24, 256)
+        self.transformer = Transformer(dim=256, depth=2, heads=4, dim_head=64, mlp_dim=512)
+        self.mlp_head = torch.nn.Linear(256, 5)
+
+    def forward(self, x):
+        return self.mlp_head(self.transformer(self.to_patch_embedding(x)).mean(dim=1))
+
+
+def _fp8_engine_worker(rank, world, port):
+    import _kernel_doubles as KD
+    from vit_pytorch_amd.fp8 import enable_fp8
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with KD.installed() as calls:
+            torch.manual_seed(9)
+            full = torch.randn(world * 8, 128, 24)
+            torch.manual_seed(70 + rank)
+            model = _WideEngineModel().to(torch.bfloat16)
+            dp = DataParallel(model, layers_per_chunk=1)
+            enable_fp8(model)
+            x = full[8 * rank:8 * rank + 8].to(torch.bfloat16)
+            for _ in range(3):                                          # step 1 records, steps 2-3 run the twelve GEMMs of a layer on fp8 operands
+                del calls[:]
+                dp.backward(dp(x).float().square().mean())
+            names = [c[0] for c in calls]
+            assert names.count("gemm_nt_fp8_v2") == 8 * 2 and names.count("gemm_tn_fp8") == 4 * 2 and "gemm_tn_bf16" not in names
+            st = model.transformer._fp8
+            assert st.ready and st.bwd_ready
+            got = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+            # every rank ends with the same (averaged) gradients although its scales come from its own shard's amax
+            for n in ("transformer.layers.0.1.net.1.weight", "transformer.layers.1.0.to_qkv.weight"):
+                gathered = [torch.zeros_like(got[n]) for _ in range(world)]
+                dist.all_gather(gathered, got[n])
+                assert all(torch.equal(t, gathered[0]) for t in gathered)
+            # and they are the full-batch 16-bit gradients to fp8 accuracy
+            E.set_grad_sink(None)
+            enable_fp8(model, enabled=False)
+            model.zero_grad(set_to_none=True)
+            model(full.to(torch.bfloat16)).float().square().mean().backward()
+            worst = 0.0
+            for n, p in model.named_parameters():
+                ref = p.grad.detach().float()
+                worst = max(worst, float((got[n] - ref).norm() / ref.norm().clamp_min(1e-12)))
+            assert worst < 1.5e-1, worst
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fp8_engine_stage_under_data_parallel_two_ranks_gloo():
+    """The fp8 state machine (per-rank delayed scales, lean saving, fp8 weight gradients written into the sink's flat buffer) under
+    DataParallel on 2 gloo ranks, kernels replaced by the CPU doubles."""
+    port = _free_port()
+    mp.spawn(_fp8_engine_worker, args=(2, port), nprocs=2, join=True)
