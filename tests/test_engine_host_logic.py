@@ -203,3 +203,30 @@ def test_fp8_needs_16bit_parameters_and_a_transformer():
     assert m16._fp8 is not None
     enable_fp8(m16, enabled=False)
     assert m16._fp8 is None
+
+
+def test_fp8_on_the_simple_vit_stack(x, monkeypatch):
+    """simple_vit.Transformer (bias-free out-projection, simple_vit.py:48) through the same fp8 state machine: all twelve GEMMs of a
+    layer on fp8 operands from the second step on, results fp8-close to its own 16-bit run."""
+    from vit_pytorch_amd.simple_vit import Transformer as SimpleTransformer
+    monkeypatch.delenv("VITK_FP8_K128", raising=False)
+
+    def make():
+        torch.manual_seed(3)
+        m = SimpleTransformer(DIM, DEPTH, HEADS, DH, MLP)
+        shapes = OrderedDict((k, tuple(v.shape)) for k, v in m.state_dict().items())
+        m.load_state_dict(make_params_for(shapes, 13))
+        return m.to(torch.bfloat16)
+
+    with KD.installed() as calls:
+        y16, dx16, g16 = run(make(), x)
+        m8 = make()
+        enable_fp8(m8)
+        run(m8, x); run(m8, x)
+        del calls[:]
+        y8, dx8, g8 = run(m8, x)
+        names = [c[0] for c in calls]
+        assert names.count("gemm_nt_fp8_v2") == 8 * DEPTH and names.count("gemm_tn_fp8") == 4 * DEPTH
+        assert "gemm_tn_bf16" not in names and "gemm_nt_bf16" not in names
+    assert set(g8) == set(g16) and all(v is not None for v in g8.values())
+    assert rel(y8, y16) < 6e-2 and rel(dx8, dx16) < 1.2e-1 and worst_grad(g8, g16) < 1.5e-1
