@@ -27,6 +27,7 @@ buffer and to be told when the transformer's gradients are complete (data-parall
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -41,7 +42,6 @@ Tensor = torch.Tensor
 F32 = torch.float32
 
 _sink_global = [None]
-_os_environ_get = __import__("os").environ.get
 
 
 def set_grad_sink(sink):
@@ -233,7 +233,7 @@ class TransformerFn(torch.autograd.Function):
         # consumed ARE their activation operands -- they are kept (1 B / element) INSTEAD of the 16-bit LayerNorm / GELU outputs
         # (2 B / element), which nothing else in the backward reads: no re-quantisation pass, no recompute pass, less memory.
         # The scales they were made under are snapshotted (the fold at the end of this forward overwrites the live ones).
-        lean8 = bool(go8 and keep and bwd8 and fp8.wgrad and fp8.backward_will_be_fp8() and _os_environ_get("VITK_FP8_LEAN", "1") != "0"
+        lean8 = bool(go8 and keep and bwd8 and fp8.wgrad and fp8.backward_will_be_fp8() and os.environ.get("VITK_FP8_LEAN", "1") != "0"
                      and all(ops.fp8_tn_ok(M, n_, k_) for n_, k_ in ((D, lp[7].shape[0]), (lp[7].shape[0], D), (D, I), (3 * I, D))))
         scales_used = fp8.scales.clone() if lean8 else None
 
