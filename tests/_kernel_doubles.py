@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- CPU doubles of the libvitk entry points the fused Transformer stage calls.
+"""TEST INFRASTRUCTURE ONLY -- CPU doubles of the libvitk entry points the three fused stages (patch embedding, Transformer, head) call.
 
 `installed()` swaps a few dozen functions of `vit_pytorch_amd.kernels` / `vit_pytorch_amd.ops` for torch-CPU stand-ins built from the
 oracle's per-op restatements (oracle/vit_oracle.py), so that the HOST LOGIC of `engine.TransformerFn` -- which tensor goes into
@@ -72,10 +72,19 @@ def _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials=None):
         C.view(M, N).copy_(acc)
 
 
+def _rows(t, rows, cols, ld):
+    """(rows, cols) view of a tensor whose logical rows are `ld` elements apart (row 0 of every image of a (B, N, D) tensor: ld = N D)."""
+    return torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset())
+
+
 def gemm_nt_bf16(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue=L.EPI_NONE, bias=None, resid=None, aux=None):
-    assert lda == Kd and ldc == N
     CALLS.append(("gemm_nt_bf16", (M, N, Kd, epilogue)))
-    _epilogue(A.reshape(M, Kd).float() @ _w_plain(W, ldw, N, Kd).t(), C, M, N, epilogue, bias, resid, aux)
+    acc = _rows(A, M, Kd, lda).float() @ _w_plain(W, ldw, N, Kd).t()
+    if ldc == N:
+        _epilogue(acc, C, M, N, epilogue, bias, resid, aux)
+    else:               # strided output rows (the head's dX written into row 0 of every image): plain / bias epilogues only
+        assert epilogue in (L.EPI_NONE, L.EPI_BIAS)
+        _rows(C, M, N, ldc).copy_(acc + (bias.float() if (epilogue == L.EPI_BIAS and bias is not None) else 0))
 
 
 def gemm_nt_bf16_gelu_bwd_colsum(A, lda, W, ldw, C, ldc, M, N, Kd, aux, partials):
@@ -129,9 +138,9 @@ def pack_w_nt(W, ldw, N, Kd, out, out_t):
 
 
 def gemm_tn_bf16(dY, ldy, X, ldx, dW, ldo, M, N, Kd, ws, splits, accumulate=False):
-    assert ldy == N and ldx == Kd and ldo == Kd
+    assert ldo == Kd
     CALLS.append(("gemm_tn_bf16", (M, N, Kd)))
-    r = dY.reshape(M, N).float().t() @ X.reshape(M, Kd).float()
+    r = _rows(dY, M, N, ldy).float().t() @ _rows(X, M, Kd, ldx).float()
     dW.view(N, Kd).copy_(r + (dW.view(N, Kd).float() if accumulate else 0))
 
 
@@ -144,33 +153,50 @@ def gemm_tn_fp8(dY8, ldy, X8, ldx, dW, ldo, M, N, Kd, ws, splits, *, alpha_y=Non
     dW.view(N, Kd).copy_(r + (dW.view(N, Kd).float() if accumulate else 0))
 
 
+def _map_rows(m, rows):
+    """vitk_rowmap (include/vitk.h): logical row r -> physical row (r / group) * gstride + r % group + offset; group <= 0: identity."""
+    r = torch.arange(rows)
+    if m.group <= 0:
+        return r
+    return (r // m.group) * m.gstride + (r % m.group) + m.offset
+
+
 def layernorm_fwd(x, w, b, y, mean, rstd, rows, D, eps=1e-5, imap=L.IDENT, omap=L.IDENT, add=None, add_group=0, add_off=0, y8=None,
                   scale8=None, amax64=None):
-    assert imap.group == 0 and omap.group == 0 and add is None, "the doubles cover the Transformer stage (identity row maps)"
-    yy, m, r = O.layer_norm_fwd(x.reshape(rows, D).float(), w.float(), None if b is None else b.float(), eps)
-    y.view(rows, D).copy_(yy); mean.copy_(m); rstd.copy_(r)
+    xin = x.reshape(-1, D)[_map_rows(imap, rows)].float()
+    yy, m, r = O.layer_norm_fwd(xin, w.float(), None if b is None else b.float(), eps)
+    if add is not None:         # positional table added on the way out (vit.py:126): row r takes add[(r % add_group) + add_off]
+        rr = torch.arange(rows)
+        yy = yy + add.reshape(-1, D)[((rr % add_group) if add_group > 0 else rr) + add_off].float()
+    oi = _map_rows(omap, rows)
+    yv = y.view(-1, D)
+    yv[oi] = yy.to(y.dtype)
+    mean.copy_(m); rstd.copy_(r)
     if amax64 is not None:
         _rec_amax(amax64, yy)
     if y8 is not None:
-        y8.view(rows, D).copy_(_q8(yy, float(scale8[0]), E4M3))
+        y8.view(-1, D)[oi] = _q8(yy, float(scale8[0]), E4M3)
 
 
 def ln_bwd(dy, x, w, mean, rstd, rows, D, *, gin=None, dx_f32=None, dx_t=None, dw=None, db=None, dcol=None, dymap=L.IDENT,
            xmap=L.IDENT, dxmap=L.IDENT, drop=None):
-    assert drop is None and dymap.group == 0 and xmap.group == 0 and dxmap.group == 0
-    dx, gw, gb = O.layer_norm_bwd(dy.reshape(rows, D).float(), x.reshape(rows, D).float(), w.float(), mean, rstd)
+    assert drop is None
+    dyr = dy.reshape(-1, D)[_map_rows(dymap, rows)].float()
+    xr = x.reshape(-1, D)[_map_rows(xmap, rows)].float()
+    dx, gw, gb = O.layer_norm_bwd(dyr, xr, w.float(), mean, rstd)
     if gin is not None:
         dx = dx + gin.reshape(rows, D).float()
+    oi = _map_rows(dxmap, rows)
     if dx_f32 is not None:
-        dx_f32.view(rows, D).copy_(dx)
+        dx_f32.view(-1, D)[oi] = dx
     if dx_t is not None:
-        dx_t.view(rows, D).copy_(dx)
+        dx_t.view(-1, D)[oi] = dx.to(dx_t.dtype)
     if dw is not None:
         dw.copy_(gw)
     if db is not None:
         db.copy_(gb)
     if dcol is not None:
-        dcol.copy_((dx_t.view(rows, D).float() if dx_t is not None else dx).sum(0))
+        dcol.copy_((dx_t.view(-1, D)[oi].float() if dx_t is not None else dx).sum(0))
 
 
 def _heads(qkv, B, N, H, d):
@@ -235,7 +261,59 @@ def colsum_partials(partials, nparts, ld, cols, out, accumulate=False):
 
 def colsum(x, rows, cols, ld, out, ws, accumulate=False):
     r = x.reshape(rows, ld)[:, :cols].float().sum(0)
-    out.copy_(r + (out.float() if accumulate else 0))
+    o = out.view(-1)                        # (cols,) however the caller shapes it ((N, D) for the positional-table gradient)
+    o.copy_(r + (o.float() if accumulate else 0))
+
+
+class _MatRef:
+    """What the double of K.mat() hands to the double of K.gemm_generic: the tensor itself + the element strides of vitk_mat."""
+
+    def __init__(self, t, s_row, s_col, s_b1, s_b2, offset):
+        self.t, self.s_row, self.s_col, self.s_b1, self.s_b2, self.offset = t, s_row, s_col, s_b1, s_b2, offset
+        self._dtype = t.dtype
+
+    def view(self, rows, cols, nb1, nb2):
+        return torch.as_strided(self.t, (nb1, nb2, rows, cols), (self.s_b1, self.s_b2, self.s_row, self.s_col), self.t.storage_offset() + self.offset)
+
+
+def mat(t, s_row, s_col, s_b1=0, s_b2=0, offset=0):
+    return _MatRef(t, s_row, s_col, s_b1, s_b2, offset)
+
+
+def gemm_generic(A, B, Cm, M, N, Kd, nb1=1, nb2=1, bias=None, alpha=1.0, beta=0.0):
+    """C[b1, b2] = alpha A[b1, b2] (M, K) . B[b1, b2] (K, N) + beta C (+ bias[n]), every operand by element strides (vitk_gemm_generic)."""
+    CALLS.append(("gemm_generic", (M, N, Kd, nb1, nb2)))
+    c = Cm.view(M, N, nb1, nb2)
+    r = alpha * (A.view(M, Kd, nb1, nb2).float() @ B.view(Kd, N, nb1, nb2).float())
+    if beta != 0.0:
+        r = r + beta * c.float()
+    if bias is not None:
+        r = r + bias.float()
+    c.copy_(r)
+
+
+def patchify(img, out, B, C, H, W, p1, p2):
+    """rearrange 'b c (h p1) (w p2) -> (b h w) (p1 p2 c)' (vit.py:100)."""
+    h, w = H // p1, W // p2
+    out.view(B * h * w, p1 * p2 * C).copy_(img.reshape(B, C, h, p1, w, p2).permute(0, 2, 4, 3, 5, 1).reshape(B * h * w, p1 * p2 * C))
+
+
+def copy_cols(src, ld_src, dst, ld_dst, rows, cols_copy, cols_dst):
+    d = _rows(dst, rows, cols_dst, ld_dst)
+    d.zero_()
+    d[:, :cols_copy] = _rows(src, rows, cols_copy, ld_src)
+
+
+def write_cls_rows(x, cls, pos, B, N, D, ncls):
+    x.view(B, N, D)[:, :ncls] = (cls.float() + pos.reshape(-1, D)[:ncls].float()).to(x.dtype)
+
+
+def mean_pool_fwd(x, out, B, N, D):
+    out.view(B, D).copy_(x.reshape(B, N, D).float().mean(1))
+
+
+def mean_pool_bwd(dout, dx, B, N, D):
+    dx.view(B, N, D).copy_((dout.reshape(B, 1, D).float() / N).expand(B, N, D))
 
 
 def transpose(x, out, rows, cols):
@@ -267,7 +345,8 @@ _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_n
                   gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,
-                  colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd,
+                  colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify,
+                  copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, mean_pool_fwd=mean_pool_fwd, mean_pool_bwd=mean_pool_bwd,
                   require_device=require_device)
 _OPS_DOUBLES = dict(attn_fwd=attn_fwd, attn_bwd=attn_bwd, ln_bwd=ln_bwd)
 
