@@ -1,9 +1,11 @@
 """TEST INFRASTRUCTURE ONLY -- CPU doubles of the libvitk entry points the three fused stages (patch embedding, Transformer, head) call.
 
 `installed()` swaps a few dozen functions of `vit_pytorch_amd.kernels` / `vit_pytorch_amd.ops` for torch-CPU stand-ins built from the
-oracle's per-op restatements (oracle/vit_oracle.py), so that the HOST LOGIC of `engine.TransformerFn` -- which tensor goes into
-which launch, the saved-activation bookkeeping, the fp8 slot / scale / recording state machine, the weight caches -- can be run
-and checked in the CPU suite, where no kernel can launch.  Nothing here is importable from the product package, the product has
+oracle's per-op restatements (oracle/vit_oracle.py), so that the HOST LOGIC of the drop-in -- which tensor goes into which launch
+with which strides and row maps, the saved-activation bookkeeping, the fp8 slot / scale / recording state machine, the weight
+caches, the data-parallel gradient sink -- can be run and checked in the CPU suite, where no kernel can launch: the fused stage
+alone (tests/test_engine_host_logic.py), whole models against the reference's goldens (ViT, SimpleViT, the three sibling variants,
+NaViT: tests/test_models_host_logic.py), two gloo ranks (tests/test_parallel_gloo.py).  Nothing here is importable from the product package, the product has
 no CPU path (`kernels.require_device` raises on CPU tensors), and no parity claim rests on these doubles: the kernels themselves
 are tested against float64 / the oracle / the reference's goldens in the `-m gpu` tests.
 
@@ -292,6 +294,68 @@ def gemm_generic(A, B, Cm, M, N, Kd, nb1=1, nb2=1, bias=None, alpha=1.0, beta=0.
     c.copy_(r)
 
 
+def _thd(t, ld, T, H, d, off=0):
+    """(T, H, d) view of per-token rows that are `ld` elements apart, starting `off` elements into the tensor."""
+    return torch.as_strided(t, (T, H, d), (ld, d, 1), t.storage_offset() + off)
+
+
+def rmsnorm_heads_fwd(x, ldx, gamma, y, ldy, rnorm, T, H, d, x_off=0):
+    """y = x / max(||x||, 1e-12) * sqrt(d) * gamma[h] per (token, head) (na_vit.py:93-101); rnorm keeps 1 / max(||x||, 1e-12)."""
+    xv = _thd(x, ldx, T, H, d, x_off).float()
+    r = 1.0 / xv.norm(dim=-1).clamp_min(1e-12)
+    _thd(y, ldy, T, H, d).copy_(xv * r.unsqueeze(-1) * (d ** 0.5) * gamma.reshape(1, H, d).float())
+    rnorm.view(T, H).copy_(r)
+
+
+def rmsnorm_heads_bwd(dy, lddy, x, ldx, gamma, rnorm, dx, lddx, dgamma, partials, T, H, d, x_off=0, dx_off=0):
+    xv = _thd(x, ldx, T, H, d, x_off).float()
+    g = _thd(dy, lddy, T, H, d).float()
+    r = rnorm.view(T, H, 1)
+    s = d ** 0.5
+    gg = g * gamma.reshape(1, H, d).float()
+    _thd(dx, lddx, T, H, d, dx_off).copy_(s * r * gg - s * r ** 3 * xv * (xv * gg).sum(-1, keepdim=True))
+    dgamma.view(H, d).copy_((g * xv * r * s).sum(0))
+
+
+def softmax_fwd(sc, p, rows, cols, scale):
+    p.view(rows, cols).copy_(O.softmax_fwd(sc.reshape(rows, cols).float() * scale))
+
+
+def softmax_bwd(p, dp, ds, rows, cols, scale):
+    """ds = scale * p * (dp - rowsum(dp * p))  (may run in place on dp)."""
+    pv, dv = p.reshape(rows, cols).float(), dp.reshape(rows, cols).float()
+    ds.view(rows, cols).copy_(scale * pv * (dv - (dv * pv).sum(-1, keepdim=True)))
+
+
+def patchify_cpp(img, out, C, H, W, p, row0, ld):
+    """NaViT patch extraction of one image, 'c (h p1) (w p2) -> (h w) (c p1 p2)' (na_vit.py:300), into rows row0.. of a (T, ld) matrix."""
+    h, w = H // p, W // p
+    _rows(out, out.numel() // ld, C * p * p, ld)[row0:row0 + h * w] = img.reshape(C, h, p, w, p).permute(1, 3, 0, 2, 4).reshape(h * w, C * p * p)
+
+
+def gather_add2(x, A, ia, B, ib, out, T, D):
+    out.view(T, D).copy_(x.reshape(T, D).float() + A.reshape(-1, D)[ia.long()].float() + B.reshape(-1, D)[ib.long()].float())
+
+
+def csr_rowsum(g, ptr, rows, out, nseg, D):
+    """out[i] = sum of g[rows[j]] for j in [ptr[i], ptr[i + 1]) (deterministic gradient of the embedding gathers)."""
+    gv = g.reshape(-1, D).float()
+    o = out.view(-1, D)
+    for i in range(nseg):
+        a, b = int(ptr[i]), int(ptr[i + 1])
+        o[i] = gv[rows[a:b].long()].sum(0) if b > a else 0
+
+
+def concat_tokens(x, front, pos, out, B, Np, F, D):
+    """out[b, i] = (i < F ? front[i] : x[b, i - F]) + (pos ? pos[i] : 0): torch.cat((tokens, x), dim=1) + pos[:N] (vit.py:122-127)."""
+    o = out.view(B, Np + F, D)
+    if F:
+        o[:, :F] = front.reshape(1, F, D).to(o.dtype)
+    o[:, F:] = x.reshape(B, Np, D)
+    if pos is not None:
+        o.copy_(o.float() + pos.reshape(-1, D)[:Np + F].float())
+
+
 def patchify(img, out, B, C, H, W, p1, p2):
     """rearrange 'b c (h p1) (w p2) -> (b h w) (p1 p2 c)' (vit.py:100)."""
     h, w = H // p1, W // p2
@@ -346,7 +410,9 @@ _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_n
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,
                   colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify,
-                  copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, mean_pool_fwd=mean_pool_fwd, mean_pool_bwd=mean_pool_bwd,
+                  copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, concat_tokens=concat_tokens, patchify_cpp=patchify_cpp, gather_add2=gather_add2, csr_rowsum=csr_rowsum,
+                  rmsnorm_heads_fwd=rmsnorm_heads_fwd, rmsnorm_heads_bwd=rmsnorm_heads_bwd,
+                  softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd, mean_pool_fwd=mean_pool_fwd, mean_pool_bwd=mean_pool_bwd,
                   require_device=require_device)
 _OPS_DOUBLES = dict(attn_fwd=attn_fwd, attn_bwd=attn_bwd, ln_bwd=ln_bwd)
 

@@ -1,5 +1,5 @@
-"""CPU: the complete drop-in models (patch embedding -> Transformer -> head: engine.PatchEmbedFn / TransformerFn / HeadFn) with the kernels
-replaced by the test doubles (tests/_kernel_doubles.py), in bfloat16, against the goldens the REFERENCE produced in float32
+"""CPU: the complete drop-in models (patch embedding -> Transformer -> head: engine.PatchEmbedFn / TransformerFn / HeadFn; the sibling
+variants and NaViT on the op-by-op functions of functional.py / na_vit.py) with the kernels replaced by the test doubles (tests/_kernel_doubles.py), in bfloat16, against the goldens the REFERENCE produced in float32
 (tests/golden/*.npz, oracle/make_golden.py).  Host logic only -- row maps, cls / positional handling, padding of odd patch widths,
 pooling, which gradient lands in which parameter; the kernels are checked on the GPU (tests/test_parity_gpu.py runs the same cases
 there).  Tolerances: float32 parameters -- round-off (logits 2e-5, every gradient tensor 1e-4); bfloat16 against the f32 outputs on these tiny
@@ -71,3 +71,53 @@ def test_dropin_models_against_reference_goldens_bf16(name):
         worst = max(worst, rel(p.grad.float(), g_ref))
         assert rel(p.grad.float(), g_ref) < 6e-2, (k, rel(p.grad.float(), g_ref))
     print(f"{name}: logits {e:.2e}, worst gradient tensor {worst:.2e}")
+
+
+# ---- sibling variants: goldens from the reference's own modules, eval mode --------------------------------------
+def _build_variant(name, dtype):
+    import importlib
+    import json
+    from collections import OrderedDict
+    from oracle.params import VARIANT_CASES, make_params_for
+    case = VARIANT_CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    mod = importlib.import_module("vit_pytorch_amd." + case["module"])
+    m = getattr(mod, case["cls"])(**case["cfg"])
+    ref_shapes = OrderedDict((k, tuple(v)) for k, v in json.loads(bytes(gold["state_dict_shapes"]).decode()))
+    assert OrderedDict((k, tuple(v.shape)) for k, v in m.state_dict().items()) == ref_shapes
+    m.load_state_dict(make_params_for(ref_shapes, case["seed"]), strict=True)
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000)
+    return m.to(dtype).eval(), img.to(dtype), gold
+
+
+@pytest.mark.parametrize("name", ["register_tokens_tiny", "patch_dropout_eval_tiny", "qk_norm_tiny"])
+def test_variants_against_reference_goldens_f32(name):
+    m, img, gold = _build_variant(name, torch.float32)
+    with KD.installed():
+        out = m(img)
+        O.loss_fn(out).backward()
+    assert rel(out, torch.from_numpy(gold["logits"])) < 2e-5
+    for k, p in m.named_parameters():
+        assert rel(p.grad, torch.from_numpy(gold["grad::" + k])) < 1e-4, k
+
+
+def test_navit_against_reference_golden_f32():
+    """NaViT (na_vit.py: packed variable-resolution images, factorised positions, q / k RMSNorm, masked attention as per-image segments,
+    attention pooling) through the drop-in's host logic with the kernel doubles, against the golden the reference produced."""
+    from oracle.params import NAVIT_CASES, make_navit_images, make_navit_params
+    from vit_pytorch_amd.na_vit import NaViT
+    name = "navit_two_packs"
+    case = NAVIT_CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    params = make_navit_params(case["cfg"], case["seed"])
+    imgs = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
+    m = NaViT(**case["cfg"])
+    m.load_state_dict(params, strict=True)
+    m = m.eval()
+    with KD.installed():
+        out = m(imgs)
+        O.loss_fn(out).backward()
+    assert tuple(out.shape) == gold["logits"].shape
+    assert rel(out, torch.from_numpy(gold["logits"])) < 2e-5
+    for k, p in m.named_parameters():
+        assert rel(p.grad, torch.from_numpy(gold["grad::" + k])) < 1e-4, k
