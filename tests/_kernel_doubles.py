@@ -346,6 +346,57 @@ def csr_rowsum(g, ptr, rows, out, nseg, D):
         o[i] = gv[rows[a:b].long()].sum(0) if b > a else 0
 
 
+class _HndRef:
+    """Double of K.hnd(): a (tokens, heads, d) view -- element (n, h, :) at offset + n * s_n + h * s_h -- that keeps its tensor."""
+
+    def __init__(self, t, s_h, s_n, offset):
+        self.t, self.s_h, self.s_n, self.offset = t, s_h, s_n, offset
+        self._dtype = t.dtype
+
+    def view(self, T, H, d):
+        return torch.as_strided(self.t, (T, H, d), (self.s_n, self.s_h, 1), self.t.storage_offset() + self.offset)
+
+
+def hnd(t, s_h, s_n, offset=0):
+    return _HndRef(t, s_h, s_n, offset)
+
+
+def _segments(cu_q, cu_k):
+    cq, ck = [int(v) for v in cu_q], [int(v) for v in cu_k]
+    return [(cq[i], cq[i + 1], ck[i], ck[i + 1]) for i in range(len(cq) - 1)]
+
+
+def attn_varlen_fwd_bf16(q, k, v, o, lse, cu_q, cu_k, blk_seg, blk_r0, nblk, tq_total, H, d, scale, drop_p=0.0, drop_seed=0):
+    """softmax(scale q k^T) v independently inside every segment (NaViT's masked attention, na_vit.py:161-166, as per-image ranges)."""
+    assert drop_p == 0.0
+    Tk = int(cu_k[-1])
+    qv, kv_, vv, ov = q.view(tq_total, H, d), k.view(Tk, H, d), v.view(Tk, H, d), o.view(tq_total, H, d)
+    for q0, q1, k0, k1 in _segments(cu_q, cu_k):
+        if q1 == q0:
+            continue
+        qs, ks, vs = (t.float().permute(1, 0, 2) for t in (qv[q0:q1], kv_[k0:k1], vv[k0:k1]))
+        sc = qs @ ks.transpose(-1, -2) * scale
+        ov[q0:q1] = (torch.softmax(sc, -1) @ vs).permute(1, 0, 2).to(ov.dtype)
+        lse.view(H, tq_total)[:, q0:q1] = torch.logsumexp(sc, -1)
+
+
+def attn_varlen_bwd_bf16(q, k, v, o, dout, lse, delta, dq, dk, dv, cu_q, cu_k, qblk_seg, qblk_r0, nqblk, kblk_seg, kblk_r0, nkblk, tq_total, H,
+                         d, scale, drop_p=0.0, drop_seed=0):
+    assert drop_p == 0.0
+    Tk = int(cu_k[-1])
+    qv, kv_, vv, dov = q.view(tq_total, H, d), k.view(Tk, H, d), v.view(Tk, H, d), dout.view(tq_total, H, d)
+    dqv, dkv_, dvv = dq.view(tq_total, H, d), dk.view(Tk, H, d), dv.view(Tk, H, d)
+    dkv_.zero_(); dvv.zero_(); dqv.zero_()
+    for q0, q1, k0, k1 in _segments(cu_q, cu_k):
+        if q1 == q0:
+            continue
+        qs, ks, vs, ds = (t.float().permute(1, 0, 2) for t in (qv[q0:q1], kv_[k0:k1], vv[k0:k1], dov[q0:q1]))
+        gq, gk, gv = O.attention_core_bwd(ds, qs, ks, vs, scale)
+        dqv[q0:q1] = gq.permute(1, 0, 2).to(dqv.dtype)
+        dkv_[k0:k1] = gk.permute(1, 0, 2).to(dkv_.dtype)
+        dvv[k0:k1] = gv.permute(1, 0, 2).to(dvv.dtype)
+
+
 def concat_tokens(x, front, pos, out, B, Np, F, D):
     """out[b, i] = (i < F ? front[i] : x[b, i - F]) + (pos ? pos[i] : 0): torch.cat((tokens, x), dim=1) + pos[:N] (vit.py:122-127)."""
     o = out.view(B, Np + F, D)
@@ -410,7 +461,8 @@ _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_n
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,
                   colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify,
-                  copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, concat_tokens=concat_tokens, patchify_cpp=patchify_cpp, gather_add2=gather_add2, csr_rowsum=csr_rowsum,
+                  copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, concat_tokens=concat_tokens, hnd=hnd, attn_varlen_fwd_bf16=attn_varlen_fwd_bf16, attn_varlen_bwd_bf16=attn_varlen_bwd_bf16,
+                  patchify_cpp=patchify_cpp, gather_add2=gather_add2, csr_rowsum=csr_rowsum,
                   rmsnorm_heads_fwd=rmsnorm_heads_fwd, rmsnorm_heads_bwd=rmsnorm_heads_bwd,
                   softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd, mean_pool_fwd=mean_pool_fwd, mean_pool_bwd=mean_pool_bwd,
                   require_device=require_device)

@@ -121,3 +121,25 @@ def test_navit_against_reference_golden_f32():
     assert rel(out, torch.from_numpy(gold["logits"])) < 2e-5
     for k, p in m.named_parameters():
         assert rel(p.grad, torch.from_numpy(gold["grad::" + k])) < 1e-4, k
+
+
+def test_navit_fused_packed_stack_bf16_against_reference_golden():
+    """bfloat16 NaViT takes engine.PackedTransformerFn (the fused packed-token stack: merged q | kv weight, RMSNorm on q / k, varlen
+    attention over per-image segments); its host logic with the doubles, against the reference's float32 golden."""
+    from oracle.params import NAVIT_CASES, make_navit_images, make_navit_params
+    from vit_pytorch_amd.na_vit import NaViT
+    case = NAVIT_CASES["navit_two_packs"]
+    gold = np.load(os.path.join(GOLD, "navit_two_packs.npz"))
+    params = make_navit_params(case["cfg"], case["seed"])
+    imgs = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
+    m = NaViT(**case["cfg"])
+    m.load_state_dict(params, strict=True)
+    m = m.to(torch.bfloat16).eval()
+    assert m.transformer._fusable(torch.empty(4, case["cfg"]["dim"], dtype=torch.bfloat16))
+    with KD.installed():
+        out = m([[im.to(torch.bfloat16) for im in g] for g in imgs])
+        O.loss_fn(out).backward()
+    e = rel(out.float(), torch.from_numpy(gold["logits"]))
+    worst = max(rel(p.grad.float(), torch.from_numpy(gold["grad::" + k])) for k, p in m.named_parameters())
+    print(f"navit bf16 (fused packed stack): logits {e:.2e}, worst gradient tensor {worst:.2e}")
+    assert e < 2e-2 and worst < 8e-2, (e, worst)
