@@ -29,7 +29,7 @@ VITK_FP8_K128=1 timeout 120 python bench.py --config vit_h14 --fp8 --steps 3 --w
 tail -1 $out/shot_h14_fp8_k128.log | cut -c1-600
 
 stamp "config 5, bf16 (same box, for the ratio)"
-timeout 120 python bench.py --config vit_h14 --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline > $out/shot_h14_bf16.log 2>&1
+timeout 120 python bench.py --config vit_h14 --precision bf16 --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline > $out/shot_h14_bf16.log 2>&1
 tail -1 $out/shot_h14_bf16.log | cut -c1-400
 
 stamp "the whole GPU suite"
