@@ -243,6 +243,36 @@ def bench_navit(args, dev):
     }), flush=True)
 
 
+def rccl_version():
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        return None
+
+
+def spawn_command(n: int, argv, port: int):
+    """The launch line `python bench.py --gpus N ...` turns itself into when no launcher set WORLD_SIZE: exactly the driver's own
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_spawn(n: int) -> int:
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(json.dumps({"error": f"--gpus {n} but torch.cuda.device_count() = {have}", "n_gpus": n, "device_count": have}), flush=True)
+        return 2
+    with socket.socket() as s:               # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(spawn_command(n, sys.argv[1:], port), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,8 +295,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args.gpus))      # plain `python bench.py --gpus N`: re-exec under torch.distributed.run, one rank per GPU
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -317,7 +349,7 @@ def main():
     # Shared GPU boxes show occasional multi-x slow phases (clock / power state; one measured run: 100.9, 39.6, 39.6 ms);
     # one such phase inside a single 20-step window would misreport the kernel work, so the window is repeated and the
     # median window reported (all windows are in ms_per_step_all).
-    dts = []
+    dts, rank_dts = [], []
     for _ in range(max(1, args.repeats)):
         sync()
         t0 = time.perf_counter()
@@ -327,10 +359,15 @@ def main():
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            every = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            rank_dts.append([float(e.item()) for e in every])
+            dt = max(rank_dts[-1])                   # the step is as slow as its slowest rank
+        else:
+            rank_dts.append([dt])
         dts.append(dt)
-    dt = sorted(dts)[len(dts) // 2]
+    mid = sorted(range(len(dts)), key=dts.__getitem__)[len(dts) // 2]
+    dt = dts[mid]
     assert torch.isfinite(loss).item(), "loss is not finite"
     taps = time_dominant_kernel(step)      # every rank: the steps contain the collectives
 
@@ -390,6 +427,8 @@ def main():
                                    + (", flat-buffer RCCL all-reduce overlapped with patch-embed backward" if world > 1 else ""),
                        "global_batch": batch * world, "per_gpu_batch": batch, "seq_len": N, "parallelism": f"dp{world}"},
             "per_gpu_images_per_s": round(value / world, 2),
+            "per_rank_images_per_s": [round(batch * args.steps / d, 2) for d in rank_dts[mid]],       # each rank's own clock, the reported window
+            "device_count": torch.cuda.device_count(), "rccl_version": rccl_version(),
             "model": {"gflop_per_image_fwd_bwd": round(gf, 3), "tflops_per_gpu": round(value / world * gf / 1e3, 2),
                       "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
                       **({"frac_note": "whole-step fraction is of the bf16 peak 2516.6 TF/s (the number comparable with the bf16 line); of the fp8 roof named in `roof` it is "
