@@ -263,10 +263,13 @@ def test_gemm_nt_rejects_bad_shapes():
 
 @pytest.mark.parametrize("M,N,Kd", [(4096, 256, 256), (5000, 768, 768), (6304, 2304, 768), (4500, 264, 520), (64, 128, 128), (1000, 768, 768), (197 * 16, 2304, 768), (333, 136, 72), (197 * 8, 768, 3072), (5000, 64, 256)])
 @pytest.mark.parametrize("odt", [BF, F32])
-@pytest.mark.parametrize("variant", ["default", "VITK_TN_DMA"])
+@pytest.mark.parametrize("variant", ["default", "w128_off", "VITK_TN_DMA"])
 def test_gemm_tn(M, N, Kd, odt, variant, monkeypatch):
-    """variant: the register-staged kernel (default) or gemm_tn_dma.hip (LDS-DMA ring)."""
+    """variant: the default (large shapes: gemm_tn_w128.hip, four waves with 128 x 128 wave tiles), the register-staged 8-wave kernel
+    (VITK_TN_W128=0) or gemm_tn_dma.hip (8 waves, LDS-DMA ring)."""
     if variant != "default":
+        monkeypatch.setenv("VITK_TN_W128", "0")
+    if variant == "VITK_TN_DMA":
         monkeypatch.setenv("VITK_TN_DMA", "1")
     dY = rnd(M, N, dtype=BF, seed=51) * (M ** -0.5); X = rnd(M, Kd, dtype=BF, seed=52)
     ref = dY.double().t() @ X.double()
@@ -291,6 +294,25 @@ def test_gemm_tn_strided_operands():
     check = L.load().vitk_gemm_tn_bf16(dYv.data_ptr(), 3 * N, Xv.data_ptr(), 2 * Kd, dW.data_ptr(), L.F32, Kd, 0, M, N, Kd,
                                        ws.data_ptr(), splits, torch.cuda.current_stream().cuda_stream)
     assert check == 0
+    assert rel(dW, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,splits", [(4999, 5), (4130, 3), (8192, 9)])
+def test_gemm_tn_w128_strided_ragged(M, splits):
+    """The large-shape kernel on column slices of wider buffers (the merged dqkv gradient), with N and K that are not multiples of
+    the 256-column tile and splits whose last one ends inside a 32-row step: rows past a split arrive as zeros through the buffer
+    descriptor's range, columns past N / K only reach outputs that are never stored.  The buffers around the slices hold NaN."""
+    N, Kd = 520, 264
+    big = torch.full((M, N + 2 * 16), float("nan"), dtype=BF, device=DEV); xb = torch.full((M, Kd + 24), float("nan"), dtype=BF, device=DEV)
+    big[:, 16:16 + N] = rnd(M, N, dtype=BF, seed=55) * (M ** -0.5); xb[:, 8:8 + Kd] = rnd(M, Kd, dtype=BF, seed=56)
+    dYv = big[:, 16:16 + N]; Xv = xb[:, 8:8 + Kd]
+    ref = dYv.double().t() @ Xv.double()
+    ws = torch.empty(splits * N * Kd, device=DEV)
+    dW = torch.empty(N, Kd, device=DEV)
+    rc = L.load().vitk_gemm_tn_bf16(dYv.data_ptr(), big.stride(0), Xv.data_ptr(), xb.stride(0), dW.data_ptr(), L.F32, Kd, 0, M, N, Kd,
+                                    ws.data_ptr(), splits, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.isfinite(dW).all()
     assert rel(dW, ref) < 1e-5
 
 

@@ -1075,6 +1075,10 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 int gemm_tn_dma_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* ws, int64_t M, int64_t N, int64_t K,
                        int64_t splits, void* stream);
 
+bool gemm_tn_w128_serves(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx, int64_t splits);
+int gemm_tn_w128_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* ws, int64_t M, int64_t N, int64_t K,
+                        int64_t splits, void* stream);
+
 static bool tn_large(int64_t M, int64_t N, int64_t K) { return M >= 4096 && N >= 256 && K >= 256 && !getenv("VITK_NO_256"); }
 
 // CUs to leave to OTHER kernels (an RCCL collective overlapping the backward): the weight-gradient GEMM launches one (tile, M-split)
@@ -1119,7 +1123,13 @@ extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int
     // gemm_tn_dma.hip (LDS-DMA ring, ping-pong slots) and gemm_tn256_kernel (register staging) measure level -- 0.975x .. 1.037x box to
     // box (tools/tn_ab.py): both are bound by the ds_read_b64_tr_b16 issue rate, not by how the tiles reach LDS.  The register-staged
     // kernel stays the default; VITK_TN_DMA=1 selects the other.
-    if (tn_large(M, N, K) && getenv("VITK_TN_DMA") && atoi(getenv("VITK_TN_DMA"))) {
+    // gemm_tn_w128.hip (round 4: four waves, 128 x 128 wave tiles, pinned asm MFMAs, double-buffered fragments) is the default for the
+    // large shapes: x1.3-1.5 over the two 8-wave kernels below (tools/tn_probe.hip); VITK_TN_W128=0 falls back to them for A/B runs.
+    const bool w128_off = getenv("VITK_TN_W128") && atoi(getenv("VITK_TN_W128")) == 0;
+    if (tn_large(M, N, K) && !w128_off && gemm_tn_w128_serves(M, N, K, ldy, ldx, splits)) {
+        const int rc = gemm_tn_w128_launch(dY, ldy, X, ldx, ws, M, N, K, splits, stream);
+        if (rc != 0) return rc;
+    } else if (tn_large(M, N, K) && getenv("VITK_TN_DMA") && atoi(getenv("VITK_TN_DMA"))) {
         const int rc = gemm_tn_dma_launch(dY, ldy, X, ldx, ws, M, N, K, splits, stream);
         if (rc != 0) return rc;
     } else if (tn_large(M, N, K)) {
