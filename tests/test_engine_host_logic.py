@@ -73,11 +73,12 @@ def test_16bit_stage_against_the_oracle(x):
 
 
 def test_16bit_forward_stream_option(x, monkeypatch):
-    """VITK_FWD_STREAM=16: the residual stream of the forward in the parameter dtype -- both residual GEMMs of a layer take the RESID16
+    """VITK_FWD_STREAM=16 (round 4: the default for bfloat16) vs =f32: the residual stream of the forward in the parameter dtype -- both residual GEMMs of a layer take the RESID16
     epilogue (16-bit residual in, 16-bit sum out), LayerNorm reads the 16-bit stream, no float32 (M, D) tensor is produced."""
     m, params = build(torch.bfloat16)
     y_ref, dx_ref, g_ref = reference(params, x)
     with KD.installed() as calls:
+        monkeypatch.setenv("VITK_FWD_STREAM", "f32")
         y32, dx32, g32 = run(m, x)
         n32 = [c[1][3] for c in calls if c[0] == "gemm_nt_bf16"]
         assert n32.count(L.EPI_RESID) == 2 * DEPTH and n32.count(L.EPI_RESID16) == 0
@@ -98,6 +99,7 @@ def fp8_calls(calls):
 @pytest.mark.parametrize("mode", ["fwd+dx+dw", "fwd+dx+dw/requantise", "fwd+dx", "fwd"])
 def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
     monkeypatch.setenv("VITK_FP8_K128", "0")
+    monkeypatch.setenv("VITK_FWD_STREAM", "f32")      # the fp8 path keeps the float32 stream: its recording step equals the 16-bit run under that stream
     lean = mode == "fwd+dx+dw"             # the forward's e4m3 copies are kept for the weight-gradient GEMMs (the default)
     monkeypatch.setenv("VITK_FP8_LEAN", "1" if lean else "0")
     backward, wgrad = mode != "fwd", mode.startswith("fwd+dx+dw")

@@ -75,9 +75,11 @@ def test_16bit_forward_stream_model_vs_reference_golden(monkeypatch):
             ref16.append(torch.from_numpy(gold["bf16::gsample::" + k]).float())
         return out.detach().clone(), rel(out, ref_logits), rel(torch.cat(mine), torch.cat(ref)), rel(torch.cat(ref16), torch.cat(ref))
 
+    monkeypatch.setenv("VITK_FWD_STREAM", "f32")
+    assert not ops.fwd_stream_16(BF)
     o32, e32, g32, g_ref16 = run()
     monkeypatch.setenv("VITK_FWD_STREAM", "16")
-    assert ops.fwd_stream_16()
+    assert ops.fwd_stream_16(BF)
     o16, e16, g16, _ = run()
     e_ref16 = rel(torch.from_numpy(gold["bf16::logits"]), ref_logits)
     print(f"16-bit forward stream: logits {e16:.2e} grads {g16:.2e}; f32 stream {e32:.2e} / {g32:.2e}; reference's own bf16 {e_ref16:.2e} / {g_ref16:.2e}")

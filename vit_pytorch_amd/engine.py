@@ -203,11 +203,11 @@ class TransformerFn(torch.autograd.Function):
         I = heads * dim_head
         scale = dim_head ** -0.5
         x = x.contiguous()
-        # the forward residual stream: float32, or (opt-in, ops.fwd_stream_16: 16-bit parameters, no fp8, no active dropout, both residual
+        # the forward residual stream: float32, or (ops.fwd_stream_16: default for bfloat16 parameters; no fp8, no active dropout, both residual
         # GEMMs on the persistent kernel) the parameter dtype -- every consumer below takes either
         depth_, I_ = len(lp) // NLP, heads * dim_head
         s16f = bool(T in ops.HALF and depth_ > 0 and drop_p == 0.0 and fp8 is None and lp[3] is not None and lp[8] is not None
-                    and ops.fwd_stream_16() and ops.stream16_ok(M, D, I_, lp[7].shape[0]))
+                    and ops.fwd_stream_16(T) and ops.stream16_ok(M, D, I_, lp[7].shape[0]))
         SD = T if s16f else F32
         if x.dtype == SD:
             xs = x

@@ -77,12 +77,19 @@ def grad_stream_16() -> bool:
     return os.environ.get("VITK_GRAD_STREAM", "16") != "f32"
 
 
-def fwd_stream_16() -> bool:
+def fwd_stream_16(T=None) -> bool:
     """The FORWARD residual stream x (vit.py:80-81) in the parameter dtype instead of float32 -- what the reference itself does when it
-    runs in bfloat16.  Opt-in (VITK_FWD_STREAM=16): halves the bytes of the stream in the two residual GEMM epilogues and in the
-    LayerNorm forward / backward reads (~1 ms of the ViT-B/16 step by byte count; unmeasured when written), at the
-    reference-bf16's own accuracy instead of the f32 stream's."""
-    return os.environ.get("VITK_FWD_STREAM", "f32") == "16"
+    runs in bfloat16: halves the bytes of the stream in the two residual GEMM epilogues and in the LayerNorm forward / backward reads.
+    Default since round 4 for bfloat16 parameters ([measured, profiles/r04_stream16_ab.log] interleaved A/B on one box: 37.00 -> 36.20
+    ms per ViT-B/16 step; logits / gradients stay inside the 1.5x-of-the-reference's-own-bf16-error gate at full depth); IEEE half
+    keeps the float32 stream (its gate is an absolute one, and a half stream can overflow where the f32 stream cannot).
+    VITK_FWD_STREAM=f32 forces float32, =16 forces the parameter dtype for either 16-bit type."""
+    v = os.environ.get("VITK_FWD_STREAM", "auto")
+    if v == "16":
+        return True
+    if v == "f32":
+        return False
+    return T is torch.bfloat16
 
 
 def stream16_ok(M: int, D: int, I: int, Fh: int) -> bool:
