@@ -15,13 +15,12 @@ Timed region: W warm-up steps, then barrier + torch.cuda.synchronize(), exactly 
 synchronize + barrier; the time is the MAX over ranks.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel class (the NT MFMA GEMM; timed instance = the FF1 GEMM with the fused
-                bias+GELU epilogue, 50,432 x 3072 x 768): algorithmic FLOPs per launch / mean launch duration
-                measured live with HIP events on the launch stream; peak = 2516.6 TFLOP/s dense bf16 MFMA.
-                `traffic` is STATIC (profiles/rNN_pmc_traffic.json, see `traffic_source`); `other_kernels` holds the
-                dFF1 GEMM (GELU' epilogue), the NT GEMM furthest below its roof.  Both are timed in extra steps with the
-                weight-gradient side stream OFF (`timed_in`): beside a concurrent dW GEMM a launch's duration measures the
-                contention, not the kernel (round 2's line reported 0.596 ms for a 0.317 ms kernel that way).
+  roofline      the step's large GEMMs are timed by CLASS on the launches of real training steps (every C-ABI call bracketed by HIP
+                events on its stream, 3 extra steps after the timed region, weight-gradient side stream off so that a launch's duration
+                is the kernel's, not the contention's).  `classes` lists every class with its kernel time per step, its share of the
+                measured step, achieved TFLOP/s and its heaviest instance; the top-level achieved / frac / avg_launch_ms are the
+                heaviest instance of the HEAVIEST class by time (round 4: the weight-gradient GEMM or the plain NT GEMMs, not FF1).
+                peak = 2516.6 TFLOP/s dense bf16 MFMA.  `traffic` is STATIC (profiles/rNN_pmc_traffic.json, see `traffic_source`).
   weight_cache_rebuild_ms
                 the timed steady state never changes the weights, so the K-blocked / transposed weight copies are built once;
                 a real training step (optimizer after every backward) rebuilds them every step.  This is the extra time of ONE
@@ -77,15 +76,17 @@ def fwd_gflop_per_image(cfg) -> float:
     return f / 1e9
 
 
-def time_dominant_kernel(step_fn, nsteps: int = 3):
-    """Mean launch durations of the two NT GEMMs with the heaviest epilogues -- FF1 (fused bias + GELU, the roofline kernel)
-    and dFF1 (GELU' + bias-gradient column sums, the NT GEMM furthest below its roof), 12 launches each per ViT-B step --
-    measured on the launches of the real training step: every call of the C-ABI entry point is bracketed by HIP events on the
-    stream it is enqueued on.  Done in `nsteps` extra steps after the timed region, so the events do not sit inside it;
-    rocprofv3's per-kernel average of the same command sees exactly these launches plus the timed ones."""
+def time_gemm_classes(step_fn, nsteps: int = 3):
+    """Per-launch durations of every large GEMM of the step, by kernel class and shape, measured on the launches of the real training
+    step: every call of the C-ABI entry point is bracketed by HIP events on the stream it is enqueued on.  Done in `nsteps` extra
+    steps after the timed region, with the weight-gradient side stream OFF (beside a concurrent GEMM a launch's duration measures the
+    contention, not the kernel).  Returns {(class, N, K): (mean ms, flops per launch, launches)}; classes:
+      tn        weight gradient dW = dY^T X (gemm_tn_w128_kernel + the slab fold)
+      ff1       NT GEMM with the fused bias + GELU epilogue       dff1   NT GEMM with the GELU' + bias-gradient column sums epilogue
+      nt_resid  NT GEMM + bias + residual (out-projection, FF2)    nt     NT GEMM, plain / bias epilogue (QKV, the three dX GEMMs)"""
     from vit_pytorch_amd import _lib as L, kernels as K
-    orig_nt, orig_bwd, orig_f8 = K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2
-    taps = {"ff1": [], "dff1": []}
+    orig = {n: getattr(K, n) for n in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum", "gemm_nt_fp8_v2", "gemm_tn_bf16")}
+    taps = {}
 
     def bracket(key, flops, fn, a, kw):
         st = torch.cuda.current_stream()
@@ -93,25 +94,25 @@ def time_dominant_kernel(step_fn, nsteps: int = 3):
         e0.record(st)
         r = fn(*a, **kw)
         e1.record(st)
-        taps[key].append((e0, e1, flops))
+        taps.setdefault(key, []).append((e0, e1, flops))
         return r
+
+    nt_class = {L.EPI_BIAS_GELU: "ff1", L.EPI_GELU_BWD: "dff1", L.EPI_RESID: "nt_resid", L.EPI_RESID16: "nt_resid"}
 
     def tapped_nt(*a, **kw):
         epi = a[9] if len(a) > 9 else kw.get("epilogue", L.EPI_NONE)
-        if epi != L.EPI_BIAS_GELU:
-            return orig_nt(*a, **kw)
-        return bracket("ff1", 2.0 * a[6] * a[7] * a[8], orig_nt, a, kw)
+        return bracket((nt_class.get(epi, "nt"), a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_nt_bf16"], a, kw)
 
     def tapped_bwd(*a, **kw):
-        return bracket("dff1", 2.0 * a[6] * a[7] * a[8], orig_bwd, a, kw)
+        return bracket(("dff1", a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_nt_bf16_gelu_bwd_colsum"], a, kw)
 
-    def tapped_f8(*a, **kw):        # --fp8: the same two GEMMs go through the fp8 entry point (a[9] = epilogue)
-        key = {L.EPI_BIAS_GELU: "ff1", L.EPI_GELU_BWD: "dff1"}.get(a[9])
-        if key is None:
-            return orig_f8(*a, **kw)
-        return bracket(key, 2.0 * a[6] * a[7] * a[8], orig_f8, a, kw)
+    def tapped_f8(*a, **kw):        # --fp8: the forward / dX GEMMs go through the fp8 entry point (a[9] = epilogue)
+        return bracket((nt_class.get(a[9], "nt"), a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_nt_fp8_v2"], a, kw)
 
-    K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2 = tapped_nt, tapped_bwd, tapped_f8
+    def tapped_tn(*a, **kw):
+        return bracket(("tn", a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_tn_bf16"], a, kw)
+
+    K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2, K.gemm_tn_bf16 = tapped_nt, tapped_bwd, tapped_f8, tapped_tn
     prev = os.environ.get("VITK_DW_STREAM")
     os.environ["VITK_DW_STREAM"] = "0"          # serialized: engine._Fork reads it per backward
     try:
@@ -119,34 +120,38 @@ def time_dominant_kernel(step_fn, nsteps: int = 3):
             step_fn()
         torch.cuda.synchronize()
     finally:
-        K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2 = orig_nt, orig_bwd, orig_f8
+        for n, f in orig.items():
+            setattr(K, n, f)
         if prev is None:
             os.environ.pop("VITK_DW_STREAM", None)
         else:
             os.environ["VITK_DW_STREAM"] = prev
-    out = {}
-    for key, tl in taps.items():
-        if tl:
-            out[key] = (sum(e0.elapsed_time(e1) for e0, e1, _ in tl) / len(tl), tl[0][2], len(tl))
-    return out
+    return {key: (sum(e0.elapsed_time(e1) for e0, e1, _ in tl) / len(tl), tl[0][2], len(tl) // nsteps) for key, tl in taps.items()}
 
 
-TRAFFIC_FILES = ("r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+# (class, N, K) of a ViT-B/16 GEMM -> the label tools/kprof.py / tools/pmc_traffic_json.py give its launch group
+TRAFFIC_LABELS = {("tn", 3072, 768): "dW ff1", ("tn", 2304, 768): "dW qkv", ("ff1", 3072, 768): "FF1 bias+GELU", ("dff1", 3072, 768): "dFF1 GELU'",
+                  ("nt", 2304, 768): "QKV", ("nt_resid", 768, 3072): "FF2 +", ("nt_resid", 768, 768): "out-proj +", ("nt", 768, 3072): "dX of FF1"}
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the roofline kernel from the newest committed PMC collection (profiles/rNN_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md).  Counters cannot be collected from inside this process: the value is STATIC (taken from that file,
-    not from this run); (None, None) if no file is there."""
+def pmc_traffic_bytes(key):
+    """HBM bytes per launch of a GEMM instance from the newest committed PMC collection (profiles/rNN_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).
+    Counters cannot be collected from inside this process: the value is STATIC (taken from that file, not from this run);
+    (None, None, None) if no file has the instance.  Returns (traffic bytes, algorithmic bytes, source)."""
+    label = TRAFFIC_LABELS.get(key)
+    if label is None:
+        return None, None, None
     for name in TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 ks = json.load(f)["kernels"]
-            return next(v["traffic_bytes"] for k, v in ks.items() if "FF1 bias+GELU" in k or "EPI_BIAS_GELU" in k or "Li2E" in k), f"profiles/{name} (static: collected in a separate rocprofv3 --pmc run)"
+            v = next(v for k, v in ks.items() if label in k)
+            return v["traffic_bytes"], v.get("algorithmic_bytes"), f"profiles/{name} (static: collected in a separate rocprofv3 --pmc run)"
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 def cpu_baseline(cfg, budget_s: float = 30.0):
@@ -369,7 +374,7 @@ def main():
     mid = sorted(range(len(dts)), key=dts.__getitem__)[len(dts) // 2]
     dt = dts[mid]
     assert torch.isfinite(loss).item(), "loss is not finite"
-    taps = time_dominant_kernel(step)      # every rank: the steps contain the collectives
+    taps = time_gemm_classes(step)      # every rank: the steps contain the collectives
 
     # one step with every weight-derived cache invalidated (= what each step of a real training loop pays) vs a steady step
     from vit_pytorch_amd import invalidate_weight_caches
@@ -392,29 +397,56 @@ def main():
         value = total_imgs / dt
         gf = 3.0 * fwd_gflop_per_image(cfg)
         N = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
-        kms, kflops, klaunches = taps["ff1"]
-        ach = kflops / (kms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic_bytes()
-        if args.fp8:
-            traffic, traffic_src = None, "not collected for the fp8 flavour (profiles/*_pmc_traffic.json is the bf16 kernel)"
-        others = []
-        if "dff1" in taps:
-            dms, dfl, dn = taps["dff1"]
-            others.append({"kernel": ("gemm_nt256pp_kernel<EPI_GELU_BWD, e5m2 x e4m3>" if args.fp8 else "gemm_ntp_kernel<EPI_GELU_BWD>") + " (dFF1: GELU' + bias-gradient column sums)", "achieved": round(dfl / (dms * 1e-3) / 1e12, 2),
-                           "frac": round(dfl / (dms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * (2.0 if (args.fp8 and model.transformer._fp8.k128) else 1.0)), 4), "avg_launch_ms": round(dms, 4), "launches_timed": dn})
-        isz = cfg["image_size"]
         k128 = bool(args.fp8 and model.transformer._fp8.k128)
+        peak = PEAK_BF16_TFLOPS * (2.0 if k128 else 1.0)
+        # GEMM classes by their share of the step (kernel time per step / measured step time); the roofline kernel is the heaviest
+        # INSTANCE (one shape) of the heaviest class
+        CLASS_NAMES = {"tn": "gemm_tn_w128_kernel + tn_reduce_kernel (weight gradients dW = dY^T X: four waves, 128 x 128 wave tiles)",
+                       "ff1": "gemm_ntp_kernel<EPI_BIAS_GELU> (persistent NT GEMM, FF1)", "dff1": "gemm_ntp_kernel<EPI_GELU_BWD> (dFF1: GELU' + bias-gradient column sums)",
+                       "nt_resid": "gemm_ntp_kernel<EPI_RESID16 / EPI_RESID> (out-projection, FF2: + bias + residual)",
+                       "nt": "gemm_ntp_kernel<EPI_NONE / EPI_BIAS> (QKV and the three dX GEMMs)"}
+        if args.fp8:
+            CLASS_NAMES = {k: v.replace("gemm_ntp_kernel", "gemm_nt256pp_kernel (fp8 operands)").replace("gemm_tn_w128_kernel", "gemm_tn_fp8") for k, v in CLASS_NAMES.items()}
+        classes = {}
+        for (cls, n_, k_), (kms_, kfl_, kn_) in taps.items():
+            c = classes.setdefault(cls, {"ms": 0.0, "flops": 0.0, "launches": 0, "inst": []})
+            c["ms"] += kms_ * kn_; c["flops"] += kfl_ * kn_; c["launches"] += kn_
+            c["inst"].append(((cls, n_, k_), kms_, kfl_, kn_))
+
+        def inst_entry(key, kms_, kfl_, kn_):
+            tr, alg, src = (None, None, None) if args.fp8 else pmc_traffic_bytes(key)
+            ach_ = kfl_ / (kms_ * 1e-3) / 1e12
+            e = {"shape": f"N={key[1]} K={key[2]} (M = {batch * N} token rows)", "achieved": round(ach_, 2), "frac": round(ach_ / peak, 4),
+                 "avg_launch_ms": round(kms_, 4), "launches_per_step": kn_, "traffic": tr, "algorithmic_bytes": alg, "traffic_source": src}
+            if alg and kfl_:       # which roof the bytes say: FLOP per algorithmic byte against the machine balance (peak / 6.3 TB/s)
+                e["flop_per_byte"] = round(kfl_ / alg, 1)
+            return e
+
+        ranked = sorted(classes.items(), key=lambda kv: -kv[1]["ms"])
+        dom_cls, dom = ranked[0]
+        dkey, dms_, dfl_, dn_ = max(dom["inst"], key=lambda t: t[1] * t[3])
+        dent = inst_entry(dkey, dms_, dfl_, dn_)
+        balance = round(peak * 1e12 / 6.3e12, 1)
+        others = []
+        for cls, c in ranked:
+            ach_c = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            top = max(c["inst"], key=lambda t: t[1] * t[3])
+            others.append({"class": cls, "kernel": CLASS_NAMES.get(cls, cls), "ms_per_step": round(c["ms"], 3), "share_of_step": round(c["ms"] / ms, 4),
+                           "launches_per_step": c["launches"], "achieved": round(ach_c, 2), "frac": round(ach_c / peak, 4),
+                           "heaviest_instance": inst_entry(*top)})
+        isz = cfg["image_size"]
         prec = "fp8" if args.fp8 else "bf16"
         # the roof a number is priced against: bf16 MFMA dense for the headline; with --fp8 the fp8 forms the GEMMs actually issue --
         # K = 32 (v_mfma_f32_16x16x32_fp8_fp8 / _fp8_bf8) run at the bf16 rate, K = 128 (v_mfma_f32_16x16x128_f8f6f4) at twice that
-        peak = PEAK_BF16_TFLOPS * (2.0 if k128 else 1.0)
         roof_name = ("fp8 MFMA dense, K = 128 f8f6f4 form: 2 x 2516.6 = 5033.2 TFLOP/s" if k128 else
                      "fp8 MFMA dense, non-scaled K = 32 forms: 2516.6 TFLOP/s (= the bf16 rate)" if args.fp8 else "bf16 MFMA dense: 2516.6 TFLOP/s")
         line = {
             "metric": "images/sec (fwd+bwd) ViT-B/16 224^2 bf16" if (args.config == "vit_b16" and not args.fp8) else f"images/sec (fwd+bwd) {args.config} {prec}",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "ms_per_step_all": [round(d / args.steps * 1e3, 3) for d in dts],
-            "weight_cache_rebuild_ms": round(weight_cache_rebuild_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "weight_cache_rebuild_ms": round(weight_cache_rebuild_ms, 3),
+            "train_loop_ms_per_step": round(ms + weight_cache_rebuild_ms, 3),      # fwd+bwd inside a loop whose optimizer changes the weights every step
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": prec, "data": "synthetic (randn images, randint labels, random-init weights)",
             **({"dtype_detail": "e4m3 x e4m3 forward GEMMs (QKV, out-projection, FF1, FF2), e5m2 gradients x e4m3 weights^T for the four dX GEMMs, "
                                 "e5m2 gradients^T x e4m3 activations for the four dW GEMMs, per-tensor delayed scaling, f32 accumulation; attention, "
@@ -433,12 +465,17 @@ def main():
                       "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
                       **({"frac_note": "whole-step fraction is of the bf16 peak 2516.6 TF/s (the number comparable with the bf16 line); of the fp8 roof named in `roof` it is "
                                        + str(round(value / world * gf / 1e3 / peak, 4))} if args.fp8 else {})},
-            "roofline": {"bound": "mfma", "kernel": ("gemm_nt256pp_kernel<EPI_BIAS_GELU, fp8> (FF1 on e4m3 operands)" if args.fp8 else
-                                                     "gemm_ntp_kernel<EPI_BIAS_GELU> (persistent NT GEMM, FF1: tokens x mlp_dim x dim at this batch)"),
-                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "roof": roof_name,
-                         "frac": round(ach / peak, 4), "avg_launch_ms": round(kms, 4), "launches_timed": klaunches,
-                         "timed_in": "3 extra steps after the timed region, weight-gradient side stream off (serialized launches)",
-                         "traffic": traffic, "traffic_source": traffic_src, "other_kernels": others},
+            "roofline": {"bound": "mfma", "kernel": CLASS_NAMES.get(dom_cls, dom_cls) + f": heaviest class of the step ({round(dom['ms'] / ms * 100, 1)} % of it), "
+                                                      f"timed instance {dent['shape']}",
+                         "achieved": dent["achieved"], "peak": peak, "unit": "TFLOP/s", "roof": roof_name, "frac": dent["frac"],
+                         "avg_launch_ms": dent["avg_launch_ms"], "launches_timed": dent["launches_per_step"] * 3,
+                         "timed_in": "3 extra steps after the timed region, weight-gradient side stream off (serialized launches); a class's share_of_step = its "
+                                     "serialized kernel time per step / the measured step",
+                         "traffic": dent["traffic"], "algorithmic_bytes": dent["algorithmic_bytes"], "traffic_source": dent["traffic_source"],
+                         "machine_balance_flop_per_byte": balance,
+                         "bound_note": "MFMA roof; an instance whose flop_per_byte is below machine_balance_flop_per_byte (peak / 6.3 TB/s) is balanced or HBM-side by its bytes "
+                                       "(FF1 at K = 768 with two 16-bit outputs: 339 FLOP/B against 399)",
+                         "classes": others},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)

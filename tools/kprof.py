@@ -23,6 +23,9 @@ def run(label, n, k, epi):
     if epi == L.EPI_RESID:
         C = torch.zeros(M, n, device=dev); resid = C; aux = None
         alg += 8 * M * n                                   # f32 residual read + f32 write
+    elif epi == L.EPI_RESID16:
+        C = torch.zeros(M, n, dtype=BF, device=dev); resid = C; aux = None
+        alg += 4 * M * n                                   # 16-bit residual read + 16-bit write
     else:
         C = torch.empty(M, n, dtype=BF, device=dev); resid = None; aux = torch.randn(M, n, device=dev).to(BF)
         alg += 2 * M * n * (2 if epi in (L.EPI_BIAS_GELU, L.EPI_GELU_BWD) else 1)   # + pre-activation written (FF1) / read (dFF1)
@@ -46,8 +49,12 @@ def run_tn(label, n, k):
     LABELS.append((label, n, k, 2 * (M * n + M * k + n * k)))
 
 
-PLAN = (("QKV", 3 * D, D, L.EPI_NONE), ("FF1 bias+GELU", F, D, L.EPI_BIAS_GELU), ("out-proj + f32 residual", D, D, L.EPI_RESID),
-        ("FF2 + f32 residual", D, F, L.EPI_RESID), ("dFF1 GELU' + column sums", F, D, L.EPI_GELU_BWD), ("dX of FF1 (K=3072)", D, F, L.EPI_NONE))
+# round 4: the forward residual stream is 16-bit by default (ops.fwd_stream_16), so the two residual GEMMs run the RESID16 epilogue;
+# KPROF_F32_STREAM=1 profiles the float32-stream flavour (rounds 1-3)
+_R = L.EPI_RESID if os.environ.get("KPROF_F32_STREAM") else L.EPI_RESID16
+_RN = "f32 residual" if os.environ.get("KPROF_F32_STREAM") else "16-bit residual"
+PLAN = (("QKV", 3 * D, D, L.EPI_NONE), ("FF1 bias+GELU", F, D, L.EPI_BIAS_GELU), (f"out-proj + {_RN}", D, D, _R),
+        (f"FF2 + {_RN}", D, F, _R), ("dFF1 GELU' + column sums", F, D, L.EPI_GELU_BWD), ("dX of FF1 (K=3072)", D, F, L.EPI_NONE))
 TN_PLAN = (("dW qkv", 3 * D, D), ("dW ff1", F, D))
 
 if __name__ == "__main__":

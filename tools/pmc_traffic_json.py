@@ -35,9 +35,11 @@ def main():
     mfma_dir, mfma_dst = (sys.argv[4:6] if len(sys.argv) >= 6 else (None, None))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     labels = []
-    for lab, n, k, epi in (("QKV", 3 * D, D, 0), ("FF1 bias+GELU", F, D, 2), ("out-proj + f32 residual", D, D, 3), ("FF2 + f32 residual", D, F, 3),
+    f32s = bool(os.environ.get("KPROF_F32_STREAM"))        # rounds 1-3: float32 forward stream (EPI_RESID); round 4 default: 16-bit (EPI_RESID16)
+    rn, re_ = ("f32 residual", 3) if f32s else ("16-bit residual", 5)
+    for lab, n, k, epi in (("QKV", 3 * D, D, 0), ("FF1 bias+GELU", F, D, 2), (f"out-proj + {rn}", D, D, re_), (f"FF2 + {rn}", D, F, re_),
                            ("dFF1 GELU' + column sums", F, D, 4), ("dX of FF1 (K=3072)", D, F, 0)):
-        alg = 2 * (M * k + n * k) + (8 * M * n if epi == 3 else 2 * M * n * (2 if epi in (2, 4) else 1))
+        alg = 2 * (M * k + n * k) + (8 * M * n if epi == 3 else 4 * M * n if epi == 5 else 2 * M * n * (2 if epi in (2, 4) else 1))
         labels.append((lab, n, k, alg))
     for lab, n, k in (("dW qkv", 3 * D, D), ("dW ff1", F, D)):
         labels.append((lab, n, k, 2 * (M * n + M * k + n * k)))

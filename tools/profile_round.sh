@@ -5,7 +5,7 @@
 #   gpurun_out/<tag>_pmc_{fetch,write}/     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/kprof.py
 #   gpurun_out/<tag>_pmc_traffic.json, <tag>_pmc_mfma_util.json, <tag>_kernel_stats_*.csv   the summaries profiles/ keeps
 set -u
-tag=${1:-r01}
+tag=${1:-r04}
 root=$PWD
 export PYTHONPATH=$root
 out=$root/gpurun_out

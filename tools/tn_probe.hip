@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -56,6 +57,8 @@ template <int N_> __device__ __forceinline__ void w_wait_vm() {
     if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N_ == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (N_ == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N_ == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N_ == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else static_assert(N_ < 0, "unsupported vmcnt");
 }
 
@@ -63,10 +66,15 @@ template <int N_> __device__ __forceinline__ void w_wait_vm() {
 // PAD = 1: gemm_tn_dma.hip's image (pieces 1088 B apart, 32-byte windows of odd rows swapped pairwise).
 // PAD = 0: pieces 1 KiB apart (5 stages = exactly the 160 KiB of a CU); the 32-byte window w of token row r sits at window
 //          w ^ (r & 7) of its 256-byte half row, so the 8 rows a 32-lane group reads fall into 8 different bank windows.
-template <int ABL, int NST, int PAD>
+// ST (store-coupling experiment for the NT epilogue question: do trickled global stores cost the LDS-DMA stream anything when the
+// waves that store never wait on vmcnt?): 0 = none; 1 = coupled: every wave issues its 8 DMA pieces AND 2 stores (1 KiB each) per
+// step, its counted wait allows for the younger stores; 2 = decoupled: waves 0, 1 issue all 32 DMA pieces of a step (16 each),
+// waves 2, 3 issue 4 stores each and never wait on vmcnt.  8 KiB of stores per step and CU either way (the rate at which an NT tile's
+// 128 KiB of 16-bit output would trickle out over 16 K-steps).
+template <int ABL, int NST, int PAD, int ST = 0>
 __global__ __launch_bounds__(256) void tn_w128_kernel(
     const __bf16* __restrict__ dY, long long ldy, const __bf16* __restrict__ X, long long ldx,
-    float* __restrict__ ws, int M, int N, int K, int rows_per_split, int tiles_k, int nwg) {
+    float* __restrict__ ws, int M, int N, int K, int rows_per_split, int tiles_k, int nwg, char* __restrict__ scratch, long long scratch_per_wave) {
     using G_ = Geo<PAD>;
     constexpr int PIECE = G_::PIECE, OPER = G_::OPER, STAGE = G_::STAGE;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -103,10 +111,16 @@ __global__ __launch_bounds__(256) void tn_w128_kernel(
     }
     const int ystep = (int)(64 * ldy), xstep = (int)(64 * ldx);        // bytes per 32 token rows
     // piece q (0..7) of step `step` into stage `stg`: q < 4 dY piece 4w + q, else X piece 4w + q - 4
-    auto dma = [&](int step, int stg, int q) __attribute__((always_inline)) {
-        char* dst = lds + stg * STAGE + (q >= 4 ? OPER : 0) + (wave * 4 + (q & 3)) * PIECE;
-        if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (void __attribute__((address_space(3)))*)dst, 16, yvo[q & 3], step * ystep, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (void __attribute__((address_space(3)))*)dst, 16, xvo[q & 3], step * xstep, 0, 0);
+    // dw = 0: this wave's own pieces; dw = 2 (ST = 2, waves 0 and 1): the pieces of wave + 2 (8 token rows further)
+    auto dma = [&](int step, int stg, int q, int dw) __attribute__((always_inline)) {
+        char* dst = lds + stg * STAGE + (q >= 4 ? OPER : 0) + ((wave + dw) * 4 + (q & 3)) * PIECE;
+        if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (void __attribute__((address_space(3)))*)dst, 16, yvo[q & 3], step * ystep + dw * 8 * (int)ldy * 2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (void __attribute__((address_space(3)))*)dst, 16, xvo[q & 3], step * xstep + dw * 8 * (int)ldx * 2, 0, 0);
+    };
+    char* sp = scratch + ((long long)blockIdx.x * 4 + wave) * scratch_per_wave + lane * 16;
+    auto store1k = [&](const bf16x8& v) __attribute__((always_inline)) {
+        asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(sp), "v"(v) : "memory");
+        sp += 1024;
     };
 
     // ---- consumer: lane (fi, fg) reads token row 4 fg + (fi >> 2) (and + 16), bytes (fi & 3) * 8 of a 32-byte window ----
@@ -155,7 +169,10 @@ __global__ __launch_bounds__(256) void tn_w128_kernel(
         if constexpr (!(ABL & 4)) w_mfma(acc[fk_][h_ * 4 + 1], XC[fk_], YC[h_ * 4 + 1]); \
         if constexpr (!(ABL & 2)) hi_ = w_tr<W_IMM_HI(G)>(ra_); \
         if constexpr (!(ABL & 4)) w_mfma(acc[fk_][h_ * 4 + 2], XC[fk_], YC[h_ * 4 + 2]); \
-        if constexpr (!(ABL & 1) && ((G) & 1)) { W_PIN(); dma((T_) + NST, SCUR, (G) >> 1); W_PIN(); } \
+        if constexpr (ROLE == 0 && ST == 1 && ((G) == 0 || (G) == 8)) store1k(XC[0]); \
+        if constexpr (ROLE == 2 && ((G) & 3) == 0) store1k(XC[0]); \
+        if constexpr (!(ABL & 1) && ROLE == 0 && ((G) & 1)) { W_PIN(); dma((T_) + NST, SCUR, (G) >> 1, 0); W_PIN(); } \
+        if constexpr (!(ABL & 1) && ROLE == 1) { W_PIN(); dma((T_) + NST, SCUR, (G) & 7, 2 * ((G) >> 3)); W_PIN(); } \
         if constexpr (!(ABL & 4)) w_mfma(acc[fk_][h_ * 4 + 3], XC[fk_], YC[h_ * 4 + 3]); \
         if constexpr (!(ABL & 2)) { if constexpr ((G) < 8) XN[F_] = w_join(lo_, hi_); else YN[F_] = w_join(lo_, hi_); } \
     } while (0)
@@ -171,19 +188,23 @@ __global__ __launch_bounds__(256) void tn_w128_kernel(
         W_GROUP(12, t_, scur, XC, YC, XN, YN, soff); W_GROUP(13, t_, scur, XC, YC, XN, YN, soff); W_GROUP(14, t_, scur, XC, YC, XN, YN, soff); W_GROUP(15, t_, scur, XC, YC, XN, YN, soff); \
         __builtin_amdgcn_s_setprio(0); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the next step's fragments are in registers */ \
-        if constexpr (!(ABL & 1)) w_wait_vm<8 * (NST - 2)>();   /* own pieces of step t + 2 landed (t + 3 .. t + NST fly) */ \
+        if constexpr (!(ABL & 1) && ROLE == 0) w_wait_vm<(ST == 1 ? 10 : 8) * (NST - 2)>();   /* own pieces of step t + 2 landed (t + 3 .. t + NST fly) */ \
+        if constexpr (!(ABL & 1) && ROLE == 1) w_wait_vm<16 * (NST - 2)>(); \
         W_PIN(); \
         __builtin_amdgcn_s_barrier();           /* stage of t + 2 visible to all, stage of t + 1 read by all */ \
         W_PIN(); \
         scur = snext_; \
     } while (0)
 
-    if (nsteps > 0) {
+    auto run = [&](auto role_c) __attribute__((always_inline)) {
+        constexpr int ROLE = decltype(role_c)::value;       // 0: DMA + compute (+ stores when ST = 1); 1: all the DMA; 2: stores only
+        if constexpr (ROLE != 2) {
 #pragma unroll
-        for (int s = 0; s < NST; ++s)
+            for (int s = 0; s < NST; ++s)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dma(s, s, q);
-        w_wait_vm<8 * (NST - 2)>();             // steps 0, 1 landed
+                for (int q = 0; q < (ROLE == 1 ? 16 : 8); ++q) dma(s, s, q & 7, 2 * (q >> 3));
+            w_wait_vm<(ROLE == 1 ? 16 : 8) * (NST - 2)>();             // steps 0, 1 landed
+        }
         W_PIN();
         __builtin_amdgcn_s_barrier();
         W_PIN();
@@ -208,6 +229,11 @@ __global__ __launch_bounds__(256) void tn_w128_kernel(
             W_STEP(t + 1, xb, yb, xa, ya);
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // nothing may land in this LDS allocation after the workgroup is gone; the asm MFMAs' results are complete before the compiler's reads of them
+    };
+    if (nsteps > 0) {
+        if constexpr (ST == 2) {
+            if (wave < 2) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 2>{});
+        } else run(std::integral_constant<int, 0>{});
     }
 #undef W_STEP
 #undef W_GROUP
@@ -243,7 +269,7 @@ __global__ void w_fill_kernel(__bf16* p, long long n, unsigned seed, float scale
 
 #define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e__), __LINE__); return 1; } } while (0)
 
-typedef void (*kern_t)(const __bf16*, long long, const __bf16*, long long, float*, int, int, int, int, int, int);
+typedef void (*kern_t)(const __bf16*, long long, const __bf16*, long long, float*, int, int, int, int, int, int, char*, long long);
 
 int main(int argc, char** argv) {
     const long long M = argc > 3 ? atoll(argv[1]) : 50432, N = argc > 3 ? atoll(argv[2]) : 3072, K = argc > 3 ? atoll(argv[3]) : 768;
@@ -260,6 +286,8 @@ int main(int argc, char** argv) {
     __bf16 *dY, *X; float *ws, *out_new, *out_ref;
     CK(hipMalloc(&dY, M * N * 2)); CK(hipMalloc(&X, M * K * 2)); CK(hipMalloc(&ws, splits * N * K * 4));
     CK(hipMalloc(&out_new, N * K * 4)); CK(hipMalloc(&out_ref, N * K * 4));
+    const long long scratch_per_wave = (rps / 32 + 4) * 4 * 1024;
+    char* scratch; CK(hipMalloc(&scratch, scratch_per_wave * 4 * nwg * splits));
     w_fill_kernel<<<(unsigned)((M * N + 255) / 256), 256>>>(dY, M * N, 1u, 0.02f);
     w_fill_kernel<<<(unsigned)((M * K + 255) / 256), 256>>>(X, M * K, 2u, 1.0f);
     struct Var { const char* name; kern_t k; int lds; };
@@ -271,11 +299,14 @@ int main(int argc, char** argv) {
         {"4 stages unpadded: all", tn_w128_kernel<0, 4, 0>, 4 * Geo<0>::STAGE}, {"4 stages unpadded: reads only", tn_w128_kernel<5, 4, 0>, 4 * Geo<0>::STAGE},
         {"5 stages unpadded: all", tn_w128_kernel<0, 5, 0>, 5 * Geo<0>::STAGE}, {"5 stages unpadded: DMA only", tn_w128_kernel<6, 5, 0>, 5 * Geo<0>::STAGE},
         {"5 stages unpadded: no DMA", tn_w128_kernel<1, 5, 0>, 5 * Geo<0>::STAGE},
+        {"4 st. padded + 8 KiB stores/step, coupled", tn_w128_kernel<0, 4, 1, 1>, 4 * Geo<1>::STAGE},
+        {"4 st. padded + 8 KiB stores/step, decoupled", tn_w128_kernel<0, 4, 1, 2>, 4 * Geo<1>::STAGE},
+        {"4 st. padded, decoupled roles, DMA only", tn_w128_kernel<6, 4, 1, 2>, 4 * Geo<1>::STAGE},
     };
     const int nvars = (int)(sizeof(vars) / sizeof(vars[0]));
     for (int a = 0; a < nvars; ++a) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(vars[a].k), hipFuncAttributeMaxDynamicSharedMemorySize, vars[a].lds));
     auto run_kernel = [&](int a) {
-        hipLaunchKernelGGL(vars[a].k, dim3((unsigned)(nwg * splits)), dim3(256), vars[a].lds, 0, dY, N, X, K, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
+        hipLaunchKernelGGL(vars[a].k, dim3((unsigned)(nwg * splits)), dim3(256), vars[a].lds, 0, dY, N, X, K, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg, scratch, scratch_per_wave);
     };
     auto run_new = [&]() { run_kernel(0); w_reduce_kernel<<<(unsigned)((N * K + 255) / 256), 256>>>(ws, (int)splits, N * K, out_new); };
     auto run_ref = [&]() { return vitk_tn(dY, N, X, K, out_ref, /*f32*/ 0, K, 0, M, N, K, ws, splits, nullptr); };
@@ -298,8 +329,10 @@ int main(int argc, char** argv) {
     printf("w128 kernel + fold: %.3f ms = %.0f TF/s;  production vitk_gemm_tn_bf16: %.3f ms = %.0f TF/s\n", ms_new / 20, fl / (ms_new / 20) / 1e9,
            ms_ref / 20, fl / (ms_ref / 20) / 1e9);
     // every variant that computes the real thing is checked against the production result, then all are timed (kernel alone)
+    const char* only = getenv("TN_PROBE_VARS");      // e.g. "0,4": time only these variants (profiling runs)
     for (int ab = 0; ab < nvars; ++ab) {
-        const bool real = strstr(vars[ab].name, ": all") != nullptr;
+        if (only) { char key[8]; snprintf(key, sizeof key, ",%d,", ab); char buf[256]; snprintf(buf, sizeof buf, ",%s,", only); if (!strstr(buf, key)) continue; }
+        const bool real = strstr(vars[ab].name, ": all") != nullptr || strstr(vars[ab].name, "coupled") != nullptr;
         double relv = -1;
         if (real) {
             CK(hipMemset(ws, 0xff, splits * N * K * 4));
