@@ -149,6 +149,14 @@ WIDE_CASES = {
                          cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072)),
     "vit_l16_full": dict(kind="vit", batch=6, seed=22, sample=1024,
                          cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096)),
+    # THE HEADLINE RUN ITSELF (round 4): BASELINE config 2 at its own batch, 256 -- M = 50,432 token rows, i.e. the tile plans, split
+    # counts and grid shapes bench.py times, end to end against the reference (f32 and its own bf16 run).  1,024 samples per gradient.
+    "vit_b16_full_b256": dict(kind="vit", batch=256, seed=23, sample=1024,
+                              cfg=dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072)),
+    # BASELINE config 5's architecture at depth 4 / batch 8 (M = 4,616): held against the reference with the activation-recompute policy
+    # FORCED ON (what config 5 takes at batch 256), so that path answers to the reference and not to the repo's own full-save run.
+    "vit_h14_d4_b8": dict(kind="vit", batch=8, seed=24, sample=1024,
+                          cfg=dict(image_size=336, patch_size=14, num_classes=1000, dim=1280, depth=4, heads=16, dim_head=80, mlp_dim=5120)),
 }
 GOLD_SAMPLE = 4096
 

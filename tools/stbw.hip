@@ -45,6 +45,29 @@ __global__ __launch_bounds__(512) void store_kernel(char* out, long long bytes_p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// the NT GEMM epilogue's pattern: a workgroup writes 256 x 256 tiles of 16-bit elements into a row-major matrix with `ld_bytes` per row:
+// wave (wm, wn) owns rows wm * 128 .. + 127 and the 128-byte piece wn of every 512-byte row segment; one instruction = 8 rows x one line.
+// tiles_per_wg tiles per workgroup, consecutive tiles ld-adjacent in n (like the grouped order) -- vs the same bytes written contiguously.
+__global__ __launch_bounds__(512) void tile_store_kernel(char* out, long long ld_bytes, int tiles_per_wg, int tiles_n, int contiguous) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 2, wn = wave & 3;
+    f32x4 v = {(float)lane, 1.f, 2.f, 3.f};
+    for (int t = 0; t < tiles_per_wg; ++t) {
+        const long long tile = (long long)blockIdx.x * tiles_per_wg + t;
+        if (contiguous) {
+            char* p = out + tile * 131072 + wave * 16384 + lane * 16;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) st16<0>(p + i * 1024, v);
+        } else {
+            const long long tm = tile / tiles_n, tn = tile % tiles_n;
+            char* p = out + (tm * 256 + wm * 128 + (lane >> 3)) * ld_bytes + tn * 512 + wn * 128 + (lane & 7) * 16;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) st16<0>(p + (long long)i * 8 * ld_bytes, v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 typedef void (*kern_t)(char*, long long, int, int, int, const char*, int);
 
 int main() {
@@ -90,6 +113,36 @@ int main() {
         const double bytes = 256.0 * 8 * 1024 * 1024;
         printf("  reads %.3f ms (%.1f GB/s per CU)  stores %.3f ms (%.1f GB/s per CU)  both %.3f ms (sum of the two alone: %.3f)\n",
                r, bytes / 256 / r / 1e6, s, bytes / 256 / s / 1e6, b, r + s);
+    }
+    printf("the NT epilogue's store pattern (256 CUs, 9 tiles of 256 x 256 x 2 B per workgroup = 302 MB), by row stride:\n");
+    {
+        char* big; CK(hipMalloc(&big, 50432LL * 6144 + (1 << 20)));
+        for (int mode = 0; mode < 4; ++mode) {
+            const long long ld = mode == 1 ? 1536 : mode == 2 ? 4608 : 6144;       // N = 768 / 2304 / 3072 columns of 2 bytes
+            const int tiles_n = (int)(ld / 512), contiguous = mode == 0;
+            float ms = 0, best = 1e9;
+            for (int r = 0; r < 3; ++r) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(tile_store_kernel, dim3(256), dim3(512), 0, 0, big, ld, 9, tiles_n, contiguous);
+                hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            const double bytes = 256.0 * 9 * 131072;
+            printf("  %-28s %.3f ms  %.2f TB/s  %.1f GB/s per CU\n", contiguous ? "contiguous tiles" : mode == 1 ? "row stride 1536 B (N = 768)" : mode == 2 ? "row stride 4608 B (N = 2304)" : "row stride 6144 B (N = 3072)",
+                   best, bytes / best / 1e9, bytes / 256 / best / 1e6);
+        }
+        // one workgroup per XCD-quarter: 64 CUs only (is the strided pattern slow per CU or only in aggregate?)
+        for (int mode = 0; mode < 2; ++mode) {
+            float ms = 0, best = 1e9;
+            for (int r = 0; r < 3; ++r) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(tile_store_kernel, dim3(64), dim3(512), 0, 0, big, 6144LL, 9, 12, mode == 0);
+                hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            const double bytes = 64.0 * 9 * 131072;
+            printf("  64 CUs, %-20s %.3f ms  %.2f TB/s  %.1f GB/s per CU\n", mode == 0 ? "contiguous" : "row stride 6144 B", best, bytes / best / 1e9, bytes / 64 / best / 1e6);
+        }
     }
     return 0;
 }
