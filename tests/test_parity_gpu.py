@@ -151,6 +151,9 @@ def test_production_widths_16bit_vs_reference_golden(name, dtype):
         assert e <= 3e-3 and g <= 3e-3, (e, g)
     else:
         assert e <= 1.5 * e16 + 1e-3 and g <= 1.5 * g16 + 1e-3, (e, e16, g, g16)
+        # at large batch the reference's OWN bf16 gradients are poor (its bf16 sums over 50,432 token rows: 2.0e-1 at batch 256), which
+        # would make the relative rule empty there: the drop-in (f32 accumulation everywhere) is also held to an absolute 2e-2
+        assert g <= 2e-2, (g, g16)
     assert worst <= 0.15, worst
 
 
