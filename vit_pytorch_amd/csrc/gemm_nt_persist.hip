@@ -403,6 +403,17 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     const bool stamp_on = p.stamps && blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == 4);
     long long* my_stamps = p.stamps ? p.stamps + (wave == 4 ? 1024 : 0) : nullptr;
 #define Q_STAMP(slot) do { if (stamp_on && c_g >= 8 && c_g < 40) my_stamps[(c_g - 8) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+    // Q_TIMELINE builds (tools/nt_timeline.py: -DQ_TIMELINE=1, a separate libvitk_tl.so): s_memtime stamps of ONE wave of one workgroup along
+    // the software-pipelined loop -- K-step starts, epilogue start, epilogue stores issued -- kept in LDS above the bias image (ds_write:
+    // the lgkmcnt domain, so the exact vmcnt counts of the DMA ring stay exact) and copied to p.stamps when the workgroup ends.
+#ifdef Q_TIMELINE
+    const bool tl_on = p.stamps && blockIdx.x == 137 && lane == 0 && wave == (p.dbg >> 8);
+    unsigned long long* const tl = reinterpret_cast<unsigned long long*>(lds + Q_LDS_BYTES + 8192);
+    int tl_n = 0;
+#define Q_TL(tag) do { if (tl_on && tl_n < 2040) { tl[tl_n++] = ((unsigned long long)__builtin_readcyclecounter() << 4) | (unsigned)(tag); } } while (0)
+#else
+#define Q_TL(tag) do { } while (0)
+#endif
     auto run_tile = [&](auto fmw_c, int m0, int n0, int mt) {
         constexpr int FMW = decltype(fmw_c)::value;      // m-fragments per wave: 8 (256-row tile) or 4 (128-row tile)
         const int a_off = FMW == 8 ? a_off8 : a_off4;
@@ -432,6 +443,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
             }
             // one K-step: MFMAs on (wf, xf), the next K-step's first fragments are read into (wn_, xn_)
             auto kstep = [&](bf16x8 (&wf)[4], bf16x8 (&xf)[4], bf16x8 (&wn_)[4], bf16x8 (&xn_)[4]) __attribute__((always_inline)) {
+                Q_TL(1);
                 const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
                 const char* nbase = lds + ((c_g + 1) & 3) * Q_STAGE_BYTES;
                 if constexpr (FMW == 8) {
@@ -552,6 +564,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                 for (int j = 0; j < FMW; ++j) asm volatile("" :: "v"(acc[i][j]));
             return;
         }
+        Q_TL(2);
         const bool interior = (m0 + 32 * FMW <= p.M) && (n0 + 256 <= p.N);
         auto body = [&](auto int_c) {
             constexpr bool INT = decltype(int_c)::value;
@@ -773,6 +786,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
         };
         if (interior) body(std::integral_constant<bool, true>{});
         else body(std::integral_constant<bool, false>{});
+        Q_TL(3);
     };
 
     // ---- dynamic tickets: the first two, drawn by wave 0 ----
@@ -830,6 +844,12 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     }
     if (!PIPE && !grp_b) QQ_BARRIER();  // pairs with group B's extra barrier
     if constexpr (PIPE) q_wait_vm<0>();  // the surplus DMAs of the last K-steps must not outlive the workgroup's LDS allocation
+#ifdef Q_TIMELINE
+    if (tl_on) {
+        p.stamps[0] = tl_n;
+        for (int i = 0; i < tl_n; ++i) p.stamps[1 + i] = (long long)tl[i];
+    }
+#endif
 }
 
 // ---- dynamic tile tickets: 64 launch slots; a slot = 8 per-XCD ticket counters + 8 per-XCD exit counters + 1 chip exit counter,
@@ -973,7 +993,11 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     if (a.tickets) a.tail_first = getenv("VITK_NTP_DYN_ORDER") ? atoi(getenv("VITK_NTP_DYN_ORDER")) : 0;
     a.dbg = getenv("VITK_NTP_DBG") ? atoi(getenv("VITK_NTP_DBG")) : 0;
     a.stamps = getenv("VITK_NTP_STAMPS") ? (long long*)strtoull(getenv("VITK_NTP_STAMPS"), nullptr, 0) : nullptr;
+#ifdef Q_TIMELINE
+    const int lds_bytes = Q_LDS_MAX;
+#else
     const int lds_bytes = Q_LDS_BYTES + pl.tiles_n * 512 + 16;      // ring + bias image (tiles_n * 256 columns of 2 bytes) + 4 ticket words
+#endif
     hipStream_t st = (hipStream_t)stream;
 #define NTP_LAUNCH1(E, P, Dn) do { \
             static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, P, Dn>, Q_LDS_MAX); \
