@@ -825,7 +825,7 @@ class PackedTransformerFn(torch.autograd.Function):
         grads: List[Optional[Tensor]] = [None] * len(lp)
         fork = _Fork(dy.device)
 
-        s16 = drop_p == 0.0 and ops.grad_stream_16()        # the backward's residual stream in the parameter dtype (see TransformerFn.backward)
+        s16 = T in ops.HALF and drop_p == 0.0 and D % 4 == 0 and ops.grad_stream_16()        # the backward's residual stream in the parameter dtype (same guards as TransformerFn.backward)
 
         def newg():
             return (None if s16 else ops.empty((Tn, D), F32, dy)), ops.empty((Tn, D), T, dy)
