@@ -49,6 +49,27 @@ def test_layernorm_fwd(xdt, ydt, wdt, rows, D):
     assert rel(rstd, 1 / torch.sqrt(x.double().var(-1, unbiased=False) + 1e-5)) < 1e-5
 
 
+@pytest.mark.parametrize("rows,D", [(50432, 768), (1577, 768), (1024, 1024), (25216 + 1, 1024), (4616 + 3, 1280), (2049, 1280)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_layernorm_fwd_16bit_rows_two_per_wave(rows, D, bias):
+    """ln_fwd16_kernel (round 4: 16-bit x, y, w of 768 / 1024 / 1280 columns, identity maps: two rows per wave, 16-byte accesses) against
+    float64, row counts that end inside a pair of rows / a block, NaN behind the last row (a half past the end must store nothing)."""
+    x = rnd(rows, D, dtype=BF, seed=21) * 2 + 0.5
+    w = (1 + 0.1 * rnd(D, seed=22)).to(BF); b = (0.1 * rnd(D, seed=23)).to(BF) if bias else None
+    ybuf = torch.full((rows + 2, D), float("nan"), dtype=BF, device=DEV); y = ybuf[:rows]
+    mbuf = torch.full((rows + 2,), float("nan"), device=DEV); rbuf = torch.full((rows + 2,), float("nan"), device=DEV)
+    K.layernorm_fwd(x, w, b, y, mbuf[:rows], rbuf[:rows], rows, D)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double() if bias else None, 1e-5)
+    assert rel(y, ref) < 4e-3
+    assert rel(mbuf[:rows], x.double().mean(-1)) < 1e-5
+    assert rel(rbuf[:rows], 1 / torch.sqrt(x.double().var(-1, unbiased=False) + 1e-5)) < 1e-5
+    assert torch.isnan(ybuf[rows:]).all() and torch.isnan(mbuf[rows:]).all() and torch.isnan(rbuf[rows:]).all()
+    # the same values as the general kernel's, element for element (same arithmetic per element; the sums are formed in another order)
+    y2 = torch.empty(rows, D, dtype=BF, device=DEV); m2 = torch.empty(rows, device=DEV); r2 = torch.empty(rows, device=DEV)
+    K.layernorm_fwd(x.float(), w, b, y2, m2, r2, rows, D)          # f32 input: the general kernel
+    assert (y.float() - y2.float()).abs().max().item() <= 2 * 2 ** -8 * ref.abs().max().item()
+
+
 def test_layernorm_fwd_rowmaps_and_posadd():
     B, Np, D = 3, 6, 64
     N = Np + 1

@@ -116,6 +116,90 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     }
 }
 
+// ---- 16-bit rows, TWO ROWS PER WAVE (round 4: the forward residual stream is 16-bit by default, ops.fwd_stream_16) -------------------
+// ln_fwd_kernel above moves a 16-bit row as 8-byte pieces (4 elements per lane and chunk): with the stream in the parameter dtype its
+// bytes fell from 232 to 155 MB at ViT-B/16 but its time did not (37 -> 38.7 us in the step, 4.0 TB/s: 8-byte accesses run at
+// 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).  Here a row of D = 256 * CPL elements is owned by HALF a wave: lane l of the half reads
+// CPL chunks of 8 elements (16 bytes) at chunk l + 32 t, so every load / store instruction moves 2 x 512 contiguous bytes; the statistics
+// are reduced inside the half (DPP rotations of the 16-lane rows + one v_permlane16_swap -- no v_permlane32_swap); the NEXT pair of rows
+// is requested before the current pair is reduced (four rows per wave in flight).  Serves x, y, w (b) of one 16-bit type, identity row
+// maps, no fused add, no fp8 side output -- the transformer layers' LayerNorms; everything else stays on ln_fwd_kernel.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += dpp_f32<0x128>(v);   // row_ror:8
+    v += dpp_f32<0x124>(v);   // row_ror:4
+    v += dpp_f32<0x122>(v);   // row_ror:2
+    v += dpp_f32<0x121>(v);   // row_ror:1
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // rows 0 <-> 1 and 2 <-> 3: each half of the wave sums its two rows
+    return __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+}
+typedef float ln_f32x8 __attribute__((ext_vector_type(8)));
+template <int CPL, bool HASB>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd16_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ w, const __bf16* __restrict__ b, __bf16* __restrict__ y,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, long long rows, float eps) {
+    constexpr int D = 256 * CPL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = lane & 31, half = lane >> 5;
+    const float invD = 1.0f / (float)D;
+    ln_f32x8 wv[CPL], bv[CPL];
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+        const bf16x8 w8 = *reinterpret_cast<const bf16x8*>(w + 8 * (hl + 32 * t));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[t][e] = (float)w8[e];
+        if constexpr (HASB) {
+            const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(b + 8 * (hl + 32 * t));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[t][e] = (float)b8[e];
+        }
+    }
+    const long long stride = (long long)gridDim.x * LN_WAVES * 2;
+    long long row = ((long long)blockIdx.x * LN_WAVES + wave) * 2 + half;
+    auto load_row = [&](long long r, bf16x8 (&dst)[CPL]) {
+        const __bf16* xr = x + (r < rows ? r : rows - 1) * (long long)D + 8 * hl;       // a half past the end re-reads the last row, stores nothing
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) dst[t] = *reinterpret_cast<const bf16x8*>(xr + 256 * t);
+    };
+    bf16x8 nx[CPL];
+    load_row(row, nx);
+    // the loop bound is wave-uniform (the even row of the pair): both halves run the same number of iterations
+    for (long long r0 = row - half; r0 < rows; r0 += stride, row += stride) {
+        ln_f32x8 v[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[t][e] = (float)nx[t][e];
+        if (r0 + stride < rows) load_row(row + stride, nx);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) s += ((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) + ((v[t][4] + v[t][5]) + (v[t][6] + v[t][7]));
+        const float mean = half_wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[t][e] - mean; q += d * d; }
+        const float var = half_wave_sum(q) * invD;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (row < rows) {
+            __bf16* yr = y + row * (long long)D + 8 * hl;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (v[t][e] - mean) * rstd * wv[t][e];
+                    if constexpr (HASB) f += bv[t][e];
+                    o[e] = (__bf16)f;
+                }
+                *reinterpret_cast<bf16x8*>(yr + 256 * t) = o;
+            }
+            if (hl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+        }
+    }
+}
+
 // Backward.  DXT is the dtype of the optional second dx output (dx_t).
 // NW waves per block: 8 for rows up to 768 columns (<= 128 VGPRs: two blocks per CU), 4 for wider rows, whose three
 // column accumulators push the kernel to ~155-170 VGPRs -- three 4-wave blocks then fit a CU (12 waves) where a single
@@ -562,6 +646,29 @@ int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* m
                            (const WT*)b, (YT*)y, mean, rstd, rows, D, eps, im, om, (const WT*)add, ag, ao);
         VITK_CHECK_LAUNCH("layernorm_fwd");
         return 0;
+    }
+    // 16-bit rows of 768 / 1024 / 1280 elements with identity maps and nothing fused: two rows per wave, 16-byte accesses (ln_fwd16_kernel);
+    // VITK_LN_FWD16=0 keeps the general kernel (A/B)
+    if constexpr (std::is_same<XT, __bf16>::value && std::is_same<YT, __bf16>::value && std::is_same<WT, __bf16>::value) {
+        static const bool off16 = getenv("VITK_LN_FWD16") && atoi(getenv("VITK_LN_FWD16")) == 0;
+        const int cpl = D / 256;
+        if (!off16 && D % 256 == 0 && cpl >= 3 && cpl <= 5 && rows >= 1024 && im.group <= 0 && om.group <= 0 && !add && !f8.p && !f8.amax && aligned16(w) && (!b || aligned16(b))) {
+#define LN_FWD16_LAUNCH(CPL_, HB_) do { \
+                static const long long resident = [] { int per_cu = 0, dev = 0, cus = 0; \
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_fwd16_kernel<CPL_, HB_>, LN_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 4; \
+                    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; \
+                    return (long long)per_cu * cus; }(); \
+                long long nb = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES); \
+                if (nb > resident) nb = resident; \
+                hipLaunchKernelGGL((ln_fwd16_kernel<CPL_, HB_>), dim3((unsigned)nb), dim3(LN_THREADS), 0, st, (const __bf16*)x, (const __bf16*)w, (const __bf16*)b, \
+                                   (__bf16*)y, mean, rstd, rows, eps); } while (0)
+#define LN_FWD16_CASE(CPL_) do { if (b) LN_FWD16_LAUNCH(CPL_, true); else LN_FWD16_LAUNCH(CPL_, false); } while (0)
+            if (cpl == 3) LN_FWD16_CASE(3); else if (cpl == 4) LN_FWD16_CASE(4); else LN_FWD16_CASE(5);
+#undef LN_FWD16_CASE
+#undef LN_FWD16_LAUNCH
+            VITK_CHECK_LAUNCH("layernorm_fwd (16-bit rows)");
+            return 0;
+        }
     }
     // nontemporal row loads (VITK_LN_FWD_NT=1): [measured, round 3] no gain here, unlike the backward -- two interleaved bench runs
     // 39.2-39.5 ms with the hint vs 39.2-39.3 without (the forward's rows are re-read soon, by the residual epilogue); left opt-in
