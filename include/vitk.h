@@ -340,6 +340,17 @@ int vitk_softmax_bwd(const void* p, const void* dp, void* ds, int dt, int64_t ro
 /* Rearrange 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit.py:100): out[(b*h*w), p1*p2*c]        */
 int vitk_patchify(const void* img, void* out, int dt, int64_t B, int64_t C, int64_t H, int64_t W,
                   int64_t p1, int64_t p2, void* stream);
+/* Fused first stage of the patch embedding (vit.py:100-101): Rearrange + LayerNorm(patch_dim) with the gather in the load -- y[(b*h*w), 768]
+ * = LayerNorm(patch vector) straight from the NCHW image, no `patches` tensor.  Serves 16-bit images of 3 channels with 16 x 16 patches
+ * (vitk_patch_ln_serves: 1 / 0); mean / rstd per patch row are kept for the backward.  The backward gives only the parameter gradients
+ * (the image needs none): partials = [2][nblk][768] floats (dgamma, dbeta; nblk = vitk_patch_ln_bwd_blocks(B*h*w)), fold them with
+ * vitk_colsum_partials.  dy = gradient at the LayerNorm output, (B*h*w, 768), 16-bit.                                             */
+int vitk_patch_ln_serves(int dt, int64_t C, int64_t H, int64_t W, int64_t p1, int64_t p2);
+int64_t vitk_patch_ln_bwd_blocks(int64_t rows);
+int vitk_patch_ln_fwd(const void* img, int dt, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t B,
+                      int64_t C, int64_t H, int64_t W, int64_t p1, int64_t p2, float eps, void* stream);
+int vitk_patch_ln_bwd_params(const void* dy, const void* img, int dt, const float* mean, const float* rstd, float* partials,
+                             int64_t B, int64_t C, int64_t H, int64_t W, int64_t p1, int64_t p2, void* stream);
 /* NaViT patch extraction of ONE image, 'c (h p1) (w p2) -> (h w) (c p1 p2)' (na_vit.py:300): out rows
  * [row0, row0 + h*w) of a (T, C*p*p) matrix (leading dimension ld).                                           */
 int vitk_patchify_cpp(const void* img, void* out, int dt, int64_t C, int64_t H, int64_t W, int64_t p,

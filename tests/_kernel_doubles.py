@@ -413,6 +413,35 @@ def patchify(img, out, B, C, H, W, p1, p2):
     out.view(B * h * w, p1 * p2 * C).copy_(img.reshape(B, C, h, p1, w, p2).permute(0, 2, 4, 3, 5, 1).reshape(B * h * w, p1 * p2 * C))
 
 
+def patch_ln_fwd(img, w, b, y, mean, rstd, B, C, H, W, p1, p2, eps=1e-5):
+    """vitk_patch_ln_fwd: rearrange (vit.py:100) + LayerNorm(patch_dim) (vit.py:101) in one call, mean / rstd kept."""
+    h, ww = H // p1, W // p2
+    P = p1 * p2 * C
+    x = img.reshape(B, C, h, p1, ww, p2).permute(0, 2, 4, 3, 5, 1).reshape(B * h * ww, P).float()
+    m = x.mean(-1); r = 1.0 / torch.sqrt(x.var(-1, unbiased=False) + eps)
+    o = (x - m[:, None]) * r[:, None] * w.float()
+    if b is not None:
+        o = o + b.float()
+    y.view(B * h * ww, P).copy_(o)
+    mean.copy_(m); rstd.copy_(r)
+    CALLS.append(("patch_ln_fwd", (B, C, H, W, p1, p2)))
+
+
+def patch_ln_bwd_params(dy, img, mean, rstd, partials, B, C, H, W, p1, p2):
+    """vitk_patch_ln_bwd_params: dgamma / dbeta partial rows of that LayerNorm, xhat re-formed from the image."""
+    h, ww = H // p1, W // p2
+    P = p1 * p2 * C
+    rows = B * h * ww
+    x = img.reshape(B, C, h, p1, ww, p2).permute(0, 2, 4, 3, 5, 1).reshape(rows, P).float()
+    xh = (x - mean[:, None]) * rstd[:, None]
+    g = dy.reshape(rows, P).float()
+    nblk = partials.numel() // (2 * P)
+    pv = partials.view(2, nblk, P)
+    pv.zero_()
+    pv[0, 0] = (g * xh).sum(0); pv[1, 0] = g.sum(0)
+    CALLS.append(("patch_ln_bwd_params", (B, C, H, W, p1, p2)))
+
+
 def copy_cols(src, ld_src, dst, ld_dst, rows, cols_copy, cols_dst):
     d = _rows(dst, rows, cols_dst, ld_dst)
     d.zero_()
@@ -460,7 +489,7 @@ _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_n
                   gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,
-                  colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify,
+                  colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify, patch_ln_fwd=patch_ln_fwd, patch_ln_bwd_params=patch_ln_bwd_params,
                   copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, concat_tokens=concat_tokens, hnd=hnd, attn_varlen_fwd_bf16=attn_varlen_fwd_bf16, attn_varlen_bwd_bf16=attn_varlen_bwd_bf16,
                   patchify_cpp=patchify_cpp, gather_add2=gather_add2, csr_rowsum=csr_rowsum,
                   rmsnorm_heads_fwd=rmsnorm_heads_fwd, rmsnorm_heads_bwd=rmsnorm_heads_bwd,

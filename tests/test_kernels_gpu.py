@@ -739,3 +739,38 @@ def test_layernorm_bwd_with_output_dropout():
     dc = torch.empty(D, device=DEV)
     K.colsum_partials(partials[2 * nblk * D:], nblk, D, D, dc)
     assert rel(dc, (dx_ref * mk).sum(0)) < 1e-4                            # and so is the bias gradient it yields
+
+
+@pytest.mark.parametrize("B,H,W", [(256, 224, 224), (3, 48, 80), (5, 16, 16), (2, 224, 224)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_patch_ln_gather_fwd_and_param_grads(B, H, W, bias):
+    """vitk_patch_ln_fwd / vitk_patch_ln_bwd_params (round 4: Rearrange + LayerNorm(patch_dim) with the gather in the load, vit.py:100-101)
+    against einops-order patches + float64 LayerNorm, row counts that end inside a pair of patches, NaN behind the last row."""
+    C, p = 3, 16
+    img = rnd(B, C, H, W, dtype=BF, seed=71) * 1.5 + 0.2
+    P = C * p * p
+    w = (1 + 0.1 * rnd(P, seed=72)).to(BF); b = (0.1 * rnd(P, seed=73)).to(BF) if bias else None
+    h, ww = H // p, W // p
+    rows = B * h * ww
+    assert K.patch_ln_serves(img, C, H, W, p, p)
+    ybuf = torch.full((rows + 2, P), float("nan"), dtype=BF, device=DEV)
+    mbuf = torch.full((rows + 2,), float("nan"), device=DEV); rbuf = torch.full((rows + 2,), float("nan"), device=DEV)
+    K.patch_ln_fwd(img, w, b, ybuf[:rows], mbuf[:rows], rbuf[:rows], B, C, H, W, p, p)
+    patches = img.double().reshape(B, C, h, p, ww, p).permute(0, 2, 4, 3, 5, 1).reshape(rows, P)      # 'b c (h p1) (w p2) -> (b h w) (p1 p2 c)'
+    ref = torch.nn.functional.layer_norm(patches, (P,), w.double(), b.double() if bias else None, 1e-5)
+    assert rel(ybuf[:rows], ref) < 4e-3
+    assert rel(mbuf[:rows], patches.mean(-1)) < 1e-5
+    assert rel(rbuf[:rows], 1 / torch.sqrt(patches.var(-1, unbiased=False) + 1e-5)) < 1e-5
+    assert torch.isnan(ybuf[rows:]).all() and torch.isnan(mbuf[rows:]).all()
+    # the same bytes as patchify + the general LayerNorm kernel would give, to the rounding of the output
+    pt = torch.empty(rows, P, dtype=BF, device=DEV); K.patchify(img, pt, B, C, H, W, p, p)
+    assert torch.equal(pt.double(), patches)
+    dy = rnd(rows, P, dtype=BF, seed=74)
+    nblk = K.patch_ln_bwd_blocks(rows)
+    part = torch.full((2 * nblk * P,), float("nan"), device=DEV)
+    K.patch_ln_bwd_params(dy, img, mbuf[:rows], rbuf[:rows], part, B, C, H, W, p, p)
+    dwv = torch.empty(P, device=DEV); dbv = torch.empty(P, device=DEV)
+    K.colsum_partials(part, nblk, P, P, dwv); K.colsum_partials(part[nblk * P:], nblk, P, P, dbv)
+    xh = (patches - patches.mean(-1, keepdim=True)) / torch.sqrt(patches.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    assert rel(dwv, (dy.double() * xh).sum(0)) < 1e-5
+    assert rel(dbv, dy.double().sum(0)) < 1e-5

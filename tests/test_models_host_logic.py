@@ -143,3 +143,25 @@ def test_navit_fused_packed_stack_bf16_against_reference_golden():
     worst = max(rel(p.grad.float(), torch.from_numpy(gold["grad::" + k])) for k, p in m.named_parameters())
     print(f"navit bf16 (fused packed stack): logits {e:.2e}, worst gradient tensor {worst:.2e}")
     assert e < 2e-2 and worst < 8e-2, (e, worst)
+
+
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+def test_patch16_gather_route_against_oracle_bf16(kind):
+    """16 x 16 patches of a 3-channel 16-bit image take the fused gather + LayerNorm(patch_dim) entry points (round 4: no `patches`
+    tensor, the backward re-gathers from the image): host routing against the oracle, and the call list shows no patchify."""
+    cfg = dict(image_size=48, patch_size=16, num_classes=5, dim=64, depth=1, heads=2, dim_head=32, mlp_dim=96)
+    params = make_params(kind, cfg, 77)
+    img = make_images(cfg, 3, 1077)
+    ref_out, ref_g = O.run_fwd_bwd(kind, cfg, params, img, torch.float32)
+    m = (ViT if kind == "vit" else SimpleViT)(**cfg)
+    m.load_state_dict(params, strict=True)
+    m = m.to(torch.bfloat16)
+    with KD.installed() as calls:
+        out = m(img.to(torch.bfloat16))
+        O.loss_fn(out).backward()
+        names = [c[0] for c in calls]
+    assert "patch_ln_fwd" in names and "patch_ln_bwd_params" in names
+    assert rel(out.float(), ref_out) < 2e-2
+    for k, p in m.named_parameters():
+        if ref_g[k].numel():
+            assert rel(p.grad.float(), ref_g[k]) < 6e-2, (k, rel(p.grad.float(), ref_g[k]))

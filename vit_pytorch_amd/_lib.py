@@ -105,6 +105,10 @@ SIGNATURES = {
     "vitk_softmax_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _f, _vp]),
     "vitk_patchify": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "vitk_patchify_cpp": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "vitk_patch_ln_serves": (_i, [_i, _i64, _i64, _i64, _i64, _i64]),
+    "vitk_patch_ln_bwd_blocks": (_i64, [_i64]),
+    "vitk_patch_ln_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
+    "vitk_patch_ln_bwd_params": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "vitk_gather_add2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "vitk_csr_rowsum": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "vitk_gelu_fwd": (_i, [_vp, _vp, _i, _i64, _vp]),

@@ -200,6 +200,134 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd16_kernel(
     }
 }
 
+// ---- patch embedding, first stage: Rearrange 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' + LayerNorm(patch_dim) (vit.py:100-101) with the
+// GATHER IN THE LOAD -- no `patches` tensor, no patchify pass (north star: "patch-embedding (im2col-into-GEMM)").  16-bit images of 3
+// channels, 16 x 16 patches (patch_dim 768 = 32 lanes x 24 elements): half a wave owns a patch; lane l of the half owns pixel row
+// i = l >> 1 and the 8 pixels j0 = 8 (l & 1) .. + 7 of it, i.e. three 16-byte loads (one per channel plane), and these 24 values
+// are exactly the 24 CONSECUTIVE elements (i * 16 + j0) * 3 .. + 23 of the patch vector ("for each pixel the 3 channels are
+// adjacent") -- the channel interleave is a renaming of registers in the f32 arithmetic, and the normalised row is written as
+// 32 lanes x 48 contiguous bytes.  Two horizontally adjacent patches per wave: 64 contiguous bytes per (channel, pixel row).
+template <bool HASB>
+__global__ __launch_bounds__(LN_THREADS) void patch_ln_fwd16_kernel(
+    const __bf16* __restrict__ img, const __bf16* __restrict__ w, const __bf16* __restrict__ b, __bf16* __restrict__ y,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, long long rows, int hp, int wp, long long plane, int W, float eps) {
+    constexpr int D = 768;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = lane & 31, half = lane >> 5;
+    const int pi = hl >> 1, pj0 = (hl & 1) * 8;
+    const float invD = 1.0f / (float)D;
+    float wv[24], bv[24];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const bf16x8 w8 = *reinterpret_cast<const bf16x8*>(w + 24 * hl + 8 * t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[8 * t + e] = (float)w8[e];
+        if constexpr (HASB) {
+            const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(b + 24 * hl + 8 * t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[8 * t + e] = (float)b8[e];
+        }
+    }
+    const long long stride = (long long)gridDim.x * LN_WAVES * 2;
+    long long row = ((long long)blockIdx.x * LN_WAVES + wave) * 2 + half;
+    const int per_img = hp * wp;
+    auto load_patch = [&](long long r, bf16x8 (&dst)[3]) {
+        const long long rr = r < rows ? r : rows - 1;
+        const long long bi = rr / per_img;
+        const int hw = (int)(rr - bi * per_img);
+        const int ph = hw / wp, pw = hw - ph * wp;
+        const __bf16* src = img + bi * 3 * plane + (long long)(ph * 16 + pi) * W + pw * 16 + pj0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[c] = *reinterpret_cast<const bf16x8*>(src + c * plane);
+    };
+    bf16x8 nx[3];
+    load_patch(row, nx);
+    for (long long r0 = row - half; r0 < rows; r0 += stride, row += stride) {
+        float v[24];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[3 * jj + c] = (float)nx[c][jj];
+        if (r0 + stride < rows) load_patch(row + stride, nx);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 24; ++e) s += v[e];
+        const float mean = half_wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 24; ++e) { const float d = v[e] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(half_wave_sum(q) * invD + eps);
+        if (row < rows) {
+            __bf16* yr = y + row * (long long)D + 24 * hl;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (v[8 * t + e] - mean) * rstd * wv[8 * t + e];
+                    if constexpr (HASB) f += bv[8 * t + e];
+                    o[e] = (__bf16)f;
+                }
+                *reinterpret_cast<bf16x8*>(yr + 8 * t) = o;
+            }
+            if (hl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+        }
+    }
+}
+
+// Its backward: only the parameter gradients exist (the image needs none): dgamma[e] = sum_rows dy[r][e] * xhat[r][e], dbeta[e] = sum_rows
+// dy[r][e], with xhat re-formed from the image by the same gather.  Per-lane accumulators for its 24 columns, the 8 half-waves of a block
+// folded through LDS, one partial row pair per block (fold with vitk_colsum_partials: partials = [2][nblk][768] floats).
+__global__ __launch_bounds__(LN_THREADS) void patch_ln_bwd16_kernel(
+    const __bf16* __restrict__ dy, const __bf16* __restrict__ img, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    float* __restrict__ partials, long long rows, int hp, int wp, long long plane, int W) {
+    constexpr int D = 768;
+    __shared__ float red[8 * D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = lane & 31, half = lane >> 5;
+    const int pi = hl >> 1, pj0 = (hl & 1) * 8;
+    const int per_img = hp * wp;
+    float aw[24], ab[24];
+#pragma unroll
+    for (int e = 0; e < 24; ++e) { aw[e] = 0.f; ab[e] = 0.f; }
+    const long long stride = (long long)gridDim.x * LN_WAVES * 2;
+    for (long long row = ((long long)blockIdx.x * LN_WAVES + wave) * 2 + half; row < rows; row += stride) {
+        const long long bi = row / per_img;
+        const int hw = (int)(row - bi * per_img);
+        const int ph = hw / wp, pw = hw - ph * wp;
+        const __bf16* src = img + bi * 3 * plane + (long long)(ph * 16 + pi) * W + pw * 16 + pj0;
+        bf16x8 xv[3], gv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xv[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + c * plane));
+        const __bf16* gr = dy + row * (long long)D + 24 * hl;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) gv[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(gr + 8 * t));
+        const float mean = mean_in[row], rstd = rstd_in[row];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int e = 3 * jj + c;
+                const float g = (float)gv[e >> 3][e & 7];
+                aw[e] += g * (((float)xv[c][jj] - mean) * rstd);
+                ab[e] += g;
+            }
+    }
+    float* mine = red + (wave * 2 + half) * D + 24 * hl;
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int e = 0; e < 24; ++e) mine[e] = pass ? ab[e] : aw[e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += LN_THREADS) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += red[k * D + c];
+            partials[((long long)pass * gridDim.x + blockIdx.x) * D + c] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 // Backward.  DXT is the dtype of the optional second dx output (dx_t).
 // NW waves per block: 8 for rows up to 768 columns (<= 128 VGPRs: two blocks per CU), 4 for wider rows, whose three
 // column accumulators push the kernel to ~155-170 VGPRs -- three 4-wave blocks then fit a CU (12 waves) where a single
@@ -797,6 +925,44 @@ extern "C" int vitk_layernorm_fwd_fp8(const void* x, int xdt, const void* w, con
     if (xdt == VITK_BF16 && ydt == VITK_BF16) return launch_ln_fwd<__bf16, __bf16, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st, f8);
     if (xdt == VITK_BF16 && ydt == VITK_F32) return launch_ln_fwd<__bf16, float, __bf16>(x, w, b, y, mean, rstd, rows, (int)D, eps, im, om, add, add_group, add_off, st, f8);
     VITK_FAIL(VITK_E_DTYPE, "layernorm_fwd: bad dtype combination");
+}
+
+// ---- fused patch gather + LayerNorm(patch_dim) (see patch_ln_fwd16_kernel) ----
+extern "C" int vitk_patch_ln_serves(int dt, int64_t C, int64_t H, int64_t W, int64_t p1, int64_t p2) {
+    return dt == VITK_BF16 && C == 3 && p1 == 16 && p2 == 16 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && !getenv("VITK_NO_PATCH_LN");
+}
+extern "C" int64_t vitk_patch_ln_bwd_blocks(int64_t rows) {
+    int64_t nb = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES);
+    return nb > 512 ? 512 : (nb < 1 ? 1 : nb);
+}
+extern "C" int vitk_patch_ln_fwd(const void* img, int dt, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t B,
+                                 int64_t C, int64_t H, int64_t W, int64_t p1, int64_t p2, float eps, void* stream) {
+    if (!img || !w || !y || !mean || !rstd) VITK_FAIL(VITK_E_ARG, "patch_ln_fwd: null pointer");
+    if (!vitk_patch_ln_serves(dt, C, H, W, p1, p2) || B <= 0) VITK_FAIL(VITK_E_SHAPE, "patch_ln_fwd: serves 16-bit images of 3 channels with 16 x 16 patches (ask vitk_patch_ln_serves)");
+    if (!aligned16(img) || !aligned16(w) || (b && !aligned16(b)) || !aligned16(y)) VITK_FAIL(VITK_E_ALIGN, "patch_ln_fwd: pointers must be 16-byte aligned");
+    const int hp = (int)(H / 16), wp = (int)(W / 16);
+    const long long rows = (long long)B * hp * wp;
+    long long nb = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES);
+    if (nb > 4096) nb = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (b) hipLaunchKernelGGL((patch_ln_fwd16_kernel<true>), dim3((unsigned)nb), dim3(LN_THREADS), 0, st, (const __bf16*)img, (const __bf16*)w, (const __bf16*)b,
+                              (__bf16*)y, mean, rstd, rows, hp, wp, (long long)H * W, (int)W, eps);
+    else hipLaunchKernelGGL((patch_ln_fwd16_kernel<false>), dim3((unsigned)nb), dim3(LN_THREADS), 0, st, (const __bf16*)img, (const __bf16*)w, (const __bf16*)nullptr,
+                            (__bf16*)y, mean, rstd, rows, hp, wp, (long long)H * W, (int)W, eps);
+    VITK_CHECK_LAUNCH("patch_ln_fwd");
+    return 0;
+}
+extern "C" int vitk_patch_ln_bwd_params(const void* dy, const void* img, int dt, const float* mean, const float* rstd, float* partials,
+                                        int64_t B, int64_t C, int64_t H, int64_t W, int64_t p1, int64_t p2, void* stream) {
+    if (!dy || !img || !mean || !rstd || !partials) VITK_FAIL(VITK_E_ARG, "patch_ln_bwd_params: null pointer");
+    if (!vitk_patch_ln_serves(dt, C, H, W, p1, p2) || B <= 0) VITK_FAIL(VITK_E_SHAPE, "patch_ln_bwd_params: serves 16-bit images of 3 channels with 16 x 16 patches");
+    if (!aligned16(img) || !aligned16(dy)) VITK_FAIL(VITK_E_ALIGN, "patch_ln_bwd_params: pointers must be 16-byte aligned");
+    const int hp = (int)(H / 16), wp = (int)(W / 16);
+    const long long rows = (long long)B * hp * wp;
+    hipLaunchKernelGGL(patch_ln_bwd16_kernel, dim3((unsigned)vitk_patch_ln_bwd_blocks(rows)), dim3(LN_THREADS), 0, (hipStream_t)stream, (const __bf16*)dy,
+                       (const __bf16*)img, mean, rstd, partials, rows, hp, wp, (long long)H * W, (int)W);
+    VITK_CHECK_LAUNCH("patch_ln_bwd_params");
+    return 0;
 }
 
 extern "C" int64_t vitk_layernorm_bwd_blocks(int64_t rows, int64_t D) {

@@ -186,6 +186,14 @@ def _recompute_policy(saved_bytes: int, device) -> bool:
     return saved_bytes > 0.45 * total
 
 
+def forward_stream_is_16bit(T, M: int, D: int, I: int, Fh: int, depth: int, drop_p: float, fp8, has_out: bool, has_b1: bool) -> bool:
+    """Whether TransformerFn runs its forward residual stream in the parameter dtype (ops.fwd_stream_16: the default for bfloat16;
+    no fp8, no active dropout, both residual GEMMs of a layer on the persistent kernel).  One predicate for the stage itself and for
+    the patch embedding in front of it (PatchEmbedFn out16)."""
+    return bool(T in ops.HALF and depth > 0 and drop_p == 0.0 and fp8 is None and has_out and has_b1
+                and ops.fwd_stream_16(T) and ops.stream16_ok(M, D, I, Fh))
+
+
 class TransformerFn(torch.autograd.Function):
     """Transformer.forward (vit.py:78-83 / simple_vit.py:74-78).  drop_p > 0 (training): the four dropouts of a layer --
     attention matrix (vit.py:60), after to_out (:48), after the GELU (:22), after the second FeedForward Linear (:24) --
@@ -206,8 +214,8 @@ class TransformerFn(torch.autograd.Function):
         # the forward residual stream: float32, or (ops.fwd_stream_16: default for bfloat16 parameters; no fp8, no active dropout, both residual
         # GEMMs on the persistent kernel) the parameter dtype -- every consumer below takes either
         depth_, I_ = len(lp) // NLP, heads * dim_head
-        s16f = bool(T in ops.HALF and depth_ > 0 and drop_p == 0.0 and fp8 is None and lp[3] is not None and lp[8] is not None
-                    and ops.fwd_stream_16(T) and ops.stream16_ok(M, D, I_, lp[7].shape[0]))
+        s16f = forward_stream_is_16bit(T, M, D, I_, lp[7].shape[0] if depth_ else 0, depth_, drop_p, fp8, depth_ > 0 and lp[3] is not None,
+                                       depth_ > 0 and lp[8] is not None)
         SD = T if s16f else F32
         if x.dtype == SD:
             xs = x
@@ -533,7 +541,9 @@ class PatchEmbedFn(torch.autograd.Function):
     simple_vit.py:90-95, :113-114).  Output: float32 residual stream (B, N, D)."""
 
     @staticmethod
-    def forward(ctx, img, p1: int, p2: int, ln1w, ln1b, w, b, ln2w, ln2b, cls, pos):
+    def forward(ctx, img, p1: int, p2: int, ln1w, ln1b, w, b, ln2w, ln2b, cls, pos, out16: bool = False):
+        """out16: write the stream in the parameter dtype (the caller knows that the transformer stage behind it runs the 16-bit
+        forward stream, forward_stream_is_16bit): saves the float32 write here and the cast there."""
         K.require_device(img, w)
         T = w.dtype
         if img.dtype != T:
@@ -552,10 +562,19 @@ class PatchEmbedFn(torch.autograd.Function):
         if pos is not None and pos.shape[0] < N:
             raise VitkError(f"sequence of {N} tokens exceeds the positional table ({pos.shape[0]} rows)")
         Mp = B * Np
-        patches = ops.empty((Mp, P), T, img)
-        K.patchify(img, patches, B, C, H, W, p1, p2)
         pn = ops.empty((Mp, P), T, img)
-        st1 = ops.ln_fwd(patches, ln1w, ln1b, Mp, P, pn)
+        # Rearrange + LayerNorm(patch_dim) (vit.py:100-101).  16-bit images of 3 channels with 16 x 16 patches: ONE kernel gathers the patch
+        # straight from the NCHW image inside the LayerNorm's load (no `patches` tensor, no patchify pass; the backward re-gathers from the
+        # image, which is kept instead); everything else: patchify, then LayerNorm.
+        gather = T in ops.HALF and K.patch_ln_serves(img, C, H, W, p1, p2)
+        if gather:
+            patches = None
+            st1 = (ops.empty((Mp,), F32, img), ops.empty((Mp,), F32, img))
+            K.patch_ln_fwd(img, ln1w, ln1b, pn, st1[0], st1[1], B, C, H, W, p1, p2, ops.LN_EPS)
+        else:
+            patches = ops.empty((Mp, P), T, img)
+            K.patchify(img, patches, B, C, H, W, p1, p2)
+            st1 = ops.ln_fwd(patches, ln1w, ln1b, Mp, P, pn)
         # patch_dim that is not a multiple of 32 (ViT-H/14: 3*14*14 = 588): zero-pad the contraction to the MFMA K-step
         Pp = (P + 31) // 32 * 32 if (T != F32 and P % 32) else P
         if Pp != P:
@@ -564,12 +583,13 @@ class PatchEmbedFn(torch.autograd.Function):
         else:
             w_mm = w
         y = ops.linear_fwd(pn, w_mm, b, Mp)
-        x0 = ops.empty((B, N, D), F32, img)
+        x0 = ops.empty((B, N, D), T if (out16 and T in ops.HALF) else F32, img)
         st2 = ops.ln_fwd(y, ln2w, ln2b, Mp, D, x0, omap=RowMap(Np, N, ncls), add=pos, add_group=Np, add_off=ncls)
         if ncls:
             K.write_cls_rows(x0, cls, pos, B, N, D, ncls)
         ctx.save_for_backward(ln1w, ln1b, w, ln2w, ln2b, *([b] if b is not None else []))
-        ctx.inter = (patches, st1, pn, y, st2)
+        ctx.inter = (patches if not gather else img, st1, pn, y, st2)
+        ctx.gather = (B, C, H, W, p1, p2) if gather else None
         ctx.pad = (Pp, w_mm if Pp != P else None)
         ctx.cls_pos = (cls, pos)
         ctx.meta = (B, Np, N, P, D, ncls, b is not None, cls is not None, pos is not None and pos.requires_grad,
@@ -589,7 +609,7 @@ class PatchEmbedFn(torch.autograd.Function):
         T = w.dtype
         Mp = B * Np
         g = g.contiguous()
-        if g.dtype != F32:
+        if g.dtype != F32 and not (g.dtype == T and T in ops.HALF):        # the 16-bit stream's gradient is consumed as it is
             g32 = ops.empty((B, N, D), F32, g)
             K.cast(g, g32)
             g = g32
@@ -625,11 +645,19 @@ class PatchEmbedFn(torch.autograd.Function):
             ops.linear_dw(dyp, pn, Mp, dw, db)
             dpn = ops.linear_dx(dyp, w, Mp)
         dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
-        ops.ln_bwd(dpn, patches, ln1w, st1[0], st1[1], Mp, P, dw=dl1w, db=dl1b)  # the image needs no gradient
+        if ctx.gather is not None:       # the image needs no gradient: only dgamma / dbeta, xhat re-formed from the image by the same gather
+            gB, gC, gH, gW, gp1, gp2 = ctx.gather
+            nblk = K.patch_ln_bwd_blocks(Mp)
+            part = ops.empty((2 * nblk * P,), F32, dpn)
+            K.patch_ln_bwd_params(dpn, patches, st1[0], st1[1], part, gB, gC, gH, gW, gp1, gp2)       # `patches` is the image here
+            K.colsum_partials(part, nblk, P, P, dl1w)
+            K.colsum_partials(part[nblk * P:], nblk, P, P, dl1b)
+        else:
+            ops.ln_bwd(dpn, patches, ln1w, st1[0], st1[1], Mp, P, dw=dl1w, db=dl1b)  # the image needs no gradient
         s = _sink()
         if s is not None:
             s.stage_done("patch_embed")
-        return (None, None, None, _ret(dl1w), _ret(dl1b), _ret(dw), _ret(db), _ret(dl2w), _ret(dl2b), _ret(dcls), _ret(dpos))
+        return (None, None, None, _ret(dl1w), _ret(dl1b), _ret(dw), _ret(db), _ret(dl2w), _ret(dl2b), _ret(dcls), _ret(dpos), None)
 
 
 def _head_dx(dl, w, out, ldo, B, D, C):

@@ -235,6 +235,26 @@ def softmax_bwd(p: Tensor, dp: Tensor, ds: Tensor, rows: int, cols: int, scale: 
     check(_lib_for(p, dp, ds).vitk_softmax_bwd(_p(p), _p(dp), _p(ds), dt(p), rows, cols, scale, _stream()), "softmax_bwd")
 
 
+# ---- fused patch gather + LayerNorm(patch_dim) (vit.py:100-101) ------------------------------------
+def patch_ln_serves(img: Tensor, C: int, H: int, W: int, p1: int, p2: int) -> bool:
+    return bool(_lib_for(img).vitk_patch_ln_serves(dt(img), C, H, W, p1, p2))
+
+
+def patch_ln_bwd_blocks(rows: int) -> int:
+    return int(L.load().vitk_patch_ln_bwd_blocks(rows))
+
+
+def patch_ln_fwd(img: Tensor, w: Tensor, b: Optional[Tensor], y: Tensor, mean: Tensor, rstd: Tensor, B: int, C: int, H: int, W: int,
+                 p1: int, p2: int, eps: float = 1e-5):
+    check(_lib_for(img, w, y).vitk_patch_ln_fwd(_p(img), dt(img), _p(w), _p(b), _p(y), _p(mean), _p(rstd), B, C, H, W, p1, p2, eps, _stream()),
+          "patch_ln_fwd")
+
+
+def patch_ln_bwd_params(dy: Tensor, img: Tensor, mean: Tensor, rstd: Tensor, partials: Tensor, B: int, C: int, H: int, W: int, p1: int, p2: int):
+    check(_lib_for(dy, img).vitk_patch_ln_bwd_params(_p(dy), _p(img), dt(img), _p(mean), _p(rstd), _p(partials), B, C, H, W, p1, p2, _stream()),
+          "patch_ln_bwd_params")
+
+
 # ---- element-wise ------------------------------------------------------------------------------
 def patchify(img: Tensor, out: Tensor, B: int, C: int, H: int, W: int, p1: int, p2: int):
     check(_lib_for(img, out).vitk_patchify(_p(img), _p(out), dt(img), B, C, H, W, p1, p2, _stream()), "patchify")

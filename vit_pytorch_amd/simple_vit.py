@@ -80,6 +80,15 @@ class Transformer(nn.Module):
     def _fusable(self) -> bool:
         return not _any_hooks(self.norm, *(blk for pair_ in self.layers for blk in pair_))
 
+    def wants_16bit_stream(self, B: int, N: int) -> bool:
+        """See vit.Transformer.wants_16bit_stream: the patch embedding then writes the stream in the parameter dtype directly."""
+        if not len(self.layers) or not self._fusable():
+            return False
+        attn, ff = self.layers[0]
+        lp = E.pack_layer_params(attn, ff)
+        return E.forward_stream_is_16bit(self.norm.weight.dtype, B * N, self.norm.weight.shape[0], self._heads * self._dim_head, lp[7].shape[0],
+                                         len(self.layers), 0.0, getattr(self, "_fp8", None), lp[3] is not None, lp[8] is not None)
+
     def forward(self, x):
         if not self._fusable():
             x = Fn.cast(x, self.norm.weight.dtype)       # in the graph: the embedding stage may have produced an f32 stream
@@ -125,8 +134,10 @@ class SimpleViT(nn.Module):
             tokens = embed(img)
             tokens = Fn.AddFn.apply(tokens, pos.unsqueeze(0).expand_as(tokens).contiguous())
         else:
+            ntok = (img.shape[-2] // embed[0].p1) * (img.shape[-1] // embed[0].p2)
             tokens = E.PatchEmbedFn.apply(img, embed[0].p1, embed[0].p2, embed[1].weight, embed[1].bias, embed[2].weight,
-                                          embed[2].bias, embed[3].weight, embed[3].bias, None, pos)
+                                          embed[2].bias, embed[3].weight, embed[3].bias, None, pos,
+                                          img.dim() == 4 and self.transformer.wants_16bit_stream(img.shape[0], ntok))
         tokens = self.transformer(tokens)
         if _has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.linear_head):
             return self.linear_head(self.to_latent(Fn.MeanTokensFn.apply(tokens)))

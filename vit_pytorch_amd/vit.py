@@ -142,6 +142,20 @@ class Transformer(Module):
             return E.dropout_fusable(self.norm.weight.dtype, B, N, D, self._heads, self._dim_head, self.layers[0][1].net[1].weight.shape[0])
         return True
 
+    def wants_16bit_stream(self, B: int, N: int) -> bool:
+        """Whether forward() on a (B, N, dim) input will run the fused stage with its residual stream in the parameter dtype: the patch
+        embedding in front of it then writes that dtype directly (engine.PatchEmbedFn out16) instead of float32 + a cast."""
+        if not len(self.layers):
+            return False
+        import types
+        D = self.norm.weight.shape[0]
+        if not self._fusable(types.SimpleNamespace(shape=(B, N, D))):
+            return False
+        attn, ff = self.layers[0]
+        return E.forward_stream_is_16bit(self.norm.weight.dtype, B * N, D, self._heads * self._dim_head, ff.net[1].weight.shape[0], len(self.layers),
+                                         float(self._dropout_p()), getattr(self, "_fp8", None), not isinstance(attn.to_out, nn.Identity),
+                                         ff.net[1].bias is not None)
+
     def forward(self, x):
         if self._fusable(x):
             params = []
@@ -193,8 +207,10 @@ class ViT(Module):
     def forward(self, img):
         pe = self.to_patch_embedding
         if self._embed_fusable():
+            ntok = (img.shape[-2] // pe[0].p1) * (img.shape[-1] // pe[0].p2) + self.cls_token.shape[0]
             x = E.PatchEmbedFn.apply(img, pe[0].p1, pe[0].p2, pe[1].weight, pe[1].bias, pe[2].weight, pe[2].bias,
-                                     pe[3].weight, pe[3].bias, self.cls_token, self.pos_embedding)
+                                     pe[3].weight, pe[3].bias, self.cls_token, self.pos_embedding,
+                                     img.dim() == 4 and self.transformer.wants_16bit_stream(img.shape[0], ntok))
         else:
             x = pe(img)
             x = _prepend_cls_add_pos(x, self.cls_token, self.pos_embedding)
