@@ -85,7 +85,7 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
       ff1       NT GEMM with the fused bias + GELU epilogue       dff1   NT GEMM with the GELU' + bias-gradient column sums epilogue
       nt_resid  NT GEMM + bias + residual (out-projection, FF2)    nt     NT GEMM, plain / bias epilogue (QKV, the three dX GEMMs)"""
     from vit_pytorch_amd import _lib as L, kernels as K
-    orig = {n: getattr(K, n) for n in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum", "gemm_nt_fp8_v2", "gemm_tn_bf16")}
+    orig = {n: getattr(K, n) for n in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum", "gemm_nt_bf16_mul_aux_colsum", "gemm_nt_fp8_v2", "gemm_tn_bf16")}
     taps = {}
 
     def bracket(key, flops, fn, a, kw):
@@ -97,7 +97,7 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
         taps.setdefault(key, []).append((e0, e1, flops))
         return r
 
-    nt_class = {L.EPI_BIAS_GELU: "ff1", L.EPI_GELU_BWD: "dff1", L.EPI_RESID: "nt_resid", L.EPI_RESID16: "nt_resid"}
+    nt_class = {L.EPI_BIAS_GELU: "ff1", L.EPI_BIAS_GELU_DG: "ff1", L.EPI_GELU_BWD: "dff1", L.EPI_MUL_AUX: "dff1", L.EPI_RESID: "nt_resid", L.EPI_RESID16: "nt_resid"}
 
     def tapped_nt(*a, **kw):
         epi = a[9] if len(a) > 9 else kw.get("epilogue", L.EPI_NONE)
@@ -106,6 +106,9 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
     def tapped_bwd(*a, **kw):
         return bracket(("dff1", a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_nt_bf16_gelu_bwd_colsum"], a, kw)
 
+    def tapped_mul(*a, **kw):
+        return bracket(("dff1", a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_nt_bf16_mul_aux_colsum"], a, kw)
+
     def tapped_f8(*a, **kw):        # --fp8: the forward / dX GEMMs go through the fp8 entry point (a[9] = epilogue)
         return bracket((nt_class.get(a[9], "nt"), a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_nt_fp8_v2"], a, kw)
 
@@ -113,6 +116,7 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
         return bracket(("tn", a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_tn_bf16"], a, kw)
 
     K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2, K.gemm_tn_bf16 = tapped_nt, tapped_bwd, tapped_f8, tapped_tn
+    K.gemm_nt_bf16_mul_aux_colsum = tapped_mul
     prev = os.environ.get("VITK_DW_STREAM")
     os.environ["VITK_DW_STREAM"] = "0"          # serialized: engine._Fork reads it per backward
     try:
@@ -402,7 +406,8 @@ def main():
         # GEMM classes by their share of the step (kernel time per step / measured step time); the roofline kernel is the heaviest
         # INSTANCE (one shape) of the heaviest class
         CLASS_NAMES = {"tn": "gemm_tn_w128_kernel + tn_reduce_kernel (weight gradients dW = dY^T X: four waves, 128 x 128 wave tiles)",
-                       "ff1": "gemm_ntp_kernel<EPI_BIAS_GELU> (persistent NT GEMM, FF1)", "dff1": "gemm_ntp_kernel<EPI_GELU_BWD> (dFF1: GELU' + bias-gradient column sums)",
+                       "ff1": "gemm_ntp_kernel<EPI_BIAS_GELU_DG> (persistent NT GEMM, FF1: bias + GELU, stores the gelu' factor for the backward)",
+                       "dff1": "gemm_ntp_kernel<EPI_MUL_AUX> (dFF1: x the stored gelu' factor + bias-gradient column sums)",
                        "nt_resid": "gemm_ntp_kernel<EPI_RESID16 / EPI_RESID> (out-projection, FF2: + bias + residual)",
                        "nt": "gemm_ntp_kernel<EPI_NONE / EPI_BIAS> (QKV and the three dX GEMMs)"}
         if args.fp8:

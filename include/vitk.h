@@ -128,6 +128,11 @@ int vitk_colsum(const void* x, int xdt, int64_t rows, int64_t cols, int64_t ld,
 #define VITK_EPI_RESID16 5     /* C16 = T(resid16 + acc (+ bias[n])): the `+ x` of vit.py:80-81 with the forward residual stream in the
                                   16-bit type (opt-in, VITK_FWD_STREAM=16); `resid` then points at 16-bit data; persistent kernel only */
 #define VITK_EPI_GELU_BWD 4    /* C = acc * gelu'(aux[m][n])   (aux = saved pre-activation)     */
+#define VITK_EPI_BIAS_GELU_DG 6 /* BIAS_GELU whose aux output is gelu'(pre) (of the rounded pre-activation) instead of pre: what the backward needs of
+                                  pre is only that factor, and with it stored the backward GEMM's epilogue is a multiplication (VITK_EPI_MUL_AUX)
+                                  instead of a second polynomial + exponential per element; persistent kernel only, no fused dropout */
+#define VITK_EPI_MUL_AUX 7     /* C = acc * aux[m][n]  (aux = the gelu' factor BIAS_GELU_DG stored); column sums as with GELU_BWD
+                                  (vitk_gemm_nt_bf16_mul_aux_colsum); persistent kernel only */
 
 /* C[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  A, W bf16, K-contiguous ("NT").
  * Requirements: K % 32 == 0; lda, ldw % 8 == 0; N % 4 == 0; pointers 16-byte aligned.
@@ -142,6 +147,9 @@ int vitk_gemm_nt_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
  * bf16-rounded C; fold them with vitk_colsum_partials(partials, R, N, N, ...).  R == 0: the shape is not served by
  * the 256-row kernel and this entry point refuses it (use vitk_gemm_nt_bf16 + vitk_colsum).                       */
 int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc);
+/* The same with VITK_EPI_MUL_AUX: C = (A . W^T) * aux, aux = the gelu' factor a VITK_EPI_BIAS_GELU_DG forward stored. */
+int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                     int64_t M, int64_t N, int64_t K, const void* aux, float* colsum_partials, void* stream);
 /* Tile schedule of the persistent NT kernel for (M, N, K) (tests, tuning): out[0] = 1 when the shape is served by it,
  * out[1] = 256-row m-tiles, out[2] = 128-row m-tiles of the tail region, out[3] = resident workgroups, out[4] = n-tiles. */
 int vitk_gemm_nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, int32_t* out5);

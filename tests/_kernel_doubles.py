@@ -53,9 +53,18 @@ def _w_plain(W, ldw, N, Kd):
 
 
 def _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials=None):
-    if epilogue in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_RESID, L.EPI_RESID16) and bias is not None:
+    if epilogue in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_BIAS_GELU_DG, L.EPI_RESID, L.EPI_RESID16) and bias is not None:
         acc = acc + bias.float()
-    if epilogue == L.EPI_BIAS_GELU:
+    if epilogue == L.EPI_BIAS_GELU_DG:                              # aux = gelu'(pre) of the pre-activation rounded to T
+        pre = acc.to(aux.dtype).float()
+        aux.view(M, N).copy_(O.gelu_bwd(torch.ones_like(pre), pre))
+        C.view(M, N).copy_(O.gelu_fwd(pre))
+    elif epilogue == L.EPI_MUL_AUX:
+        C.view(M, N).copy_(acc * aux.view(M, N).float())
+        if partials is not None:
+            partials.zero_()
+            partials[:N] = C.view(M, N).float().sum(0)
+    elif epilogue == L.EPI_BIAS_GELU:
         aux.view(M, N).copy_(acc)                                   # pre-activation, rounded to T
         if C is not None:                                           # (fp8, lean saving: only the e4m3 copy is wanted)
             C.view(M, N).copy_(O.gelu_fwd(aux.view(M, N).float()))
@@ -92,6 +101,11 @@ def gemm_nt_bf16(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue=L.EPI_NONE, bias=Non
 def gemm_nt_bf16_gelu_bwd_colsum(A, lda, W, ldw, C, ldc, M, N, Kd, aux, partials):
     CALLS.append(("gemm_nt_bf16_gelu_bwd_colsum", (M, N, Kd)))
     _epilogue(A.reshape(M, Kd).float() @ _w_plain(W, ldw, N, Kd).t(), C, M, N, L.EPI_GELU_BWD, None, None, aux, partials)
+
+
+def gemm_nt_bf16_mul_aux_colsum(A, lda, W, ldw, C, ldc, M, N, Kd, aux, partials):
+    CALLS.append(("gemm_nt_bf16_mul_aux_colsum", (M, N, Kd)))
+    _epilogue(A.reshape(M, Kd).float() @ _w_plain(W, ldw, N, Kd).t(), C, M, N, L.EPI_MUL_AUX, None, None, aux, partials)
 
 
 def gemm_nt_fp8_v2(A, lda, W, ldw, C, ldc, M, N, Kd, epilogue, *, a_kind, bias=None, resid=None, aux=None, partials=None, alpha=1.0,
@@ -485,7 +499,7 @@ def require_device(*ts):
     return None
 
 
-_K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_nt_bf16_gelu_bwd_colsum, gemm_nt_fp8_v2=gemm_nt_fp8_v2,
+_K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_nt_bf16_gelu_bwd_colsum, gemm_nt_bf16_mul_aux_colsum=gemm_nt_bf16_mul_aux_colsum, gemm_nt_fp8_v2=gemm_nt_fp8_v2,
                   gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,

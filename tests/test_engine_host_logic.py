@@ -100,6 +100,7 @@ def fp8_calls(calls):
 def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
     monkeypatch.setenv("VITK_FP8_K128", "0")
     monkeypatch.setenv("VITK_FWD_STREAM", "f32")      # the fp8 path keeps the float32 stream: its recording step equals the 16-bit run under that stream
+    monkeypatch.setenv("VITK_GELU_DG", "0")           # ... and saves the pre-activation (the 16-bit default stores the gelu' factor instead)
     lean = mode == "fwd+dx+dw"             # the forward's e4m3 copies are kept for the weight-gradient GEMMs (the default)
     monkeypatch.setenv("VITK_FP8_LEAN", "1" if lean else "0")
     backward, wgrad = mode != "fwd", mode.startswith("fwd+dx+dw")

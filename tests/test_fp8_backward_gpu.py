@@ -230,6 +230,7 @@ def test_fp8_training_step_against_reference_golden(name, k128, wgrad, monkeypat
     """wgrad=False: forward + dX GEMMs on fp8 (8 of a layer's 12 GEMMs); wgrad=True: the weight-gradient GEMMs too (all 12)."""
     monkeypatch.setenv("VITK_FP8_K128", k128)
     monkeypatch.setenv("VITK_FWD_STREAM", "f32")      # the fp8 path keeps the float32 stream: its recording step equals the 16-bit run under that stream
+    monkeypatch.setenv("VITK_GELU_DG", "0")           # ... and saves the pre-activation (the 16-bit default stores the gelu' factor instead)
     case = WIDE_CASES[name]
     params = make_params(case["kind"], case["cfg"], case["seed"])
     img = make_images(case["cfg"], case["batch"], case["seed"] + 1000).to(DEV, dtype=BF)

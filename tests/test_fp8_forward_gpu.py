@@ -23,6 +23,7 @@ def rel(a, b):
 @pytest.mark.parametrize("kind", ["vit", "simple_vit"])
 def test_fp8_forward_against_16bit_and_oracle(kind, monkeypatch):
     monkeypatch.setenv("VITK_FWD_STREAM", "f32")      # the fp8 path keeps the float32 stream: its recording step equals the 16-bit run under that stream
+    monkeypatch.setenv("VITK_GELU_DG", "0")           # ... and saves the pre-activation (the 16-bit default stores the gelu' factor instead)
     params = make_params(kind, CFG, 7)
     img = make_images(CFG, 8, 1007)                      # M = 8 * 197 = 1576 rows: the 256-row kernel's range
     cls = ViT if kind == "vit" else SimpleViT

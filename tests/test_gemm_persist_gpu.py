@@ -195,3 +195,36 @@ def test_dynamic_tickets_equal_static_lists(M, N, Kd, monkeypatch):
             if k != "part":                     # (the column-sum partial rows are per m-tile: same values, checked via their sum)
                 assert torch.equal(ref[k], got[k]), k
         assert rel(got["part"].double().sum(0), ref["part"].double().sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,Kd", [(50432, 3072, 768), (1182, 3072, 768), (2049, 512, 256), (4616, 5120, 1280)])
+def test_gelu_factor_epilogue_pair(M, N, Kd):
+    """EPI_BIAS_GELU_DG (forward: C = gelu(pre), aux = gelu'(pre) of the rounded pre-activation) and EPI_MUL_AUX (backward: C = acc * aux +
+    column sums) of the persistent kernel against float64 -- and against the pair they replace (EPI_BIAS_GELU saving pre + EPI_GELU_BWD):
+    the same gelu output bit for bit, the backward product within one more 16-bit rounding."""
+    import math
+    from vit_pytorch_amd import ops
+    if not ops.gelu_dg_ok(BF, M, N, Kd):
+        pytest.skip("shape not served")
+    torch.manual_seed(5)
+    A = (torch.randn(M, Kd, device=DEV) * 0.7).to(BF); W = (torch.randn(N, Kd, device=DEV) * Kd ** -0.5).to(BF); b = (torch.randn(N, device=DEV) * 0.3).to(BF)
+    act, dg = ops.linear_fwd(A, W, b, M, gelu=True, save_dg=True)
+    act0, pre0 = ops.linear_fwd(A, W, b, M, gelu=True)
+    assert torch.equal(act, act0)
+    pre = (A.double() @ W.double().t() + b.double()).to(BF).double()        # the kernel rounds the pre-activation first
+    phi = 0.5 * (1 + torch.erf(pre / math.sqrt(2)))
+    dref = phi + pre * torch.exp(-pre * pre / 2) / math.sqrt(2 * math.pi)
+    # the pre-activation itself carries the f32-accumulation error of one rounding step on a few elements: compare where both agree
+    same = pre0.double() == pre
+    assert same.double().mean().item() > 0.99
+    assert (dg.double() - dref)[same].abs().max().item() <= 2 ** -8 * 1.2 + 1e-4
+    # backward: dY (M, N2) . W2 (N2, N) * factor, N2 = Kd
+    dY = (torch.randn(M, Kd, device=DEV) * 0.5).to(BF); W2 = (torch.randn(Kd, N, device=DEV) * Kd ** -0.5).to(BF)
+    db = torch.empty(N, dtype=BF, device=DEV); db0 = torch.empty(N, dtype=BF, device=DEV)
+    dx, done = ops.linear_dx(dY, W2, M, gelu_dg=dg, db=db)
+    dx0, done0 = ops.linear_dx(dY, W2, M, gelu_pre=pre0, db=db0)
+    assert done and done0
+    ref = (dY.double() @ W2.double()) * dg.double()
+    assert rel(dx, ref) < 4e-3
+    assert rel(db, dx.double().sum(0)) < 4e-3              # column sums of the ROUNDED output, like GELU_BWD
+    assert rel(dx, dx0.double()) < 6e-3                     # vs the pair it replaces: one more rounding of the factor

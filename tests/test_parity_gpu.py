@@ -314,10 +314,20 @@ def test_activation_recompute_matches_full_save(dtype, monkeypatch):
     monkeypatch.setenv("VITK_RECOMPUTE", "1")
     out1, g1 = run_mine("vit", cfg, params, img, dtype)
     assert torch.equal(out0, out1)
-    tol = 1e-6 if dtype == torch.float32 else 3e-3
+    # 16-bit: the full-save run stores the gelu' FACTOR (round 4, ops.gelu_dg_ok: one more 16-bit rounding inside dFF1), the recompute run the
+    # pre-activation: 6e-3 between them; with VITK_GELU_DG=0 the two runs differ only by the rebuilt GELU: 3e-3 as before
+    tol = 1e-6 if dtype == torch.float32 else 6e-3
     for k in g0:
         if g0[k].numel():
             assert rel(g1[k], g0[k]) <= tol, (k, rel(g1[k], g0[k]))
+    if dtype != torch.float32:
+        monkeypatch.setenv("VITK_GELU_DG", "0")
+        monkeypatch.setenv("VITK_RECOMPUTE", "0")
+        out2, g2 = run_mine("vit", cfg, params, img, dtype)
+        assert torch.equal(out2, out1)
+        for k in g2:
+            if g2[k].numel():
+                assert rel(g1[k], g2[k]) <= 3e-3, (k, rel(g1[k], g2[k]))
 
 
 def test_cpu_input_fails_loudly():

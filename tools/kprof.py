@@ -29,13 +29,14 @@ def run(label, n, k, epi):
     else:
         C = torch.empty(M, n, dtype=BF, device=dev); resid = None; aux = torch.randn(M, n, device=dev).to(BF)
         alg += 2 * M * n * (2 if epi in (L.EPI_BIAS_GELU, L.EPI_GELU_BWD) else 1)   # + pre-activation written (FF1) / read (dFF1)
+    dg = not os.environ.get("KPROF_NO_DG")      # round 4 default: FF1 stores the gelu' factor (EPI_BIAS_GELU_DG), dFF1 multiplies (EPI_MUL_AUX)
     for _ in range(ITERS):
         if epi == L.EPI_GELU_BWD:
             rows = K.gemm_nt_colsum_rows(M, n, k, n)
             cs = torch.empty(rows * n, device=dev)
-            K.gemm_nt_bf16_gelu_bwd_colsum(A, k, W, ldw, C, n, M, n, k, aux, cs)
+            (K.gemm_nt_bf16_mul_aux_colsum if dg else K.gemm_nt_bf16_gelu_bwd_colsum)(A, k, W, ldw, C, n, M, n, k, aux, cs)
         else:
-            K.gemm_nt_bf16(A, k, W, ldw, C, n, M, n, k, epi, bias=bias, resid=resid, aux=aux)
+            K.gemm_nt_bf16(A, k, W, ldw, C, n, M, n, k, L.EPI_BIAS_GELU_DG if (dg and epi == L.EPI_BIAS_GELU) else epi, bias=bias, resid=resid, aux=aux)
     torch.cuda.synchronize()
     LABELS.append((label, n, k, alg))
 

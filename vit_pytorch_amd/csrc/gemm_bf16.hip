@@ -949,6 +949,14 @@ extern "C" int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, con
     return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, VITK_EPI_GELU_BWD, nullptr, nullptr, aux, colsum_partials, stream);
 }
 
+extern "C" int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                                int64_t N, int64_t K, const void* aux, float* colsum_partials, void* stream) {
+    if (!aux) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16_mul_aux_colsum: null pointer");
+    if (colsum_partials && vitk_gemm_nt_colsum_rows(M, N, K, ldc) == 0)
+        VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16_mul_aux_colsum: shape not served by the persistent kernel (vitk_gemm_nt_colsum_rows() == 0)");
+    return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, VITK_EPI_MUL_AUX, nullptr, nullptr, const_cast<void*>(aux), colsum_partials, stream);
+}
+
 namespace {
 int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                  int epilogue, const void* bias, const float* resid, void* aux, float* csum, void* stream, bool fp8, float alpha,
@@ -982,6 +990,11 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
         // VITK_NTP_EPIS = bit mask over VITK_EPI_* overrides (GELU_BWD always: its column-sum rows follow the persistent plan).
         const NtpPlan q = ntp_plan(M, N, K, ldc, aux);
         const unsigned epis = getenv("VITK_NTP_EPIS") ? (unsigned)atoi(getenv("VITK_NTP_EPIS")) : 0x1fu;
+        if (epilogue == VITK_EPI_BIAS_GELU_DG || epilogue == VITK_EPI_MUL_AUX) {       // the gelu'-factor pair (round 4): the persistent kernel only
+            if (!q.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: EPI_BIAS_GELU_DG / EPI_MUL_AUX are served by the persistent kernel only (vitk_gemm_nt_plan() says which shapes)");
+            if (!aux || drop_t || (epilogue == VITK_EPI_BIAS_GELU_DG && !bias)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS_GELU_DG needs bias and aux, EPI_MUL_AUX aux; no fused dropout");
+            return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, 0u, 0u, 1.0f, stream);
+        }
         if (epilogue == VITK_EPI_RESID16) {       // 16-bit forward residual stream (opt-in): the persistent kernel only
             if (!q.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: EPI_RESID16 is served by the persistent kernel only (vitk_gemm_nt_plan() says which shapes)");
             if (!resid || !aligned8(resid) || drop_t) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_RESID16 needs an 8-byte aligned 16-bit resid and no dropout");

@@ -163,6 +163,17 @@ __device__ __forceinline__ q_f32x8 q_gelu_grad8(q_f32x8 x) {
     for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(w[i]);
     return __builtin_elementwise_fma(x * q_splat8(0.39894228040143267794f), e, q_phi8(x));
 }
+// GELU and its derivative of the same 8 values with ONE evaluation of Phi (the BIAS_GELU_DG epilogue: the forward GEMM stores gelu'(pre) for
+// the backward instead of pre, so that the backward's epilogue is a multiplication -- same operations per element as q_gelu8 / q_gelu_grad8)
+__device__ __forceinline__ void q_gelu_both8(q_f32x8 x, q_f32x8& g, q_f32x8& dg) {
+    const q_f32x8 ph = q_phi8(x);
+    const q_f32x8 w = x * x * q_splat8(-0.72134752044448170368f);
+    q_f32x8 e;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(w[i]);
+    g = x * ph;
+    dg = __builtin_elementwise_fma(x * q_splat8(0.39894228040143267794f), e, ph);
+}
 __device__ __forceinline__ q_f32x8 q_widen8(bf16x8 v) {
     q_f32x8 r;
 #pragma unroll
@@ -177,7 +188,7 @@ __device__ __forceinline__ bf16x8 q_narrow8(q_f32x8 v) {
 }
 
 template <int EPI> __host__ __device__ constexpr bool q_has_bias() {
-    return EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_RESID || EPI == VITK_EPI_RESID16;
+    return EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_GELU_DG || EPI == VITK_EPI_RESID || EPI == VITK_EPI_RESID16;
 }
 
 __device__ __forceinline__ unsigned q_dpp_xor1(unsigned v) {       // value of lane ^ 1 (quad_perm [1,0,3,2])
@@ -681,7 +692,8 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                 __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
                 // GELU_BWD: saved pre-activations, fetched DP fragment rows ahead.  Interior tiles: uncounted asm loads + exact-count
                 // waits (see q_gload_f32x4); per fragment row 2 loads and 2 stores
-                constexpr bool ASM_PRE = (EPI == VITK_EPI_GELU_BWD) && INT && Q_EPI_ASM_PRE;
+                constexpr bool AUX_IN = (EPI == VITK_EPI_GELU_BWD || EPI == VITK_EPI_MUL_AUX);      // an (M, N) 16-bit operand read in the epilogue
+                constexpr bool ASM_PRE = AUX_IN && INT && Q_EPI_ASM_PRE;
                 constexpr int DP = ASM_PRE ? Q_EPI_DEPTH_PRE : 2;
                 bf16x8 hpre[DP][2];
                 auto fetch_pre = [&](int f, bf16x8 (&dst)[2]) {
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                         }
                     }
                 };
-                if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                if constexpr (AUX_IN) {
 #pragma unroll
                     for (int f = 0; f < DP; ++f) fetch_pre(f, hpre[f]);
                 }
@@ -734,9 +746,14 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                                     g8[e] = drop_keep(hrow, (unsigned)(ncol8 + e), p.drop_t) ? (__bf16)((float)g8[e] * p.inv_keep) : (__bf16)0.f;
                             }
                             if (ok) *reinterpret_cast<bf16x8*>(Cb + o) = g8;
-                        } else if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                        } else if constexpr (EPI == VITK_EPI_BIAS_GELU_DG) {
+                            q_f32x8 gl, dgl;
+                            q_gelu_both8(q_widen8(v), gl, dgl);              // of the ROUNDED pre-activation, like BIAS_GELU
+                            if (ok) *reinterpret_cast<bf16x8*>(p.aux + o) = q_narrow8(dgl);
+                            if (ok) *reinterpret_cast<bf16x8*>(Cb + o) = q_narrow8(gl);
+                        } else if constexpr (AUX_IN) {
                             const bf16x8 h8 = hpre[f % DP][pr];
-                            q_f32x8 g = q_widen8(v) * q_gelu_grad8(q_widen8(h8));
+                            q_f32x8 g = q_widen8(v) * (EPI == VITK_EPI_MUL_AUX ? q_widen8(h8) : q_gelu_grad8(q_widen8(h8)));
                             if (p.drop_t) {     // factor of the forward's dropout(gelu(pre)) at (m, n): same decision, same 1 / (1 - p)
                                 const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
 #pragma unroll
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                             }
                         }
                     }
-                    if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                    if constexpr (AUX_IN) {
                         if constexpr (f + DP < FMW) fetch_pre(f + DP, hpre[f % DP]);
                     }
                 };
@@ -760,7 +777,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                     frow(std::integral_constant<int, 4>{}); frow(std::integral_constant<int, 5>{});
                     frow(std::integral_constant<int, 6>{}); frow(std::integral_constant<int, 7>{});
                 }
-                if constexpr (EPI == VITK_EPI_GELU_BWD) {
+                if constexpr (AUX_IN) {
                     if (p.csum) {
                         // bias gradient by-product: the 8 lanes (c ^ 1, 4 row groups) that own the same 8 columns are summed in
                         // registers; one partial row per (m-tile, wm)
@@ -1015,6 +1032,8 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
         case VITK_EPI_BIAS_GELU: NTP_LAUNCH(VITK_EPI_BIAS_GELU); break;
         case VITK_EPI_RESID: NTP_LAUNCH(VITK_EPI_RESID); break;
         case VITK_EPI_GELU_BWD: NTP_LAUNCH(VITK_EPI_GELU_BWD); break;
+        case VITK_EPI_BIAS_GELU_DG: NTP_LAUNCH(VITK_EPI_BIAS_GELU_DG); break;
+        case VITK_EPI_MUL_AUX: NTP_LAUNCH(VITK_EPI_MUL_AUX); break;
         case VITK_EPI_RESID16: NTP_LAUNCH(VITK_EPI_RESID16); break;
         default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: bad epilogue %d", epilogue);
     }

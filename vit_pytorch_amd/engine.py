@@ -244,6 +244,11 @@ class TransformerFn(torch.autograd.Function):
         lean8 = bool(go8 and keep and bwd8 and fp8.wgrad and fp8.backward_will_be_fp8() and os.environ.get("VITK_FP8_LEAN", "1") != "0"
                      and all(ops.fp8_tn_ok(M, n_, k_) for n_, k_ in ((D, lp[7].shape[0]), (lp[7].shape[0], D), (D, I), (3 * I, D))))
         scales_used = fp8.scales.clone() if lean8 else None
+        # the FeedForward GEMM stores the gelu' factor instead of the pre-activation (ops.gelu_dg_ok) when the backward will want only
+        # that of it: not under recompute (the GELU output is rebuilt from the pre-activation), fp8 or active dropout
+        dg_mode = bool(keep and depth and not recompute and drop_p == 0.0 and fp8 is None and lp[8] is not None
+                       and ops.gelu_dg_ok(T, M, lp[7].shape[0], D))
+        ctx.dg_mode = dg_mode
 
         def gemm8(a8, sc_a, w, out, Nn, Kd, epi, **kw):       # out (M, Nn) = a8 (M, Kd) e4m3 . e4m3(w)^T under the two per-tensor scales
             w8, wsc = fp8.weight(w)
@@ -299,7 +304,7 @@ class TransformerFn(torch.autograd.Function):
                     x3 = ops.linear_fwd(act, w2, b2, M, resid=x2)
             else:
                 st2 = ops.ln_fwd(x2, ln2w, ln2b, M, D, a2)
-                act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True, drop=site(li, 2))
+                act, pre = ops.linear_fwd(a2, w1, b1, M, gelu=True, drop=site(li, 2), save_dg=dg_mode)      # dg_mode: `pre` holds gelu'(pre)
                 x3 = ops.linear_fwd(act, w2, b2, M, resid=x2, drop=site(li, 3))
             if keep:
                 if lean8:
@@ -456,6 +461,8 @@ class TransformerFn(torch.autograd.Function):
                 dpre, db_done = dx8(q3, w2, L.EPI_GELU_BWD, pre, db1, c8=(dpre_8, sc5, am5)), True
                 qd = (dpre_8, sc5)
                 del dpre_8
+            elif ctx.dg_mode:                      # `pre` is the gelu' factor the forward stored: the epilogue multiplies
+                dpre, db_done = ops.linear_dx(gT, w2, M, gelu_dg=pre, db=db1)
             elif db1 is not None:
                 dpre, db_done = ops.linear_dx(gT, w2, M, gelu_pre=pre, db=db1, drop=site(li, 2))   # b1's gradient out of the GEMM epilogue
             else:

@@ -163,6 +163,13 @@ def gemm_nt_bf16_gelu_bwd_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Te
                                                      _stream()), "gemm_nt_bf16_gelu_bwd_colsum")
 
 
+def gemm_nt_bf16_mul_aux_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
+                                aux: Tensor, partials: Optional[Tensor]):
+    """C = (A . W^T) * aux (EPI_MUL_AUX: aux = the gelu' factor an EPI_BIAS_GELU_DG forward stored) + column sums of C."""
+    check(_lib_for(A, W, C, aux).vitk_gemm_nt_bf16_mul_aux_colsum(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, _p(aux), _p(partials),
+                                                     _stream()), "gemm_nt_bf16_mul_aux_colsum")
+
+
 def set_cu_reserve(cus: int, dtype=None):
     """CUs the weight-gradient GEMMs leave to other kernels (vitk_set_cu_reserve; process-wide per library flavour)."""
     lib = L.load_f16() if dtype == torch.float16 else L.load()

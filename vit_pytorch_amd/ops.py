@@ -193,15 +193,32 @@ def _gemm_nt_f32(x: Tensor, W: Tensor, M: int, resid: Optional[Tensor], bias: Op
     return out
 
 
+def gelu_dg_ok(T, M: int, Fh: int, D: int) -> bool:
+    """The FeedForward pair FF1 (M, Fh) = a (M, D) . W1^T and dFF1 (M, Fh) = dy (M, D) . W2 can store / consume the gelu' FACTOR instead of
+    the pre-activation (EPI_BIAS_GELU_DG / EPI_MUL_AUX: both on the persistent NT kernel).  Round 4: FF1's epilogue holds Phi(pre) anyway,
+    one exp2 more per element gives gelu'(pre); the backward GEMM's epilogue then multiplies instead of evaluating the polynomial and the
+    exponential again (it was the slowest NT kernel of the step, VALU-bound in its epilogue).  VITK_GELU_DG=0 switches it off."""
+    return (T in HALF and os.environ.get("VITK_GELU_DG", "1") != "0" and D % 32 == 0 and Fh % 32 == 0 and _persistent_nt(M, Fh, D)
+            and K.gemm_nt_colsum_rows(M, Fh, D, Fh) > 0)
+
+
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bool = False,
-               resid: Optional[Tensor] = None, out_dtype=None, drop: Optional[Tuple[float, int]] = None):
+               resid: Optional[Tensor] = None, out_dtype=None, drop: Optional[Tuple[float, int]] = None, save_dg: bool = False):
     """y = x @ W^T + b  (vit.py:20,23,44,47,102).  x: (M,K) T contiguous; W: (N,K) T.
 
-    gelu=True  -> returns (gelu(y), y)         (vit.py:20-21 fused)
+    gelu=True  -> returns (gelu(y), y)         (vit.py:20-21 fused); with save_dg (caller checked gelu_dg_ok): (gelu(y), gelu'(y))
     resid      -> returns resid + y as float32 (the `+ x` of vit.py:80-81 fused), new buffer
     """
     N, Kd = W.shape
     T = x.dtype
+    if save_dg:
+        if not (gelu and drop is None and bias is not None and resid is None and gelu_dg_ok(T, M, N, Kd)):
+            raise L.VitkError("linear_fwd: save_dg needs gelu, a bias, no dropout and a shape gelu_dg_ok accepts")
+        Wn, ldw = nt_weight(W, M, False)
+        act = empty((M, N), T, x)
+        dg = empty((M, N), T, x)
+        K.gemm_nt_bf16(x, Kd, Wn, ldw, act, N, M, N, Kd, L.EPI_BIAS_GELU_DG, bias=bias, aux=dg)
+        return act, dg
     if drop is not None and not fused_dropout_ok(T, M, N, Kd):
         raise L.VitkError("linear_fwd: fused dropout needs a shape served by the 256-row kernel (caller must check fused_dropout_ok)")
     if drop is None and _f32_nt_ok(x, M, N, Kd) and (out_dtype is None or out_dtype == F32):
@@ -329,13 +346,26 @@ def transpose_weight(W: Tensor, pad_to: int = 0) -> Tensor:
 
 
 def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = None, db: Optional[Tensor] = None,
-              drop: Optional[Tuple[float, int]] = None):
-    """dX = dY @ W  (optionally * gelu'(pre): the GELU backward fused as an epilogue).
+              drop: Optional[Tuple[float, int]] = None, gelu_dg: Optional[Tensor] = None):
+    """dX = dY @ W  (optionally * gelu'(pre): the GELU backward fused as an epilogue; gelu_dg = that factor itself, stored by a
+    linear_fwd(save_dg=True) forward: the epilogue only multiplies).
 
-    With gelu_pre and db: returns (dX, done) -- done is True when colsum(dX), the bias gradient of the Linear that
+    With gelu_pre / gelu_dg and db: returns (dX, done) -- done is True when colsum(dX), the bias gradient of the Linear that
     produced `pre`, was written to db as a by-product of the GEMM epilogue (otherwise the caller still owes it)."""
     N, Kd = W.shape
     T = dy.dtype
+    if gelu_dg is not None:
+        if gelu_pre is not None or drop is not None or not gelu_dg_ok(T, M, Kd, N):
+            raise L.VitkError("linear_dx: gelu_dg goes without gelu_pre / dropout and with a shape gelu_dg_ok accepts")
+        dx = empty((M, Kd), T, dy)
+        Wt, ldt = nt_weight(W, M, True)
+        R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
+        part = empty((R * Kd,), F32, dy) if db is not None else None
+        K.gemm_nt_bf16_mul_aux_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_dg, part)
+        if db is not None:
+            K.colsum_partials(part, R, Kd, Kd, db)
+            return dx, True
+        return dx
     if drop is None and _f32_nt_ok(dy, M, Kd, N):
         dx = _gemm_nt_f32(dy, transpose_weight(W), M, None, None)          # (M, N) @ (Kd, N)^T
         if gelu_pre is not None:
