@@ -812,6 +812,8 @@ class PackedTransformerFn(torch.autograd.Function):
             raise VitkError("PackedTransformerFn: this shape does not take the fused dropout path (caller must check packed_dropout_fusable)")
         site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
         att_drop = lambda li: site(li, 0) or (0.0, 0)
+        dg_mode = bool(keep and depth and drop_p == 0.0 and lp[8] is not None and ops.gelu_dg_ok(T, Tn, lp[7].shape[0], D))     # see TransformerFn
+        ctx.dg_mode = dg_mode
         for li in range(depth):
             ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
             a1 = ops.empty((Tn, D), T, xs)
@@ -830,7 +832,7 @@ class PackedTransformerFn(torch.autograd.Function):
             x2 = ops.linear_fwd(o, wout, None, Tn, resid=xs, drop=site(li, 1))
             a2 = ops.empty((Tn, D), T, xs)
             st2 = ops.ln_fwd(x2, ln2g, None, Tn, D, a2)
-            act, pre = ops.linear_fwd(a2, w1, b1, Tn, gelu=True, drop=site(li, 2))
+            act, pre = ops.linear_fwd(a2, w1, b1, Tn, gelu=True, drop=site(li, 2), save_dg=dg_mode)      # dg_mode: `pre` holds gelu'(pre) (TransformerFn)
             x3 = ops.linear_fwd(act, w2, b2, Tn, resid=x2, drop=site(li, 3))
             if keep:
                 saved.append((xs, a1, st1, wcat, qkv, gqf, gkf, qn, kn, rq, rk, o, lse, x2, a2, st2, pre, act))
@@ -884,7 +886,10 @@ class PackedTransformerFn(torch.autograd.Function):
             K.cast(dcol, db2)
             grads[base + 9], grads[base + 10] = dw2, db2
             dw1, db1 = _grad_buf(w1), _grad_buf(b1)
-            dpre, db_done = ops.linear_dx(gb, w2, Tn, gelu_pre=pre, db=db1, drop=site(li, 2))
+            if ctx.dg_mode:
+                dpre, db_done = ops.linear_dx(gb, w2, Tn, gelu_dg=pre, db=db1)
+            else:
+                dpre, db_done = ops.linear_dx(gb, w2, Tn, gelu_pre=pre, db=db1, drop=site(li, 2))
             db_todo = None if db_done else db1
             fork.run(lambda: ops.linear_dw(dpre, a2, Tn, dw1, db_todo), dpre, a2, dw1, db1)
             grads[base + 7], grads[base + 8] = dw1, db1
