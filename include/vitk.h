@@ -246,6 +246,15 @@ int vitk_test_occupy_cus(int ncus, float ms, void* stream);
 int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int64_t ldx,
                       void* dW, int odt, int64_t ldo, int accumulate,
                       int64_t M, int64_t N, int64_t K, float* ws, int64_t splits, void* stream);
+/* TWO weight gradients over the same M token rows in one launch (e.g. to_qkv's and to_out's, vit.py:44,47): their tiles share the split
+ * count, so the pair fills the chip with fewer, larger M-splits -- fewer f32 slabs, one launch and one fold less.  Same operand rules as
+ * vitk_gemm_tn_bf16 for each problem; odt = dtype of both outputs; ws: splits * (N0*K0 + N1*K1) floats;
+ * splits = vitk_gemm_tn_pair_splits(...) -- 0 means "not served as a pair, call vitk_gemm_tn_bf16 twice".                         */
+int64_t vitk_gemm_tn_pair_splits(int64_t M, int64_t N0, int64_t K0, int64_t N1, int64_t K1);
+int vitk_gemm_tn_bf16_pair(const void* dY0, int64_t ldy0, const void* X0, int64_t ldx0, void* dW0, int64_t ldo0, int accumulate0,
+                           int64_t N0, int64_t K0, const void* dY1, int64_t ldy1, const void* X1, int64_t ldx1, void* dW1,
+                           int64_t ldo1, int accumulate1, int64_t N1, int64_t K1, int odt, int64_t M, float* ws, int64_t splits,
+                           void* stream);
 
 /* Generic strided batched GEMM for everything the fast kernels do not cover (f32 validation
  * mode, odd extents, the materialising attention path needed by forward hooks on `attend`):

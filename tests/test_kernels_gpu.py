@@ -774,3 +774,30 @@ def test_patch_ln_gather_fwd_and_param_grads(B, H, W, bias):
     xh = (patches - patches.mean(-1, keepdim=True)) / torch.sqrt(patches.var(-1, unbiased=False, keepdim=True) + 1e-5)
     assert rel(dwv, (dy.double() * xh).sum(0)) < 1e-5
     assert rel(dbv, dy.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N0,K0,N1,K1", [(50432, 2304, 768, 768, 768), (25216, 3072, 1024, 1024, 1024), (5000, 520, 264, 768, 256)])
+@pytest.mark.parametrize("odt", [BF, F32])
+def test_gemm_tn_pair(M, N0, K0, N1, K1, odt, monkeypatch):
+    """(opt-in, VITK_TN_PAIR=1: correct and faster kernel by kernel, slower inside the step -- see vitk_gemm_tn_pair_splits)
+    vitk_gemm_tn_bf16_pair: two weight gradients over the same token rows in one launch of the four-wave kernel (shared split count,
+    slabs [N0*K0 | N1*K1] per split) against float64, and bit-identical to the two single launches when those use the same split count."""
+    monkeypatch.setenv("VITK_TN_PAIR", "1")
+    splits = K.gemm_tn_pair_splits(M, N0, K0, N1, K1)
+    assert splits > 0
+    dY0 = rnd(M, N0, dtype=BF, seed=81) * (M ** -0.5); X0 = rnd(M, K0, dtype=BF, seed=82)
+    dY1 = rnd(M, N1, dtype=BF, seed=83) * (M ** -0.5); X1 = rnd(M, K1, dtype=BF, seed=84)
+    dW0 = torch.empty(N0, K0, dtype=odt, device=DEV); dW1 = torch.empty(N1, K1, dtype=odt, device=DEV)
+    ws = torch.full((splits * (N0 * K0 + N1 * K1),), float("nan"), device=DEV)
+    K.gemm_tn_bf16_pair(dY0, N0, X0, K0, dW0, dY1, N1, X1, K1, dW1, M, ws, splits)
+    tol = 1e-5 if odt == F32 else 4e-3
+    assert rel(dW0, dY0.double().t() @ X0.double()) < tol
+    assert rel(dW1, dY1.double().t() @ X1.double()) < tol
+    for dY, X, dW, n, k in ((dY0, X0, dW0, N0, K0), (dY1, X1, dW1, N1, K1)):
+        ref = torch.empty(n, k, dtype=odt, device=DEV)
+        w1 = torch.empty(splits * n * k, device=DEV)
+        K.gemm_tn_bf16(dY, n, X, k, ref, k, M, n, k, w1, splits)           # same split count -> same partial sums, same fold order
+        assert torch.equal(ref, dW)
+    K.gemm_tn_bf16_pair(dY0, N0, X0, K0, dW0, dY1, N1, X1, K1, dW1, M, ws, splits, accumulate0=True)
+    assert rel(dW0, 2 * (dY0.double().t() @ X0.double())) < 2 * tol
+    assert rel(dW1, dY1.double().t() @ X1.double()) < tol

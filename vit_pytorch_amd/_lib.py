@@ -86,6 +86,8 @@ SIGNATURES = {
     "vitk_get_cu_reserve": (_i, []),
     "vitk_test_occupy_cus": (_i, [_i, _f, _vp]),
     "vitk_gemm_tn_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "vitk_gemm_tn_pair_splits": (_i64, [_i64, _i64, _i64, _i64, _i64]),
+    "vitk_gemm_tn_bf16_pair": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _i64, _i, _i64, _vp, _i64, _vp]),
     "vitk_gemm_generic": (_i, [Mat, Mat, Mat, _vp, _i, _i64, _i64, _i64, _i64, _i64, _f, _f, _vp]),
     "vitk_attn_fwd_bf16": (_i, [BHND, BHND, BHND, BHND, _vp, _i64, _i64, _i64, _i64, _f, _vp]),
     "vitk_attn_bwd_bf16": (_i, [BHND, BHND, BHND, BHND, BHND, _vp, _vp, BHND, BHND, BHND, _i64, _i64, _i64, _i64, _f, _vp]),

@@ -278,11 +278,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
 
 template <typename OT>
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, long long NK, int K,
-                                                         OT* __restrict__ out, long long ldo, int accumulate) {
+                                                         OT* __restrict__ out, long long ldo, int accumulate, long long slab_stride) {
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= NK) return;
     f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
-    for (int p = 1; p < splits; ++p) s += *reinterpret_cast<const f32x4*>(ws + (long long)p * NK + i4);
+    for (int p = 1; p < splits; ++p) s += *reinterpret_cast<const f32x4*>(ws + (long long)p * slab_stride + i4);
     const long long n = i4 / K, k = i4 % K;  // K % 4 == 0 -> the 4 elements share a row
     OT* o = out + n * ldo + k;
     if (accumulate) s += load4<OT>(o);
@@ -1089,6 +1089,8 @@ int gemm_tn_dma_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, 
                        int64_t splits, void* stream);
 
 bool gemm_tn_w128_serves(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx, int64_t splits);
+int gemm_tn_w128_launch2(const void* dY0, int64_t ldy0, const void* X0, int64_t ldx0, int64_t N0, int64_t K0, const void* dY1, int64_t ldy1,
+                         const void* X1, int64_t ldx1, int64_t N1, int64_t K1, float* ws, int64_t M, int64_t splits, void* stream);
 int gemm_tn_w128_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* ws, int64_t M, int64_t N, int64_t K,
                         int64_t splits, void* stream);
 
@@ -1166,7 +1168,53 @@ extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int
     const long long NK = (long long)N * K;
     const unsigned blocks = (unsigned)((NK / 4 + 255) / 256);
     VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((tn_reduce_kernel<OT>), dim3(blocks), dim3(256), 0, st, ws, (int)splits, NK, (int)K,
-                                                  (OT*)dW, (long long)ldo, accumulate));
+                                                  (OT*)dW, (long long)ldo, accumulate, NK));
     VITK_CHECK_LAUNCH("gemm_tn_reduce");
     return 0;
 }
+
+// ---- two weight gradients over the same token rows in ONE launch (gemm_tn_w128.hip: TnProblem) -------------------------------------------
+// splits for the pair (0: not served -- call vitk_gemm_tn_bf16 twice): both problems large, the kernel's 32-bit offsets hold
+extern "C" int64_t vitk_gemm_tn_pair_splits(int64_t M, int64_t N0, int64_t K0, int64_t N1, int64_t K1) {
+    if (!tn_large(M, N0, K0) || !tn_large(M, N1, K1) || (N0 & 7) || (K0 & 7) || (N1 & 7) || (K1 & 7)) return 0;
+    if (getenv("VITK_TN_W128") && atoi(getenv("VITK_TN_W128")) == 0) return 0;
+    // OPT-IN (VITK_TN_PAIR=1).  [measured, profiles/r04_tn_pair_ab.log] the pair saves slabs, a launch and a fold, but inside the step it LOSES
+    // 0.5 ms (31.75 -> 32.25 ms, two interleaved runs each): to_out's weight gradient then waits for the attention backward instead of
+    // filling the side stream beside it, and the side stream's overlap with the dX chain is worth more than the saved traffic.
+    if (!(getenv("VITK_TN_PAIR") && atoi(getenv("VITK_TN_PAIR")) == 1)) return 0;
+    const int64_t tiles = ((N0 + 255) / 256) * ((K0 + 255) / 256) + ((N1 + 255) / 256) * ((K1 + 255) / 256);
+    const int reserve = g_cu_reserve.load();
+    int64_t s = reserve ? (256 - reserve) / tiles : (256 + tiles / 2) / tiles;
+    const int64_t max_by_rows = (M + 511) / 512;
+    if (s > max_by_rows) s = max_by_rows;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    const int64_t ldmax = (N0 > K0 ? N0 : K0) > (N1 > K1 ? N1 : K1) ? (N0 > K0 ? N0 : K0) : (N1 > K1 ? N1 : K1);
+    if (!gemm_tn_w128_serves(M, N0, K0, ldmax, ldmax, s)) return 0;
+    return s;
+}
+
+extern "C" int vitk_gemm_tn_bf16_pair(const void* dY0, int64_t ldy0, const void* X0, int64_t ldx0, void* dW0, int64_t ldo0, int accumulate0,
+                                      int64_t N0, int64_t K0, const void* dY1, int64_t ldy1, const void* X1, int64_t ldx1, void* dW1,
+                                      int64_t ldo1, int accumulate1, int64_t N1, int64_t K1, int odt, int64_t M, float* ws, int64_t splits,
+                                      void* stream) {
+    if (!dY0 || !X0 || !dW0 || !dY1 || !X1 || !dW1 || !ws) VITK_FAIL(VITK_E_ARG, "gemm_tn_bf16_pair: null pointer");
+    if (splits < 1 || splits != vitk_gemm_tn_pair_splits(M, N0, K0, N1, K1))
+        VITK_FAIL(VITK_E_SHAPE, "gemm_tn_bf16_pair: splits must be vitk_gemm_tn_pair_splits(M, N0, K0, N1, K1) (0 = pair not served)");
+    if ((ldy0 & 7) || (ldx0 & 7) || (ldo0 & 3) || (ldy1 & 7) || (ldx1 & 7) || (ldo1 & 3) || !aligned16(dY0) || !aligned16(X0) || !aligned16(dW0) ||
+        !aligned16(dY1) || !aligned16(X1) || !aligned16(dW1) || !aligned16(ws))
+        VITK_FAIL(VITK_E_ALIGN, "gemm_tn_bf16_pair: ldy/ldx %% 8, ldo %% 4 and 16-byte aligned pointers required");
+    if (!gemm_tn_w128_serves(M, N0, K0, ldy0 > ldy1 ? ldy0 : ldy1, ldx0 > ldx1 ? ldx0 : ldx1, splits))
+        VITK_FAIL(VITK_E_SHAPE, "gemm_tn_bf16_pair: row strides beyond the kernel's 32-bit offsets");
+    const int rc = gemm_tn_w128_launch2(dY0, ldy0, X0, ldx0, N0, K0, dY1, ldy1, X1, ldx1, N1, K1, ws, M, splits, stream);
+    if (rc != 0) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const long long NK0 = (long long)N0 * K0, NK1 = (long long)N1 * K1, stride = NK0 + NK1;
+    VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((tn_reduce_kernel<OT>), dim3((unsigned)((NK0 / 4 + 255) / 256)), dim3(256), 0, st, ws, (int)splits, NK0,
+                                                  (int)K0, (OT*)dW0, (long long)ldo0, accumulate0, stride));
+    VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((tn_reduce_kernel<OT>), dim3((unsigned)((NK1 / 4 + 255) / 256)), dim3(256), 0, st, ws + NK0, (int)splits, NK1,
+                                                  (int)K1, (OT*)dW1, (long long)ldo1, accumulate1, stride));
+    VITK_CHECK_LAUNCH("gemm_tn_pair_reduce");
+    return 0;
+}
+

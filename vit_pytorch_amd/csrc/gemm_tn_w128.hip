@@ -73,18 +73,29 @@ __device__ __forceinline__ bf16x8 w_join(s16x4 lo, s16x4 hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// One or TWO problems per launch (vitk_gemm_tn_bf16_pair): the tiles of both share the split count and the token rows M, so that e.g. the
+// weight gradients of to_qkv (27 tiles at ViT-B/16) and of to_out (9 tiles) fill the chip as 36 tiles x 7 splits -- 252 f32 slabs instead
+// of 27 x 9 + 9 x 28 = 495, one launch + one fold less per layer.  A split's slab holds problem 0's N0 x K0 floats, then problem 1's.
+struct TnProblem { const __bf16* dY; long long ldy; const __bf16* X; long long ldx; int N, K, tiles_k, nwg; };
+
 template <int ABL>
-__global__ __launch_bounds__(256) void gemm_tn_w128_kernel(
-    const __bf16* __restrict__ dY, long long ldy, const __bf16* __restrict__ X, long long ldx,
-    float* __restrict__ ws, int M, int N, int K, int rows_per_split, int tiles_k, int nwg) {
+__global__ __launch_bounds__(256) void gemm_tn_w128_kernel(const TnProblem p0, const TnProblem p1, float* __restrict__ ws, int M, int rows_per_split,
+                                                           long long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;        // wave tile: 128 (n) x 128 (k)
     const int lin = w_xcd_swizzle(blockIdx.x, (int)gridDim.x);
-    const int split = lin / nwg;
-    const int wg = lin % nwg;
+    const int nwg_all = p0.nwg + p1.nwg;
+    const int split = lin / nwg_all;
+    int wg = lin % nwg_all;
+    const bool second = wg >= p0.nwg;               // wave-uniform: every field below lives in SGPRs
+    if (second) wg -= p0.nwg;
+    const __bf16* __restrict__ dY = second ? p1.dY : p0.dY;
+    const __bf16* __restrict__ X = second ? p1.X : p0.X;
+    const long long ldy = second ? p1.ldy : p0.ldy, ldx = second ? p1.ldx : p0.ldx;
+    const int N = second ? p1.N : p0.N, K = second ? p1.K : p0.K, tiles_k = second ? p1.tiles_k : p0.tiles_k;
     const int tn = wg / tiles_k, tk = wg % tiles_k;
     const int n0 = tn * 256, k0 = tk * 256;
     const int mbeg = split * rows_per_split;
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_tn_w128_kernel(
 #undef W_READ_ONE
 
     // partial tile -> ws[split][n][k]: 16 bytes per lane (4 consecutive k)
-    float* out = ws + (long long)split * N * K;
+    float* out = ws + (long long)split * slab_stride + (second ? (long long)p0.N * p0.K : 0);
 #pragma unroll
     for (int fn = 0; fn < 8; ++fn) {
         const int n = n0 + wn * 128 + fn * 16 + fi;
@@ -222,6 +233,9 @@ __global__ __launch_bounds__(256) void gemm_tn_w128_kernel(
 
 }  // namespace
 
+int gemm_tn_w128_launch2(const void* dY0, int64_t ldy0, const void* X0, int64_t ldx0, int64_t N0, int64_t K0, const void* dY1, int64_t ldy1,
+                         const void* X1, int64_t ldx1, int64_t N1, int64_t K1, float* ws, int64_t M, int64_t splits, void* stream);
+
 // The descriptor offsets are 32-bit: (rows of a split + the 4 steps the DMA stream runs past its end) x row stride must stay below 2^31.
 bool gemm_tn_w128_serves(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx, int64_t splits) {
     long long rps = (M + splits - 1) / splits;
@@ -232,15 +246,27 @@ bool gemm_tn_w128_serves(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t l
 
 int gemm_tn_w128_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* ws, int64_t M, int64_t N, int64_t K,
                         int64_t splits, void* stream) {
-    const int tiles_n = (int)((N + 255) / 256), tiles_k = (int)((K + 255) / 256);
-    const int nwg = tiles_n * tiles_k;
+    return gemm_tn_w128_launch2(dY, ldy, X, ldx, N, K, nullptr, 0, nullptr, 0, 0, 0, ws, M, splits, stream);
+}
+
+// two problems (the second may be absent: dY1 == nullptr) behind one split count; slab of a split = [N0 * K0 | N1 * K1] floats
+int gemm_tn_w128_launch2(const void* dY0, int64_t ldy0, const void* X0, int64_t ldx0, int64_t N0, int64_t K0, const void* dY1, int64_t ldy1,
+                         const void* X1, int64_t ldx1, int64_t N1, int64_t K1, float* ws, int64_t M, int64_t splits, void* stream) {
+    auto mk = [](const void* dY, int64_t ldy, const void* X, int64_t ldx, int64_t N, int64_t K) {
+        TnProblem p{};
+        p.dY = (const __bf16*)dY; p.ldy = ldy; p.X = (const __bf16*)X; p.ldx = ldx; p.N = (int)N; p.K = (int)K;
+        p.tiles_k = dY ? (int)((K + 255) / 256) : 1;
+        p.nwg = dY ? (int)((N + 255) / 256) * p.tiles_k : 0;
+        return p;
+    };
+    const TnProblem p0 = mk(dY0, ldy0, X0, ldx0, N0, K0), p1 = mk(dY1, ldy1, X1, ldx1, N1, K1);
     long long rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     static const int rc__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_w128_kernel<0>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
     if (rc__ != 0) VITK_FAIL(rc__, "gemm_tn_bf16: cannot enable %d B of LDS", W_LDS_BYTES);
-    hipLaunchKernelGGL(gemm_tn_w128_kernel<0>, dim3((unsigned)(nwg * splits)), dim3(256), W_LDS_BYTES, (hipStream_t)stream,
-                       (const __bf16*)dY, (long long)ldy, (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
+    hipLaunchKernelGGL(gemm_tn_w128_kernel<0>, dim3((unsigned)((p0.nwg + p1.nwg) * splits)), dim3(256), W_LDS_BYTES, (hipStream_t)stream, p0, p1, ws,
+                       (int)M, (int)rps, (long long)(N0 * K0 + (dY1 ? N1 * K1 : 0)));
     VITK_CHECK_LAUNCH("gemm_tn_bf16 (w128)");
     return 0;
 }

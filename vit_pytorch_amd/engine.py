@@ -490,8 +490,11 @@ class TransformerFn(torch.autograd.Function):
             if wout is not None:
                 q2 = q5(li, 6, g2T) if f8 is not None else None
                 dwo = _grad_buf(wout)
+                pair_out = None
                 if f8 is not None:
                     fork.run(lambda: dw(li, q2, g2T, o, 3, dwo, x8=o_8), g2T, o, dwo, q2, o_8)
+                elif T in ops.HALF and K.gemm_tn_pair_splits(M, wqkv.shape[0], wqkv.shape[1], wout.shape[0], wout.shape[1]) > 0:
+                    pair_out = (g2T, o, dwo)        # opt-in (VITK_TN_PAIR=1): issued together with to_qkv's weight gradient below, one launch
                 else:
                     fork.run(lambda: ops.linear_dw(g2T, o, M, dwo), g2T, o, dwo)
                 grads[base + 3] = dwo
@@ -501,13 +504,18 @@ class TransformerFn(torch.autograd.Function):
                 del q2
             else:
                 do = g2T
+                pair_out = None
             dqkv = ops.attn_bwd(qkv, o, do, att_saved, B, N, heads, dim_head, scale, drop=site(li, 0))
             qq = q5(li, 7, dqkv) if f8 is not None else None
             dwq = _grad_buf(wqkv)
             if f8 is not None:
                 fork.run(lambda: dw(li, qq, dqkv, a1, 0, dwq, x8=a1_8), dqkv, a1, dwq, qq, a1_8)
+            elif pair_out is not None:
+                po = pair_out
+                fork.run(lambda: ops.linear_dw_pair(dqkv, a1, dwq, po[0], po[1], po[2], M), dqkv, a1, dwq, *po)
             else:
                 fork.run(lambda: ops.linear_dw(dqkv, a1, M, dwq), dqkv, a1, dwq)
+            pair_out = None
             grads[base + 2] = dwq
             da1 = dx8(qq, wqkv) if qq is not None else ops.linear_dx(dqkv, wqkv, M)
             del dqkv, do, qkv, o, qq, o_8, a1_8

@@ -186,6 +186,19 @@ def gemm_tn_bf16(dY: Tensor, ldy: int, X: Tensor, ldx: int, dW: Tensor, ldo: int
                                      _p(ws), splits, _stream()), "gemm_tn_bf16")
 
 
+def gemm_tn_pair_splits(M: int, N0: int, K0: int, N1: int, K1: int) -> int:
+    return int(L.load().vitk_gemm_tn_pair_splits(M, N0, K0, N1, K1))
+
+
+def gemm_tn_bf16_pair(dY0: Tensor, ldy0: int, X0: Tensor, ldx0: int, dW0: Tensor, dY1: Tensor, ldy1: int, X1: Tensor, ldx1: int, dW1: Tensor,
+                      M: int, ws: Tensor, splits: int, accumulate0: bool = False, accumulate1: bool = False):
+    """dW0 (N0, K0) = dY0^T X0 and dW1 (N1, K1) = dY1^T X1 over the same M token rows in one launch (vitk_gemm_tn_bf16_pair)."""
+    (N0, K0), (N1, K1) = dW0.shape, dW1.shape
+    check(_lib_for(dY0, X0, dW0, dY1, X1, dW1, ws).vitk_gemm_tn_bf16_pair(_p(dY0), ldy0, _p(X0), ldx0, _p(dW0), K0, int(accumulate0), N0, K0,
+                                                                    _p(dY1), ldy1, _p(X1), ldx1, _p(dW1), K1, int(accumulate1), N1, K1,
+                                                                    dt(dW0), M, _p(ws), splits, _stream()), "gemm_tn_bf16_pair")
+
+
 def mat(t: Tensor, s_row: int, s_col: int, s_b1: int = 0, s_b2: int = 0, offset: int = 0) -> Mat:
     m = Mat(t.data_ptr() + offset * t.element_size(), dt(t), s_b1, s_b2, s_row, s_col)
     m._dtype = t.dtype
