@@ -85,7 +85,8 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
       ff1       NT GEMM with the fused bias + GELU epilogue       dff1   NT GEMM with the GELU' + bias-gradient column sums epilogue
       nt_resid  NT GEMM + bias + residual (out-projection, FF2)    nt     NT GEMM, plain / bias epilogue (QKV, the three dX GEMMs)"""
     from vit_pytorch_amd import _lib as L, kernels as K
-    orig = {n: getattr(K, n) for n in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum", "gemm_nt_bf16_mul_aux_colsum", "gemm_nt_fp8_v2", "gemm_tn_bf16")}
+    orig = {n: getattr(K, n) for n in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum", "gemm_nt_bf16_mul_aux_colsum", "gemm_nt_fp8_v2", "gemm_tn_bf16",
+                                       "gemm_tn_bf16_pair")}
     taps = {}
 
     def bracket(key, flops, fn, a, kw):
@@ -117,6 +118,11 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
 
     K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2, K.gemm_tn_bf16 = tapped_nt, tapped_bwd, tapped_f8, tapped_tn
     K.gemm_nt_bf16_mul_aux_colsum = tapped_mul
+
+    def tapped_pair(*a, **kw):          # (dY0, ldy0, X0, ldx0, dW0, dY1, ldy1, X1, ldx1, dW1, M, ws, splits): two weight gradients, one launch
+        (n0, k0), (n1, k1) = a[4].shape, a[9].shape
+        return bracket(("tn", f"{n0}+{n1}", f"{k0}|{k1}"), 2.0 * a[10] * (n0 * k0 + n1 * k1), orig["gemm_tn_bf16_pair"], a, kw)
+    K.gemm_tn_bf16_pair = tapped_pair
     prev = os.environ.get("VITK_DW_STREAM")
     os.environ["VITK_DW_STREAM"] = "0"          # serialized: engine._Fork reads it per backward
     try:

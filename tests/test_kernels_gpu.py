@@ -779,10 +779,8 @@ def test_patch_ln_gather_fwd_and_param_grads(B, H, W, bias):
 @pytest.mark.parametrize("M,N0,K0,N1,K1", [(50432, 2304, 768, 768, 768), (25216, 3072, 1024, 1024, 1024), (5000, 520, 264, 768, 256)])
 @pytest.mark.parametrize("odt", [BF, F32])
 def test_gemm_tn_pair(M, N0, K0, N1, K1, odt, monkeypatch):
-    """(opt-in, VITK_TN_PAIR=1: correct and faster kernel by kernel, slower inside the step -- see vitk_gemm_tn_pair_splits)
-    vitk_gemm_tn_bf16_pair: two weight gradients over the same token rows in one launch of the four-wave kernel (shared split count,
+    """vitk_gemm_tn_bf16_pair: two weight gradients over the same token rows in one launch of the four-wave kernel (shared split count,
     slabs [N0*K0 | N1*K1] per split) against float64, and bit-identical to the two single launches when those use the same split count."""
-    monkeypatch.setenv("VITK_TN_PAIR", "1")
     splits = K.gemm_tn_pair_splits(M, N0, K0, N1, K1)
     assert splits > 0
     dY0 = rnd(M, N0, dtype=BF, seed=81) * (M ** -0.5); X0 = rnd(M, K0, dtype=BF, seed=82)

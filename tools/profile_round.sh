@@ -13,7 +13,7 @@ mkdir -p $out
 timeout 400 python bench.py > $out/${tag}_bench.json.log 2> $out/${tag}_bench.err
 tail -1 $out/${tag}_bench.json.log | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_two_streams -o run --output-format csv -- python $root/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline > $out/${tag}_stats_two_streams.log 2>&1
+VITK_DW_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_two_streams -o run --output-format csv -- python $root/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline > $out/${tag}_stats_two_streams.log 2>&1
 VITK_DW_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_serialized -o run --output-format csv -- python $root/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline > $out/${tag}_stats_serialized.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o run --output-format csv -- python $root/tools/kprof.py > $out/${tag}_pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write -o run --output-format csv -- python $root/tools/kprof.py > $out/${tag}_pmc_write.log 2>&1

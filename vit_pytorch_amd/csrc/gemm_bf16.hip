@@ -1178,10 +1178,10 @@ extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int
 extern "C" int64_t vitk_gemm_tn_pair_splits(int64_t M, int64_t N0, int64_t K0, int64_t N1, int64_t K1) {
     if (!tn_large(M, N0, K0) || !tn_large(M, N1, K1) || (N0 & 7) || (K0 & 7) || (N1 & 7) || (K1 & 7)) return 0;
     if (getenv("VITK_TN_W128") && atoi(getenv("VITK_TN_W128")) == 0) return 0;
-    // OPT-IN (VITK_TN_PAIR=1).  [measured, profiles/r04_tn_pair_ab.log] the pair saves slabs, a launch and a fold, but inside the step it LOSES
-    // 0.5 ms (31.75 -> 32.25 ms, two interleaved runs each): to_out's weight gradient then waits for the attention backward instead of
-    // filling the side stream beside it, and the side stream's overlap with the dX chain is worth more than the saved traffic.
-    if (!(getenv("VITK_TN_PAIR") && atoi(getenv("VITK_TN_PAIR")) == 1)) return 0;
+    // VITK_TN_PAIR=0 switches it off.  [measured, profiles/r04_tn_pair_ab.log, r04_dw_stream_ab.log] with the launches of a step serialized (the
+    // default since round 4) the pair is worth 0.2-0.3 ms of the ViT-B/16 step; beside a side stream it LOSES 0.5 ms (the deferred gradient no
+    // longer overlaps the attention backward) -- engine.TransformerFn pairs only when its side stream is off.
+    if (getenv("VITK_TN_PAIR") && atoi(getenv("VITK_TN_PAIR")) == 0) return 0;
     const int64_t tiles = ((N0 + 255) / 256) * ((K0 + 255) / 256) + ((N1 + 255) / 256) * ((K1 + 255) / 256);
     const int reserve = g_cu_reserve.load();
     int64_t s = reserve ? (256 - reserve) / tiles : (256 + tiles / 2) / tiles;

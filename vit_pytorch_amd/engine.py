@@ -101,7 +101,11 @@ class _Fork:
 
     def __init__(self, device):
         import os
-        self.enabled = device.type == "cuda" and os.environ.get("VITK_DW_STREAM", "1") != "0"
+        # OFF by default since round 4 (VITK_DW_STREAM=1 switches it on).  [measured, profiles/r04_dw_stream_ab.log, three interleaved pairs
+        # on one box] with the four-wave weight-gradient kernel (one workgroup needs a whole CU: 136 KB of LDS, 512 registers per wave) the
+        # side stream costs the ViT-B/16 step 0.46 ms (32.10 vs 31.64 ms): what it overlapped in rounds 1-3 -- the tails of the 8-wave
+        # kernels -- is gone, and two full-chip GEMMs time-slicing the CUs evict each other's operand panels from the L2s.
+        self.enabled = device.type == "cuda" and os.environ.get("VITK_DW_STREAM", "0") == "1"
         self._held = []
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
@@ -493,8 +497,11 @@ class TransformerFn(torch.autograd.Function):
                 pair_out = None
                 if f8 is not None:
                     fork.run(lambda: dw(li, q2, g2T, o, 3, dwo, x8=o_8), g2T, o, dwo, q2, o_8)
-                elif T in ops.HALF and K.gemm_tn_pair_splits(M, wqkv.shape[0], wqkv.shape[1], wout.shape[0], wout.shape[1]) > 0:
-                    pair_out = (g2T, o, dwo)        # opt-in (VITK_TN_PAIR=1): issued together with to_qkv's weight gradient below, one launch
+                elif not fork.enabled and T in ops.HALF and K.gemm_tn_pair_splits(M, wqkv.shape[0], wqkv.shape[1], wout.shape[0], wout.shape[1]) > 0:
+                    # issued together with to_qkv's weight gradient below, ONE launch (ops.linear_dw_pair: 36 tiles x 7 splits instead of
+                    # 27 x 9 and 9 x 28 -- half the f32 slabs, a launch and a fold less: 31.55 -> 31.29 ms per step, same box).  Only without
+                    # the side stream: beside the dX chain the deferred gradient loses more overlap than the pair saves (+0.5 ms measured).
+                    pair_out = (g2T, o, dwo)
                 else:
                     fork.run(lambda: ops.linear_dw(g2T, o, M, dwo), g2T, o, dwo)
                 grads[base + 3] = dwo

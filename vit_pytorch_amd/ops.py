@@ -430,8 +430,8 @@ def linear_dw(dy: Tensor, x: Tensor, M: int, dW: Tensor, db: Optional[Tensor] = 
 
 def linear_dw_pair(dy0: Tensor, x0: Tensor, dW0: Tensor, dy1: Tensor, x1: Tensor, dW1: Tensor, M: int):
     """Two weight gradients over the same token rows (to_out's and to_qkv's of a layer) -- ONE launch of the split-M kernel where the
-    pair is served (K.gemm_tn_pair_splits: opt-in VITK_TN_PAIR=1, both large, 16-bit): 36 tiles x 7 splits at ViT-B/16 instead of 27 x 9
-    and 9 x 28, i.e. half the f32 slabs, one launch and one fold less; otherwise (the default) two linear_dw calls."""
+    pair is served (K.gemm_tn_pair_splits: both large, 16-bit; VITK_TN_PAIR=0 switches it off): 36 tiles x 7 splits at ViT-B/16 instead of 27 x 9
+    and 9 x 28, i.e. half the f32 slabs, one launch and one fold less; otherwise two linear_dw calls."""
     (N0, K0), (N1, K1) = dW0.shape, dW1.shape
     if dy0.dtype in HALF and dy1.dtype == dy0.dtype and dW0.dtype == dW1.dtype and dW0.dtype in HALF + (F32,):
         splits = K.gemm_tn_pair_splits(M, N0, K0, N1, K1)
