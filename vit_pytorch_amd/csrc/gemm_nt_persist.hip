@@ -443,6 +443,10 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
             //      critical path, against 16 MFMAs = 272.  Every M block below is ONE basic block (unconditional reads, DMA issue
             //      without branches -- see issue4) so that the sched_group_barriers can interleave it.
             bf16x8 f0w[4], f0x[4], f1w[4], f1x[4], xg[4];
+            // [measured, profiles/r04_nt_timeline.log: ~1,400 cycles per tile go by here with idle matrix cores and idle DMA issue.  Tried twice in
+            //  round 4 and reverted: carrying these fragments from the previous tile's last K-step (which has read them) across the epilogue, and
+            //  reading them half-way through the epilogue into registers of accumulator rows already stored -- either way the kernel, which
+            //  sits at 256 registers, takes 70-300 bytes of scratch per lane, and the scratch build faulted on the device.]
             {   // fragments of this tile's first K-step (exposed once per tile; its stage was made visible by the previous B)
                 const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
 #pragma unroll
@@ -989,8 +993,12 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     a.bias = (const __bf16*)bias; a.resid = resid; a.aux = (__bf16*)aux; a.csum = csum;
     a.tiles_n = pl.tiles_n; a.group_n = pl.group_n; a.tm_main = pl.tm_main; a.tail_tm = pl.tail_tm;
     a.n_main = pl.n_main; a.n_tail = pl.n_tail; a.nt = pl.nt;
-    static const int tail_first = getenv("VITK_NTP_TAIL_LAST") ? 0 : 1;
-    a.tail_first = tail_first;      // (static lists; with tickets the 128-row tiles go LAST, see below)
+    // (static lists; with tickets the 128-row tiles go LAST, see below).  Tail FIRST de-phases the workgroups that own a half tile for the
+    // rest of the launch, tail LAST keeps the sharers of an activation panel in step: [measured, profiles/r04_nt_tile_order_knobs_*] the FF1
+    // GEMM (N = 3072: twelve n-tiles per panel, two 16-bit outputs) fetches 373 instead of 530 MB with the tail last and runs 3.97 instead of
+    // 4.12 ms per step; every other epilogue is level or slightly better tail-first.  VITK_NTP_TAIL_LAST = 1 / 0 forces one order for all.
+    static const int tail_env = getenv("VITK_NTP_TAIL_LAST") ? (atoi(getenv("VITK_NTP_TAIL_LAST")) ? 0 : 1) : -1;
+    a.tail_first = tail_env >= 0 ? tail_env : ((epilogue == VITK_EPI_BIAS_GELU || epilogue == VITK_EPI_BIAS_GELU_DG) ? 0 : 1);
     // main-loop flavour: software-pipelined (default) or the R/M slot ping-pong (VITK_NTP_PIPE=0).  [measured] kernel by kernel the
     // pipelined loop is ~5 % ahead (8-shape sum 1.688 vs 1.783 ms), inside the training step the two are level (42.7-43.1 vs
     // 43.0-43.2 ms on the same box).
