@@ -71,7 +71,7 @@ template <int N_> __device__ __forceinline__ void w_wait_vm() {
 // step, its counted wait allows for the younger stores; 2 = decoupled: waves 0, 1 issue all 32 DMA pieces of a step (16 each),
 // waves 2, 3 issue 4 stores each and never wait on vmcnt.  8 KiB of stores per step and CU either way (the rate at which an NT tile's
 // 128 KiB of 16-bit output would trickle out over 16 K-steps).
-template <int ABL, int NST, int PAD, int ST = 0>
+template <int ABL, int NST, int PAD, int ST = 0, int DPL = 0>
 __global__ __launch_bounds__(256) void tn_w128_kernel(
     const __bf16* __restrict__ dY, long long ldy, const __bf16* __restrict__ X, long long ldx,
     float* __restrict__ ws, int M, int N, int K, int rows_per_split, int tiles_k, int nwg, char* __restrict__ scratch, long long scratch_per_wave) {
@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256) void tn_w128_kernel(
         if constexpr (!(ABL & 4)) w_mfma(acc[fk_][h_ * 4 + 2], XC[fk_], YC[h_ * 4 + 2]); \
         if constexpr (ROLE == 0 && ST == 1 && ((G) == 0 || (G) == 8)) store1k(XC[0]); \
         if constexpr (ROLE == 2 && ((G) & 3) == 0) store1k(XC[0]); \
-        if constexpr (!(ABL & 1) && ROLE == 0 && ((G) & 1)) { W_PIN(); dma((T_) + NST, SCUR, (G) >> 1, 0); W_PIN(); } \
+        /* DPL: where the 8 DMA pieces of a step sit -- 0: after every second group; 1: groups 0-7; 2: groups 8-15; 3: as 0, no s_setprio */ \
+        if constexpr (!(ABL & 1) && ROLE == 0 && (DPL == 0 || DPL == 3) && ((G) & 1)) { W_PIN(); dma((T_) + NST, SCUR, (G) >> 1, 0); W_PIN(); } \
+        if constexpr (!(ABL & 1) && ROLE == 0 && DPL == 1 && (G) < 8) { W_PIN(); dma((T_) + NST, SCUR, (G), 0); W_PIN(); } \
+        if constexpr (!(ABL & 1) && ROLE == 0 && DPL == 2 && (G) >= 8) { W_PIN(); dma((T_) + NST, SCUR, (G) - 8, 0); W_PIN(); } \
         if constexpr (!(ABL & 1) && ROLE == 1) { W_PIN(); dma((T_) + NST, SCUR, (G) & 7, 2 * ((G) >> 3)); W_PIN(); } \
         if constexpr (!(ABL & 4)) w_mfma(acc[fk_][h_ * 4 + 3], XC[fk_], YC[h_ * 4 + 3]); \
         if constexpr (!(ABL & 2)) { if constexpr ((G) < 8) XN[F_] = w_join(lo_, hi_); else YN[F_] = w_join(lo_, hi_); } \
@@ -181,12 +184,12 @@ __global__ __launch_bounds__(256) void tn_w128_kernel(
         const int t_ = (T_); \
         const int snext_ = scur + 1 == NST ? 0 : scur + 1; \
         const unsigned soff = snext_ * STAGE; \
-        __builtin_amdgcn_s_setprio(1); \
+        if constexpr (DPL != 3) __builtin_amdgcn_s_setprio(1); \
         W_GROUP(0, t_, scur, XC, YC, XN, YN, soff); W_GROUP(1, t_, scur, XC, YC, XN, YN, soff); W_GROUP(2, t_, scur, XC, YC, XN, YN, soff); W_GROUP(3, t_, scur, XC, YC, XN, YN, soff); \
         W_GROUP(4, t_, scur, XC, YC, XN, YN, soff); W_GROUP(5, t_, scur, XC, YC, XN, YN, soff); W_GROUP(6, t_, scur, XC, YC, XN, YN, soff); W_GROUP(7, t_, scur, XC, YC, XN, YN, soff); \
         W_GROUP(8, t_, scur, XC, YC, XN, YN, soff); W_GROUP(9, t_, scur, XC, YC, XN, YN, soff); W_GROUP(10, t_, scur, XC, YC, XN, YN, soff); W_GROUP(11, t_, scur, XC, YC, XN, YN, soff); \
         W_GROUP(12, t_, scur, XC, YC, XN, YN, soff); W_GROUP(13, t_, scur, XC, YC, XN, YN, soff); W_GROUP(14, t_, scur, XC, YC, XN, YN, soff); W_GROUP(15, t_, scur, XC, YC, XN, YN, soff); \
-        __builtin_amdgcn_s_setprio(0); \
+        if constexpr (DPL != 3) __builtin_amdgcn_s_setprio(0); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the next step's fragments are in registers */ \
         if constexpr (!(ABL & 1) && ROLE == 0) w_wait_vm<(ST == 1 ? 10 : 8) * (NST - 2)>();   /* own pieces of step t + 2 landed (t + 3 .. t + NST fly) */ \
         if constexpr (!(ABL & 1) && ROLE == 1) w_wait_vm<16 * (NST - 2)>(); \
@@ -299,6 +302,9 @@ int main(int argc, char** argv) {
         {"4 stages unpadded: all", tn_w128_kernel<0, 4, 0>, 4 * Geo<0>::STAGE}, {"4 stages unpadded: reads only", tn_w128_kernel<5, 4, 0>, 4 * Geo<0>::STAGE},
         {"5 stages unpadded: all", tn_w128_kernel<0, 5, 0>, 5 * Geo<0>::STAGE}, {"5 stages unpadded: DMA only", tn_w128_kernel<6, 5, 0>, 5 * Geo<0>::STAGE},
         {"5 stages unpadded: no DMA", tn_w128_kernel<1, 5, 0>, 5 * Geo<0>::STAGE},
+        {"DMA in groups 0-7: all", tn_w128_kernel<0, 4, 1, 0, 1>, 4 * Geo<1>::STAGE},
+        {"DMA in groups 8-15: all", tn_w128_kernel<0, 4, 1, 0, 2>, 4 * Geo<1>::STAGE},
+        {"no s_setprio: all", tn_w128_kernel<0, 4, 1, 0, 3>, 4 * Geo<1>::STAGE},
         {"4 st. padded + 8 KiB stores/step, coupled", tn_w128_kernel<0, 4, 1, 1>, 4 * Geo<1>::STAGE},
         {"4 st. padded + 8 KiB stores/step, decoupled", tn_w128_kernel<0, 4, 1, 2>, 4 * Geo<1>::STAGE},
         {"4 st. padded, decoupled roles, DMA only", tn_w128_kernel<6, 4, 1, 2>, 4 * Geo<1>::STAGE},
