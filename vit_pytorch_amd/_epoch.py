@@ -46,3 +46,10 @@ def note_grad_mode(enabled: bool) -> None:
 
 def caller_grad_mode() -> bool:
     return getattr(_TLS, "grad", True)
+
+
+def reset_grad_mode() -> None:
+    """Called by the fused Functions at the end of their forward: the note is ONE-SHOT.  A later .apply() that nobody announced (a direct
+    caller, a future module) then sees the default -- grad enabled: activations are kept, backward works -- instead of whatever an
+    earlier no_grad forward left behind (which would make backward crash on an empty ctx.saved)."""
+    _TLS.grad = True

@@ -878,13 +878,23 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
 // one line serialise at ~27 ns each and 256 workgroups draw two tickets at once in the prologue); a launch leaves its slot zeroed
 __device__ unsigned q_ticket_pool[64 * Q_TK_SLOT_WORDS];
 unsigned* q_ticket_slot(hipStream_t st) {
-    static unsigned* base = [] {
-        void* ptr = nullptr;
-        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(q_ticket_pool)) != hipSuccess) return (unsigned*)nullptr;
-        return (unsigned*)ptr;
-    }();
+    // the symbol has one address PER DEVICE the module is loaded on: resolved for the current device (one process per GPU is the deployment;
+    // a single process driving several GPUs gets each device's own pool)
+    static std::mutex mu;
+    static unsigned* bases[64] = {};
     static std::atomic<unsigned> seq{0};
-    if (!base) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    unsigned* base;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!bases[dev]) {
+            void* ptr = nullptr;
+            if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(q_ticket_pool)) != hipSuccess) return nullptr;
+            bases[dev] = (unsigned*)ptr;
+        }
+        base = bases[dev];
+    }
     (void)st;
     return base + (seq.fetch_add(1) & 63) * Q_TK_SLOT_WORDS;      // zero-initialised; every launch's last workgroup leaves its slot zeroed again
 }

@@ -36,7 +36,7 @@ from . import kernels as K
 from . import ops
 from . import _lib as L
 from ._lib import RowMap, VitkError
-from ._epoch import caller_grad_mode
+from ._epoch import caller_grad_mode, reset_grad_mode
 
 Tensor = torch.Tensor
 F32 = torch.float32
@@ -322,6 +322,7 @@ class TransformerFn(torch.autograd.Function):
         y = ops.empty((B, N, D), T, xs)
         stf = ops.ln_fwd(xs, norm_w, norm_b, M, D, y)
         ctx.saved = saved
+        reset_grad_mode()       # the caller's note was for THIS forward only (_epoch.py)
         ctx.x_last = xs
         ctx.stf = stf
         ctx.meta = (heads, dim_head, depth, B, N, D, x.dtype)
@@ -855,6 +856,7 @@ class PackedTransformerFn(torch.autograd.Function):
         y = ops.empty((Tn, D), T, xs)
         stf = ops.ln_fwd(xs, norm_g, None, Tn, D, y)
         ctx.saved = saved
+        reset_grad_mode()       # the caller's note was for THIS forward only (_epoch.py)
         ctx.x_last, ctx.stf = xs, stf
         ctx.meta = (segs, heads, dim_head, depth, Tn, D, x.dtype)
         ctx.drop = (drop_p, drop_seed)
