@@ -99,13 +99,15 @@ class _Fork:
     whatever main-stream kernel reuses the memory is ordered behind the side-stream reader by the streams themselves."""
     LAG = int(__import__("os").environ.get("VITK_DW_LAG", "6"))    # launches (6 = a layer and a half) whose inputs stay referenced
 
-    def __init__(self, device):
+    def __init__(self, device, fp8: bool = False):
         import os
-        # OFF by default since round 4 (VITK_DW_STREAM=1 switches it on).  [measured, profiles/r04_dw_stream_ab.log, three interleaved pairs
+        # bfloat16 / float16 weight gradients: OFF by default since round 4 (VITK_DW_STREAM=1 switches it on).  [measured, profiles/r04_dw_stream_ab.log, three interleaved pairs
         # on one box] with the four-wave weight-gradient kernel (one workgroup needs a whole CU: 136 KB of LDS, 512 registers per wave) the
         # side stream costs the ViT-B/16 step 0.46 ms (32.10 vs 31.64 ms): what it overlapped in rounds 1-3 -- the tails of the 8-wave
         # kernels -- is gone, and two full-chip GEMMs time-slicing the CUs evict each other's operand panels from the L2s.
-        self.enabled = device.type == "cuda" and os.environ.get("VITK_DW_STREAM", "0") == "1"
+        # fp8 weight gradients (gemm_tn256_f8_kernel, eight waves, 22 % of the ViT-H/14 step): ON by default -- that kernel still leaves the
+        # CU resources a second resident workgroup needs, and serializing it costs the fp8 step 7 % [measured, profiles/r04e_h14_dw_stream_ab.log].
+        self.enabled = device.type == "cuda" and os.environ.get("VITK_DW_STREAM", "1" if fp8 else "0") == "1"
         self._held = []
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
@@ -419,7 +421,7 @@ class TransformerFn(torch.autograd.Function):
             if db is not None:
                 ops.colsum(dyT, M, Nw, db)
 
-        fork = _Fork(dy.device)
+        fork = _Fork(dy.device, fp8=f8 is not None)
         # final LayerNorm (vit.py:83)
         g, gb = newg()
         dnw, dnb = _grad_buf(norm_w), _grad_buf(norm_b)
