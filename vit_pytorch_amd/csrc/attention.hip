@@ -22,8 +22,11 @@
 //             dV^T = dO^T P, dK^T = Q^T dS (A via transpose reads of dO / Q)          (key-tile outer)
 // Softmax is online in the exp2 domain with a LAZY reference maximum and MFMA row sums (see attn_fwd_kernel);
 // backward recomputes P from the saved row log-sum-exp.  LDS rows are padded to 160 B: conflict-free for both the b128 row
-// reads and the b64 transpose reads.
+// reads and the b64 transpose reads.  The variable-length (packed) kernels -- NaViT, and every fixed-length shape these kernels
+// do not take -- live in attention_varlen.hip; the rest of this file holds the head-wise q/k normalisation of NaViT and the
+// materialising softmax pair of the fallback path.
 #include "common.h"
+#include "attention_frag.h"
 #include "attention_pipe.h"
 
 namespace {
@@ -31,8 +34,6 @@ namespace {
 constexpr int AT_LD = 160;  // bytes per LDS row: 64 bf16 + 32 B pad
 constexpr int AT_THREADS = 512;  // 8 waves per (batch, head): query / key tiles are dealt round-robin to the waves
 constexpr int AT_WAVES = AT_THREADS / 64;
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
 
 struct BHND { __bf16* p; long long s_b, s_h, s_n; };
 
@@ -80,37 +81,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int col0, 
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
-__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
-    bf16x8 r = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
-    return r;
-}
-__device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b) {
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)b[e];
-    return s;
-}
-// Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48 hold the same query/key column):
-// v_permlane16_swap / v_permlane32_swap exchange the groups in the VALU -- no LDS round trip and no
-// s_waitcnt lgkmcnt(0) in the middle of the fragment reads, unlike ds_bpermute (__shfl_xor).
-__device__ __forceinline__ float groups_max(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    x = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
-    u = __builtin_bit_cast(unsigned, x);
-    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
-}
-__device__ __forceinline__ float groups_sum(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    x = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
-    u = __builtin_bit_cast(unsigned, x);
-    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
-}
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-
 // R = 16-row query tiles a wave carries at once: every K / V fragment read from LDS feeds R MFMAs, so R = 2 halves
 // the LDS traffic per flop and gives the scheduler two independent softmax chains; with 8 waves it also covers
 // N <= 256 (ViT-B/L: 13 tiles) in ONE pass instead of two unbalanced ones.
@@ -460,375 +430,6 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
     compute();
 }
 
-// ==========================================================================================
-// Variable-length (packed) attention: the NaViT path (na_vit.py:115-169, 255-402).
-// The reference pads every pack to (b, n) and feeds F.scaled_dot_product_attention a dense boolean
-// (b, 1, n, n) mask "same image AND key not padding" (na_vit.py:335-337).  Here tokens of all images of
-// all packs live UNPADDED in one (T, H*d) matrix and attention is computed per SEGMENT (= image): query
-// rows [cu_q[s], cu_q[s+1]) against key rows [cu_k[s], cu_k[s+1]).  No mask is ever built or read: the
-// block-diagonal structure is the launch geometry.  The attention-pool step (one learned query per image
-// against that image's tokens, na_vit.py:371-387) is the same kernel with cu_q = 0,1,2,...
-// One workgroup = (segment, 128-query block, head); K/V are streamed through LDS in 128-key chunks with the
-// same online-softmax inner step as the fixed-length kernels.
-// ==========================================================================================
-// a workgroup handles 16 * AT_WAVES = 128 queries (or keys, in the dK/dV kernel)
-constexpr int VL_CH = 128;             // rows per LDS chunk
-
-struct HND { __bf16* p; long long s_h, s_n; };   // element (n, h, d) at p + n*s_n + h*s_h + d
-
-// Head-dimension traits.  DH = 64: 2 MFMA K-steps, 160-byte LDS rows.  DH = 80 (ViT-H/14, vit.py dim_head=80):
-// the contraction over d is padded to 96 = 3 K-steps with zero columns, LDS rows are 208 bytes (13 x 16: every
-// 16 consecutive rows start in distinct 4-bank windows for ds_read_b128), the output has 5 blocks of 16 columns.
-template <int DH> struct HD {
-    static constexpr int NKS = (DH + 31) / 32;      // MFMA K-steps over d
-    static constexpr int NFD = DH / 16;             // 16-column output blocks
-    // bytes per LDS row: 64 NKS of data + 16 (an odd number of 16-byte slots: 16 consecutive rows start in distinct 4-bank windows);
-    // DH = 64 keeps the 160 it was measured with.  DH = 32 / 48 / 96 (round 3): 80 / 144 / 208.  Static LDS (2 chunks of 128 rows) caps
-    // the row at 256 bytes: DH <= 96.
-    static constexpr int LD = DH == 64 ? 160 : NKS * 64 + 16;
-    static constexpr int NCH = NKS * 4;             // 16-byte chunks per LDS row that are read by fragments
-};
-
-// One 128-row chunk of TWO (n, h, d) tensors, global -> registers -> LDS in two separate steps, so that the loads of
-// chunk c+1 are in flight while chunk c is being multiplied (a plain load/store loop is serialised by the compiler and
-// left the whole workgroup waiting on HBM once per chunk).  NP 16-byte pieces per thread and tensor: 2 (d = 64) or 3.
-template <int DH> struct ChunkRegs {
-    static constexpr int NP = VL_CH * HD<DH>::NCH / AT_THREADS;
-    bf16x8 a[NP], b[NP];
-};
-template <int DH>
-__device__ __forceinline__ void chunk_load(ChunkRegs<DH>& r, const __bf16* srca, long long sna, const __bf16* srcb, long long snb,
-                                           int rows, int rows_pad, int tid) {
-    constexpr int NCH = HD<DH>::NCH;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < ChunkRegs<DH>::NP; ++j) {
-        const int c = tid + j * AT_THREADS, row = c / NCH, col8 = c % NCH;
-        r.a[j] = zero8; r.b[j] = zero8;
-        if (c < rows_pad * NCH && row < rows && col8 * 8 < DH) {
-            r.a[j] = *reinterpret_cast<const bf16x8*>(srca + (long long)row * sna + col8 * 8);
-            r.b[j] = *reinterpret_cast<const bf16x8*>(srcb + (long long)row * snb + col8 * 8);
-        }
-    }
-}
-template <int DH>
-__device__ __forceinline__ void chunk_store(const ChunkRegs<DH>& r, char* tilea, char* tileb, int rows_pad, int tid) {
-    constexpr int NCH = HD<DH>::NCH, LD = HD<DH>::LD;
-#pragma unroll
-    for (int j = 0; j < ChunkRegs<DH>::NP; ++j) {
-        const int c = tid + j * AT_THREADS, row = c / NCH, col8 = c % NCH;
-        if (c < rows_pad * NCH) {
-            *reinterpret_cast<bf16x8*>(tilea + row * LD + col8 * 16) = r.a[j];
-            *reinterpret_cast<bf16x8*>(tileb + row * LD + col8 * 16) = r.b[j];
-        }
-    }
-}
-template <int DH>
-__device__ __forceinline__ bf16x8 row_frag_t(const char* tile, int row0, int ks, int fi, int fg) {
-    return *reinterpret_cast<const bf16x8*>(tile + (row0 + fi) * HD<DH>::LD + (ks * 32 + 8 * fg) * 2);
-}
-template <int DH>
-__device__ __forceinline__ bf16x8 tr_frag_t(const char* tile, int row0, int col0, int fi, int fg) {
-    constexpr int LD = HD<DH>::LD;
-    const char* p = tile + (row0 + 4 * fg + (fi >> 2)) * LD + (col0 + (fi & 3) * 4) * 2;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 16 * LD));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-// one row of a (n, h, d) tensor as NKS register fragments: lane (i, g) holds row[ks*32 + 8g .. +7] (zero beyond DH)
-template <int DH>
-__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[HD<DH>::NKS], const __bf16* rowp, int fg) {
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < HD<DH>::NKS; ++ks) f[ks] = (ks * 32 + 8 * fg < DH) ? *reinterpret_cast<const bf16x8*>(rowp + ks * 32 + 8 * fg) : zero8;
-}
-template <int DH>
-__device__ __forceinline__ f32x4 mfma_over_d(const char* tile, int row0, const bf16x8 (&b)[HD<DH>::NKS], int fi, int fg) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < HD<DH>::NKS; ++ks) acc = MFMA(row_frag_t<DH>(tile, row0, ks, fi, fg), b[ks], acc);
-    return acc;
-}
-
-template <int DH>
-__global__ __launch_bounds__(AT_THREADS) void attn_varlen_fwd_kernel(
-    HND q, HND k, HND v, HND o, float* __restrict__ lse, const int* __restrict__ cu_q, const int* __restrict__ cu_k,
-    const int* __restrict__ blk_seg, const int* __restrict__ blk_r0, int tq_total, float scale_log2e, unsigned drop_t,
-    unsigned drop_seed, float inv_keep) {
-    constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
-    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fi = lane & 15, fg = lane >> 4;
-    char* Ks = smem;
-    char* Vs = smem + VL_CH * LD;
-    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
-    const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
-    const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
-    const int qi = blk_r0[blockIdx.x] + wave * 16 + fi;        // row inside the segment
-    const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nq;
-    const int qrow = qs + (qi < nq ? qi : nq - 1);
-    bf16x8 qf[NKS];
-    load_row_frags<DH>(qf, q.p + (long long)qrow * q.s_n + h * q.s_h, fg);
-    const __bf16* kbase = k.p + (long long)ks0 * k.s_n + h * k.s_h;
-    const __bf16* vbase = v.p + (long long)ks0 * v.s_n + h * v.s_h;
-    ChunkRegs<DH> cr;
-    {
-        const int rows = nk < VL_CH ? nk : VL_CH;
-        chunk_load<DH>(cr, kbase, k.s_n, vbase, v.s_n, rows, ((rows + 31) >> 5) << 5, tid);
-    }
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
-    const float c = scale_log2e;                      // > 0 (host check)
-    float mref = -INFINITY;                           // lazy reference maximum, row sums by MFMA: see attn_fwd_kernel
-    f32x4 acc[NFD], accl = z4;
-#pragma unroll
-    for (int fd = 0; fd < NFD; ++fd) acc[fd] = z4;
-    for (int c0 = 0; c0 < nk; c0 += VL_CH) {
-        const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
-        const int rows_pad = ((rows + 31) >> 5) << 5;
-        __syncthreads();
-        chunk_store<DH>(cr, Ks, Vs, rows_pad, tid);
-        __syncthreads();
-        if (c0 + VL_CH < nk) {                        // next chunk: in flight while this one is multiplied
-            const int nrows = nk - c0 - VL_CH < VL_CH ? nk - c0 - VL_CH : VL_CH;
-            chunk_load<DH>(cr, kbase + (long long)(c0 + VL_CH) * k.s_n, k.s_n, vbase + (long long)(c0 + VL_CH) * v.s_n, v.s_n, nrows,
-                           ((nrows + 31) >> 5) << 5, tid);
-        }
-        if (!wave_active) continue;
-        for (int s = 0; s < (rows_pad >> 5); ++s) {
-            f32x4 st[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) st[hh] = mfma_over_d<DH>(Ks, s * 32 + hh * 16, qf, fi, fg);
-            if (s * 32 + 32 > rows) {                 // padding keys: only in the last step of the last chunk
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (s * 32 + hh * 16 + 4 * fg + e >= rows) st[hh][e] = -INFINITY;
-            }
-            float mloc = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
-            mloc = fmaxf(fmaxf(mloc, st[0][3]), st[1][0]);
-            mloc = fmaxf(fmaxf(mloc, st[1][1]), st[1][2]);
-            mloc = fmaxf(mloc, st[1][3]);
-            if (__builtin_amdgcn_ballot_w64(mloc * c > mref + 8.0f) != 0) {
-                const float m_new = fmaxf(mref, groups_max(mloc) * c);
-                const float alpha = __builtin_amdgcn_exp2f(mref - m_new);
-#pragma unroll
-                for (int fd = 0; fd < NFD; ++fd) acc[fd] *= alpha;
-                accl *= alpha;
-                mref = m_new;
-            }
-            const float nm = -mref;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
-            bf16x8 pb = pack8(st[0], st[1]);
-            accl = MFMA(ones, pb, accl);
-            if (drop_t) {     // attention dropout (na_vit.py:163 dropout_p): row = (head, global query row), column = key inside the image
-                const unsigned hrow = drop_row((unsigned)(h * tq_total + qrow), drop_seed);
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (!drop_keep(hrow, (unsigned)(c0 + s * 32 + hh * 16 + 4 * fg + e), drop_t)) st[hh][e] = 0.f;
-                pb = pack8(st[0], st[1]);
-            }
-#pragma unroll
-            for (int fd = 0; fd < NFD; ++fd) acc[fd] = MFMA(tr_frag_t<DH>(Vs, s * 32, fd * 16, fi, fg), pb, acc[fd]);
-        }
-    }
-    if (wave_active && qi < nq) {
-        const float ls = accl[0];
-        const float inv = inv_keep / ls;
-        __bf16* op = o.p + (long long)(qs + qi) * o.s_n + h * o.s_h + 4 * fg;
-#pragma unroll
-        for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(op + fd * 16, acc[fd] * inv);
-        if (fg == 0) lse[(long long)h * tq_total + qs + qi] = (mref + log2f(ls)) * LN2;
-    }
-}
-
-template <int DH>
-__global__ __launch_bounds__(AT_THREADS) void attn_varlen_bwd_dq_kernel(
-    HND q, HND k, HND v, HND o, HND dout, const float* __restrict__ lse, float* __restrict__ delta, HND dq,
-    const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
-    const int* __restrict__ blk_r0, int tq_total, float scale, unsigned drop_t, unsigned drop_seed, float inv_keep) {
-    constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
-    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fi = lane & 15, fg = lane >> 4;
-    char* Ks = smem;
-    char* Vs = smem + VL_CH * LD;
-    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
-    const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
-    const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
-    const int qi = blk_r0[blockIdx.x] + wave * 16 + fi;
-    const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nq;
-    const int qrow = qs + (qi < nq ? qi : nq - 1);
-    const __bf16* kbase = k.p + (long long)ks0 * k.s_n + h * k.s_h;
-    const __bf16* vbase = v.p + (long long)ks0 * v.s_n + h * v.s_h;
-    ChunkRegs<DH> cr;
-    {
-        const int rows = nk < VL_CH ? nk : VL_CH;
-        chunk_load<DH>(cr, kbase, k.s_n, vbase, v.s_n, rows, ((rows + 31) >> 5) << 5, tid);
-    }
-    bf16x8 qf[NKS], df[NKS], of[NKS];
-    load_row_frags<DH>(qf, q.p + (long long)qrow * q.s_n + h * q.s_h, fg);
-    load_row_frags<DH>(df, dout.p + (long long)qrow * dout.s_n + h * dout.s_h, fg);
-    load_row_frags<DH>(of, o.p + (long long)qrow * o.s_n + h * o.s_h, fg);
-    float dl = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) dl += dot8(df[ks], of[ks]);
-    dl = groups_sum(dl);
-    if (wave_active && qi < nq && fg == 0) delta[(long long)h * tq_total + qs + qi] = dl;
-    const float nl2 = -lse[(long long)h * tq_total + qrow] * LOG2E;
-    const float scale_log2e = scale * LOG2E;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[NFD];
-#pragma unroll
-    for (int fd = 0; fd < NFD; ++fd) acc[fd] = z4;
-    for (int c0 = 0; c0 < nk; c0 += VL_CH) {
-        const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
-        const int rows_pad = ((rows + 31) >> 5) << 5;
-        __syncthreads();
-        chunk_store<DH>(cr, Ks, Vs, rows_pad, tid);
-        __syncthreads();
-        if (c0 + VL_CH < nk) {
-            const int nrows = nk - c0 - VL_CH < VL_CH ? nk - c0 - VL_CH : VL_CH;
-            chunk_load<DH>(cr, kbase + (long long)(c0 + VL_CH) * k.s_n, k.s_n, vbase + (long long)(c0 + VL_CH) * v.s_n, v.s_n, nrows,
-                           ((nrows + 31) >> 5) << 5, tid);
-        }
-        if (!wave_active) continue;
-        for (int s = 0; s < (rows_pad >> 5); ++s) {
-            f32x4 ds[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int row0 = s * 32 + hh * 16;
-                const f32x4 st = mfma_over_d<DH>(Ks, row0, qf, fi, fg);
-                f32x4 dp = mfma_over_d<DH>(Vs, row0, df, fi, fg);
-                if (drop_t) {
-                    const unsigned hrow = drop_row((unsigned)(h * tq_total + qrow), drop_seed);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        dp[e] = drop_keep(hrow, (unsigned)(c0 + row0 + 4 * fg + e), drop_t) ? dp[e] * inv_keep : 0.f;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)          // `scale` of dS is applied once, to dQ
-                    ds[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, nl2)) * (dp[e] - dl);
-                if (row0 + 16 > rows) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (row0 + 4 * fg + e >= rows) ds[hh][e] = 0.f;
-                }
-            }
-            const bf16x8 dsb = pack8(ds[0], ds[1]);
-#pragma unroll
-            for (int fd = 0; fd < NFD; ++fd) acc[fd] = MFMA(tr_frag_t<DH>(Ks, s * 32, fd * 16, fi, fg), dsb, acc[fd]);
-        }
-    }
-    if (wave_active && qi < nq) {
-        __bf16* dqp = dq.p + (long long)(qs + qi) * dq.s_n + h * dq.s_h + 4 * fg;
-#pragma unroll
-        for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(dqp + fd * 16, acc[fd] * scale);
-    }
-}
-
-template <int DH>
-__global__ __launch_bounds__(AT_THREADS, 4) void attn_varlen_bwd_dkv_kernel(
-    HND q, HND k, HND v, HND dout, const float* __restrict__ lse, const float* __restrict__ delta, HND dk, HND dv,
-    const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
-    const int* __restrict__ blk_r0, int tq_total, float scale, unsigned drop_t, unsigned drop_seed, float inv_keep) {
-    constexpr int NKS = HD<DH>::NKS, NFD = HD<DH>::NFD, LD = HD<DH>::LD;
-    __shared__ __attribute__((aligned(16))) char smem[2 * VL_CH * LD + 3 * VL_CH * sizeof(float)];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fi = lane & 15, fg = lane >> 4;
-    char* Qs = smem;
-    char* Ds = smem + VL_CH * LD;
-    float* lse_s = reinterpret_cast<float*>(smem + 2 * VL_CH * LD);
-    float* del_s = lse_s + VL_CH;
-    unsigned* hq_s = reinterpret_cast<unsigned*>(del_s + VL_CH);       // dropout row hashes of the chunk's query rows
-    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
-    const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
-    const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
-    const int ki = blk_r0[blockIdx.x] + wave * 16 + fi;        // key row inside the segment
-    const bool wave_active = blk_r0[blockIdx.x] + wave * 16 < nk;
-    const int krow = ks0 + (ki < nk ? ki : nk - 1);
-    const __bf16* qbase = q.p + (long long)qs * q.s_n + h * q.s_h;
-    const __bf16* dbase = dout.p + (long long)qs * dout.s_n + h * dout.s_h;
-    const float* lbase = lse + (long long)h * tq_total + qs;
-    const float* dlbase = delta + (long long)h * tq_total + qs;
-    ChunkRegs<DH> cr;
-    float lv = 0.f, dv_ = 0.f;                                  // one row of -lse*log2e / -delta per thread (tid < 128)
-    unsigned hv = 0u;
-    auto prefetch = [&](int c0) {
-        const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
-        chunk_load<DH>(cr, qbase + (long long)c0 * q.s_n, q.s_n, dbase + (long long)c0 * dout.s_n, dout.s_n, rows, ((rows + 31) >> 5) << 5, tid);
-        lv = 0.f; dv_ = 0.f;
-        if (tid < rows) { lv = -lbase[c0 + tid] * LOG2E; dv_ = -dlbase[c0 + tid]; }
-        hv = drop_row((unsigned)(h * tq_total + qs + c0 + tid), drop_seed);
-    };
-    prefetch(0);
-    bf16x8 kf[NKS], vf[NKS];
-    load_row_frags<DH>(kf, k.p + (long long)krow * k.s_n + h * k.s_h, fg);
-    load_row_frags<DH>(vf, v.p + (long long)krow * v.s_n + h * v.s_h, fg);
-    const float scale_log2e = scale * LOG2E;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 accK[NFD], accV[NFD];
-#pragma unroll
-    for (int fd = 0; fd < NFD; ++fd) { accK[fd] = z4; accV[fd] = z4; }
-    for (int c0 = 0; c0 < nq; c0 += VL_CH) {
-        const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
-        const int rows_pad = ((rows + 31) >> 5) << 5;
-        __syncthreads();
-        chunk_store<DH>(cr, Qs, Ds, rows_pad, tid);
-        if (tid < VL_CH) { lse_s[tid] = lv; del_s[tid] = dv_; hq_s[tid] = hv; }
-        __syncthreads();
-        if (c0 + VL_CH < nq) prefetch(c0 + VL_CH);
-        if (!wave_active) continue;
-        for (int s = 0; s < (rows_pad >> 5); ++s) {
-            f32x4 p[2], ds[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int row0 = s * 32 + hh * 16;
-                const f32x4 st = mfma_over_d<DH>(Qs, row0, kf, fi, fg);
-                const f32x4 dp = mfma_over_d<DH>(Ds, row0, vf, fi, fg);
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l4[e]));
-                    if (drop_t) {
-                        const float km = drop_keep(hq_s[row0 + 4 * fg + e], (unsigned)ki, drop_t) ? inv_keep : 0.f;
-                        ds[hh][e] = p[hh][e] * (dp[e] * km + d4[e]);
-                        p[hh][e] *= km;
-                    } else {
-                        ds[hh][e] = p[hh][e] * (dp[e] + d4[e]);                // `scale` is applied once, to dK
-                    }
-                }
-                if (row0 + 16 > rows) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (row0 + 4 * fg + e >= rows) { p[hh][e] = 0.f; ds[hh][e] = 0.f; }
-                }
-            }
-            const bf16x8 pb = pack8(p[0], p[1]);
-            const bf16x8 dsb = pack8(ds[0], ds[1]);
-#pragma unroll
-            for (int fd = 0; fd < NFD; ++fd) {
-                accV[fd] = MFMA(tr_frag_t<DH>(Ds, s * 32, fd * 16, fi, fg), pb, accV[fd]);
-                accK[fd] = MFMA(tr_frag_t<DH>(Qs, s * 32, fd * 16, fi, fg), dsb, accK[fd]);
-            }
-        }
-    }
-    if (wave_active && ki < nk) {
-        __bf16* dkp = dk.p + (long long)(ks0 + ki) * dk.s_n + h * dk.s_h + 4 * fg;
-        __bf16* dvp = dv.p + (long long)(ks0 + ki) * dv.s_n + h * dv.s_h + 4 * fg;
-#pragma unroll
-        for (int fd = 0; fd < NFD; ++fd) { store4<__bf16>(dkp + fd * 16, accK[fd] * scale); store4<__bf16>(dvp + fd * 16, accV[fd]); }
-    }
-}
-
 // q/k normalisation of NaViT (na_vit.py:93-101): y = x / max(||x||_2, 1e-12) * sqrt(d) * gamma[h, :] per (token, head).
 // x viewed (T, H, 64) with token stride ld; 16 lanes per (token, head), 4 elements per lane.
 template <typename T>
@@ -1077,85 +678,6 @@ extern "C" int vitk_softmax_bwd(const void* p, const void* dp, void* ds, int dt,
     VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                                                 (const T*)p, (const T*)dp, (T*)ds, (long long)rows, (int)cols, scale));
     VITK_CHECK_LAUNCH("softmax_bwd");
-    return 0;
-}
-
-namespace {
-HND to_hnd(vitk_hnd t) { return HND{(__bf16*)t.p, (long long)t.s_h, (long long)t.s_n}; }
-bool hnd_ok(vitk_hnd t) { return t.p && aligned16(t.p) && (t.s_h % 8 == 0) && (t.s_n % 8 == 0); }
-}  // namespace
-
-extern "C" int vitk_attn_varlen_fwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse, const int32_t* cu_q,
-                                         const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0, int64_t nblk,
-                                         int64_t tq_total, int64_t H, int64_t d, float scale, void* stream) {
-    return vitk_attn_varlen_fwd_bf16_drop(q, k, v, o, lse, cu_q, cu_k, blk_seg, blk_r0, nblk, tq_total, H, d, scale, 0.f, 0u, stream);
-}
-
-extern "C" int vitk_attn_varlen_fwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse, const int32_t* cu_q,
-                                              const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0, int64_t nblk,
-                                              int64_t tq_total, int64_t H, int64_t d, float scale, float drop_p, uint32_t drop_seed,
-                                              void* stream) {
-    if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_fwd_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
-    if (H * tq_total > 0xffffffffLL) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: H * tokens exceeds the 32-bit dropout row index");
-    if (d != 32 && d != 48 && d != 64 && d != 80 && d != 96) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: needs dim_head 32, 48, 64, 80 or 96 (got %lld)", (long long)d);
-    if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_fwd_bf16: scale must be positive (got %g)", (double)scale);
-    if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !lse || !cu_q || !cu_k || !blk_seg || !blk_r0)
-        VITK_FAIL(VITK_E_ALIGN, "attn_varlen_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
-    if (nblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: empty problem");
-#define VL_FWD(DHV) hipLaunchKernelGGL(attn_varlen_fwd_kernel<DHV>, dim3((unsigned)nblk, (unsigned)H), dim3(AT_THREADS), 0, (hipStream_t)stream, to_hnd(q), \
-                       to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E, drop_thresh(drop_p), drop_seed, \
-                       1.0f / (1.0f - drop_p))
-    switch ((int)d) {
-        case 32: VL_FWD(32); break;
-        case 48: VL_FWD(48); break;
-        case 64: VL_FWD(64); break;
-        case 80: VL_FWD(80); break;
-        default: VL_FWD(96); break;
-    }
-#undef VL_FWD
-    VITK_CHECK_LAUNCH("attn_varlen_fwd_bf16");
-    return 0;
-}
-
-extern "C" int vitk_attn_varlen_bwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, vitk_hnd dout, const float* lse,
-                                         float* delta, vitk_hnd dq, vitk_hnd dk, vitk_hnd dv, const int32_t* cu_q,
-                                         const int32_t* cu_k, const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
-                                         const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk, int64_t tq_total,
-                                         int64_t H, int64_t d, float scale, void* stream) {
-    return vitk_attn_varlen_bwd_bf16_drop(q, k, v, o, dout, lse, delta, dq, dk, dv, cu_q, cu_k, qblk_seg, qblk_r0, nqblk, kblk_seg, kblk_r0,
-                                          nkblk, tq_total, H, d, scale, 0.f, 0u, stream);
-}
-
-extern "C" int vitk_attn_varlen_bwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, vitk_hnd dout, const float* lse,
-                                              float* delta, vitk_hnd dq, vitk_hnd dk, vitk_hnd dv, const int32_t* cu_q,
-                                              const int32_t* cu_k, const int32_t* qblk_seg, const int32_t* qblk_r0, int64_t nqblk,
-                                              const int32_t* kblk_seg, const int32_t* kblk_r0, int64_t nkblk, int64_t tq_total,
-                                              int64_t H, int64_t d, float scale, float drop_p, uint32_t drop_seed, void* stream) {
-    if (!(drop_p >= 0.f && drop_p < 1.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_bwd_bf16: dropout p must be in [0, 1) (got %g)", (double)drop_p);
-    if (H * tq_total > 0xffffffffLL) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: H * tokens exceeds the 32-bit dropout row index");
-    const unsigned drop_t = drop_thresh(drop_p);
-    const float inv_keep = 1.0f / (1.0f - drop_p);
-    if (d != 32 && d != 48 && d != 64 && d != 80 && d != 96) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: needs dim_head 32, 48, 64, 80 or 96 (got %lld)", (long long)d);
-    if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_bwd_bf16: scale must be positive (got %g)", (double)scale);
-    if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !hnd_ok(dout) || !hnd_ok(dq) || !hnd_ok(dk) || !hnd_ok(dv) || !lse ||
-        !delta || !cu_q || !cu_k || !qblk_seg || !qblk_r0 || !kblk_seg || !kblk_r0)
-        VITK_FAIL(VITK_E_ALIGN, "attn_varlen_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
-    if (nqblk <= 0 || nkblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: empty problem");
-    hipStream_t st = (hipStream_t)stream;
-#define VL_BWD(DHV) do { \
-    hipLaunchKernelGGL(attn_varlen_bwd_dq_kernel<DHV>, dim3((unsigned)nqblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k), \
-                       to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep); \
-    hipLaunchKernelGGL(attn_varlen_bwd_dkv_kernel<DHV>, dim3((unsigned)nkblk, (unsigned)H), dim3(AT_THREADS), 0, st, to_hnd(q), to_hnd(k), \
-                       to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep); } while (0)
-    switch ((int)d) {
-        case 32: VL_BWD(32); break;
-        case 48: VL_BWD(48); break;
-        case 64: VL_BWD(64); break;
-        case 80: VL_BWD(80); break;
-        default: VL_BWD(96); break;
-    }
-#undef VL_BWD
-    VITK_CHECK_LAUNCH("attn_varlen_bwd_dkv");
     return 0;
 }
 

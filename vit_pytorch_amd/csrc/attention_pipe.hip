@@ -28,6 +28,7 @@
 // (vitk_split2), every product keeps hi.hi + hi.lo + lo.hi, the probabilities / dS are split the same way, outputs are f32:
 // ~2^-16 per product instead of 2^-8, on the SAME staging, pipelining, masking and softmax code as the 16-bit kernels.
 #include "common.h"
+#include "attention_frag.h"
 #include "attention_pipe.h"
 #include <stdlib.h>
 #include <string.h>
@@ -35,9 +36,6 @@
 
 namespace {
 
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 struct TND { const __bf16* p; long long s_b, s_h, s_n; };      // 16-bit operand, element strides
 struct OND { void* p; long long s_b, s_h, s_n; };              // output (16-bit, or f32 when NS == 2)
@@ -55,10 +53,6 @@ __device__ __forceinline__ f32x4 mm(const Fr<NS>& a, const Fr<NS>& b, f32x4 c) {
     if constexpr (NS == 2) { c = MFMA(a.t[1], b.t[0], c); c = MFMA(a.t[0], b.t[1], c); }
     return MFMA(a.t[0], b.t[0], c);
 }
-__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
-    bf16x8 r = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
-    return r;
-}
 // two f32 fragments -> NS 16-bit terms
 template <int NS>
 __device__ __forceinline__ Fr<NS> split_pack(f32x4 a, f32x4 b) {
@@ -72,23 +66,6 @@ __device__ __forceinline__ Fr<NS> split_pack(f32x4 a, f32x4 b) {
     }
     return r;
 }
-__device__ __forceinline__ float groups_max(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    x = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
-    u = __builtin_bit_cast(unsigned, x);
-    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
-}
-__device__ __forceinline__ float groups_sum(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    x = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
-    u = __builtin_bit_cast(unsigned, x);
-    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
-}
-
 // ---- swizzled LDS image -------------------------------------------------------------------------------------------------
 // 16 rows x (32 of the 64 columns) as an MFMA A/B operand: lane (i = lane & 15, g = lane >> 4) holds tile[row0 + i][ks*32 + 8g .. +7]
 __device__ __forceinline__ bf16x8 sw_row(const char* tile, int row0, int ks, int fi, int fg) {
