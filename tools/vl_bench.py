@@ -76,7 +76,9 @@ def run(name, lens, H, d, scale):
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-run(f"ViT-H/14 B={B} N=577 H=16 d=80", [577] * B, 16, 80, 80 ** -0.5)
+run(f"ViT-H/14 B={B} N=577 H=16 d=80" + (f" DBG={os.environ['VITK_VL_DBG']}" if os.environ.get("VITK_VL_DBG") else ""), [577] * B, 16, 80, 80 ** -0.5)
+if os.environ.get("VL_BENCH_ONLY") == "h14":
+    sys.exit(0)
 rng = np.random.RandomState(0)
 lens = [int(a * b) for a, b in zip(rng.randint(4, 41, size=48), rng.randint(4, 41, size=48))]
 run(f"NaViT {len(lens)} images {sum(lens)} tokens H=16 d=64", lens, 16, 64, 1.0)

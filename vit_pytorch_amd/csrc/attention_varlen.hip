@@ -38,6 +38,10 @@
 
 namespace {
 
+#ifndef VL_EARLY_TR
+#define VL_EARLY_TR 0        // 1: the transposing reads of a step are issued at its top (in flight under the S / dP MFMAs and the
+#endif                       //    softmax arithmetic), 0: right in front of their MFMAs.  [measured, profiles/r04f_vl_bench_early.log]
+                             //    equal within 2 % either way; 0 needs 8-16 registers less
 constexpr int VL_BLK = 128;            // rows per block (host tables: segments.Segments.BLOCK)
 constexpr int VL_CH = 64;              // rows per LDS chunk
 
@@ -161,14 +165,50 @@ struct Tiles {
     __device__ __forceinline__ int grow(int r) const { const int x = row(r); return seg0 + (x < n ? x : (n > 0 ? n - 1 : 0)); }
 };
 
+// Which (block, head) a workgroup takes.  The blocks of one (segment, head) stream the SAME K|V (or Q|dO) rows, and the hardware
+// deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2: with (block, head) = plain grid coordinates the
+// five blocks of a ViT-H/14 head ran on five XCDs and every one of them pulled the head's 185 KB through the fabric -- [measured,
+// profiles/r04f_vl_ablation.log] the kernels were bound by that staging (forward 248 us at batch 64, of which LDS-DMA + barriers
+// alone 236 us, arithmetic alone 156 us).  Here XCD x = id % 8 walks the contiguous range [x per, (x + 1) per) of an ORDER in which
+// the blocks that share rows are neighbours: they run back to back on one XCD and all but the first hit its L2.
+constexpr int VL_GROUP = 16;
+// order 2 (the default): the heads in 8 chunks, inside a chunk groups of VL_GROUP blocks x the chunk's heads -- an XCD takes H / 8
+// heads of ALL segments (balanced whatever the segment lengths) and works on them side by side (neighbouring heads share 128-byte
+// lines).  Order 0: head-major over all blocks (an XCD takes its heads one after the other); order 1: groups of VL_GROUP blocks x all
+// heads (an XCD takes a range of SEGMENTS: whole token rows, but their lengths decide the balance).  [measured,
+// profiles/r04f_vl_orders.log] ViT-H/14 shape, batch 256, forward / backward us: order 0: 958 / 2,462, 1: 905 / 2,373, 2: 893 / 2,339;
+// NaViT mix of 48 images: 116 / 364, 160 / 439, 116 / 367.  VITK_VL_ORDER overrides.
+__device__ __forceinline__ bool vl_block_of(int nblk, int nheads, int order, int& blk, int& h) {
+    const int per = gridDim.x >> 3;
+    int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (v >= nblk * nheads) return false;
+    if (order == 0) { h = v / nblk; blk = v - h * nblk; return true; }
+    int h0 = 0, hc = nheads;
+    if (order == 2) {
+        const int q = v / nblk;             // chunk c holds the heads [c H / 8, (c + 1) H / 8)
+        int c = 0;
+        while (((c + 1) * nheads) / 8 <= q) ++c;
+        h0 = (c * nheads) / 8; hc = ((c + 1) * nheads) / 8 - h0;
+        v -= h0 * nblk;
+    }
+    const int g = v / (hc * VL_GROUP);
+    const int rem = v - g * (hc * VL_GROUP);
+    const int left = nblk - g * VL_GROUP;
+    const int gl = left < VL_GROUP ? left : VL_GROUP;       // blocks in this group (the last one may be short)
+    const int hl = rem / gl;
+    h = h0 + hl;
+    blk = g * VL_GROUP + (rem - hl * gl);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // forward: O = softmax(scale Q K^T) V, row log-sum-exp saved for the backward
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DH, int R, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_varlen_fwd_kernel(
+template <int DH, int R, int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW, (NW == 8 && DH <= 80 && !DROP && !VL_EARLY_TR) ? 6 : 2) void attn_varlen_fwd_kernel(
     HND q, HND k, HND v, HND o, float* __restrict__ lse, const int* __restrict__ cu_q, const int* __restrict__ cu_k,
     const int* __restrict__ blk_seg, const int* __restrict__ blk_r0, int tq_total, float scale_log2e, unsigned drop_t,
-    unsigned drop_seed, float inv_keep) {
+    unsigned drop_seed, float inv_keep, int nblk, int nheads, int dbg) {
     using T = HD<DH>;
     constexpr int NKS = T::NKS, NFD = T::NFD, LD = T::LD, TILE = T::TILE;
     static_assert(16 * R * NW == VL_BLK, "a block is 128 rows");
@@ -177,10 +217,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_fwd_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, fg = lane >> 4;
     const unsigned troff = tr_lane_off<LD>(fi, fg);
-    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
+    // (block, head) of this workgroup: see vl_block_of
+    int blk, h;
+    if (!vl_block_of(nblk, nheads, dbg >> 8, blk, h)) return;
+    const int seg = blk_seg[blk];
     const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
     const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
-    const int t0 = blk_r0[blockIdx.x] + wave * (16 * R);       // first row of this wave's first tile
+    const int t0 = blk_r0[blk] + wave * (16 * R);       // first row of this wave's first tile
     const bool wave_active = t0 < nq;
     const __bf16* kbase = k.p + (long long)ks0 * k.s_n + h * k.s_h;
     const __bf16* vbase = v.p + (long long)ks0 * v.s_n + h * v.s_h;
@@ -210,15 +253,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_fwd_kernel(
     for (int c0 = 0; c0 < nk; c0 += VL_CH, buf ^= 1) {
         const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
-        VL_SYNC();                                    // chunk c0 has landed; the other buffer has been read by everyone
-        if (c0 + VL_CH < nk) stage(c0 + VL_CH, buf ^ 1);
-        if (!wave_active) continue;
+        if (!(dbg & 4) || c0 == 0) VL_SYNC();         // chunk c0 has landed; the other buffer has been read by everyone
+        if (c0 + VL_CH < nk && !(dbg & 1)) stage(c0 + VL_CH, buf ^ 1);
+        if (!wave_active || (dbg & 2)) continue;
         const char* Ks = smem + 2 * buf * TILE;
         const char* Vs = Ks + TILE;
         for (int s = 0; s < (rows_pad >> 5); ++s) {
             bf16x8 kf[2][NKS];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) read_rows<NKS, LD>(kf[hh], Ks, s * 32 + hh * 16, fi, fg);
+            s16x4 lo[NFD], hi[NFD];
+            if constexpr (VL_EARLY_TR) tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Vs) + troff + s * (32 * LD));
             bf16x8 pb[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -251,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_fwd_kernel(
                     for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
                 pb[r] = pack8(st[0], st[1]);
                 accl[r] = MFMA(ones, pb[r], accl[r]);          // softmax denominators: of the UNDROPPED probabilities
-                if (drop_t) {     // attention dropout (na_vit.py:163 dropout_p): row = (head, global query row), column = key inside the image
+                if constexpr (DROP) {     // attention dropout (na_vit.py:163 dropout_p): row = (head, global query row), column = key inside the image
                     const unsigned hrow = drop_row((unsigned)(h * tq_total + tl.grow(r)), drop_seed);
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh)
@@ -262,8 +307,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_fwd_kernel(
                 }
             }
             {
-                s16x4 lo[NFD], hi[NFD];
-                tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Vs) + troff + s * (32 * LD));
+                if constexpr (!VL_EARLY_TR) tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Vs) + troff + s * (32 * LD));
                 tr_wait<NFD>(lo, hi);
 #pragma unroll
                 for (int fd = 0; fd < NFD; ++fd) {
@@ -291,11 +335,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_fwd_kernel(
 // ------------------------------------------------------------------------------------------------------------------------
 // backward, query-block outer: dQ = scale dS K with dS = P (dP - delta); writes delta = rowsum(dO O) for the dK/dV kernel
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DH, int R, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80) ? 3 : 2) void attn_varlen_bwd_dq_kernel(
+template <int DH, int R, int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80 && !VL_EARLY_TR) ? 3 : 2) void attn_varlen_bwd_dq_kernel(
     HND q, HND k, HND v, HND o, HND dout, const float* __restrict__ lse, float* __restrict__ delta, HND dq,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
-    const int* __restrict__ blk_r0, int tq_total, float scale, unsigned drop_t, unsigned drop_seed, float inv_keep) {
+    const int* __restrict__ blk_r0, int tq_total, float scale, unsigned drop_t, unsigned drop_seed, float inv_keep, int nblk, int nheads, int dbg) {
     using T = HD<DH>;
     constexpr int NKS = T::NKS, NFD = T::NFD, LD = T::LD, TILE = T::TILE;
     static_assert(16 * R * NW == VL_BLK, "a block is 128 rows");
@@ -304,10 +348,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80) ? 3 : 2) void attn_v
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, fg = lane >> 4;
     const unsigned troff = tr_lane_off<LD>(fi, fg);
-    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
+    // (block, head) of this workgroup: see vl_block_of
+    int blk, h;
+    if (!vl_block_of(nblk, nheads, dbg >> 8, blk, h)) return;
+    const int seg = blk_seg[blk];
     const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
     const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
-    const int t0 = blk_r0[blockIdx.x] + wave * (16 * R);
+    const int t0 = blk_r0[blk] + wave * (16 * R);
     const bool wave_active = t0 < nq;
     const __bf16* kbase = k.p + (long long)ks0 * k.s_n + h * k.s_h;
     const __bf16* vbase = v.p + (long long)ks0 * v.s_n + h * v.s_h;
@@ -345,13 +392,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80) ? 3 : 2) void attn_v
     for (int c0 = 0; c0 < nk; c0 += VL_CH, buf ^= 1) {
         const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
-        VL_SYNC();
-        if (c0 + VL_CH < nk) stage(c0 + VL_CH, buf ^ 1);
-        if (!wave_active) continue;
+        if (!(dbg & 4) || c0 == 0) VL_SYNC();
+        if (c0 + VL_CH < nk && !(dbg & 1)) stage(c0 + VL_CH, buf ^ 1);
+        if (!wave_active || (dbg & 2)) continue;
         const char* Ks = smem + 2 * buf * TILE;
         const char* Vs = Ks + TILE;
         for (int s = 0; s < (rows_pad >> 5); ++s) {
             bf16x8 dsb[R];
+            s16x4 lo[NFD], hi[NFD];
+            if constexpr (VL_EARLY_TR) tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Ks) + troff + s * (32 * LD));
             {
                 bf16x4 dsh[R][2];
 #pragma unroll
@@ -364,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80) ? 3 : 2) void attn_v
                     for (int r = 0; r < R; ++r) {
                         const f32x4 st = mfma_over_d<NKS>(kfr, qf[r]);
                         f32x4 dp = mfma_over_d<NKS>(vfr, df[r]);
-                        if (drop_t) {
+                        if constexpr (DROP) {
                             const unsigned hrow = drop_row((unsigned)(h * tq_total + tl.grow(r)), drop_seed);
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -386,8 +435,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80) ? 3 : 2) void attn_v
                 for (int r = 0; r < R; ++r) dsb[r] = cat8(dsh[r][0], dsh[r][1]);
             }
             {
-                s16x4 lo[NFD], hi[NFD];
-                tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Ks) + troff + s * (32 * LD));
+                if constexpr (!VL_EARLY_TR) tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Ks) + troff + s * (32 * LD));
                 tr_wait<NFD>(lo, hi);
 #pragma unroll
                 for (int fd = 0; fd < NFD; ++fd) {
@@ -412,11 +460,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80) ? 3 : 2) void attn_v
 // ------------------------------------------------------------------------------------------------------------------------
 // backward, key-block outer: dV = P^T dO, dK = scale dS^T Q (reads the delta the dQ kernel wrote)
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DH, int R, int NW>
+template <int DH, int R, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
     HND q, HND k, HND v, HND dout, const float* __restrict__ lse, const float* __restrict__ delta, HND dk, HND dv,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, const int* __restrict__ blk_seg,
-    const int* __restrict__ blk_r0, int tq_total, float scale, unsigned drop_t, unsigned drop_seed, float inv_keep) {
+    const int* __restrict__ blk_r0, int tq_total, float scale, unsigned drop_t, unsigned drop_seed, float inv_keep, int nblk, int nheads, int dbg) {
     using T = HD<DH>;
     constexpr int NKS = T::NKS, NFD = T::NFD, LD = T::LD, TILE = T::TILE;
     static_assert(16 * R * NW == VL_BLK && NW >= 2, "a block is 128 rows; waves 0 and 1 stage lse / delta");
@@ -427,10 +475,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, fg = lane >> 4;
     const unsigned troff = tr_lane_off<LD>(fi, fg);
-    const int seg = blk_seg[blockIdx.x], h = blockIdx.y;
+    // (block, head) of this workgroup: see vl_block_of
+    int blk, h;
+    if (!vl_block_of(nblk, nheads, dbg >> 8, blk, h)) return;
+    const int seg = blk_seg[blk];
     const int qs = cu_q[seg], nq = cu_q[seg + 1] - qs;
     const int ks0 = cu_k[seg], nk = cu_k[seg + 1] - ks0;
-    const int t0 = blk_r0[blockIdx.x] + wave * (16 * R);       // first key row (inside the segment) of this wave's first tile
+    const int t0 = blk_r0[blk] + wave * (16 * R);       // first key row (inside the segment) of this wave's first tile
     const bool wave_active = t0 < nk;
     const __bf16* qbase = q.p + (long long)qs * q.s_n + h * q.s_h;
     const __bf16* dbase = dout.p + (long long)qs * dout.s_n + h * dout.s_h;
@@ -463,9 +514,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
     for (int c0 = 0; c0 < nq; c0 += VL_CH, buf ^= 1) {
         const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
         const int rows_pad = ((rows + 31) >> 5) << 5;
-        VL_SYNC();
-        if (c0 + VL_CH < nq) stage(c0 + VL_CH, buf ^ 1);
-        if (!wave_active) continue;
+        if (!(dbg & 4) || c0 == 0) VL_SYNC();
+        if (c0 + VL_CH < nq && !(dbg & 1)) stage(c0 + VL_CH, buf ^ 1);
+        if (!wave_active || (dbg & 2)) continue;
         const char* Qs = smem + 2 * buf * TILE;
         const char* Ds = Qs + TILE;
         const float* lse_s = reinterpret_cast<const float*>(stats + 512 * buf);
@@ -483,7 +534,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + row0 + 4 * fg) * (-LOG2E);
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + row0 + 4 * fg);
                     unsigned hq[4] = {0u, 0u, 0u, 0u};         // dropout row hashes of this lane's four query rows
-                    if (drop_t) {
+                    if constexpr (DROP) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) hq[e] = drop_row((unsigned)(h * tq_total + qs + c0 + row0 + 4 * fg + e), drop_seed);
                     }
@@ -495,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             p[e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l4[e]));
-                            if (drop_t) {
+                            if constexpr (DROP) {
                                 const float km = drop_keep(hq[e], (unsigned)tl.row(r), drop_t) ? inv_keep : 0.f;
                                 ds[e] = p[e] * (dp[e] * km - d4[e]);
                                 p[e] *= km;
@@ -514,10 +565,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
 #pragma unroll
                 for (int r = 0; r < R; ++r) { pb[r] = cat8(ph[r][0], ph[r][1]); dsb[r] = cat8(dsh[r][0], dsh[r][1]); }
             }
+            s16x4 qlo[NFD], qhi[NFD];
             {
                 s16x4 lo[NFD], hi[NFD];
                 tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Ds) + troff + s * (32 * LD));
                 tr_wait<NFD>(lo, hi);
+                // the Q^T fragments of the dK product: in flight under the dV MFMAs
+                if constexpr (VL_EARLY_TR) tr_read_all<NFD, LD>(qlo, qhi, lds_addr_of(Qs) + troff + s * (32 * LD));
 #pragma unroll
                 for (int fd = 0; fd < NFD; ++fd) {
                     const bf16x8 dt = tr_join(lo[fd], hi[fd]);
@@ -526,8 +580,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
                 }
             }
             {
-                s16x4 lo[NFD], hi[NFD];
-                tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Qs) + troff + s * (32 * LD));
+                s16x4 (&lo)[NFD] = qlo; s16x4 (&hi)[NFD] = qhi;
+                if constexpr (!VL_EARLY_TR) tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Qs) + troff + s * (32 * LD));
                 tr_wait<NFD>(lo, hi);
 #pragma unroll
                 for (int fd = 0; fd < NFD; ++fd) {
@@ -554,9 +608,21 @@ HND to_hnd(vitk_hnd t) { return HND{(__bf16*)t.p, (long long)t.s_h, (long long)t
 bool hnd_ok(vitk_hnd t) { return t.p && aligned16(t.p) && (t.s_h % 8 == 0) && (t.s_n % 8 == 0); }
 
 // geometry of the launches: 2 = (R, NW) = (2, 4), the default; 1 = (1, 8).  VITK_ATTN_VL overrides (A/B runs).
-int vl_geometry() {
-    static const int g = [] { const char* e = getenv("VITK_ATTN_VL"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }();
+// experiments (VITK_VL_DBG): bit 0 = no LDS-DMA after the first chunk, bit 1 = no arithmetic, bit 2 = no barrier after the first (results are wrong)
+// bits 8..: order of the workgroups (vl_block_of), VITK_VL_ORDER
+int vl_dbg() {
+    static const int g = [] { const char* e = getenv("VITK_VL_DBG"); const char* o = getenv("VITK_VL_ORDER");
+                              return (e ? atoi(e) & 255 : 0) | ((o ? atoi(o) : 2) << 8); }();
     return g;
+}
+// one workgroup per (block, head), rounded up to a multiple of the 8 XCDs (vl_block_of retires the surplus)
+unsigned vl_grid(int64_t nblk, int64_t H) { return (unsigned)((nblk * H + 7) / 8 * 8); }
+// geometry of the launches: 2 = (R, NW) = (2, 4), 1 = (1, 8).  [measured, profiles/r04f_vl_orders.log] d = 80, N = 577: (2, 4) is 6 % ahead
+// in the backward (2,339 vs 2,482 us at batch 256) and level in the forward; d = 64 (NaViT mix): (1, 8) is 6 % ahead in the forward and
+// level in the backward.  VITK_ATTN_VL = 1 / 2 overrides (A/B runs).
+int vl_geometry(int64_t d) {
+    static const int g = [] { const char* e = getenv("VITK_ATTN_VL"); return e ? atoi(e) : 0; }();
+    return g == 1 || g == 2 ? g : (d > 64 ? 2 : 1);
 }
 
 }  // namespace
@@ -577,11 +643,12 @@ extern "C" int vitk_attn_varlen_fwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v
     if (!(scale > 0.f)) VITK_FAIL(VITK_E_ARG, "attn_varlen_fwd_bf16: scale must be positive (got %g)", (double)scale);
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !lse || !cu_q || !cu_k || !blk_seg || !blk_r0)
         VITK_FAIL(VITK_E_ALIGN, "attn_varlen_fwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
-    if (nblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: empty problem");
-#define VL_FWD_G(DHV, R_, NW_) hipLaunchKernelGGL((attn_varlen_fwd_kernel<DHV, R_, NW_>), dim3((unsigned)nblk, (unsigned)H), dim3(64 * NW_), 0, \
+    if (nblk <= 0 || H <= 0 || H > 65535 || nblk * H > 0x7ffffff0LL) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_fwd_bf16: empty problem or more than 2^31 workgroups");
+#define VL_FWD_G(DHV, R_, NW_, DR_) hipLaunchKernelGGL((attn_varlen_fwd_kernel<DHV, R_, NW_, DR_>), dim3(vl_grid(nblk, H)), dim3(64 * NW_), 0, \
                        (hipStream_t)stream, to_hnd(q), to_hnd(k), to_hnd(v), to_hnd(o), lse, cu_q, cu_k, blk_seg, blk_r0, (int)tq_total, scale * LOG2E, \
-                       drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p))
-#define VL_FWD(DHV) do { const int g = vl_geometry(); if (g == 2) VL_FWD_G(DHV, 2, 4); else VL_FWD_G(DHV, 1, 8); } while (0)
+                       drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p), (int)nblk, (int)H, vl_dbg())
+#define VL_FWD(DHV) do { const int g = vl_geometry(d); const bool dr = drop_thresh(drop_p) != 0u; \
+    if (g == 2) { if (dr) VL_FWD_G(DHV, 2, 4, true); else VL_FWD_G(DHV, 2, 4, false); } else { if (dr) VL_FWD_G(DHV, 1, 8, true); else VL_FWD_G(DHV, 1, 8, false); } } while (0)
     switch ((int)d) {
         case 32: VL_FWD(32); break;
         case 48: VL_FWD(48); break;
@@ -618,14 +685,16 @@ extern "C" int vitk_attn_varlen_bwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v
     if (!hnd_ok(q) || !hnd_ok(k) || !hnd_ok(v) || !hnd_ok(o) || !hnd_ok(dout) || !hnd_ok(dq) || !hnd_ok(dk) || !hnd_ok(dv) || !lse ||
         !delta || !cu_q || !cu_k || !qblk_seg || !qblk_r0 || !kblk_seg || !kblk_r0)
         VITK_FAIL(VITK_E_ALIGN, "attn_varlen_bwd_bf16: tensors must be non-null, 16-byte aligned with strides %% 8 == 0");
-    if (nqblk <= 0 || nkblk <= 0 || H <= 0 || H > 65535) VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: empty problem");
+    if (nqblk <= 0 || nkblk <= 0 || H <= 0 || H > 65535 || nqblk * H > 0x7ffffff0LL || nkblk * H > 0x7ffffff0LL)
+        VITK_FAIL(VITK_E_SHAPE, "attn_varlen_bwd_bf16: empty problem or more than 2^31 workgroups");
     hipStream_t st = (hipStream_t)stream;
-#define VL_BWD_G(DHV, R_, NW_) do { \
-    hipLaunchKernelGGL((attn_varlen_bwd_dq_kernel<DHV, R_, NW_>), dim3((unsigned)nqblk, (unsigned)H), dim3(64 * NW_), 0, st, to_hnd(q), to_hnd(k), \
-                       to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep); \
-    hipLaunchKernelGGL((attn_varlen_bwd_dkv_kernel<DHV, R_, NW_>), dim3((unsigned)nkblk, (unsigned)H), dim3(64 * NW_), 0, st, to_hnd(q), to_hnd(k), \
-                       to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep); } while (0)
-#define VL_BWD(DHV) do { const int g = vl_geometry(); if (g == 2) VL_BWD_G(DHV, 2, 4); else VL_BWD_G(DHV, 1, 8); } while (0)
+#define VL_BWD_G(DHV, R_, NW_, DR_) do { \
+    hipLaunchKernelGGL((attn_varlen_bwd_dq_kernel<DHV, R_, NW_, DR_>), dim3(vl_grid(nqblk, H)), dim3(64 * NW_), 0, st, to_hnd(q), to_hnd(k), \
+                       to_hnd(v), to_hnd(o), to_hnd(dout), lse, delta, to_hnd(dq), cu_q, cu_k, qblk_seg, qblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep, (int)nqblk, (int)H, vl_dbg()); \
+    hipLaunchKernelGGL((attn_varlen_bwd_dkv_kernel<DHV, R_, NW_, DR_>), dim3(vl_grid(nkblk, H)), dim3(64 * NW_), 0, st, to_hnd(q), to_hnd(k), \
+                       to_hnd(v), to_hnd(dout), lse, delta, to_hnd(dk), to_hnd(dv), cu_q, cu_k, kblk_seg, kblk_r0, (int)tq_total, scale, drop_t, drop_seed, inv_keep, (int)nkblk, (int)H, vl_dbg()); } while (0)
+#define VL_BWD(DHV) do { const int g = vl_geometry(d); const bool dr = drop_thresh(drop_p) != 0u; \
+    if (g == 2) { if (dr) VL_BWD_G(DHV, 2, 4, true); else VL_BWD_G(DHV, 2, 4, false); } else { if (dr) VL_BWD_G(DHV, 1, 8, true); else VL_BWD_G(DHV, 1, 8, false); } } while (0)
     switch ((int)d) {
         case 32: VL_BWD(32); break;
         case 48: VL_BWD(48); break;
