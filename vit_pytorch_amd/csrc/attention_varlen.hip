@@ -264,37 +264,52 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DH <= 80 && !DROP && !VL_EARLY
             for (int hh = 0; hh < 2; ++hh) read_rows<NKS, LD>(kf[hh], Ks, s * 32 + hh * 16, fi, fg);
             s16x4 lo[NFD], hi[NFD];
             if constexpr (VL_EARLY_TR) tr_read_all<NFD, LD>(lo, hi, lds_addr_of(Vs) + troff + s * (32 * LD));
+            // The R tiles go through the step phase by phase (scores, decision, exponentials) so that each phase is ONE basic block in which
+            // hipcc interleaves the R independent chains; the rare raise of the reference maximum is decided for all tiles at once.
             bf16x8 pb[R];
+            f32x4 st[R][2];
+            float mloc[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                f32x4 st[2];
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) st[hh] = mfma_over_d<NKS>(kf[hh], qf[r]);
-                if (s * 32 + 32 > rows) {             // padding keys: only in the last step of the last chunk
+                for (int hh = 0; hh < 2; ++hh) st[r][hh] = mfma_over_d<NKS>(kf[hh], qf[r]);
+            if (s * 32 + 32 > rows) {                 // padding keys: only in the last step of the last chunk
+#pragma unroll
+                for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (s * 32 + hh * 16 + 4 * fg + e >= rows) st[hh][e] = -INFINITY;
-                }
-                float mloc = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
-                mloc = fmaxf(fmaxf(mloc, st[0][3]), st[1][0]);
-                mloc = fmaxf(fmaxf(mloc, st[1][1]), st[1][2]);
-                mloc = fmaxf(mloc, st[1][3]);
-                if (__builtin_amdgcn_ballot_w64(mloc * c > mref[r] + 8.0f) != 0) {
-                    const float m_new = fmaxf(mref[r], groups_max(mloc) * c);
+                            if (s * 32 + hh * 16 + 4 * fg + e >= rows) st[r][hh][e] = -INFINITY;
+            }
+            bool raise = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float m = fmaxf(fmaxf(st[r][0][0], st[r][0][1]), st[r][0][2]);
+                m = fmaxf(fmaxf(m, st[r][0][3]), st[r][1][0]);
+                m = fmaxf(fmaxf(m, st[r][1][1]), st[r][1][2]);
+                mloc[r] = fmaxf(m, st[r][1][3]);
+                raise = raise || (mloc[r] * c > mref[r] + 8.0f);
+            }
+            if (__builtin_amdgcn_ballot_w64(raise) != 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {         // a tile whose scores did not call for it is rescaled by a harmless alpha <= 1 too
+                    const float m_new = fmaxf(mref[r], groups_max(mloc[r]) * c);
                     const float alpha = __builtin_amdgcn_exp2f(mref[r] - m_new);
 #pragma unroll
                     for (int fd = 0; fd < NFD; ++fd) acc[r][fd] *= alpha;
                     accl[r] *= alpha;
                     mref[r] = m_new;
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
                 const float nm = -mref[r];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
-                pb[r] = pack8(st[0], st[1]);
+                    for (int e = 0; e < 4; ++e) st[r][hh][e] = __builtin_amdgcn_exp2f(fmaf(st[r][hh][e], c, nm));
+                pb[r] = pack8(st[r][0], st[r][1]);
                 accl[r] = MFMA(ones, pb[r], accl[r]);          // softmax denominators: of the UNDROPPED probabilities
                 if constexpr (DROP) {     // attention dropout (na_vit.py:163 dropout_p): row = (head, global query row), column = key inside the image
                     const unsigned hrow = drop_row((unsigned)(h * tq_total + tl.grow(r)), drop_seed);
@@ -302,8 +317,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DH <= 80 && !DROP && !VL_EARLY
                     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (!drop_keep(hrow, (unsigned)(c0 + s * 32 + hh * 16 + 4 * fg + e), drop_t)) st[hh][e] = 0.f;
-                    pb[r] = pack8(st[0], st[1]);
+                            if (!drop_keep(hrow, (unsigned)(c0 + s * 32 + hh * 16 + 4 * fg + e), drop_t)) st[r][hh][e] = 0.f;
+                    pb[r] = pack8(st[r][0], st[r][1]);
                 }
             }
             {
