@@ -599,7 +599,7 @@ __global__ __launch_bounds__(1024) void attn_dkv_pipe_kernel(const DkvArgs<NS> a
 // ==========================================================================================================================
 // backward, FUSED: dQ, dK, dV of one (batch, head) item in ONE pass over the scores (16-bit operands, 192 < N <= 208: the ViT-B/L
 // sequence lengths at 224^2 / patch 16).  Why: the two-kernel backward computes S and exp twice (7 matmul units instead of 5), reads
-// q, k, v, dO twice (927 MB instead of 618 MB at ViT-B/16 batch 256), and -- measured, see DESIGN section 4, round 3 -- spends half
+// q, k, v, dO twice (927 MB instead of 618 MB at ViT-B/16 batch 256), and -- measured, see DESIGN_HISTORY.md, round 3 -- spends half
 // its time on the rows every wave fetches for itself at the start of an item.  Here NO compute wave loads from global memory
 // (KT = 1 described, the flavour in use):
 //

@@ -72,7 +72,7 @@ def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, rows: i
 def grad_stream_16() -> bool:
     """The backward's residual stream (the gradient that flows through the `+ x` of vit.py:80-81) in the parameter dtype -- what
     torch autograd does when the reference runs in bfloat16 -- instead of float32: the LayerNorm backward, an HBM-bound kernel,
-    moves 386 instead of 619 MB per launch.  On by default for 16-bit parameters without active
+    moves 386 instead of 619 MB per launch (DESIGN_HISTORY.md, round 3).  On by default for 16-bit parameters without active
     dropout; VITK_GRAD_STREAM=f32 keeps the float32 stream (the forward stream is float32 either way)."""
     return os.environ.get("VITK_GRAD_STREAM", "16") != "f32"
 
