@@ -311,7 +311,9 @@ int vitk_dropout_keep(uint8_t* keep, int64_t rows, int64_t cols, float p, uint32
  * packed without padding into (T, H*d) matrices addressed as p + n*s_n + h*s_h + d; attention runs per segment
  * (= image): query rows [cu_q[s], cu_q[s+1]) against key rows [cu_k[s], cu_k[s+1]).  No mask is materialised.
  * blk_seg/blk_r0 (int32, device): for every 128-row block of the launch, its segment and its first row inside the
- * segment (query blocks for fwd and dQ, key blocks for dK/dV).  lse, delta: f32 (H, tq_total).  bf16, d == 64. */
+ * segment (query blocks for fwd and dQ, key blocks for dK/dV), SORTED BY SEGMENT (the kernels run blocks that are
+ * neighbours in the table on one XCD: blocks of one segment share its K|V rows).  lse, delta: f32 (H, tq_total).
+ * 16-bit, d in {32, 48, 64, 80, 96} (ViT-H/14's dim_head 80 runs here as B segments of N rows); nblk * H < 2^31.     */
 typedef struct vitk_hnd { void* p; int64_t s_h, s_n; } vitk_hnd;
 int vitk_attn_varlen_fwd_bf16(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd o, float* lse,
                               const int32_t* cu_q, const int32_t* cu_k, const int32_t* blk_seg, const int32_t* blk_r0,
