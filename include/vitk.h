@@ -337,8 +337,9 @@ int vitk_attn_varlen_bwd_bf16_drop(vitk_hnd q, vitk_hnd k, vitk_hnd v, vitk_hnd 
                                    void* stream);
 
 /* NaViT q/k normalisation (RMSNorm, na_vit.py:93-101): y = x / max(||x||, 1e-12) * sqrt(d) * gamma[h, :] for every
- * (token, head); x, y viewed (T, H, 64) with token strides ldx / ldy.  rnorm: f32 (T*H) saved for backward.
- * Backward also needs `partials`: f32 workspace of vitk_rmsnorm_heads_rows(T, H) * 64 floats.                  */
+ * (token, head); x, y viewed (T, H, d) with token strides ldx / ldy (d % 4 == 0, d <= 256: the reference leaves dim_head
+ * free, na_vit.py:119; strides % 4 == 0).  rnorm: f32 (T*H) saved for backward.
+ * Backward also needs `partials`: f32 workspace of vitk_rmsnorm_heads_rows(T, H) * 64 * ceil(d / 64) floats.    */
 int64_t vitk_rmsnorm_heads_rows(int64_t T, int64_t H);
 int vitk_rmsnorm_heads_fwd(const void* x, int64_t ldx, const void* gamma, void* y, int64_t ldy, float* rnorm, int dt,
                            int64_t T, int64_t H, int64_t d, void* stream);

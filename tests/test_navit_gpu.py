@@ -79,21 +79,23 @@ def test_attention_pool_geometry_one_query_per_image():
         start += n
 
 
+@pytest.mark.parametrize("d", [64, 32, 80, 96, 128, 20, 256])
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
-def test_rmsnorm_heads(dtype):
-    T, H, d = 37, 3, 64
+def test_rmsnorm_heads(dtype, d):
+    """dim_head is free in the reference (na_vit.py:119): 16 lanes x 4 elements per 64-column chunk, d % 4 == 0, d <= 256"""
+    T, H = 37, 3
     x = torch.randn(T, 2 * H * d).to(dtype).to(DEV)       # read the first half of a wider matrix (like to_kv's output)
     gamma = (1 + 0.2 * torch.randn(H, d)).to(dtype).to(DEV)
     y = torch.empty(T, H * d, dtype=dtype, device=DEV); rn = torch.empty(T * H, device=DEV)
     K.rmsnorm_heads_fwd(x, 2 * H * d, gamma, y, H * d, rn, T, H, d)
     xd = x[:, :H * d].double().view(T, H, d).requires_grad_(True); gd = gamma.double().requires_grad_(True)
-    ref = torch.nn.functional.normalize(xd, dim=-1) * 8.0 * gd
+    ref = torch.nn.functional.normalize(xd, dim=-1) * d ** 0.5 * gd
     tol = 3e-6 if dtype == torch.float32 else 5e-3
     assert rel(y, ref.reshape(T, H * d)) < tol
     dy = torch.randn(T, H * d).to(dtype).to(DEV)
     ref.backward(dy.double().view(T, H, d))
     dx = torch.zeros(T, 2 * H * d, dtype=dtype, device=DEV); dg = torch.empty(H, d, dtype=dtype, device=DEV)
-    part = torch.empty(K.rmsnorm_heads_rows(T, H) * 64, device=DEV)
+    part = torch.empty(K.rmsnorm_heads_partials(T, H, d), device=DEV)
     K.rmsnorm_heads_bwd(dy, H * d, x, 2 * H * d, gamma, rn, dx, 2 * H * d, dg, part, T, H, d)
     assert rel(dx[:, :H * d], xd.grad.reshape(T, H * d)) < tol * 2
     assert rel(dg, gd.grad) < tol * 2

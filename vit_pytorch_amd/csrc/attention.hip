@@ -431,68 +431,100 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
 }
 
 // q/k normalisation of NaViT (na_vit.py:93-101): y = x / max(||x||_2, 1e-12) * sqrt(d) * gamma[h, :] per (token, head).
-// x viewed (T, H, 64) with token stride ld; 16 lanes per (token, head), 4 elements per lane.
-template <typename T>
+// x viewed (T, H, d) with token stride ld; 16 lanes per (token, head), 4 elements per lane and 64-column chunk (NC = ceil(d / 64) chunks;
+// d % 4 == 0, d <= 256: the reference takes any dim_head, na_vit.py:119; lanes past d in the last chunk carry zeros).
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void rmsnorm_heads_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma, T* __restrict__ y,
-                                                                 float* __restrict__ rnorm, long long pairs, int H, long long ldx, long long ldy) {
+                                                                 float* __restrict__ rnorm, long long pairs, int H, int d, float sqrt_d,
+                                                                 long long ldx, long long ldy) {
     const int sub = threadIdx.x & 15;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     for (long long pr = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); pr < pairs; pr += (long long)gridDim.x * 16) {
         const long long t = pr / H; const int h = (int)(pr % H);
-        const f32x4 v = load4<T>(x + t * ldx + h * 64 + sub * 4);
-        float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        f32x4 v[NC];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e = c * 64 + sub * 4;
+            v[c] = e < d ? load4<T>(x + t * ldx + (long long)h * d + e) : z4;
+            ss += v[c][0] * v[c][0] + v[c][1] * v[c][1] + v[c][2] * v[c][2] + v[c][3] * v[c][3];
+        }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
         const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        const f32x4 g = load4<T>(gamma + h * 64 + sub * 4);
-        store4<T>(y + t * ldy + h * 64 + sub * 4, v * g * (rn * 8.0f));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e = c * 64 + sub * 4;
+            if (e < d) {
+                const f32x4 g = load4<T>(gamma + (long long)h * d + e);
+                store4<T>(y + t * ldy + (long long)h * d + e, v[c] * g * (rn * sqrt_d));
+            }
+        }
         if (sub == 0) rnorm[pr] = rn;
     }
 }
-// dx = s*rn*(g*dy - xhat * sum(g*dy*xhat)), xhat = x*rn, s = sqrt(d) = 8; dgamma[h,:] += dy * xhat * s (partials per block)
-template <typename T>
+// dx = s*rn*(g*dy - xhat * sum(g*dy*xhat)), xhat = x*rn, s = sqrt(d); dgamma[h,:] += dy * xhat * s (partials per block, rows of 64 NC floats)
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void rmsnorm_heads_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ gamma,
                                                                  const float* __restrict__ rnorm, T* __restrict__ dx, float* __restrict__ partials,
-                                                                 long long pairs, int H, long long lddy, long long ldx, long long lddx) {
+                                                                 long long pairs, int H, int d, float sqrt_d, long long lddy, long long ldx, long long lddx) {
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     // each 16-lane group accumulates dgamma for the heads it meets; heads cycle with period H over pairs, so a
     // group that strides by (gridDim*16) pairs keeps a fixed head only if that stride is a multiple of H: enforce it
-    f32x4 accg = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) accg[c] = z4;
     const long long stride = (long long)gridDim.x * 16;
     const long long first = (long long)blockIdx.x * 16 + grp;
     const int h = (int)(first % H);
     for (long long pr = first; pr < pairs; pr += stride) {
         const long long t = pr / H;
-        const f32x4 d = load4<T>(dy + t * lddy + h * 64 + sub * 4);
-        const f32x4 v = load4<T>(x + t * ldx + h * 64 + sub * 4);
-        const f32x4 g = load4<T>(gamma + h * 64 + sub * 4);
         const float rn = rnorm[pr];
-        const f32x4 xh = v * rn;
-        const f32x4 gd = g * d;
-        float dot = gd[0] * xh[0] + gd[1] * xh[1] + gd[2] * xh[2] + gd[3] * xh[3];
+        f32x4 dv[NC], xh[NC], gd[NC];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e = c * 64 + sub * 4;
+            const bool act = e < d;
+            dv[c] = act ? load4<T>(dy + t * lddy + (long long)h * d + e) : z4;
+            const f32x4 v = act ? load4<T>(x + t * ldx + (long long)h * d + e) : z4;
+            const f32x4 g = act ? load4<T>(gamma + (long long)h * d + e) : z4;
+            xh[c] = v * rn;
+            gd[c] = g * dv[c];
+            dot += gd[c][0] * xh[c][0] + gd[c][1] * xh[c][1] + gd[c][2] * xh[c][2] + gd[c][3] * xh[c][3];
+        }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
-        store4<T>(dx + t * lddx + h * 64 + sub * 4, (gd - xh * dot) * (rn * 8.0f));
-        accg += d * xh * 8.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e = c * 64 + sub * 4;
+            if (e < d) store4<T>(dx + t * lddx + (long long)h * d + e, (gd[c] - xh[c] * dot) * (rn * sqrt_d));
+            accg[c] += dv[c] * xh[c] * sqrt_d;
+        }
     }
-    // partials[(blockIdx*16 + grp)][64] ; row's head = (blockIdx*16+grp) % H  (stride % H == 0 is guaranteed by the host)
-    *reinterpret_cast<f32x4*>(partials + ((long long)blockIdx.x * 16 + grp) * 64 + sub * 4) = accg;
+    // partials[(blockIdx*16 + grp)][64 NC] ; row's head = (blockIdx*16+grp) % H  (stride % H == 0 is guaranteed by the host)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        *reinterpret_cast<f32x4*>(partials + ((long long)blockIdx.x * 16 + grp) * (64 * NC) + c * 64 + sub * 4) = accg[c];
 }
-// dgamma[h][c] = sum over partial rows r with r % H == h.  64 columns x 16 row phases per head: the list is thousands of
+// dgamma[h][c] = sum over partial rows r with r % H == h.  64 columns x 16 row phases per (head, chunk): the list is thousands of
 // rows long (2048 per head at NaViT sizes) and a single wave walking it paid one memory latency per row (0.48 ms per
 // call, 17 % of the NaViT step before this).
 template <typename T>
-__global__ __launch_bounds__(1024) void rmsnorm_heads_dgamma_kernel(const float* __restrict__ partials, long long nrows, int H, T* __restrict__ dgamma) {
+__global__ __launch_bounds__(1024) void rmsnorm_heads_dgamma_kernel(const float* __restrict__ partials, long long nrows, int H, int d, int dpad,
+                                                                     T* __restrict__ dgamma) {
     __shared__ float red[16][64];
-    const int h = blockIdx.x, c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int h = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
     float s = 0.f;
-    for (long long r = h + (long long)ph * H; r < nrows; r += (long long)16 * H) s += partials[r * 64 + c];
-    red[ph][c] = s;
+    for (long long r = h + (long long)ph * H; r < nrows; r += (long long)16 * H) s += partials[r * dpad + c];
+    red[ph][threadIdx.x & 63] = s;
     __syncthreads();
-    if (ph == 0) {
+    if (ph == 0 && c < d) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][c];
-        dgamma[h * 64 + c] = from_f32<T>(t);
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x & 63];
+        dgamma[(long long)h * d + c] = from_f32<T>(t);
     }
 }
 
@@ -692,13 +724,17 @@ extern "C" int64_t vitk_rmsnorm_heads_rows(int64_t T, int64_t H) {
     return blocks * 16;
 }
 
+#define VITK_RMS_NC(nc, ...) do { switch (nc) { case 1: { constexpr int NC_ = 1; __VA_ARGS__; } break; case 2: { constexpr int NC_ = 2; __VA_ARGS__; } break; \
+    case 3: { constexpr int NC_ = 3; __VA_ARGS__; } break; default: { constexpr int NC_ = 4; __VA_ARGS__; } break; } } while (0)
+
 extern "C" int vitk_rmsnorm_heads_fwd(const void* x, int64_t ldx, const void* gamma, void* y, int64_t ldy, float* rnorm, int dt,
                                       int64_t T, int64_t H, int64_t d, void* stream) {
     if (!x || !gamma || !y || !rnorm) VITK_FAIL(VITK_E_ARG, "rmsnorm_heads_fwd: null pointer");
-    if (d != 64 || T <= 0 || H <= 0 || (ldx & 3) || (ldy & 3)) VITK_FAIL(VITK_E_SHAPE, "rmsnorm_heads_fwd: needs dim_head == 64");
+    if (d <= 0 || d > 256 || (d & 3) || T <= 0 || H <= 0 || (ldx & 3) || (ldy & 3)) VITK_FAIL(VITK_E_SHAPE, "rmsnorm_heads_fwd: needs dim_head %% 4 == 0, dim_head <= 256, row strides %% 4 == 0");
     long long blocks = (T * H + 15) / 16; if (blocks > 4096) blocks = 4096;
-    VITK_DISPATCH_DT(dt, Tt, hipLaunchKernelGGL((rmsnorm_heads_fwd_kernel<Tt>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                                                 (const Tt*)x, (const Tt*)gamma, (Tt*)y, rnorm, (long long)(T * H), (int)H, (long long)ldx, (long long)ldy));
+    const float sd = sqrtf((float)d);
+    VITK_DISPATCH_DT(dt, Tt, VITK_RMS_NC((int)((d + 63) / 64), hipLaunchKernelGGL((rmsnorm_heads_fwd_kernel<Tt, NC_>), dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, (const Tt*)x, (const Tt*)gamma, (Tt*)y, rnorm, (long long)(T * H), (int)H, (int)d, sd, (long long)ldx, (long long)ldy)));
     VITK_CHECK_LAUNCH("rmsnorm_heads_fwd");
     return 0;
 }
@@ -706,15 +742,18 @@ extern "C" int vitk_rmsnorm_heads_fwd(const void* x, int64_t ldx, const void* ga
 extern "C" int vitk_rmsnorm_heads_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma, const float* rnorm,
                                       void* dx, int64_t lddx, void* dgamma, float* partials, int dt, int64_t T, int64_t H, int64_t d,
                                       void* stream) {
+    // partials: vitk_rmsnorm_heads_rows(T, H) rows of 64 * ceil(d / 64) floats
     if (!dy || !x || !gamma || !rnorm || !dx || !dgamma || !partials) VITK_FAIL(VITK_E_ARG, "rmsnorm_heads_bwd: null pointer");
-    if (d != 64 || T <= 0 || H <= 0) VITK_FAIL(VITK_E_SHAPE, "rmsnorm_heads_bwd: needs dim_head == 64");
+    if (d <= 0 || d > 256 || (d & 3) || T <= 0 || H <= 0 || (lddy & 3) || (ldx & 3) || (lddx & 3)) VITK_FAIL(VITK_E_SHAPE, "rmsnorm_heads_bwd: needs dim_head %% 4 == 0, dim_head <= 256, row strides %% 4 == 0");
     const long long nrows = vitk_rmsnorm_heads_rows(T, H);
+    const int nc = (int)((d + 63) / 64), dpad = 64 * nc;
+    const float sd = sqrtf((float)d);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(partials, 0, (size_t)nrows * 64 * sizeof(float), st) != hipSuccess) VITK_FAIL(1, "rmsnorm_heads_bwd: memset failed");
+    if (hipMemsetAsync(partials, 0, (size_t)nrows * dpad * sizeof(float), st) != hipSuccess) VITK_FAIL(1, "rmsnorm_heads_bwd: memset failed");
     VITK_DISPATCH_DT(dt, Tt, {
-        hipLaunchKernelGGL((rmsnorm_heads_bwd_kernel<Tt>), dim3((unsigned)(nrows / 16)), dim3(256), 0, st, (const Tt*)dy, (const Tt*)x,
-                           (const Tt*)gamma, rnorm, (Tt*)dx, partials, (long long)(T * H), (int)H, (long long)lddy, (long long)ldx, (long long)lddx);
-        hipLaunchKernelGGL((rmsnorm_heads_dgamma_kernel<Tt>), dim3((unsigned)H), dim3(1024), 0, st, partials, nrows, (int)H, (Tt*)dgamma);
+        VITK_RMS_NC(nc, hipLaunchKernelGGL((rmsnorm_heads_bwd_kernel<Tt, NC_>), dim3((unsigned)(nrows / 16)), dim3(256), 0, st, (const Tt*)dy, (const Tt*)x,
+                           (const Tt*)gamma, rnorm, (Tt*)dx, partials, (long long)(T * H), (int)H, (int)d, sd, (long long)lddy, (long long)ldx, (long long)lddx));
+        hipLaunchKernelGGL((rmsnorm_heads_dgamma_kernel<Tt>), dim3((unsigned)H, (unsigned)nc), dim3(1024), 0, st, partials, nrows, (int)H, (int)d, dpad, (Tt*)dgamma);
     });
     VITK_CHECK_LAUNCH("rmsnorm_heads_bwd");
     return 0;

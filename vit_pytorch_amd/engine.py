@@ -815,8 +815,8 @@ class PackedTransformerFn(torch.autograd.Function):
         _check_dims(D, "NaViT Transformer")
         I = heads * dim_head
         d = dim_head
-        if T not in ops.HALF or d != 64:
-            raise VitkError("PackedTransformerFn: fused NaViT stack needs 16-bit parameters and dim_head == 64")
+        if not ops.attn_varlen_ok(T, d):
+            raise VitkError("PackedTransformerFn: fused NaViT stack needs 16-bit parameters and dim_head 32 / 48 / 64 / 80 / 96")
         x = x.contiguous()
         if x.dtype == F32:
             xs = x
@@ -933,7 +933,7 @@ class PackedTransformerFn(torch.autograd.Function):
                                    K.hnd(dqkv, d, 3 * I, offset=2 * I), segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0,
                                    segs.nqblk, segs.kblk_seg, segs.kblk_r0, segs.nkblk, Tn, heads, d, 1.0, *att_drop(li))
             dgq = torch.empty_like(gqf); dgk = torch.empty_like(gkf)
-            part = ops.empty((K.rmsnorm_heads_rows(Tn, heads) * 64,), F32, dy)
+            part = ops.empty((K.rmsnorm_heads_partials(Tn, heads, d),), F32, dy)
             K.rmsnorm_heads_bwd(dqn, I, qkv, 3 * I, gqf, rq, dqkv, 3 * I, dgq, part, Tn, heads, d)
             K.rmsnorm_heads_bwd(dkn, I, qkv, 3 * I, gkf, rk, dqkv, 3 * I, dgk, part, Tn, heads, d, x_off=I, dx_off=I)
             grads[base + 3], grads[base + 4] = dgq.view(gq.shape), dgk.view(gk.shape)

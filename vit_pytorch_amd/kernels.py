@@ -348,6 +348,11 @@ def rmsnorm_heads_rows(T: int, H: int) -> int:
     return int(L.load().vitk_rmsnorm_heads_rows(T, H))
 
 
+def rmsnorm_heads_partials(T: int, H: int, d: int) -> int:
+    """floats of the `partials` workspace of rmsnorm_heads_bwd: vitk_rmsnorm_heads_rows(T, H) rows of 64 * ceil(d / 64)"""
+    return rmsnorm_heads_rows(T, H) * ((d + 63) // 64 * 64)
+
+
 def rmsnorm_heads_fwd(x: Tensor, ldx: int, gamma: Tensor, y: Tensor, ldy: int, rnorm: Tensor, T: int, H: int, d: int,
                       x_off: int = 0):
     check(_lib_for(x, gamma, y, rnorm).vitk_rmsnorm_heads_fwd(x.data_ptr() + x_off * x.element_size(), ldx, _p(gamma), _p(y), ldy, _p(rnorm),

@@ -81,22 +81,23 @@ class _QKNormAttnFn(torch.autograd.Function):
         Tk = kv.shape[0]
         d = I // heads
         T = q.dtype
-        if d != 64:
-            raise VitkError(f"q / k RMSNorm attention (NaViT, simple_vit_with_qk_norm) needs dim_head == 64 in every dtype (got {d}): vitk_rmsnorm_heads_* are written for it")
+        if d % 4 or d > 256:
+            raise VitkError(f"q / k RMSNorm attention (NaViT, simple_vit_with_qk_norm) needs dim_head % 4 == 0 and dim_head <= 256 (got {d}): vitk_rmsnorm_heads_* are written for 16-byte lanes")
+        flash = ops.attn_varlen_ok(T, d)       # 16-bit, dim_head 32 / 48 / 64 / 80 / 96; everything else: per-segment materialising path
         qn = torch.empty_like(q); kn = torch.empty((Tk, I), dtype=T, device=q.device)
         rq = torch.empty(Tq * heads, dtype=F32, device=q.device); rk = torch.empty(Tk * heads, dtype=F32, device=q.device)
         gqf, gkf = gq.reshape(heads, d).contiguous(), gk.reshape(heads, d).contiguous()
         K.rmsnorm_heads_fwd(q, I, gqf, qn, I, rq, Tq, heads, d)
         K.rmsnorm_heads_fwd(kv, 2 * I, gkf, kn, I, rk, Tk, heads, d)
         o = torch.empty((Tq, I), dtype=T, device=q.device)
-        if T in (torch.bfloat16, torch.float16):
+        if flash:
             lse = torch.empty((heads, Tq), dtype=F32, device=q.device)
             K.attn_varlen_fwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I), lse,
                                    segs.cu_q, segs.cu_k, segs.qblk_seg, segs.qblk_r0, segs.nqblk, Tq, heads, d, 1.0, drop_p, drop_seed)
             saved = lse
-        else:  # f32 validation mode: per-segment materialising path on the coverage kernels
+        else:  # f32 validation mode (and head widths the flash kernels do not take): per-segment materialising path on the coverage kernels
             if drop_p > 0.0:
-                raise VitkError("attention dropout of NaViT is fused into the 16-bit attention kernels only (use bfloat16 / float16, or eval())")
+                raise VitkError("attention dropout of NaViT is fused into the 16-bit attention kernels only (bfloat16 / float16 with dim_head 32 / 48 / 64 / 80 / 96, or eval())")
             saved = []
             for s in range(segs.nseg):
                 q0, nq = int(segs.cu_q_host[s]), segs.q_lens[s]
@@ -112,6 +113,7 @@ class _QKNormAttnFn(torch.autograd.Function):
         ctx.save_for_backward(q, kv, gqf, gkf, qn, kn, o, rq, rk)
         ctx.att = saved
         ctx.meta = (segs, heads, d, gq.shape, gk.shape)
+        ctx.flash = flash
         ctx.drop = (drop_p, drop_seed)
         return o
 
@@ -125,7 +127,7 @@ class _QKNormAttnFn(torch.autograd.Function):
         do = Fn._to(do, T)
         dqn = torch.empty_like(qn); dkn = torch.empty_like(kn)
         dkv = torch.empty_like(kv)
-        if T in (torch.bfloat16, torch.float16):
+        if ctx.flash:
             delta = torch.empty((heads, Tq), dtype=F32, device=q.device)
             K.attn_varlen_bwd_bf16(K.hnd(qn, d, I), K.hnd(kn, d, I), K.hnd(kv, d, 2 * I, offset=I), K.hnd(o, d, I),
                                    K.hnd(do, d, I), ctx.att, delta, K.hnd(dqn, d, I), K.hnd(dkn, d, I),
@@ -146,8 +148,8 @@ class _QKNormAttnFn(torch.autograd.Function):
                 K.gemm_generic(K.mat(dP, 1, nk, 0, nq * nk), K.mat(qn, I, 1, 0, d, offset=q0 * I), K.mat(dkn, I, 1, 0, d, offset=k0 * I), nk, d, nq, nb1=1, nb2=heads)
         dq = torch.empty_like(q)
         dgq = torch.empty_like(gqf); dgk = torch.empty_like(gkf)
-        pq = torch.empty(K.rmsnorm_heads_rows(Tq, heads) * 64, dtype=F32, device=q.device)
-        pk = torch.empty(K.rmsnorm_heads_rows(Tk, heads) * 64, dtype=F32, device=q.device)
+        pq = torch.empty(K.rmsnorm_heads_partials(Tq, heads, d), dtype=F32, device=q.device)
+        pk = torch.empty(K.rmsnorm_heads_partials(Tk, heads, d), dtype=F32, device=q.device)
         K.rmsnorm_heads_bwd(dqn, I, q, I, gqf, rq, dq, I, dgq, pq, Tq, heads, d)
         K.rmsnorm_heads_bwd(dkn, I, kv, 2 * I, gkf, rk, dkv, 2 * I, dgk, pk, Tk, heads, d)
         return dq, dkv, dgq.view(gq_shape), dgk.view(gk_shape), None, None, None, None
@@ -336,7 +338,7 @@ class Transformer(nn.Module):
         if x.dtype not in (torch.bfloat16, torch.float16) or self.norm.gamma.dtype != x.dtype:
             return False
         for attn, ff in self.layers:
-            if attn.q_norm.gamma.shape[-1] != 64:
+            if not ops.attn_varlen_ok(x.dtype, attn.q_norm.gamma.shape[-1]):       # the flash kernels' head widths: 32 / 48 / 64 / 80 / 96
                 return False
             if any(bool(m._forward_hooks) or bool(m._forward_pre_hooks) for m in list(attn.modules()) + list(ff.modules())):
                 return False
@@ -348,7 +350,7 @@ class Transformer(nn.Module):
         if p > 0. and len(self.layers):
             from . import engine as E
             attn, ff = self.layers[0]
-            return E.packed_dropout_fusable(x.dtype, x.shape[0], x.shape[1], attn.heads, 64, ff[1].weight.shape[0])
+            return E.packed_dropout_fusable(x.dtype, x.shape[0], x.shape[1], attn.heads, attn.q_norm.gamma.shape[-1], ff[1].weight.shape[0])
         return True
 
     def forward(self, x, segs: Segments):
@@ -358,13 +360,14 @@ class Transformer(nn.Module):
             for attn, ff in self.layers:
                 params += E.pack_navit_layer_params(attn, ff)
             heads = self.layers[0][0].heads if len(self.layers) else 1
+            dim_head = self.layers[0][0].q_norm.gamma.shape[-1] if len(self.layers) else 64
             p = self._dropout_p()
             seed = 0
             if p > 0.:
                 seed = (int(torch.initial_seed()) + 0x9E3779B1 * self._drop_state()[0] + 0x85EBCA6B * self._drop_state()[1] + 0x632BE5AB * Fn.dist_rank()) & 0xffffffff
                 self.__dict__["_drop_calls"] = self._drop_state()[0] + 1
             note_grad_mode(torch.is_grad_enabled())      # Function.forward cannot see no_grad(): it decides what to keep from this
-            return E.PackedTransformerFn.apply(x, segs, heads, 64, float(p), seed, self.norm.gamma, *params)
+            return E.PackedTransformerFn.apply(x, segs, heads, dim_head, float(p), seed, self.norm.gamma, *params)
         for attn, ff in self.layers:
             x = Fn.AddFn.apply(attn(x, segs), x)
             x = Fn.AddFn.apply(ff(x), x)

@@ -130,7 +130,7 @@ class SimpleViT(nn.Module):
     def forward(self, img):
         embed = self.to_patch_embedding
         pos = self._pos_on(img.device, embed[2].weight.dtype)
-        if _any_hooks(embed):
+        if _any_hooks(embed) or embed[1].weight.shape[0] % 4:     # hooks, or a patch_dim off the fused stage's 16-byte rows (147): op by op
             tokens = embed(img)
             tokens = Fn.AddFn.apply(tokens, pos.unsqueeze(0).expand_as(tokens).contiguous())
         else:

@@ -7,7 +7,7 @@ and the 1 / sqrt(dim_head) score scale is dropped.  The reference's `linear_head
 `state_dict` keys and outputs are the contract.
 
 Kernels: the per-head RMSNorm (`vitk_rmsnorm_heads_*`) and the scale-1 attention are the ones NaViT uses (na_vit._QKNormAttnFn,
-chunked flash kernels over one segment per image; dim_head must be 64 in every mode: the per-head RMSNorm kernels are written for it); LayerNorm / Linear / GELU / residual
+chunked flash kernels over one segment per image; dim_head % 4 == 0, <= 256: the per-head RMSNorm kernels take 16-byte lanes); LayerNorm / Linear / GELU / residual
 adds are the op-level Functions of functional.py.
 """
 from __future__ import annotations
@@ -60,7 +60,7 @@ class _HeadRMSNormFn(torch.autograd.Function):
         dy = Fn._to(dy, x.dtype)
         dx = torch.empty_like(x)
         dg = torch.empty_like(g)
-        part = torch.empty(K.rmsnorm_heads_rows(T, heads) * 64, dtype=torch.float32, device=x.device)
+        part = torch.empty(K.rmsnorm_heads_partials(T, heads, d), dtype=torch.float32, device=x.device)
         K.rmsnorm_heads_bwd(dy, I, x, I, g, r, dx, I, dg, part, T, heads, d)
         return dx, dg.view(gshape), None
 
