@@ -54,7 +54,10 @@ template <int DH> struct HD {
     static constexpr int NFD = DH / 16;             // 16-column output blocks
     // bytes per LDS row: the smallest 32 x odd >= the row's data (96 / 96 / 160 / 160 / 224 for d = 32 / 48 / 64 / 80 / 96).  Row
     // fragments read 64 NKS bytes of a row: for d = 48 / 80 that is 32 bytes into the NEXT row (finite data against zero columns
-    // of the register operand); past the last tile lies a zeroed 32-byte slack (SLACK)
+    // of the register operand); past the last tile lies a zeroed 32-byte slack (SLACK).  The last row of buffer 0's second tile
+    // reads into the START OF BUFFER 1, which a segment of one chunk (<= 64 rows) never stages: the kernels zero those 32 bytes
+    // too before their first barrier (found by tests/test_fuzz_gpu.py in IEEE half: stale LDS bits there are Inf / NaN patterns one
+    // time in 32, and 0 x NaN reached dK / dV / dQ)
     static constexpr int LD = ((DH * 2 + 31) / 32) % 2 ? (DH * 2 + 31) / 32 * 32 : (DH * 2 + 31) / 32 * 32 + 32;
     static_assert(LD >= DH * 2 && LD + 32 >= NKS * 64 && (LD / 32) % 2 == 1, "row pitch");
     static constexpr int SLACK = NKS * 64 > LD ? 32 : 0;
@@ -227,7 +230,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DH <= 80 && !DROP && !VL_EARLY
     const bool wave_active = t0 < nq;
     const __bf16* kbase = k.p + (long long)ks0 * k.s_n + h * k.s_h;
     const __bf16* vbase = v.p + (long long)ks0 * v.s_n + h * v.s_h;
-    if (tid < T::SLACK / 4) reinterpret_cast<unsigned*>(smem + 4 * TILE)[tid] = 0u;      // published by the first VL_SYNC
+    if (tid < T::SLACK / 4) {       // published by the first VL_SYNC; buffer 1 is first staged behind that barrier
+        reinterpret_cast<unsigned*>(smem + 4 * TILE)[tid] = 0u;
+        reinterpret_cast<unsigned*>(smem + 2 * TILE)[tid] = 0u;        // a ONE-chunk segment never stages buffer 1: see HD::SLACK
+    }
     auto stage = [&](int c0, int buf) {
         const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
         dma_chunk<DH, NW>(kbase + (long long)c0 * k.s_n, k.s_n, rows, smem + 2 * buf * TILE, wave, lane);
@@ -373,7 +379,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80 && !VL_EARLY_TR) ? 3 
     const bool wave_active = t0 < nq;
     const __bf16* kbase = k.p + (long long)ks0 * k.s_n + h * k.s_h;
     const __bf16* vbase = v.p + (long long)ks0 * v.s_n + h * v.s_h;
-    if (tid < T::SLACK / 4) reinterpret_cast<unsigned*>(smem + 4 * TILE)[tid] = 0u;      // published by the first VL_SYNC
+    if (tid < T::SLACK / 4) {       // published by the first VL_SYNC; buffer 1 is first staged behind that barrier
+        reinterpret_cast<unsigned*>(smem + 4 * TILE)[tid] = 0u;
+        reinterpret_cast<unsigned*>(smem + 2 * TILE)[tid] = 0u;        // a ONE-chunk segment never stages buffer 1: see HD::SLACK
+    }
     auto stage = [&](int c0, int buf) {
         const int rows = nk - c0 < VL_CH ? nk - c0 : VL_CH;
         dma_chunk<DH, NW>(kbase + (long long)c0 * k.s_n, k.s_n, rows, smem + 2 * buf * TILE, wave, lane);
@@ -502,7 +511,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
     const __bf16* dbase = dout.p + (long long)qs * dout.s_n + h * dout.s_h;
     const float* lbase = lse + (long long)h * tq_total + qs;
     const float* dlbase = delta + (long long)h * tq_total + qs;
-    if (tid < T::SLACK / 4) reinterpret_cast<unsigned*>(smem + 4 * TILE)[tid] = 0u;      // published by the first VL_SYNC
+    if (tid < T::SLACK / 4) {       // published by the first VL_SYNC; buffer 1 is first staged behind that barrier
+        reinterpret_cast<unsigned*>(smem + 4 * TILE)[tid] = 0u;
+        reinterpret_cast<unsigned*>(smem + 2 * TILE)[tid] = 0u;        // a ONE-chunk segment never stages buffer 1: see HD::SLACK
+    }
     auto stage = [&](int c0, int buf) {
         const int rows = nq - c0 < VL_CH ? nq - c0 : VL_CH;
         dma_chunk<DH, NW>(qbase + (long long)c0 * q.s_n, q.s_n, rows, smem + 2 * buf * TILE, wave, lane);
