@@ -254,3 +254,53 @@ def test_one_chunk_segments_odd_head_width_fp16(dim_head):
             assert all(torch.isfinite(g).all() for g in grads.values()), (dim_head, dtype, rep)
             assert rel(out, ref_out) <= tol and rel(cat(grads), cat(ref_g)) <= tol, (dim_head, dtype, rep)
         torch.randn(4096, 4096, device=DEV) @ torch.randn(4096, 4096, device=DEV)        # someone else's f32 data through the CUs' LDS
+
+
+_LARGE_M = [s for s in range(N_DRAWS) if (lambda k, c, b: b * ((c["image_size"][0] // c["patch_size"][0]) * (c["image_size"][1] // c["patch_size"][1]) + (k == "vit")) >= 1024)(*draw(s))]
+_FLAG_SETS = [
+    {"VITK_RECOMPUTE": "1"},                                   # activation recompute (what config 5 takes at batch 256)
+    {"VITK_FWD_STREAM": "f32", "VITK_GRAD_STREAM": "f32"},     # float32 residual streams in both directions (the round-1..3 layout)
+    {"VITK_FWD_STREAM": "16"},                                 # 16-bit forward stream forced
+    {"VITK_GELU_DG": "0", "VITK_DW_STREAM": "1"},              # pre-activation saved instead of the gelu' factor; weight gradients on the side stream
+    {"VITK_RECOMPUTE": "1", "VITK_GRAD_STREAM": "f32", "VITK_DW_STREAM": "1"},
+]
+
+
+@pytest.mark.parametrize("flags", range(len(_FLAG_SETS)))
+@pytest.mark.parametrize("seed", _LARGE_M[:10])
+def test_random_configuration_under_engine_switches(seed, flags, monkeypatch):
+    """The engine's documented switches (engine.py / ops.py: read at call time) select other combinations of the same kernels --
+    recompute, the residual streams' dtypes, which FeedForward pair, the weight-gradient side stream.  Every combination must stay
+    inside the bf16 gate on the large-M draws (the only ones where the switches change a launch)."""
+    for k, v in _FLAG_SETS[flags].items():
+        monkeypatch.setenv(k, v)
+    kind, cfg, batch = draw(seed)
+    e, g, e_ref, g_ref = _errors(kind, cfg, batch, seed, run_mine)
+    assert e <= 1.5 * e_ref + 1e-3 and g <= 1.5 * g_ref + 1e-3, (_FLAG_SETS[flags], kind, cfg, batch, e, e_ref, g, g_ref)
+
+
+@pytest.mark.parametrize("seed", range(8, 20))
+def test_random_navit_flat_list_grouping(seed):
+    """group_images=True on a flat list of images (na_vit.py:288-296) packs them greedily by group_max_seq_len
+    (group_images_by_max_seq_len, na_vit.py:38-77); the logits come back in the order of the list, and -- attention being per image --
+    equal the logits of the same images handed over one pack each.  bf16, both runs on the GPU; the ungrouped run is the one the
+    oracle checks elsewhere."""
+    cfg, packs = draw_navit(seed)
+    images = [im for pack in make_navit_images(cfg, packs, 1090 + seed) for im in pack]
+    r = np.random.RandomState(seed)
+    extra = [(int(r.randint(1, 5)) * cfg["patch_size"], int(r.randint(1, 5)) * cfg["patch_size"]) for _ in range(int(r.randint(1, 6)))]
+    images += [im for pack in make_navit_images(cfg, [extra], 2090 + seed) for im in pack]           # a few very small images (1 .. 16 patches)
+    params = make_navit_params(cfg, 90 + seed)
+    m = NaViT(**cfg)
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV, dtype=torch.bfloat16).eval()
+    dev = [im.to(DEV, dtype=torch.bfloat16) for im in images]
+    with torch.no_grad():
+        one_each = m([[im] for im in dev])
+        for max_len in (64, 300, 2048):
+            p = cfg["patch_size"]
+            if max(im.shape[-2] // p * (im.shape[-1] // p) for im in dev) > max_len:
+                continue                       # an image longer than the limit is an assertion of the reference (na_vit.py:60)
+            grouped = m(dev, group_images=True, group_max_seq_len=max_len)
+            assert tuple(grouped.shape) == tuple(one_each.shape)
+            assert rel(grouped, one_each) <= 2e-2, (cfg, max_len, rel(grouped, one_each))
