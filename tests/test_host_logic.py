@@ -203,3 +203,19 @@ def test_weight_cache_switches(monkeypatch):
     assert E.weight_key(w) != k0
     monkeypatch.setenv("VITK_WEIGHT_CACHE", "0")
     assert E.weight_key(w) != E.weight_key(w)
+
+
+def test_weight_key_changes_across_every_torch_optimizer_step():
+    """torch's fused optimizers (torch._fused_adamw_ & co.) update parameters without bumping `_version` [measured, torch 2.10]; the
+    derived-weight caches must still see the step (the global optimizer-step post hook of _epoch.py)."""
+    import torch
+    from vit_pytorch_amd import _epoch as E
+    for make in (lambda p: torch.optim.SGD([p], lr=0.1), lambda p: torch.optim.AdamW([p], lr=0.1, foreach=True),
+                 lambda p: torch.optim.AdamW([p], lr=0.1, fused=True), lambda p: torch.optim.Adam([p], lr=0.1, fused=True)):
+        w = torch.nn.Parameter(torch.ones(4, 4))
+        opt = make(w)
+        w.grad = torch.ones(4, 4)
+        k0, v0 = E.weight_key(w), w.detach().clone()
+        opt.step()
+        assert not torch.equal(w.detach(), v0)
+        assert E.weight_key(w) != k0, type(opt).__name__

@@ -1,7 +1,13 @@
 """Generation counter of the parameter VALUES, for caches derived from weights (transposed copies for the dX GEMMs, e4m3
 copies for the fp8 forward).  torch bumps `tensor._version` on in-place torch ops, but this package's fused optimizer
 (`optim.Adam.step` -> `vitk_adam_step`) writes parameters through raw pointers, which torch cannot see -- it bumps this
-counter instead, and every cache keys on (data_ptr, _version, weights_epoch)."""
+counter instead, and every cache keys on (data_ptr, _version, weights_epoch).
+
+torch's own FUSED optimizers are in the same position: `torch.optim.AdamW(..., fused=True)` (`torch._fused_adamw_`) updates the
+parameters WITHOUT touching their version counters ([measured] torch 2.10: `_version` 4 -> 4 across a step, foreach / single-tensor
+flavours 2 per step) -- found by tests/test_train_loop_gpu.py: the K-blocked weight copies kept serving the initial weights and the
+model silently stopped learning through the fused GEMMs.  So a global optimizer-step post hook (every torch.optim.Optimizer subclass,
+whatever its implementation) bumps the epoch too."""
 _EPOCH = [0]
 
 
@@ -24,11 +30,22 @@ def weight_key(w):
     return (w.data_ptr(), w._version, _EPOCH[0], tuple(w.shape), w.dtype)
 
 
+def _install_optimizer_hook() -> None:
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:       # a torch without global optimizer hooks: version counters and invalidate_weight_caches() remain
+        return
+    register_optimizer_step_post_hook(lambda optimizer, args, kwargs: bump_weights_epoch())
+
+
+_install_optimizer_hook()
+
+
 def invalidate_weight_caches() -> None:
     """Call after writing parameter VALUES behind torch's back -- `p.data.mul_()`, `p.data.copy_()`, `dist.broadcast(p.data)`, a raw
     pointer write: `tensor.data` views do not bump `p._version`, so the caches keyed on it (K-blocked / transposed / split / e4m3
-    weight copies) would keep serving the old values.  `load_state_dict`, optimizers and every in-place op ON THE PARAMETER ITSELF
-    are seen without it.  `VITK_WEIGHT_CACHE=0` disables the caches altogether (every call re-derives its copies: debugging)."""
+    weight copies) would keep serving the old values.  `load_state_dict`, every torch.optim optimizer (a global step hook bumps the
+    epoch: the fused flavours do not touch version counters) and every in-place op ON THE PARAMETER ITSELF are seen without it.  `VITK_WEIGHT_CACHE=0` disables the caches altogether (every call re-derives its copies: debugging)."""
     bump_weights_epoch()
 
 
