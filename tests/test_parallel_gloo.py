@@ -338,3 +338,43 @@ def test_fp8_engine_stage_under_data_parallel_two_ranks_gloo():
     DataParallel on 2 gloo ranks, kernels replaced by the CPU doubles."""
     port = _free_port()
     mp.spawn(_fp8_engine_worker, args=(2, port), nprocs=2, join=True)
+
+
+# ---- a model called TWICE before one backward (siamese / DINO-style student passes, dino.py:283-290) under DataParallel ----------------
+def _twice_worker(rank, world, port):
+    import _kernel_doubles as KD
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with KD.installed():
+            torch.manual_seed(17)
+            full_a = torch.randn(world * 3, 16, 24); full_b = torch.randn(world * 3, 16, 24)
+            torch.manual_seed(80 + rank)
+            model = _EngineModel().to(torch.bfloat16)
+            dp = DataParallel(model, layers_per_chunk=3)
+            dp.sink.log = []
+            xa = full_a[3 * rank:3 * rank + 3].to(torch.bfloat16); xb = full_b[3 * rank:3 * rank + 3].to(torch.bfloat16)
+            loss = dp(xa).float().square().mean() + (dp(xb).float() - 1).square().mean()
+            dp.backward(loss)
+            # every fused parameter met the sink twice: the second gradients went through autograd and were reduced on their own
+            fused = [i for i, p in enumerate(dp.sink.params) if any(p is q for q in model.transformer.parameters())]
+            assert set(fused) <= dp.sink._multi and fused
+            got = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.sink.params, dp.sink.views))
+            E.set_grad_sink(None)
+            model.zero_grad(set_to_none=True)
+            (model(full_a.to(torch.bfloat16)).float().square().mean() + (model(full_b.to(torch.bfloat16)).float() - 1).square().mean()).backward()
+            for n, p in model.named_parameters():
+                ref = p.grad.detach().float()
+                err = (got[n] - ref).norm() / ref.norm().clamp_min(1e-12)
+                assert err < 3e-2, (n, float(err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_called_twice_per_step_under_data_parallel_two_ranks_gloo():
+    """The flat gradient buffer holds ONE slot per parameter and the backward kernels overwrite it: a second use of the model in
+    the same step must not replace the first gradient (it did before round 4's fix: only the last call's gradient survived)."""
+    port = _free_port()
+    mp.spawn(_twice_worker, args=(2, port), nprocs=2, join=True)

@@ -109,6 +109,7 @@ class FlatGradSink:
         self._by_ptr: Dict[int, int] = {p.data_ptr(): i for i, p in enumerate(self.params) if p.numel()}
         self._view_ptrs = {v.data_ptr() for v, p in zip(self.views, self.params) if p.numel()}
         self._filled = set()
+        self._multi = set()
         self.side = torch.cuda.Stream(device=self.device, priority=comm_priority) if self.device.type == "cuda" else None
         self.log = None      # tests: list collecting (offset, length) of every all-reduce this rank issues
         self._early_launched = False
@@ -156,6 +157,12 @@ class FlatGradSink:
     def buffer_for(self, param: torch.Tensor) -> Optional[torch.Tensor]:
         i = self._by_ptr.get(param.data_ptr())
         if i is None:
+            return None
+        if i in self._filled:
+            # the parameter's SECOND gradient of this step (the model was called twice before backward: siamese / DINO-style
+            # student passes, dino.py:283-290): the slot already holds -- and may already have sent -- the first one, so this one
+            # goes through autograd's own accumulation into p.grad and finish_step() reduces and adds it
+            self._multi.add(i)
             return None
         self._filled.add(i)
         return self.views[i]
@@ -228,6 +235,7 @@ class FlatGradSink:
     # ---- step-facing ----------------------------------------------------------------------------
     def begin_step(self):
         self._filled.clear()
+        self._multi.clear()
         self._cursor = 0
         self._early_launched = self._late_launched = False
         for p in self.params:
@@ -266,6 +274,15 @@ class FlatGradSink:
                 for i in missing:                                # arrived after their segment had already gone out
                     if (early_was if i < self.n_early else late_was) and self.params[i].numel():
                         self._allreduce(self.views[i])
+        if self._multi:
+            if self.world > 1 and self.side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self.side)
+            for i in sorted(self._multi):           # further gradients of a parameter used more than once: autograd summed them in p.grad
+                extra = self.params[i].grad
+                if extra is not None and extra.data_ptr() != self.views[i].data_ptr():
+                    if self.world > 1:
+                        self._allreduce(extra)
+                    self.views[i].add_(extra)
         for p, v in zip(self.params, self.views):
             p.grad = v
 
