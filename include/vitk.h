@@ -360,6 +360,10 @@ int vitk_softmax_bwd(const void* p, const void* dp, void* ds, int dt, int64_t ro
 /* Rearrange 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit.py:100): out[(b*h*w), p1*p2*c]        */
 int vitk_patchify(const void* img, void* out, int dt, int64_t B, int64_t C, int64_t H, int64_t W,
                   int64_t p1, int64_t p2, void* stream);
+/* Its gradient with respect to the image (autograd through einops.Rearrange, vit.py:100, when the input requires a gradient):
+ * dimg (B, C, H, W) <- dpatch (B*h*w, p1*p2*C), every pixel written exactly once.                                           */
+int vitk_unpatchify(const void* dpatch, void* dimg, int dt, int64_t B, int64_t C, int64_t H, int64_t W,
+                    int64_t p1, int64_t p2, void* stream);
 /* Fused first stage of the patch embedding (vit.py:100-101): Rearrange + LayerNorm(patch_dim) with the gather in the load -- y[(b*h*w), 768]
  * = LayerNorm(patch vector) straight from the NCHW image, no `patches` tensor.  Serves 16-bit images of 3 channels with 16 x 16 patches
  * (vitk_patch_ln_serves: 1 / 0); mean / rstd per patch row are kept for the backward.  The backward gives only the parameter gradients

@@ -433,6 +433,12 @@ def patchify(img, out, B, C, H, W, p1, p2):
     out.view(B * h * w, p1 * p2 * C).copy_(img.reshape(B, C, h, p1, w, p2).permute(0, 2, 4, 3, 5, 1).reshape(B * h * w, p1 * p2 * C))
 
 
+def unpatchify(dpatch, dimg, B, C, H, W, p1, p2):
+    """gradient of patchify with respect to the image (every pixel belongs to one patch element)."""
+    h, w = H // p1, W // p2
+    dimg.view(B, C, H, W).copy_(dpatch.reshape(B, h, w, p1, p2, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, H, W))
+
+
 def patch_ln_fwd(img, w, b, y, mean, rstd, B, C, H, W, p1, p2, eps=1e-5):
     """vitk_patch_ln_fwd: rearrange (vit.py:100) + LayerNorm(patch_dim) (vit.py:101) in one call, mean / rstd kept."""
     h, ww = H // p1, W // p2
@@ -509,7 +515,7 @@ _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_n
                   gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_bf16_pair=gemm_tn_bf16_pair, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,
-                  colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify, patch_ln_fwd=patch_ln_fwd, patch_ln_bwd_params=patch_ln_bwd_params,
+                  colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify, unpatchify=unpatchify, patch_ln_fwd=patch_ln_fwd, patch_ln_bwd_params=patch_ln_bwd_params,
                   copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, concat_tokens=concat_tokens, hnd=hnd, attn_varlen_fwd_bf16=attn_varlen_fwd_bf16, attn_varlen_bwd_bf16=attn_varlen_bwd_bf16,
                   patchify_cpp=patchify_cpp, gather_add2=gather_add2, csr_rowsum=csr_rowsum,
                   rmsnorm_heads_fwd=rmsnorm_heads_fwd, rmsnorm_heads_bwd=rmsnorm_heads_bwd,

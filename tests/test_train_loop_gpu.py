@@ -53,3 +53,75 @@ def test_weight_caches_follow_the_optimizer(opt_name, fp8, monkeypatch):
     assert torch.equal(final, final0)
     assert all(torch.equal(a, b) for a, b in zip(ps, ps0))
     assert losses[-1] < losses[0]                     # and it trains
+
+
+# ---- usage patterns of a training script around the model ---------------------------------------------------------------------------
+from oracle import vit_oracle as O  # noqa: E402
+from vit_pytorch_amd import SimpleViT  # noqa: E402
+from vit_pytorch_amd.parallel import DataParallel  # noqa: E402
+
+
+def _rel(a, b):
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_gradient_accumulation_and_model_called_twice(dtype, tol):
+    """Two micro-batches accumulated into .grad (backward twice, no zero_grad), and the model called twice inside ONE graph (siamese /
+    DINO-style, dino.py:283-290), both equal the gradient of the summed loss computed call by call -- plain model and under
+    DataParallel (whose flat buffer holds one slot per parameter)."""
+    params = make_params("vit", CFG, 11)
+    xa = make_images(CFG, 8, 3001).to(DEV, dtype=dtype); xb = make_images(CFG, 5, 3002).to(DEV, dtype=dtype)
+
+    def fresh():
+        m = ViT(**CFG); m.load_state_dict(params)
+        return m.to(DEV, dtype=dtype)
+
+    def grads(m):
+        return torch.cat([p.grad.float().flatten() for p in m.parameters() if p.numel()])
+
+    la = lambda o: o.float().square().mean()
+    lb = lambda o: (o.float() - 1).square().mean()
+    m = fresh(); la(m(xa)).backward(); ga = grads(m)
+    m = fresh(); lb(m(xb)).backward(); gb = grads(m)
+    want = ga + gb
+    m = fresh(); la(m(xa)).backward(); lb(m(xb)).backward()
+    assert _rel(grads(m), want) <= tol                                   # accumulation over micro-batches
+    m = fresh(); (la(m(xa)) + lb(m(xb))).backward()
+    assert _rel(grads(m), want) <= tol                                   # two calls, one graph
+    m = fresh(); dp = DataParallel(m, broadcast=False)
+    dp.backward(la(dp(xa)) + lb(dp(xb)))
+    assert _rel(grads(m), want) <= tol                                   # ... with the gradients in the flat buffer
+
+
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+@pytest.mark.parametrize("cfg_name", ["small_patch_generic", "b16_gather"])
+def test_input_image_gradient_matches_the_oracle(kind, cfg_name):
+    """img.requires_grad_(): the reference differentiates through Rearrange + LayerNorm(patch_dim) (vit.py:100-101); so does the drop-in
+    (vitk_unpatchify behind the LayerNorm backward) -- through the generic patchify path and through the gather-in-the-load path
+    (16 x 16 x 3 patches, 16-bit), against torch autograd over the oracle's forward (f32: 1e-3; bf16: 3e-2)."""
+    cfg = (dict(image_size=32, patch_size=4, num_classes=10, dim=64, depth=1, heads=2, dim_head=32, mlp_dim=128, channels=4) if cfg_name == "small_patch_generic"
+           else dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=1, heads=2, dim_head=64, mlp_dim=256))
+    params = make_params(kind, cfg, 23)
+    img = make_images(cfg, 3, 1023)
+    # reference gradient: autograd through the oracle's forward functions (float64)
+    p64 = {k: v.double() for k, v in params.items()}
+    x64 = img.double().requires_grad_(True)
+    fwd = O.vit_fwd if kind == "vit" else O.simple_vit_fwd
+    kw = dict(patch_size=cfg["patch_size"], depth=cfg["depth"], heads=cfg["heads"], dim_head=cfg["dim_head"])
+    if kind == "vit":
+        kw["pool"] = "cls"
+    O.loss_fn(fwd(x64, p64, **kw)).backward()
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 3e-2)):
+        m = (ViT if kind == "vit" else SimpleViT)(**cfg); m.load_state_dict(params); m = m.to(DEV, dtype=dtype)
+        x = img.to(DEV, dtype=dtype).requires_grad_(True)
+        O.loss_fn(m(x)).backward()
+        assert x.grad is not None and x.grad.shape == x.shape
+        assert _rel(x.grad, x64.grad) <= tol, (kind, cfg_name, dtype, _rel(x.grad, x64.grad))
+        # and through the op-by-op route (a hook on the embedding's LayerNorm takes the stage off the fused Function)
+        h = m.to_patch_embedding[1].register_forward_hook(lambda *a: None)
+        x2 = img.to(DEV, dtype=dtype).requires_grad_(True)
+        O.loss_fn(m(x2)).backward()
+        h.remove()
+        assert _rel(x2.grad, x64.grad) <= tol, (kind, cfg_name, dtype, "op by op")

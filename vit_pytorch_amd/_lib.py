@@ -107,6 +107,7 @@ SIGNATURES = {
     "vitk_softmax_fwd": (_i, [_vp, _vp, _i, _i64, _i64, _f, _vp]),
     "vitk_softmax_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _f, _vp]),
     "vitk_patchify": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "vitk_unpatchify": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "vitk_patchify_cpp": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "vitk_patch_ln_serves": (_i, [_i, _i64, _i64, _i64, _i64, _i64]),
     "vitk_patch_ln_bwd_blocks": (_i64, [_i64]),

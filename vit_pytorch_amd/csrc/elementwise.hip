@@ -56,6 +56,30 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ img
     }
 }
 
+// the gradient of that Rearrange with respect to the image: every pixel belongs to exactly one patch element, so this is the
+// inverse scatter (dimg[b][c][ph p1 + i][pw p2 + j] = dpatch[(b, ph, pw)][(i p2 + j) C + c]) -- the reference differentiates through
+// einops.Rearrange (vit.py:100) whenever the input requires a gradient (saliency maps, adversarial inputs)
+template <typename T>
+__global__ __launch_bounds__(256) void unpatchify_kernel(const T* __restrict__ dpatch, T* __restrict__ dimg, long long rows,
+                                                          int C, int H, int W, int p1, int p2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hp = H / p1, wp = W / p2;
+    const int P = p1 * p2 * C;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+        const long long b = row / (hp * wp);
+        const int hw = (int)(row % (hp * wp));
+        const int ph = hw / wp, pw = hw % wp;
+        T* dst = dimg + b * (long long)C * H * W + (long long)(ph * p1) * W + pw * p2;
+        const T* src = dpatch + row * (long long)P;
+        for (int e = lane; e < P; e += 64) {
+            const int c = e % C;
+            const int ij = e / C;
+            const int j = ij % p2, i = ij / p2;
+            dst[(long long)c * H * W + (long long)i * W + j] = src[e];
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -522,6 +546,17 @@ extern "C" int vitk_patchify(const void* img, void* out, int dt, int64_t B, int6
     VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((patchify_kernel<T>), dim3(ew_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                                                 (const T*)img, (T*)out, rows, (int)C, (int)H, (int)W, (int)p1, (int)p2));
     VITK_CHECK_LAUNCH("patchify");
+    return 0;
+}
+
+extern "C" int vitk_unpatchify(const void* dpatch, void* dimg, int dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p1,
+                               int64_t p2, void* stream) {
+    if (!dpatch || !dimg) VITK_FAIL(VITK_E_ARG, "unpatchify: null pointer");
+    if (B <= 0 || C <= 0 || p1 <= 0 || p2 <= 0 || H % p1 || W % p2) VITK_FAIL(VITK_E_SHAPE, "unpatchify: image not divisible by patch");
+    const long long rows = B * (H / p1) * (W / p2);
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((unpatchify_kernel<T>), dim3(ew_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)dpatch, (T*)dimg, rows, (int)C, (int)H, (int)W, (int)p1, (int)p2));
+    VITK_CHECK_LAUNCH("unpatchify");
     return 0;
 }
 

@@ -615,6 +615,7 @@ class PatchEmbedFn(torch.autograd.Function):
         ctx.save_for_backward(ln1w, ln1b, w, ln2w, ln2b, *([b] if b is not None else []))
         ctx.inter = (patches if not gather else img, st1, pn, y, st2)
         ctx.gather = (B, C, H, W, p1, p2) if gather else None
+        ctx.geom = (B, C, H, W, p1, p2)
         ctx.pad = (Pp, w_mm if Pp != P else None)
         ctx.cls_pos = (cls, pos)
         ctx.meta = (B, Np, N, P, D, ncls, b is not None, cls is not None, pos is not None and pos.requires_grad,
@@ -670,7 +671,21 @@ class PatchEmbedFn(torch.autograd.Function):
             ops.linear_dw(dyp, pn, Mp, dw, db)
             dpn = ops.linear_dx(dyp, w, Mp)
         dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
-        if ctx.gather is not None:       # the image needs no gradient: only dgamma / dbeta, xhat re-formed from the image by the same gather
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            # the INPUT requires a gradient (saliency maps, adversarial inputs: the reference differentiates through Rearrange + LayerNorm,
+            # vit.py:100-101): LayerNorm(patch_dim) backward with its dx, then the inverse scatter of the Rearrange
+            gB, gC, gH, gW, gp1, gp2 = ctx.geom
+            if ctx.gather is not None:                        # the gather path kept the image instead of the patches: re-form them
+                img_saved = patches
+                patches = ops.empty((Mp, P), T, dpn)
+                K.patchify(img_saved, patches, gB, gC, gH, gW, gp1, gp2)
+            dpatch = ops.empty((Mp, P), T, dpn)
+            ops.ln_bwd(dpn, patches, ln1w, st1[0], st1[1], Mp, P, dx_t=dpatch if T != F32 else None, dx_f32=dpatch if T == F32 else None,
+                       dw=dl1w, db=dl1b)
+            dimg = ops.empty((gB, gC, gH, gW), T, dpn)
+            K.unpatchify(dpatch, dimg, gB, gC, gH, gW, gp1, gp2)
+        elif ctx.gather is not None:     # the image needs no gradient: only dgamma / dbeta, xhat re-formed from the image by the same gather
             gB, gC, gH, gW, gp1, gp2 = ctx.gather
             nblk = K.patch_ln_bwd_blocks(Mp)
             part = ops.empty((2 * nblk * P,), F32, dpn)
@@ -682,7 +697,7 @@ class PatchEmbedFn(torch.autograd.Function):
         s = _sink()
         if s is not None:
             s.stage_done("patch_embed")
-        return (None, None, None, _ret(dl1w), _ret(dl1b), _ret(dw), _ret(db), _ret(dl2w), _ret(dl2b), _ret(dcls), _ret(dpos), None)
+        return (dimg, None, None, _ret(dl1w), _ret(dl1b), _ret(dw), _ret(db), _ret(dl2w), _ret(dl2b), _ret(dcls), _ret(dpos), None)
 
 
 def _head_dx(dl, w, out, ldo, B, D, C):

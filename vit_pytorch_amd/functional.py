@@ -213,13 +213,18 @@ class PatchifyFn(torch.autograd.Function):
             raise VitkError("Image dimensions must be divisible by the patch size.")
         out = torch.empty((B, (H // p1) * (W // p2), p1 * p2 * C), dtype=img.dtype, device=img.device)
         K.patchify(img, out, B, C, H, W, p1, p2)
+        ctx.geom = (B, C, H, W, p1, p2)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.needs_input_grad[0]:
-            raise VitkError("gradient with respect to the input image is not implemented")
-        return None, None, None
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        B, C, H, W, p1, p2 = ctx.geom              # the input itself requires a gradient (saliency, adversarial inputs): the inverse scatter
+        g = g.contiguous()
+        dimg = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device)
+        K.unpatchify(g, dimg, B, C, H, W, p1, p2)
+        return dimg, None, None
 
 
 class ScoresFn(torch.autograd.Function):

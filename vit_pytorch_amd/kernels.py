@@ -280,6 +280,11 @@ def patchify(img: Tensor, out: Tensor, B: int, C: int, H: int, W: int, p1: int, 
     check(_lib_for(img, out).vitk_patchify(_p(img), _p(out), dt(img), B, C, H, W, p1, p2, _stream()), "patchify")
 
 
+def unpatchify(dpatch: Tensor, dimg: Tensor, B: int, C: int, H: int, W: int, p1: int, p2: int):
+    """gradient of patchify with respect to the image: (B*h*w, p1*p2*C) -> (B, C, H, W)"""
+    check(_lib_for(dpatch, dimg).vitk_unpatchify(_p(dpatch), _p(dimg), dt(dpatch), B, C, H, W, p1, p2, _stream()), "unpatchify")
+
+
 def gelu_fwd(x: Tensor, y: Tensor):
     check(_lib_for(x, y).vitk_gelu_fwd(_p(x), _p(y), dt(x), x.numel(), _stream()), "gelu_fwd")
 

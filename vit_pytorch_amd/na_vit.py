@@ -482,6 +482,9 @@ class NaViT(nn.Module):
         for image, keep, n in zip(images, keeps, lens):
             if image.dtype != dtype:
                 raise VitkError(f"image dtype {image.dtype} != parameter dtype {dtype}")
+            if image.requires_grad and torch.is_grad_enabled():
+                # the patches are gathered outside autograd: say so instead of handing back an image without a gradient
+                raise VitkError("NaViT: the gradient with respect to the input images is not implemented (vit.ViT / SimpleViT provide it)")
             image = image.contiguous()
             ih, iw = image.shape[-2:]
             if keep is None:
