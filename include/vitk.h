@@ -394,6 +394,10 @@ int vitk_add_rows(const void* a, int adt, const void* b, int bdt, const void* bi
                   void* out, int odt, int64_t rows, int64_t cols, void* stream);
 /* dtype conversion / copy, n elements */
 int vitk_cast(const void* x, int xdt, void* y, int ydt, int64_t n, void* stream);
+/* The same conversion for `count` tensors (host tables of pointers and element counts) in ceil(count / 64) launches: what
+ * torch.autocast does to the weights of a float32 model once per forward (the reference under `torch.autocast`, or accelerate's
+ * mixed precision, train_vit_decorr.py:74) and to their gradients on the way back.  float32 tensors 16-byte aligned, 16-bit 8-byte. */
+int vitk_cast_many(const void* const* src, void* const* dst, const int64_t* numel, int64_t count, int xdt, int ydt, void* stream);
 /* x[b, 0:ncls, :] = cls[0:ncls, :] + pos[0:ncls, :] for every b (vit.py:122-127); x f32 or T   */
 int vitk_write_cls_rows(void* x, int xdt, const void* cls, const void* pos, int pdt,
                         int64_t B, int64_t N, int64_t D, int64_t ncls, void* stream);

@@ -135,3 +135,54 @@ def test_native_comm_entry_points_world_size_one():
     s.synchronize()
     assert torch.equal(y, torch.ones_like(y))
     c.close()
+
+
+# ---- torch's own DistributedDataParallel around the drop-in (what accelerate gives the reference: train_vit_decorr.py:74-78) ----------
+def _ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from vit_pytorch_amd import SimpleViT, ViT
+        worst = 0.0
+        for cls, cfg in ((ViT, dict(image_size=112, patch_size=8, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, pool="mean")),   # M = 6 x 196 = 1176
+                         (SimpleViT, dict(image_size=32, patch_size=8, num_classes=10, dim=64, depth=2, heads=2, mlp_dim=128))):
+            torch.manual_seed(100 + rank)                               # DDP broadcasts rank 0's weights at construction
+            model = cls(**cfg).to("cuda", dtype=torch.bfloat16)
+            ddp = DDP(model, device_ids=[0])
+            torch.manual_seed(200 + rank)
+            x = torch.randn(6, 3, cfg["image_size"], cfg["image_size"], device="cuda").to(torch.bfloat16)
+            for step in range(2):                                       # the second step runs on DDP's rebuilt buckets
+                ddp.zero_grad(set_to_none=True)
+                ddp(x).float().square().mean().backward()
+            got = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.numel()}
+            model.zero_grad(set_to_none=True)
+            model(x).float().square().mean().backward()                 # local gradients, no wrapper
+            for n, p in model.named_parameters():
+                if not p.numel():
+                    continue
+                avg = p.grad.detach().float().clone()
+                dist.all_reduce(avg)
+                avg /= world
+                worst = max(worst, ((got[n] - avg).norm() / (avg.norm() + 1e-12)).item())
+        q.put((rank, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_ddp_wraps_the_drop_in_two_ranks_one_gpu():
+    """torch.nn.parallel.DistributedDataParallel is what the reference's training script ends up with; the drop-in's fused autograd
+    Functions must feed its per-parameter hooks like any module (a (0, dim) cls_token under pool='mean' included)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(2)]
+    assert all(w < 2e-2 for _, w in res), res

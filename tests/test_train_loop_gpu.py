@@ -125,3 +125,73 @@ def test_input_image_gradient_matches_the_oracle(kind, cfg_name):
         O.loss_fn(m(x2)).backward()
         h.remove()
         assert _rel(x2.grad, x64.grad) <= tol, (kind, cfg_name, dtype, "op by op")
+
+
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+def test_autocast_around_a_float32_model_runs_the_16bit_engine(kind):
+    """`with torch.autocast("cuda", dtype=torch.bfloat16): model(x)` on float32 master weights -- mixed-precision training as accelerate
+    sets it up around the reference (train_vit_decorr.py:74).  The fused engine runs on 16-bit copies of the parameters
+    (functional.autocast_aware): the logits are bit-identical to those of the same weights in a bfloat16 model, they come back in
+    bfloat16 like the reference's autocast Linear gives them, the gradients arrive in float32 on the master parameters and equal the
+    bfloat16 model's (rounded to bf16 there), and a forward hook on the model fires once."""
+    cfg = dict(CFG) if kind == "vit" else {k: v for k, v in CFG.items()}
+    params = make_params(kind, cfg, 31)
+    cls = ViT if kind == "vit" else SimpleViT
+    img = make_images(cfg, 8, 3100)
+    m32 = cls(**cfg); m32.load_state_dict(params); m32 = m32.to(DEV)
+    m16 = cls(**cfg); m16.load_state_dict(params); m16 = m16.to(DEV, dtype=torch.bfloat16)
+    fired = []
+    h = m32.register_forward_hook(lambda mod, i, o: fired.append(o.dtype))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m32(img.to(DEV))
+        loss = out.float().square().mean()
+    loss.backward()
+    h.remove()
+    ref = m16(img.to(DEV, dtype=torch.bfloat16))
+    ref.float().square().mean().backward()
+    assert fired == [torch.bfloat16] and out.dtype == torch.bfloat16
+    assert torch.equal(out, ref)
+    for (n, p), (_, q) in zip(m32.named_parameters(), m16.named_parameters()):
+        if p.numel():
+            assert p.grad is not None and p.grad.dtype == torch.float32, n
+            assert torch.equal(p.grad.to(torch.bfloat16), q.grad), n
+    # outside autocast the float32 model is the float32 (validation-accuracy) model it was
+    out32 = m32(img.to(DEV))
+    assert out32.dtype == torch.float32 and _rel(out32, ref) < 3e-2 and not torch.equal(out32.to(torch.bfloat16), ref)
+
+
+def test_autocast_fp16_with_grad_scaler_trains():
+    params = make_params("vit", CFG, 31)
+    m = ViT(**CFG); m.load_state_dict(params); m = m.to(DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=3e-4, fused=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    losses = []
+    for it in range(4):
+        x = make_images(CFG, 8, 2000 + it).to(DEV)
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = m(x)
+            loss = out.float().square().mean()
+        assert out.dtype == torch.float16
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.item())
+    assert all(torch.isfinite(p).all() for p in m.parameters()) and losses[-1] < losses[0], losses
+
+
+def test_autocast_navit():
+    from oracle.params import make_navit_images, make_navit_params
+    from vit_pytorch_amd.na_vit import NaViT
+    cfg = dict(image_size=64, patch_size=8, num_classes=7, dim=64, depth=2, heads=2, mlp_dim=96)
+    sizes = [[(32, 48), (16, 16), (64, 24)], [(40, 40), (8, 56)]]
+    params = make_navit_params(cfg, 5)
+    imgs = make_navit_images(cfg, sizes, 1005)
+    m32 = NaViT(**cfg); m32.load_state_dict(params); m32 = m32.to(DEV).eval()
+    m16 = NaViT(**cfg); m16.load_state_dict(params); m16 = m16.to(DEV, dtype=torch.bfloat16).eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m32([[im.to(DEV) for im in g] for g in imgs])
+    out.float().square().mean().backward()
+    ref = m16([[im.to(DEV, dtype=torch.bfloat16) for im in g] for g in imgs])
+    assert out.dtype == torch.bfloat16 and torch.equal(out, ref)
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 for p in m32.parameters() if p.numel())

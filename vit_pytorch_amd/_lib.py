@@ -119,6 +119,7 @@ SIGNATURES = {
     "vitk_gelu_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "vitk_add_rows": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i64, _vp]),
     "vitk_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
+    "vitk_cast_many": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "vitk_write_cls_rows": (_i, [_vp, _i, _vp, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
     "vitk_mean_pool_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),
     "vitk_mean_pool_bwd": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),

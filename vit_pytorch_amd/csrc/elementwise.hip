@@ -144,6 +144,26 @@ __global__ __launch_bounds__(256) void cast_kernel(const XT* __restrict__ x, YT*
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = from_f32<YT>(to_f32<XT>(x[n4 * 4 + threadIdx.x]));
 }
 
+// Many tensors in one launch (torch.autocast around a float32 model: every parameter is converted to the 16-bit compute type once per
+// forward, and every 16-bit gradient back to float32 once per backward -- ~150 tensors for ViT-B, from a (D,) LayerNorm bias to a
+// 2.4 M-element Linear weight; one launch per tensor would be ~150 launch latencies at the head of every step).  The pointer table
+// travels as the kernel argument (CM_MAX tensors per launch); block b serves 8,192 elements of the tensor whose block range holds b.
+constexpr int CM_MAX = 64;
+constexpr long long CM_PER_BLOCK = 8192;
+struct CastMany { const void* src[CM_MAX]; void* dst[CM_MAX]; long long n[CM_MAX]; int blk0[CM_MAX + 1]; int count; };
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void cast_many_kernel(CastMany a) {
+    int lo = 0, hi = a.count;                  // uniform binary search: blk0[lo] <= blockIdx.x < blk0[lo + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= a.blk0[mid]) lo = mid; else hi = mid; }
+    const XT* __restrict__ x = (const XT*)a.src[lo];
+    YT* __restrict__ y = (YT*)a.dst[lo];
+    const long long n = a.n[lo], n4 = n >> 2;
+    const long long b0 = (long long)((int)blockIdx.x - a.blk0[lo]) * (CM_PER_BLOCK / 4);
+    const long long b1 = b0 + CM_PER_BLOCK / 4 < n4 ? b0 + CM_PER_BLOCK / 4 : n4;
+    for (long long i = b0 + threadIdx.x; i < b1; i += 256) store4<YT>(y + 4 * i, load4<XT>(x + 4 * i));
+    if ((int)blockIdx.x == a.blk0[lo] && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = from_f32<YT>(to_f32<XT>(x[n4 * 4 + threadIdx.x]));
+}
+
 // Adam / AdamW step over one flat range (torch.optim.Adam semantics, train_vit_decorr.py:68-70,110):
 //   g' = g + wd * p (coupled) | p *= 1 - lr * wd (decoupled);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2
 //   p -= (lr / c1) * m / (sqrt(v) / sqrt(c2) + eps)            c1 = 1 - b1^t, c2 = 1 - b2^t
@@ -625,6 +645,40 @@ extern "C" int vitk_cast(const void* x, int xdt, void* y, int ydt, int64_t n, vo
     else if (xdt == VITK_BF16 && ydt == VITK_BF16) hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)x, (__bf16*)y, (long long)n);
     else VITK_FAIL(VITK_E_DTYPE, "cast: bad dtype");
     VITK_CHECK_LAUNCH("cast");
+    return 0;
+}
+
+extern "C" int vitk_cast_many(const void* const* src, void* const* dst, const int64_t* numel, int64_t count, int xdt, int ydt, void* stream) {
+    if (count <= 0) return 0;
+    if (!src || !dst || !numel) VITK_FAIL(VITK_E_ARG, "cast_many: null table");
+    if (!((xdt == VITK_F32 || xdt == VITK_BF16) && (ydt == VITK_F32 || ydt == VITK_BF16))) VITK_FAIL(VITK_E_DTYPE, "cast_many: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t t = 0;
+    while (t < count) {
+        CastMany a;
+        a.count = 0; a.blk0[0] = 0;
+        while (t < count && a.count < CM_MAX) {
+            const int64_t n = numel[t];
+            if (n < 0 || (n > 0 && (!src[t] || !dst[t]))) VITK_FAIL(VITK_E_ARG, "cast_many: null pointer / negative size in the table");
+            if (n > 0) {
+                // 16-byte vector accesses on the float32 side, 8-byte on the 16-bit side
+                if (((uintptr_t)src[t] & (xdt == VITK_F32 ? 15 : 7)) || ((uintptr_t)dst[t] & (ydt == VITK_F32 ? 15 : 7))) VITK_FAIL(VITK_E_ARG, "cast_many: misaligned tensor");
+                const long long blocks = (n + CM_PER_BLOCK - 1) / CM_PER_BLOCK;
+                if (a.blk0[a.count] + blocks > 0x3fffffff) { if (a.count == 0) VITK_FAIL(VITK_E_SHAPE, "cast_many: tensor too large"); break; }
+                a.src[a.count] = src[t]; a.dst[a.count] = dst[t]; a.n[a.count] = n;
+                a.blk0[a.count + 1] = a.blk0[a.count] + (int)blocks;
+                ++a.count;
+            }
+            ++t;
+        }
+        if (a.count == 0) continue;
+        const dim3 grid((unsigned)a.blk0[a.count]);
+        if (xdt == VITK_F32 && ydt == VITK_BF16) hipLaunchKernelGGL((cast_many_kernel<float, __bf16>), grid, dim3(256), 0, st, a);
+        else if (xdt == VITK_BF16 && ydt == VITK_F32) hipLaunchKernelGGL((cast_many_kernel<__bf16, float>), grid, dim3(256), 0, st, a);
+        else if (xdt == VITK_F32) hipLaunchKernelGGL((cast_many_kernel<float, float>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((cast_many_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, a);
+        VITK_CHECK_LAUNCH("cast_many");
+    }
     return 0;
 }
 

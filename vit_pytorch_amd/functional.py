@@ -62,6 +62,84 @@ def cast(x: Tensor, dtype) -> Tensor:
     return x if x.dtype == dtype else CastFn.apply(x, dtype)
 
 
+class CastParamsFn(torch.autograd.Function):
+    """Every float32 parameter of a model to the 16-bit compute type in ceil(count / 64) launches (vitk_cast_many), and their 16-bit
+    gradients back to float32 the same way -- ONE autograd node, so the way back is one multi-tensor conversion at the end of the
+    backward.  This is what torch.autocast does to the weights of the reference's nn.Linear layers, op by op."""
+
+    @staticmethod
+    def forward(ctx, dtype, *params):
+        outs = [torch.empty(p.shape, dtype=dtype, device=p.device) for p in params]
+        live = [(p.detach().contiguous(), o) for p, o in zip(params, outs) if p.numel()]
+        K.cast_many([a for a, _ in live], [b for _, b in live])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        outs = [None if g is None else torch.empty(g.shape, dtype=F32, device=g.device) for g in gs]
+        live = [(g.contiguous(), o) for g, o in zip(gs, outs) if g is not None and g.numel()]
+        if live:
+            half = {g.dtype for g, _ in live}
+            for hd in half:       # (one source dtype per call)
+                K.cast_many([g for g, _ in live if g.dtype == hd], [o for g, o in live if g.dtype == hd])
+        return (None, *outs)
+
+
+def _autocast_dtype():
+    """The 16-bit dtype of an active torch.autocast region on the GPU, else None."""
+    try:
+        if not torch.is_autocast_enabled("cuda"):
+            return None
+        d = torch.get_autocast_dtype("cuda")
+    except TypeError:       # older torch: no device argument
+        if not torch.is_autocast_enabled():
+            return None
+        d = torch.get_autocast_gpu_dtype()
+    return d if d in (torch.bfloat16, torch.float16) else None
+
+
+def autocast_aware(forward):
+    """Decorator of a top-level model's forward.  The reference under `torch.autocast("cuda", dtype=torch.bfloat16)` -- or accelerate's
+    mixed precision around train_vit_decorr.py:74 -- keeps float32 master parameters and runs its Linear layers on 16-bit copies.  The
+    fused engine is not made of torch ops, so autocast cannot reach into it; instead, a float32 model called inside an autocast region
+    runs the 16-bit engine on 16-bit copies of its parameters (CastParamsFn: gradients arrive in float32 on the master parameters, a
+    GradScaler sees what it expects) and returns 16-bit logits like the reference's last Linear does.  Models that already are 16-bit,
+    and calls outside autocast, go straight through."""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapped(self, x, *args, **kwargs):
+        dt = _autocast_dtype()
+        if dt is None:
+            return forward(self, x, *args, **kwargs)
+        named = [(n, p) for n, p in self.named_parameters() if p.dtype == F32 and p.is_cuda]
+        if not named:
+            with torch.autocast("cuda", enabled=False):
+                return forward(self, x, *args, **kwargs)
+        cast_all = CastParamsFn.apply(dt, *[p for _, p in named])
+        swap = {n: c for (n, _), c in zip(named, cast_all)}
+        for n, b in self.named_buffers():
+            if b.dtype == F32 and b.is_cuda and b.is_floating_point():
+                swap[n] = _to(b, dt)
+
+        def conv(v):
+            if isinstance(v, torch.Tensor):
+                return cast(v, dt) if v.is_floating_point() else v
+            if isinstance(v, (list, tuple)):
+                return type(v)(conv(u) for u in v)
+            return v
+
+        with torch.autocast("cuda", enabled=False):
+            try:
+                from torch.nn.utils.stateless import _reparametrize_module
+            except ImportError:       # public route: re-enters __call__ (hooks on the top-level module then fire twice)
+                return torch.func.functional_call(self, swap, (conv(x), *args), kwargs, strict=False)
+            with _reparametrize_module(self, swap, strict=False):
+                return forward(self, conv(x), *args, **kwargs)
+
+    return wrapped
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):

@@ -302,6 +302,23 @@ def cast(x: Tensor, y: Tensor):
     check(_lib_for(x, y).vitk_cast(_p(x), dt(x), _p(y), dt(y), x.numel(), _stream()), "cast")
 
 
+def cast_many(srcs, dsts):
+    """dsts[i] <- srcs[i] (dtype conversion) for lists of contiguous tensors, one dtype per side: ceil(len / 64) launches."""
+    import ctypes
+    if not srcs:
+        return
+    n = len(srcs)
+    if len(dsts) != n or any(s.numel() != d.numel() or not s.is_contiguous() or not d.is_contiguous() for s, d in zip(srcs, dsts)):
+        raise L.VitkError("cast_many: lists of contiguous tensors with matching element counts are required")
+    if len({s.dtype for s in srcs}) != 1 or len({d.dtype for d in dsts}) != 1:
+        raise L.VitkError("cast_many: one dtype per side")
+    ps = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    pd = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    ne = (ctypes.c_int64 * n)(*[s.numel() for s in srcs])
+    check(_lib_for(srcs[0], dsts[0]).vitk_cast_many(ctypes.cast(ps, ctypes.c_void_p), ctypes.cast(pd, ctypes.c_void_p), ctypes.cast(ne, ctypes.c_void_p),
+                                                  n, dt(srcs[0]), dt(dsts[0]), _stream()), "cast_many")
+
+
 def write_cls_rows(x: Tensor, cls: Tensor, pos: Tensor, B: int, N: int, D: int, ncls: int):
     check(_lib_for(x, cls, pos).vitk_write_cls_rows(_p(x), dt(x), _p(cls), _p(pos), dt(pos), B, N, D, ncls, _stream()),
           "write_cls_rows")

@@ -423,6 +423,7 @@ class NaViT(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    @Fn.autocast_aware
     def forward(self, batched_images, group_images=False, group_max_seq_len=2048):
         p, c, device = self.patch_size, self.channels, self.device
         has_token_dropout = self.calc_token_dropout is not None and self.training

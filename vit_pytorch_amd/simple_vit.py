@@ -127,6 +127,7 @@ class SimpleViT(nn.Module):
             slot[key] = self.pos_embedding.to(device, dtype=dtype).contiguous()
         return slot[key]
 
+    @Fn.autocast_aware
     def forward(self, img):
         embed = self.to_patch_embedding
         pos = self._pos_on(img.device, embed[2].weight.dtype)

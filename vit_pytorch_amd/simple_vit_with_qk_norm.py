@@ -140,6 +140,7 @@ class SimpleViT(nn.Module):
         self.to_latent = nn.Identity()
         self.linear_head = Fn.LayerNorm(dim)        # sic: simple_vit_with_qk_norm.py:128
 
+    @Fn.autocast_aware
     def forward(self, img):
         x = self.to_patch_embedding(img)
         x = Fn.ConcatTokensFn.apply(x, None, self.pos_embedding.to(x.device, dtype=x.dtype))      # x += pos (simple_vit_with_qk_norm.py:134)

@@ -45,6 +45,7 @@ class SimpleViT(nn.Module):
             slot[key] = torch.cat([pos.new_zeros(R, pos.shape[1]), pos], dim=0).contiguous()
         return slot[key]
 
+    @Fn.autocast_aware
     def forward(self, img):
         x = self.to_patch_embedding(img)
         R = self.register_tokens.shape[0]

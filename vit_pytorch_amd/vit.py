@@ -206,6 +206,7 @@ class ViT(Module):
             return False
         return not (self.training and self.dropout.p > 0.) and not _has_fwd_hooks(self.dropout)
 
+    @Fn.autocast_aware
     def forward(self, img):
         pe = self.to_patch_embedding
         if self._embed_fusable():

@@ -67,6 +67,7 @@ class ViT(nn.Module):
         self.to_latent = nn.Identity()
         self.mlp_head = nn.Sequential(Fn.LayerNorm(dim), Fn.Linear(dim, num_classes))
 
+    @Fn.autocast_aware
     def forward(self, img):
         x = self.to_patch_embedding(img)
         x = Fn.ConcatTokensFn.apply(x, None, self.pos_embedding)                 # x += pos_embedding
