@@ -195,3 +195,35 @@ def test_autocast_navit():
     ref = m16([[im.to(DEV, dtype=torch.bfloat16) for im in g] for g in imgs])
     assert out.dtype == torch.bfloat16 and torch.equal(out, ref)
     assert all(p.grad is not None and p.grad.dtype == torch.float32 for p in m32.parameters() if p.numel())
+
+
+def test_ema_teacher_updated_through_data_is_seen_every_step(monkeypatch):
+    """The DINO / BYOL loop (dino.py:95-99,303): the teacher is a deepcopy of the student whose weights are moved by `.data` writes after
+    every optimizer step -- invisible to the parameters' version counters.  The optimizer step in between bumps the weights epoch, so the
+    teacher's derived weight copies are rebuilt before its next forward: same logits as the cache-free run, step by step."""
+    import copy
+
+    def run():
+        params = make_params("vit", CFG, 11)
+        student = ViT(**CFG); student.load_state_dict(params); student = student.to(DEV, dtype=torch.bfloat16)
+        teacher = copy.deepcopy(student).requires_grad_(False)
+        opt = torch.optim.SGD(student.parameters(), lr=0.05)
+        outs = []
+        for it in range(3):
+            x = make_images(CFG, 8, 2000 + it).to(DEV, dtype=torch.bfloat16)
+            with torch.no_grad():
+                t = teacher(x)
+            outs.append(t.clone())
+            opt.zero_grad(set_to_none=True)
+            (student(x).float() - t.float()).square().mean().add(student(x).float().square().mean()).backward()
+            opt.step()
+            for ps, pt in zip(student.parameters(), teacher.parameters()):
+                pt.data.lerp_(ps.data, 0.5)
+        return outs
+
+    monkeypatch.delenv("VITK_WEIGHT_CACHE", raising=False)
+    a = run()
+    monkeypatch.setenv("VITK_WEIGHT_CACHE", "0")
+    b = run()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[1], a[2])
