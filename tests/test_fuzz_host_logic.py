@@ -1,0 +1,99 @@
+"""CPU: the seeded random configurations of tests/test_fuzz_gpu.py through the drop-in's HOST LOGIC with the kernels replaced by the
+test doubles (tests/_kernel_doubles.py: the oracle's per-op restatements in the kernels' calling conventions), in float32 against the
+oracle -- which tests/test_oracle_fuzz_vs_reference.py holds to the reference itself on these very draws.  What this covers without a
+GPU: the dispatch between the fused stages and the op-by-op path (patch_dim 147 -> op by op), row maps / cls / positional handling at
+rectangular patches and 1 / 4 channels, pooling, which gradient lands where, the image gradient, a model called twice, NaViT's
+packing at ragged sizes and free dim_head.  Tolerance: round-off (logits 2e-5, gradients 2e-4 of the concatenated vector)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import _kernel_doubles as KD  # noqa: E402
+import test_fuzz_gpu as F  # noqa: E402  (the draws)
+from oracle import navit_oracle as NO  # noqa: E402
+from oracle import vit_oracle as O  # noqa: E402
+from oracle.params import make_images, make_navit_images, make_navit_params, make_params  # noqa: E402
+from vit_pytorch_amd import SimpleViT, ViT  # noqa: E402
+from vit_pytorch_amd.na_vit import NaViT  # noqa: E402
+
+
+def rel(a, b):
+    a = a.detach().double().flatten(); b = b.detach().double().flatten()
+    n = b.norm().item()
+    return (a - b).norm().item() / (n if n > 0 else 1.0)
+
+
+@pytest.fixture(autouse=True)
+def _plain_f32_routes(monkeypatch):
+    # float32 on the MFMA kernels (three-term bf16 split, ops.f32_on_mfma) and the hi + lo flash attention are compositions of GPU kernels
+    # without doubles; the plain float32 routes run the same host logic
+    monkeypatch.setenv("VITK_F32_MFMA", "0")
+    monkeypatch.setenv("VITK_F32_FLASH", "0")
+
+
+@pytest.mark.parametrize("seed", range(F.N_DRAWS))
+def test_fuzz_draw_host_logic_f32(seed):
+    kind, cfg, batch = F.draw(seed)
+    batch = min(batch, 6)                       # host logic does not depend on the batch; keep the CPU suite short
+    params = make_params(kind, cfg, 50 + seed)
+    img = make_images(cfg, batch, 1050 + seed)
+    ref_out, ref_g = O.run_fwd_bwd(kind, cfg, params, img, torch.float32)
+    m = (ViT if kind == "vit" else SimpleViT)(**cfg)
+    m.load_state_dict(params, strict=True)
+    x = img.clone().requires_grad_(seed % 3 == 0)          # a third of the draws also ask for the image gradient
+    with KD.installed():
+        out = m(x)
+        O.loss_fn(out).backward()
+    keys = [k for k in params if params[k].numel()]
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    cat = lambda d: torch.cat([d[k].detach().float().flatten() for k in keys])
+    assert rel(out, ref_out) <= 2e-5 and rel(cat(grads), cat(ref_g)) <= 2e-4, (kind, cfg, batch)
+    if x.requires_grad:
+        p64 = {k: v.double() for k, v in params.items()}
+        x64 = img.double().requires_grad_(True)
+        kw = dict(patch_size=cfg["patch_size"], depth=cfg["depth"], heads=cfg["heads"], dim_head=cfg["dim_head"])
+        if kind == "vit":
+            kw.update(pool=cfg["pool"], num_classes=cfg["num_classes"])
+        O.loss_fn((O.vit_fwd if kind == "vit" else O.simple_vit_fwd)(x64, p64, **kw)).backward()
+        assert x.grad is not None and rel(x.grad, x64.grad) <= 2e-4, (kind, cfg, rel(x.grad, x64.grad))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_navit_fuzz_draw_host_logic_f32(seed):
+    cfg, packs = F.draw_navit(seed)
+    params = make_navit_params(cfg, 90 + seed)
+    images = make_navit_images(cfg, packs, 1090 + seed)
+    ref_out, ref_g = NO.run_fwd_bwd(cfg, params, images, torch.float32)
+    m = NaViT(**cfg)
+    m.load_state_dict(params, strict=True)
+    m.eval()
+    with KD.installed():
+        out = m(images)
+        O.loss_fn(out).backward()
+    keys = [k for k in ref_g if ref_g[k].numel()]
+    cat = lambda d: torch.cat([d[k].detach().float().flatten() for k in keys])
+    assert rel(out, ref_out) <= 2e-5 and rel(cat({k: p.grad for k, p in m.named_parameters()}), cat(ref_g)) <= 2e-4, (cfg, packs)
+
+
+def test_model_called_twice_and_accumulation_host_logic():
+    kind, cfg, _ = F.draw(4)
+    params = make_params(kind, cfg, 54)
+    xa, xb = make_images(cfg, 3, 1), make_images(cfg, 2, 2)
+    la = lambda o: o.float().square().mean()
+    lb = lambda o: (o.float() - 1).square().mean()
+
+    def fresh():
+        m = ViT(**cfg); m.load_state_dict(params)
+        return m
+
+    g = lambda m: torch.cat([p.grad.flatten() for p in m.parameters() if p.numel()])
+    with KD.installed():
+        m = fresh(); la(m(xa)).backward(); ga = g(m)
+        m = fresh(); lb(m(xb)).backward(); gb = g(m)
+        m = fresh(); (la(m(xa)) + lb(m(xb))).backward(); both = g(m)
+        m = fresh(); la(m(xa)).backward(); lb(m(xb)).backward(); acc = g(m)
+    assert rel(both, ga + gb) <= 1e-5 and rel(acc, ga + gb) <= 1e-5
