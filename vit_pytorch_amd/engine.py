@@ -790,7 +790,7 @@ def _cat_rows(a: Tensor, b: Tensor) -> Tensor:
     import weakref
     from ._epoch import weight_key
     capturing = torch.cuda.is_current_stream_capturing()
-    cacheable = not capturing and isinstance(a, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter)
+    cacheable = not capturing and ops.is_weight(a) and ops.is_weight(b)
     k = (id(a), id(b))
     if cacheable:
         ka, kb = weight_key(a), weight_key(b)

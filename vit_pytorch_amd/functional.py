@@ -117,6 +117,8 @@ def autocast_aware(forward):
             with torch.autocast("cuda", enabled=False):
                 return forward(self, x, *args, **kwargs)
         cast_all = CastParamsFn.apply(dt, *[p for _, p in named])
+        for c in cast_all:
+            c._vitk_weight = True            # ops.is_weight: these get the K-blocked / transposed copies a Parameter gets
         swap = {n: c for (n, _), c in zip(named, cast_all)}
         for n, b in self.named_buffers():
             if b.dtype == F32 and b.is_cuda and b.is_floating_point():

@@ -287,6 +287,12 @@ def packed_weights_on() -> bool:
     return _os.environ.get("VITK_PACK_W", "1") not in ("0", "") and "VITK_NTP_EPIS" not in _os.environ
 
 
+def is_weight(W: Tensor) -> bool:
+    """A tensor whose derived copies (K-blocked packs, W^T) are worth making and keeping: a Parameter, or the 16-bit copy of one that
+    functional.autocast_aware made for this forward (tagged `_vitk_weight`; its cache entries die with it at the end of the step)."""
+    return isinstance(W, torch.nn.Parameter) or getattr(W, "_vitk_weight", False)
+
+
 def nt_weight(W: Tensor, M: int, transposed: bool):
     """(operand, ldw) for the NT GEMM whose "W" is this weight: `transposed=False` -- y = x W^T (rows N, reduction K);
     `transposed=True` -- dX = dY W (rows K, reduction N).  For shapes the persistent kernel serves, a K-blocked copy
@@ -296,7 +302,7 @@ def nt_weight(W: Tensor, M: int, transposed: bool):
     capture.  Raw `.data` writes to a parameter need `vit_pytorch_amd.invalidate_weight_caches()` (they do not bump `_version`)."""
     N, Kd = W.shape
     rows, red = (Kd, N) if transposed else (N, Kd)
-    if (W.dtype in HALF and isinstance(W, torch.nn.Parameter) and W.is_contiguous() and red % 32 == 0 and packed_weights_on()
+    if (W.dtype in HALF and is_weight(W) and W.is_contiguous() and red % 32 == 0 and packed_weights_on()
             and _persistent_nt(M, rows, red)):
         capturing = torch.cuda.is_current_stream_capturing()
         key = weight_key(W)
@@ -339,7 +345,7 @@ def transpose_weight(W: Tensor, pad_to: int = 0) -> Tensor:
     K.transpose(W, Wt, N, Kd)
     if pad_to and pad_to > N:
         Wt = pad_cols(Wt, Kd, N, pad_to)
-    if not capturing and isinstance(W, torch.nn.Parameter):
+    if not capturing and is_weight(W):
         wid = id(W)
         _WT_CACHE[wid] = (weakref.ref(W, lambda _r, wid=wid: _WT_CACHE.pop(wid, None)), key, pad_to, Wt)
     return Wt
