@@ -165,3 +165,33 @@ def test_patch16_gather_route_against_oracle_bf16(kind):
     for k, p in m.named_parameters():
         if ref_g[k].numel():
             assert rel(p.grad.float(), ref_g[k]) < 6e-2, (k, rel(p.grad.float(), ref_g[k]))
+
+
+def test_torch_compile_runs_the_drop_in_eagerly():
+    """`torch.compile(model)` of a user's script: the fused stages are ctypes calls behind autograd Functions, which TorchDynamo cannot
+    trace (it raised InternalTorchDynamoError before functional.eager_modules); every module of the package is marked
+    `torch.compiler.disable`, so the compiled model runs them eagerly -- alone and inside a larger compiled module."""
+    case = CASES["vit_cls_tiny"]
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000)
+    m = ViT(**case["cfg"])
+    m.load_state_dict(params, strict=True)
+
+    class Around(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+            self.post = torch.nn.Linear(case["cfg"]["num_classes"], 3)
+
+        def forward(self, x):
+            return self.post(torch.relu(self.inner(x)))
+
+    with KD.installed():
+        ref = m(img)
+        out = torch.compile(m, backend="eager")(img)
+        O.loss_fn(out).backward()
+        assert torch.equal(out, ref) and all(p.grad is not None for p in m.parameters() if p.numel())
+        w = Around(m)
+        refw = w(img)
+        outw = torch.compile(w, backend="eager")(img)
+        assert torch.allclose(outw, refw, atol=1e-6)

@@ -227,3 +227,16 @@ def test_ema_teacher_updated_through_data_is_seen_every_step(monkeypatch):
     b = run()
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert not torch.equal(a[1], a[2])
+
+
+def test_torch_compile_runs_the_drop_in_eagerly_on_the_gpu():
+    """torch.compile(model) must not crash on the ctypes-backed fused stages (functional.eager_modules marks every module of the package
+    `torch.compiler.disable`): same logits as the plain call, gradients arrive.  backend="eager": Dynamo's tracing is what is at stake."""
+    params = make_params("vit", CFG, 11)
+    m = ViT(**CFG); m.load_state_dict(params); m = m.to(DEV, dtype=torch.bfloat16)
+    x = make_images(CFG, 8, 3300).to(DEV, dtype=torch.bfloat16)
+    ref = m(x)
+    cm = torch.compile(m, backend="eager")
+    out = cm(x)
+    out.float().square().mean().backward()
+    assert torch.equal(out, ref) and all(p.grad is not None for p in m.parameters() if p.numel())

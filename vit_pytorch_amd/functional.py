@@ -85,6 +85,19 @@ class CastParamsFn(torch.autograd.Function):
         return (None, *outs)
 
 
+def eager_modules(namespace) -> None:
+    """Call at the end of a module file: every nn.Module defined there runs OUTSIDE torch.compile / TorchDynamo (`torch.compiler.disable`
+    on its forward).  The fused stages are autograd Functions over ctypes calls into libvitk -- nothing Dynamo can trace (fake tensors
+    have no device pointers; it raised InternalTorchDynamoError instead of breaking the graph) and nothing Inductor could improve: a
+    user's `torch.compile(model)` (or a compiled model that contains one of these modules) runs these parts eagerly, the rest compiled."""
+    disable = getattr(getattr(torch, "compiler", None), "disable", None)
+    if disable is None:
+        return
+    for obj in list(namespace.values()):
+        if isinstance(obj, type) and issubclass(obj, nn.Module) and obj.__module__ == namespace.get("__name__") and "forward" in obj.__dict__:
+            obj.forward = disable(obj.__dict__["forward"])
+
+
 def _autocast_dtype():
     """The 16-bit dtype of an active torch.autocast region on the GPU, else None."""
     try:
@@ -549,3 +562,6 @@ class Patchify(nn.Module):
 
     def extra_repr(self):
         return f"'b c (h p1) (w p2) -> b (h w) (p1 p2 c)', p1={self.p1}, p2={self.p2}"
+
+
+eager_modules(globals())

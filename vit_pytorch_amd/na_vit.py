@@ -513,3 +513,6 @@ class NaViT(nn.Module):
 
         x = self.to_latent(x)
         return self.mlp_head(x)
+
+
+Fn.eager_modules(globals())

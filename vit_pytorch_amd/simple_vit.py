@@ -143,3 +143,6 @@ class SimpleViT(nn.Module):
         if _has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.linear_head):
             return self.linear_head(self.to_latent(Fn.MeanTokensFn.apply(tokens)))
         return E.HeadFn.apply(tokens, True, self.linear_head.weight, self.linear_head.bias)
+
+
+Fn.eager_modules(globals())

@@ -56,3 +56,6 @@ class SimpleViT(nn.Module):
         x = Fn.MeanTokensFn.apply(x)
         x = self.to_latent(x)
         return self.linear_head(x)
+
+
+Fn.eager_modules(globals())

@@ -250,3 +250,6 @@ class _ClsRowFn(torch.autograd.Function):
 def _prepend_cls_add_pos(x, cls, pos):
     """cat(cls, x) + pos[:seq] (vit.py:122-127) for the non-fused embedding path: one launch for the whole batch."""
     return Fn.ConcatTokensFn.apply(x, cls, pos)
+
+
+Fn.eager_modules(globals())

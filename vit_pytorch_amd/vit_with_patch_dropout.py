@@ -83,3 +83,6 @@ class ViT(nn.Module):
 def _first_token(x):
     from .vit import _ClsRowFn
     return _ClsRowFn.apply(x)
+
+
+Fn.eager_modules(globals())
