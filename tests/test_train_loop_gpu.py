@@ -240,3 +240,20 @@ def test_torch_compile_runs_the_drop_in_eagerly_on_the_gpu():
     out = cm(x)
     out.float().square().mean().backward()
     assert torch.equal(out, ref) and all(p.grad is not None for p in m.parameters() if p.numel())
+
+
+def test_autocast_around_the_standalone_transformer_block():
+    """vit.Transformer used on its own (T2T-ViT builds its layers from it, t2t.py:45,57) with float32 parameters inside an autocast
+    region: the 16-bit engine on 16-bit parameter copies, like the whole model."""
+    from vit_pytorch_amd.vit import Transformer
+    torch.manual_seed(3)
+    t32 = Transformer(dim=256, depth=2, heads=4, dim_head=64, mlp_dim=512).to(DEV)
+    t16 = Transformer(dim=256, depth=2, heads=4, dim_head=64, mlp_dim=512).to(DEV, dtype=torch.bfloat16)
+    t16.load_state_dict({k: v.to(torch.bfloat16) for k, v in t32.state_dict().items()})
+    x = torch.randn(8, 197, 256, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = t32(x)
+    out.float().square().mean().backward()
+    ref = t16(x.to(torch.bfloat16))
+    assert out.dtype == torch.bfloat16 and torch.equal(out, ref)
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 for p in t32.parameters())

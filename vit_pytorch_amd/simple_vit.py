@@ -89,6 +89,7 @@ class Transformer(nn.Module):
         return E.forward_stream_is_16bit(self.norm.weight.dtype, B * N, self.norm.weight.shape[0], self._heads * self._dim_head, lp[7].shape[0],
                                          len(self.layers), 0.0, getattr(self, "_fp8", None), lp[3] is not None, lp[8] is not None)
 
+    @Fn.autocast_aware
     def forward(self, x):
         if not self._fusable():
             x = Fn.cast(x, self.norm.weight.dtype)       # in the graph: the embedding stage may have produced an f32 stream

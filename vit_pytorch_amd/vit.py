@@ -156,6 +156,7 @@ class Transformer(Module):
                                          float(self._dropout_p()), getattr(self, "_fp8", None), not isinstance(attn.to_out, nn.Identity),
                                          ff.net[1].bias is not None)
 
+    @Fn.autocast_aware           # the block on its own inside an autocast region (t2t.py:45,57 builds its layers from it)
     def forward(self, x):
         if self._fusable(x):
             params = []
