@@ -83,3 +83,45 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(L.VitkError, match="not built"):
         L.load()
+
+
+C_HOST = r"""
+/* a host in plain C: what a maintainer binding libvitk from C / cgo / JNI compiles (INTEGRATION.md) */
+#include <stdio.h>
+#include <string.h>
+#include "vitk.h"
+
+int main(void) {
+    int32_t plan[5] = {0, 0, 0, 0, 0};
+    printf("version %d\n", vitk_version());
+    if (vitk_gemm_nt_plan(50432, 2304, 768, 2304, plan) != 0) return 2;
+    printf("plan %d %d %d %d %d\n", (int)plan[0], (int)plan[1], (int)plan[2], (int)plan[3], (int)plan[4]);
+    printf("splits %lld\n", (long long)vitk_gemm_tn_splits(50432, 2304, 768));
+    printf("rows %lld\n", (long long)vitk_rmsnorm_heads_rows(4096, 16));
+    /* argument validation happens on the host, before any launch: a null pointer is VITK_E_ARG with a message */
+    int rc = vitk_cast(NULL, 0, NULL, 1, 16, NULL);
+    printf("rc %d msg %s\n", rc, vitk_last_error());
+    return rc == VITK_E_ARG && strlen(vitk_last_error()) > 0 ? 0 : 3;
+}
+"""
+
+
+def test_header_is_c99_and_a_plain_c_host_links_and_runs(lib, tmp_path):
+    """`extern "C"`, plain pointers and sizes: the header compiles as strict C99 (and as C++), and a C program linked against
+    libvitk.so calls the host-side entry points without a GPU."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", HEADER], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", HEADER], check=True)
+    src = tmp_path / "host.c"
+    src.write_text(C_HOST)
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-l:" + os.path.basename(L.LIB_PATH),
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert f"version {lib.vitk_version()}" in r.stdout and "plan" in r.stdout and "rc -" in r.stdout
