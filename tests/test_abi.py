@@ -76,6 +76,18 @@ def test_host_side_validation_without_gpu(lib):
     assert rc == -2 and b"dim_head" in lib.vitk_last_error()
     assert lib.vitk_gemm_tn_splits(50432, 2304, 768) >= 1
     assert lib.vitk_layernorm_bwd_blocks(50432, 768) == 512 and lib.vitk_layernorm_bwd_blocks(50432, 1024) == 768
+    # round 4's entry points: the multi-tensor cast, the image gradient of the Rearrange, the per-head RMSNorm at a free dim_head
+    tab = (ctypes.c_void_p * 2)(p, p + 2)                       # second float32 tensor not 16-byte aligned
+    n2 = (ctypes.c_int64 * 2)(8, 8)
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    assert lib.vitk_cast_many(cv(tab), cv(tab), cv(n2), 0, 0, 1, None) == 0                       # empty table: nothing to do
+    assert lib.vitk_cast_many(None, cv(tab), cv(n2), 2, 0, 1, None) == -1
+    assert lib.vitk_cast_many(cv(tab), cv(tab), cv(n2), 2, 0, 1, None) == -1 and b"misaligned" in lib.vitk_last_error()
+    assert lib.vitk_cast_many(cv(tab), cv(tab), cv(n2), 2, 0, 7, None) == -4                      # unknown dtype tag (VITK_E_DTYPE)
+    assert lib.vitk_unpatchify(p, p, 0, 2, 3, 30, 32, 4, 4, None) == -2 and b"divisible" in lib.vitk_last_error()
+    assert lib.vitk_unpatchify(None, p, 0, 2, 3, 32, 32, 4, 4, None) == -1
+    assert lib.vitk_rmsnorm_heads_fwd(p, 96, p, p, 96, p, 0, 4, 2, 50, None) == -2 and b"dim_head" in lib.vitk_last_error()    # 50 % 4 != 0
+    assert lib.vitk_rmsnorm_heads_fwd(p, 640, p, p, 640, p, 0, 4, 2, 320, None) == -2                                           # > 256
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
