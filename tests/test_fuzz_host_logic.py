@@ -97,3 +97,90 @@ def test_model_called_twice_and_accumulation_host_logic():
         m = fresh(); (la(m(xa)) + lb(m(xb))).backward(); both = g(m)
         m = fresh(); la(m(xa)).backward(); lb(m(xb)).backward(); acc = g(m)
     assert rel(both, ga + gb) <= 1e-5 and rel(acc, ga + gb) <= 1e-5
+
+
+@pytest.mark.parametrize("pattern", ["head_only", "last_layer_and_head", "norms_and_biases", "embedding_only"])
+def test_partially_frozen_models_host_logic(pattern):
+    """Linear probing / partial fine-tuning: `requires_grad_(False)` on parts of the model.  The trainable parameters get the gradients
+    the fully trainable model computes for them, the frozen ones get none, and nothing upstream of the lowest trainable parameter is
+    required to exist."""
+    cfg = dict(image_size=32, patch_size=8, num_classes=7, dim=32, depth=3, heads=2, dim_head=16, mlp_dim=64, pool="cls")
+    params = make_params("vit", cfg, 77)
+    img = make_images(cfg, 4, 1077)
+    _, ref_g = O.run_fwd_bwd("vit", cfg, params, img, torch.float32)
+    m = ViT(**cfg)
+    m.load_state_dict(params, strict=True)
+    train = {"head_only": lambda n: n.startswith("mlp_head"),
+             "last_layer_and_head": lambda n: n.startswith(("mlp_head", "transformer.layers.2", "transformer.norm")),
+             "norms_and_biases": lambda n: "norm" in n or n.endswith(".bias"),
+             "embedding_only": lambda n: n.startswith(("to_patch_embedding", "cls_token", "pos_embedding"))}[pattern]
+    for n, p in m.named_parameters():
+        p.requires_grad_(bool(train(n)))
+    with KD.installed():
+        out = m(img)
+        O.loss_fn(out).backward()
+    for n, p in m.named_parameters():
+        if train(n) and p.numel():
+            assert p.grad is not None and rel(p.grad, ref_g[n]) <= 2e-4, (pattern, n)
+        elif not train(n):
+            assert p.grad is None, (pattern, n)
+
+
+@pytest.mark.parametrize("reentrant", [False, True])
+def test_torch_checkpoint_around_the_transformer_host_logic(reentrant):
+    """torch.utils.checkpoint around the fused Transformer stage (a memory knob users of the reference reach for): same logits and
+    gradients as the plain call, in both flavours (the reentrant one runs the first forward under no_grad -- the stage then keeps
+    nothing -- and a second one inside backward)."""
+    from torch.utils.checkpoint import checkpoint
+    cfg = dict(image_size=32, patch_size=8, num_classes=7, dim=32, depth=2, heads=2, dim_head=16, mlp_dim=64, pool="mean")
+    params = make_params("vit", cfg, 78)
+    img = make_images(cfg, 3, 1078)
+    _, ref_g = O.run_fwd_bwd("vit", cfg, params, img, torch.float32)
+
+    class Ckpt(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x):
+            return checkpoint(self.inner, x, use_reentrant=reentrant)
+
+    m = ViT(**cfg)
+    m.load_state_dict(params, strict=True)
+    with KD.installed():
+        plain = m(img)
+        m.transformer = Ckpt(m.transformer)
+        out = m(img)
+        O.loss_fn(out).backward()
+    assert torch.equal(out, plain)
+    for n, p in m.named_parameters():
+        if p.numel():
+            assert p.grad is not None and rel(p.grad, ref_g[n.replace("transformer.inner.", "transformer.")]) <= 2e-4, n
+
+
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+def test_swapped_heads_host_logic(kind):
+    """`model.mlp_head = nn.Identity()` (features) and a fresh nn.Linear / nn.Sequential head (fine-tuning) are everyday edits of a
+    reference model (vit.py:137-138 just calls `self.mlp_head(x)`): the drop-in calls whatever sits there instead of assuming the Linear
+    its constructor built."""
+    cfg = dict(image_size=32, patch_size=8, num_classes=7, dim=32, depth=2, heads=2, dim_head=16, mlp_dim=64)
+    if kind == "vit":
+        cfg["pool"] = "cls"
+    params = make_params(kind, cfg, 79)
+    img = make_images(cfg, 3, 1079)
+    m = (ViT if kind == "vit" else SimpleViT)(**cfg)
+    m.load_state_dict(params, strict=True)
+    head_name = "mlp_head" if kind == "vit" else "linear_head"
+    w, b = params[head_name + ".weight"], params[head_name + ".bias"]
+    with KD.installed():
+        logits = m(img)
+        setattr(m, head_name, torch.nn.Identity())
+        feats = m(img)
+        assert tuple(feats.shape) == (3, cfg["dim"])
+        assert rel(feats @ w.T + b, logits) <= 1e-5                    # the features ARE the input of the head that was there
+        new_head = torch.nn.Sequential(torch.nn.LayerNorm(cfg["dim"]), torch.nn.Linear(cfg["dim"], 3))
+        setattr(m, head_name, new_head)
+        out = m(img)
+        O.loss_fn(out).backward()
+    assert tuple(out.shape) == (3, 3) and new_head[1].weight.grad is not None
+    assert all(p.grad is not None for n, p in m.named_parameters() if p.numel())

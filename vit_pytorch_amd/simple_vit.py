@@ -139,9 +139,10 @@ class SimpleViT(nn.Module):
             ntok = (img.shape[-2] // embed[0].p1) * (img.shape[-1] // embed[0].p2)
             tokens = E.PatchEmbedFn.apply(img, embed[0].p1, embed[0].p2, embed[1].weight, embed[1].bias, embed[2].weight,
                                           embed[2].bias, embed[3].weight, embed[3].bias, None, pos,
-                                          img.dim() == 4 and self.transformer.wants_16bit_stream(img.shape[0], ntok))
+                                          img.dim() == 4 and getattr(self.transformer, "wants_16bit_stream", lambda b, n: False)(img.shape[0], ntok))
         tokens = self.transformer(tokens)
-        if _has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.linear_head):
+        if (_has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.linear_head) or not isinstance(self.linear_head, nn.Linear)
+                or not isinstance(self.to_latent, nn.Identity)):        # hooks, or a head / to_latent the user swapped in: call them (simple_vit.py:117-120)
             return self.linear_head(self.to_latent(Fn.MeanTokensFn.apply(tokens)))
         return E.HeadFn.apply(tokens, True, self.linear_head.weight, self.linear_head.bias)
 

@@ -214,7 +214,7 @@ class ViT(Module):
             ntok = (img.shape[-2] // pe[0].p1) * (img.shape[-1] // pe[0].p2) + self.cls_token.shape[0]
             x = E.PatchEmbedFn.apply(img, pe[0].p1, pe[0].p2, pe[1].weight, pe[1].bias, pe[2].weight, pe[2].bias,
                                      pe[3].weight, pe[3].bias, self.cls_token, self.pos_embedding,
-                                     img.dim() == 4 and self.transformer.wants_16bit_stream(img.shape[0], ntok))
+                                     img.dim() == 4 and getattr(self.transformer, "wants_16bit_stream", lambda b, n: False)(img.shape[0], ntok))
         else:
             x = pe(img)
             x = _prepend_cls_add_pos(x, self.cls_token, self.pos_embedding)
@@ -225,7 +225,10 @@ class ViT(Module):
         if self.mlp_head is None:
             return x
 
-        head_plain = not (_has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.mlp_head))
+        # the fused pool + Linear serves the modules the constructor built; a head the user swapped in (`model.mlp_head = nn.Identity()` for
+        # features, a new nn.Linear / nn.Sequential for fine-tuning) or a non-trivial to_latent is simply called, as vit.py:137-138 does
+        head_plain = (isinstance(self.mlp_head, nn.Linear) and isinstance(self.to_latent, nn.Identity)
+                      and not (_has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.mlp_head)))
         if head_plain:
             return E.HeadFn.apply(x, self.pool == 'mean', self.mlp_head.weight, self.mlp_head.bias)
         x = Fn.MeanTokensFn.apply(x) if self.pool == 'mean' else _ClsRowFn.apply(x)
