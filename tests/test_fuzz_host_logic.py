@@ -184,3 +184,84 @@ def test_swapped_heads_host_logic(kind):
         O.loss_fn(out).backward()
     assert tuple(out.shape) == (3, 3) and new_head[1].weight.grad is not None
     assert all(p.grad is not None for n, p in m.named_parameters() if p.numel())
+
+
+class _LoRALinear(torch.nn.Linear):
+    """what PEFT-style code puts in place of a Linear: a subclass whose forward adds a low-rank update"""
+
+    def __init__(self, base: torch.nn.Linear, rank=4):
+        super().__init__(base.in_features, base.out_features, bias=base.bias is not None)
+        self.weight = base.weight
+        if base.bias is not None:
+            self.bias = base.bias
+        g = torch.Generator().manual_seed(5)
+        self.A = torch.nn.Parameter(0.1 * torch.randn(rank, base.in_features, generator=g))
+        self.B = torch.nn.Parameter(0.1 * torch.randn(base.out_features, rank, generator=g))
+
+    def forward(self, x):
+        return torch.nn.functional.linear(x, self.weight + self.B @ self.A, self.bias)
+
+
+def _count_fused(monkeypatch):
+    from vit_pytorch_amd import engine as E
+    calls = {"transformer": 0, "embed": 0, "head": 0}
+    for name, fn in (("transformer", E.TransformerFn), ("embed", E.PatchEmbedFn), ("head", E.HeadFn)):
+        orig = fn.apply
+
+        def wrapped(*a, _orig=orig, _name=name, **kw):
+            calls[_name] += 1
+            return _orig(*a, **kw)
+        monkeypatch.setattr(fn, "apply", staticmethod(wrapped))
+    return calls
+
+
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+def test_model_surgery_takes_the_module_path_and_pristine_models_the_fused_one(kind, monkeypatch):
+    """The fused stages read parameters and never call the modules -- legitimate only while the modules are exactly what the constructor
+    built.  A pristine model runs the three fused stages (embedding, Transformer, head); after typical surgery (a LoRA subclass of Linear
+    in place of to_qkv, a custom stem, an extra block) the affected stage runs op by op, the modules that are there get called, and the
+    result is the one the edited model defines (the oracle on the merged weights)."""
+    cfg = dict(image_size=32, patch_size=8, num_classes=7, dim=32, depth=2, heads=2, dim_head=16, mlp_dim=64)
+    if kind == "vit":
+        cfg["pool"] = "cls"
+    params = make_params(kind, cfg, 81)
+    img = make_images(cfg, 3, 1081)
+    cls = ViT if kind == "vit" else SimpleViT
+    calls = _count_fused(monkeypatch)
+    with KD.installed():
+        m = cls(**cfg); m.load_state_dict(params, strict=True)
+        ref = m(img)
+        assert calls == {"transformer": 1, "embed": 1, "head": 1}
+        # 1. LoRA on the first layer's to_qkv
+        attn = m.transformer.layers[0][0]
+        lora = _LoRALinear(attn.to_qkv)
+        attn.to_qkv = lora
+        out = m(img)
+        assert calls["transformer"] == 1 and calls["embed"] == 2           # the stack ran through its modules
+        merged = dict(params); merged["transformer.layers.0.0.to_qkv.weight"] = (lora.weight + lora.B @ lora.A).detach()
+        want, _ = O.run_fwd_bwd(kind, cfg, merged, img, torch.float32)
+        assert rel(out, want) <= 2e-5 and rel(out, ref) > 1e-3
+        O.loss_fn(out).backward()
+        assert lora.A.grad is not None and lora.B.grad is not None and lora.A.grad.abs().sum() > 0
+        # 2. a custom stem in place of to_patch_embedding (same output shape): the embedding stage is simply called
+        m2 = cls(**cfg); m2.load_state_dict(params, strict=True)
+        n_patches = (32 // 8) ** 2
+
+        class Stem(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.proj = torch.nn.Linear(3 * 8 * 8, cfg["dim"])
+
+            def forward(self, x):
+                b = x.shape[0]
+                return self.proj(x.reshape(b, 3, 4, 8, 4, 8).permute(0, 2, 4, 3, 5, 1).reshape(b, n_patches, -1))
+        before = dict(calls)
+        m2.to_patch_embedding = Stem()
+        y = m2(img)
+        assert tuple(y.shape) == tuple(ref.shape) and calls["embed"] == before["embed"] and calls["transformer"] == before["transformer"] + 1
+        # 3. a foreign block appended to the stack
+        m3 = cls(**cfg); m3.load_state_dict(params, strict=True)
+        m3.transformer.layers.append(torch.nn.ModuleList([torch.nn.Identity(), torch.nn.Identity()]))
+        before = dict(calls)
+        y3 = m3(img)
+        assert calls["transformer"] == before["transformer"] and torch.isfinite(y3).all()

@@ -85,6 +85,26 @@ class CastParamsFn(torch.autograd.Function):
         return (None, *outs)
 
 
+def observed(m: nn.Module) -> bool:
+    """Somebody registered a hook that expects to see this module run (forward, forward-pre, backward, backward-pre): the fused stages
+    never call the module, so a model with such a hook inside a stage runs that stage op by op."""
+    return bool(m._forward_hooks) or bool(m._forward_pre_hooks) or bool(m._backward_hooks) or bool(getattr(m, "_backward_pre_hooks", None))
+
+
+def exactly(m, *classes) -> bool:
+    """`m` is an instance of exactly one of these classes -- not of a subclass: a user's LoRALinear(nn.Linear) / QuantLinear / spectral-norm
+    wrapper overrides forward, and a fused stage that read only `.weight` would silently drop what that forward adds."""
+    return type(m) in classes
+
+
+def plain_linear(m) -> bool:
+    return exactly(m, Linear, nn.Linear) and not getattr(m, "parametrizations", None)
+
+
+def plain_layernorm(m) -> bool:
+    return exactly(m, LayerNorm, nn.LayerNorm) and m.elementwise_affine and m.weight is not None
+
+
 def eager_modules(namespace) -> None:
     """Call at the end of a module file: every nn.Module defined there runs OUTSIDE torch.compile / TorchDynamo (`torch.compiler.disable`
     on its forward).  The fused stages are autograd Functions over ctypes calls into libvitk -- nothing Dynamo can trace (fake tensors

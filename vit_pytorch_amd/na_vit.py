@@ -337,12 +337,23 @@ class Transformer(nn.Module):
         fused too when the GEMM shapes are those the fused-dropout epilogues serve (engine.packed_dropout_fusable)."""
         if x.dtype not in (torch.bfloat16, torch.float16) or self.norm.gamma.dtype != x.dtype:
             return False
-        for attn, ff in self.layers:
+        for pair_ in self.layers:
+            if len(pair_) != 2:
+                return False
+            attn, ff = pair_
+            # exactly the blocks the constructor builds (na_vit.py:96-169): model surgery (a LoRA / quantised Linear subclass, an extra
+            # module, a foreign block) runs op by op through the modules that are there
+            if not (type(attn) is Attention and type(ff) is nn.Sequential and len(ff) == 6 and type(ff[0]) is LayerNorm and Fn.plain_linear(ff[1])
+                    and Fn.exactly(ff[2], Fn.GELU) and Fn.exactly(ff[3], Fn.Dropout) and Fn.plain_linear(ff[4]) and Fn.exactly(ff[5], Fn.Dropout)
+                    and type(attn.norm) is LayerNorm and type(attn.q_norm) is RMSNorm and type(attn.k_norm) is RMSNorm
+                    and Fn.plain_linear(attn.to_q) and Fn.plain_linear(attn.to_kv) and type(attn.to_out) is nn.Sequential and len(attn.to_out) == 2
+                    and Fn.plain_linear(attn.to_out[0]) and Fn.exactly(attn.to_out[1], Fn.Dropout)):
+                return False
             if not ops.attn_varlen_ok(x.dtype, attn.q_norm.gamma.shape[-1]):       # the flash kernels' head widths: 32 / 48 / 64 / 80 / 96
                 return False
-            if any(bool(m._forward_hooks) or bool(m._forward_pre_hooks) for m in list(attn.modules()) + list(ff.modules())):
+            if any(Fn.observed(m) for m in list(attn.modules()) + list(ff.modules())):
                 return False
-        if self.norm._forward_hooks or self.norm._forward_pre_hooks:
+        if Fn.observed(self.norm) or type(self.norm) is not LayerNorm:
             return False
         p = self._dropout_p()
         if p is None:

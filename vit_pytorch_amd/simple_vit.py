@@ -78,6 +78,21 @@ class Transformer(nn.Module):
             nn.ModuleList([Attention(dim, heads=heads, dim_head=dim_head), FeedForward(dim, mlp_dim)]) for _ in range(depth))
 
     def _fusable(self) -> bool:
+        """Nothing observes the inside of the stack, and every block is exactly what the constructor builds (simple_vit.py:23-62) -- model
+        surgery (a LoRA / quantised Linear subclass, an extra module, a foreign block) runs op by op through the modules that are there."""
+        for pair_ in self.layers:
+            if len(pair_) != 2:
+                return False
+            attn, ff = pair_
+            if type(attn) is not Attention or type(ff) is not FeedForward:
+                return False
+            net = ff.net
+            if not (Fn.plain_layernorm(attn.norm) and Fn.plain_linear(attn.to_qkv) and attn.to_qkv.bias is None and Fn.exactly(attn.attend, Fn.Softmax)
+                    and Fn.plain_linear(attn.to_out) and attn.to_out.bias is None and type(net) is nn.Sequential and len(net) == 4
+                    and Fn.plain_layernorm(net[0]) and Fn.plain_linear(net[1]) and Fn.exactly(net[2], Fn.GELU) and Fn.plain_linear(net[3])):
+                return False
+        if not Fn.plain_layernorm(self.norm):
+            return False
         return not _any_hooks(self.norm, *(blk for pair_ in self.layers for blk in pair_))
 
     def wants_16bit_stream(self, B: int, N: int) -> bool:
@@ -131,8 +146,11 @@ class SimpleViT(nn.Module):
     @Fn.autocast_aware
     def forward(self, img):
         embed = self.to_patch_embedding
-        pos = self._pos_on(img.device, embed[2].weight.dtype)
-        if _any_hooks(embed) or embed[1].weight.shape[0] % 4:     # hooks, or a patch_dim off the fused stage's 16-byte rows (147): op by op
+        # exactly Rearrange -> LayerNorm -> Linear -> LayerNorm as built (simple_vit.py:90-95); a stem the user swapped in is simply called
+        built = (type(embed) is nn.Sequential and len(embed) == 4 and Fn.exactly(embed[0], Fn.Patchify) and Fn.plain_layernorm(embed[1])
+                 and Fn.plain_linear(embed[2]) and Fn.plain_layernorm(embed[3]))
+        pos = self._pos_on(img.device, embed[2].weight.dtype if built else next(self.transformer.parameters()).dtype)
+        if not built or _any_hooks(embed) or embed[1].weight.shape[0] % 4:     # surgery, hooks, or a patch_dim off the fused stage's 16-byte rows (147): op by op
             tokens = embed(img)
             tokens = Fn.AddFn.apply(tokens, pos.unsqueeze(0).expand_as(tokens).contiguous())
         else:
@@ -141,8 +159,8 @@ class SimpleViT(nn.Module):
                                           embed[2].bias, embed[3].weight, embed[3].bias, None, pos,
                                           img.dim() == 4 and getattr(self.transformer, "wants_16bit_stream", lambda b, n: False)(img.shape[0], ntok))
         tokens = self.transformer(tokens)
-        if (_has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.linear_head) or not isinstance(self.linear_head, nn.Linear)
-                or not isinstance(self.to_latent, nn.Identity)):        # hooks, or a head / to_latent the user swapped in: call them (simple_vit.py:117-120)
+        if (_has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.linear_head) or not Fn.plain_linear(self.linear_head)
+                or type(self.to_latent) is not nn.Identity):        # hooks, or a head / to_latent the user swapped in: call them (simple_vit.py:117-120)
             return self.linear_head(self.to_latent(Fn.MeanTokensFn.apply(tokens)))
         return E.HeadFn.apply(tokens, True, self.linear_head.weight, self.linear_head.bias)
 

@@ -20,7 +20,24 @@ def pair(t):
 
 
 def _has_fwd_hooks(m: Module) -> bool:
-    return bool(m._forward_hooks) or bool(m._forward_pre_hooks)
+    return Fn.observed(m)
+
+
+def _pristine_block(attn, ff) -> bool:
+    """The (attention, feed-forward) pair is exactly what the constructor builds (vit.py:15-64): only then may the fused stage read the
+    parameters and skip the modules.  Model surgery -- a LoRA / quantised Linear subclass in place of to_qkv, an extra module in `net`, a
+    foreign block appended to `layers` -- takes the op-by-op path, which calls whatever modules are there."""
+    if type(attn) is not Attention or type(ff) is not FeedForward:
+        return False
+    if not (Fn.plain_layernorm(attn.norm) and Fn.plain_linear(attn.to_qkv) and attn.to_qkv.bias is None
+            and Fn.exactly(attn.attend, Fn.Softmax) and Fn.exactly(attn.dropout, Fn.Dropout)):
+        return False
+    out = attn.to_out
+    if not (type(out) is nn.Identity or (type(out) is nn.Sequential and len(out) == 2 and Fn.plain_linear(out[0]) and Fn.exactly(out[1], Fn.Dropout))):
+        return False
+    net = ff.net
+    return (type(net) is nn.Sequential and len(net) == 6 and Fn.plain_layernorm(net[0]) and Fn.plain_linear(net[1]) and Fn.exactly(net[2], Fn.GELU)
+            and Fn.exactly(net[3], Fn.Dropout) and Fn.plain_linear(net[4]) and Fn.exactly(net[5], Fn.Dropout))
 
 
 class FeedForward(Module):
@@ -120,10 +137,13 @@ class Transformer(Module):
     def _fusable(self, x) -> bool:
         """The fused engine covers the block when nothing needs to observe its inside; active dropout is fused too when
         the shapes are those the fused-dropout kernels serve (engine.dropout_fusable), else the block runs op by op."""
-        for attn, ff in self.layers:
-            if _has_fwd_hooks(attn.attend) or any(_has_fwd_hooks(m) for m in list(attn.modules()) + list(ff.modules())):
+        for pair_ in self.layers:
+            if len(pair_) != 2 or not _pristine_block(pair_[0], pair_[1]):
                 return False
-        if _has_fwd_hooks(self.norm):
+            attn, ff = pair_
+            if any(_has_fwd_hooks(m) for m in list(attn.modules()) + list(ff.modules())):
+                return False
+        if _has_fwd_hooks(self.norm) or not Fn.plain_layernorm(self.norm):
             return False
         # widths that are not multiples of 4 (T2T-ViT's token-to-token layers: 147, 1323 -- t2t.py:45) run op by op on the
         # any-width kernels; the fused engine's vector kernels need 16-byte rows
@@ -201,6 +221,10 @@ class ViT(Module):
 
     def _embed_fusable(self) -> bool:
         pe = self.to_patch_embedding
+        # exactly Rearrange -> LayerNorm -> Linear -> LayerNorm as built (vit.py:99-104); a stem the user swapped in is simply called
+        if not (type(pe) is nn.Sequential and len(pe) == 4 and Fn.exactly(pe[0], Fn.Patchify) and Fn.plain_layernorm(pe[1])
+                and Fn.plain_linear(pe[2]) and Fn.plain_layernorm(pe[3]) and isinstance(self.dropout, nn.Dropout)):
+            return False
         if any(_has_fwd_hooks(m) for m in pe.modules()):
             return False
         if pe[1].weight.shape[0] % 4:        # patch_dim off the 16-byte rows of the fused stage (7 x 7 x 3 = 147): op by op on the any-width kernels
@@ -227,7 +251,7 @@ class ViT(Module):
 
         # the fused pool + Linear serves the modules the constructor built; a head the user swapped in (`model.mlp_head = nn.Identity()` for
         # features, a new nn.Linear / nn.Sequential for fine-tuning) or a non-trivial to_latent is simply called, as vit.py:137-138 does
-        head_plain = (isinstance(self.mlp_head, nn.Linear) and isinstance(self.to_latent, nn.Identity)
+        head_plain = (Fn.plain_linear(self.mlp_head) and type(self.to_latent) is nn.Identity
                       and not (_has_fwd_hooks(self.to_latent) or _has_fwd_hooks(self.mlp_head)))
         if head_plain:
             return E.HeadFn.apply(x, self.pool == 'mean', self.mlp_head.weight, self.mlp_head.bias)
