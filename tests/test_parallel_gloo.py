@@ -378,3 +378,38 @@ def test_model_called_twice_per_step_under_data_parallel_two_ranks_gloo():
     the same step must not replace the first gradient (it did before round 4's fix: only the last call's gradient survived)."""
     port = _free_port()
     mp.spawn(_twice_worker, args=(2, port), nprocs=2, join=True)
+
+
+# ---- torch's own DistributedDataParallel around the fused stage (what accelerate gives the reference), 2 ranks, CPU doubles ------------
+def _torch_ddp_worker(rank, world, port):
+    import _kernel_doubles as KD
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with KD.installed():
+            torch.manual_seed(23)
+            full = torch.randn(world * 3, 16, 24)
+            torch.manual_seed(90 + rank)                                # DDP broadcasts rank 0's parameters at construction
+            model = _EngineModel()
+            ddp = DDP(model)
+            x = full[3 * rank:3 * rank + 3]
+            for _ in range(2):                                          # second step: DDP's rebuilt buckets
+                ddp.zero_grad(set_to_none=True)
+                ddp(x).float().square().mean().backward()
+            got = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+            model.zero_grad(set_to_none=True)
+            model(full).float().square().mean().backward()              # the whole batch in one process = the average of the rank losses
+            for n, p in model.named_parameters():
+                err = (got[n] - p.grad).norm() / p.grad.norm().clamp_min(1e-12)
+                assert err < 1e-4, (n, float(err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_ddp_around_the_fused_stage_two_ranks_gloo():
+    """DistributedDataParallel's per-parameter autograd hooks are fed by the fused Functions like by any module: gradients equal the
+    single-process full-batch run (float32, doubles)."""
+    port = _free_port()
+    mp.spawn(_torch_ddp_worker, args=(2, port), nprocs=2, join=True)
