@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 133
+#define VITK_VERSION 134
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
