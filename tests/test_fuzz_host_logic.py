@@ -265,3 +265,28 @@ def test_model_surgery_takes_the_module_path_and_pristine_models_the_fused_one(k
         before = dict(calls)
         y3 = m3(img)
         assert calls["transformer"] == before["transformer"] and torch.isfinite(y3).all()
+
+
+@pytest.mark.parametrize("flags", [{"VITK_RECOMPUTE": "1"}, {"VITK_FWD_STREAM": "f32", "VITK_GRAD_STREAM": "f32"}, {"VITK_FWD_STREAM": "16"},
+                                   {"VITK_GELU_DG": "0"}, {"VITK_RECOMPUTE": "1", "VITK_GRAD_STREAM": "f32"}])
+@pytest.mark.parametrize("seed", [2, 4, 9, 19, 21, 29])
+def test_fuzz_draw_under_engine_switches_bf16_host_logic(seed, flags, monkeypatch):
+    """The engine's switches (recompute, stream dtypes, FeedForward pair) change WHICH tensors the host code allocates, saves and hands to
+    which kernel; with the doubles in bfloat16 every combination must give the oracle's result to 16-bit accuracy on the large-M draws
+    (tests/test_fuzz_gpu.py runs the same matrix on the real kernels)."""
+    for k, v in flags.items():
+        monkeypatch.setenv(k, v)
+    kind, cfg, batch = F.draw(seed)
+    params = make_params(kind, cfg, 50 + seed)
+    img = make_images(cfg, batch, 1050 + seed)
+    ref_out, ref_g = O.run_fwd_bwd(kind, cfg, params, img, torch.float32)
+    m = (ViT if kind == "vit" else SimpleViT)(**cfg)
+    m.load_state_dict(params, strict=True)
+    m = m.to(torch.bfloat16)
+    with KD.installed():
+        out = m(img.to(torch.bfloat16))
+        O.loss_fn(out).backward()
+    keys = [k for k in params if params[k].numel()]
+    cat = lambda d: torch.cat([d[k].detach().float().flatten() for k in keys])
+    e, g = rel(out.float(), ref_out), rel(cat({k: p.grad for k, p in m.named_parameters()}), cat(ref_g))
+    assert e <= 3e-2 and g <= 6e-2, (flags, kind, cfg, batch, e, g)
