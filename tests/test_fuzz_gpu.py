@@ -208,7 +208,9 @@ def test_random_configuration_inference_modes(seed):
 @pytest.mark.parametrize("seed", [2, 4, 7, 12, 19, 29, 31, 35])
 def test_random_configuration_fp8_operands(seed):
     """enable_fp8 on draws whose token count reaches the large-M kernels (the fp8 GEMMs serve K % 64 == 0 shapes on the 256-row
-    kernel; everything else of such a model stays on the 16-bit kernels).  Gate: the self-stated fp8 tolerance of
+    kernel; everything else of such a model stays on the 16-bit kernels -- of these eight seeds only draw 7 engages the fp8 GEMMs
+    (ops.fp8_gemm_ok); the other engaging draws below 200 -- 42, 46, 70, 87, 92, 117, 154, 160, 161, 177, 190 -- run through the host logic
+    with the doubles in tests/test_fuzz_host_logic.py and are the next seeds to add here once a GPU run has seen them).  Gate: the self-stated fp8 tolerance of
     test_fp8_gpu.py -- 3e-2 logits / 5e-2 concatenated gradient against the f32 oracle (no north-star figure exists for fp8)."""
     from vit_pytorch_amd.fp8 import enable_fp8
     kind, cfg, batch = draw(seed)
