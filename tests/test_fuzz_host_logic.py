@@ -322,8 +322,12 @@ def test_fuzz_draw_fp8_host_logic(seed):
     st = m.transformer._fp8
     from vit_pytorch_amd import ops
     n_tok = (cfg["image_size"][0] // cfg["patch_size"][0]) * (cfg["image_size"][1] // cfg["patch_size"][1]) + 1
-    engaged = ops.fp8_gemm_ok(batch * n_tok, cfg["dim"], cfg["heads"] * cfg["dim_head"], cfg["mlp_dim"])
-    assert st.ready == engaged and st.bwd_ready == engaged           # shapes the fp8 GEMMs do not serve stay on the 16-bit kernels, silently
+    M_, D_, I_, F_ = batch * n_tok, cfg["dim"], cfg["heads"] * cfg["dim_head"], cfg["mlp_dim"]
+    engaged = ops.fp8_gemm_ok(M_, D_, I_, F_)
+    engaged_bwd = engaged and ops.fp8_out_ok(M_, D_, I_) and ops.fp8_bwd_ok(M_, D_, I_, F_)
+    # shapes the fp8 GEMMs do not serve stay on the 16-bit kernels, silently -- the whole stack, or (inner width off the e5m2 dX / dW kernels'
+    # multiples: dim_head 16 / 24 / 48 / 96 with few heads) only its backward
+    assert st.ready == engaged and st.bwd_ready == engaged_bwd
     assert engaged == any(n.startswith("gemm_nt_fp8") for n in names)
     print(f"fp8 host logic draw {seed}: logits {e:.2e} grads {g:.2e}; fp8 GEMM calls {sum(n.startswith('gemm_nt_fp8') or n == 'gemm_tn_fp8' for n in names)}")
     assert e <= 6e-2 and g <= 1.5e-1, (cfg, batch, e, g)
