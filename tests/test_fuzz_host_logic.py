@@ -331,3 +331,28 @@ def test_fuzz_draw_fp8_host_logic(seed):
     assert engaged == any(n.startswith("gemm_nt_fp8") for n in names)
     print(f"fp8 host logic draw {seed}: logits {e:.2e} grads {g:.2e}; fp8 GEMM calls {sum(n.startswith('gemm_nt_fp8') or n == 'gemm_tn_fp8' for n in names)}")
     assert e <= 6e-2 and g <= 1.5e-1, (cfg, batch, e, g)
+
+
+def test_navit_surgery_takes_the_module_path():
+    """NaViT in bfloat16 runs the fused packed stack only on blocks that are exactly what its constructor builds (na_vit.py:96-169); a LoRA
+    subclass in place of `to_q` takes the op-by-op path, is called, changes the result and trains."""
+    from oracle.params import NAVIT_CASES
+    case = NAVIT_CASES["navit_two_packs"]
+    params = make_navit_params(case["cfg"], case["seed"])
+    imgs = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
+    m = NaViT(**case["cfg"])
+    m.load_state_dict(params, strict=True)
+    m = m.to(torch.bfloat16).eval()
+    probe = torch.empty(4, case["cfg"]["dim"], dtype=torch.bfloat16)
+    assert m.transformer._fusable(probe)
+    x = [[im.to(torch.bfloat16) for im in g] for g in imgs]
+    with KD.installed():
+        base = m(x)
+        attn = m.transformer.layers[0][0]
+        lora = _LoRALinear(attn.to_q.float()).to(torch.bfloat16)
+        attn.to_q = lora
+        assert not m.transformer._fusable(probe)
+        out = m(x)
+        O.loss_fn(out).backward()
+    assert rel(out.float(), base.float()) > 1e-3
+    assert lora.A.grad is not None and lora.A.grad.float().abs().sum() > 0 and lora.B.grad is not None
