@@ -923,10 +923,11 @@ extern "C" int64_t vitk_gemm_nt_fp8_colsum_rows(int64_t M, int64_t N, int64_t K,
     return 2 * ((M + 32 * pl.fm - 1) / (32 * pl.fm));
 }
 
+static int64_t nt_persist_colsum_rows(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int64_t ldc);
 extern "C" int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const NtpPlan q = ntp_plan(M, N, K, ldc, nullptr);      // the persistent kernel serves every 16-bit call it accepts
-    if (q.ok) return ntp_colsum_rows(q);
+    if (q.ok) return nt_persist_colsum_rows(q, M, N, K, ldc);
     const NtPlan pl = nt_plan(M, N, K, ldc, nullptr);
     if (!pl.large) return 0;
     return 2 * ((M + 32 * pl.fm - 1) / (32 * pl.fm));
@@ -955,6 +956,48 @@ extern "C" int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, cons
     if (colsum_partials && vitk_gemm_nt_colsum_rows(M, N, K, ldc) == 0)
         VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16_mul_aux_colsum: shape not served by the persistent kernel (vitk_gemm_nt_colsum_rows() == 0)");
     return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, VITK_EPI_MUL_AUX, nullptr, nullptr, const_cast<void*>(aux), colsum_partials, stream);
+}
+
+// ---- the persistent NT kernels: four-wave kernel (gemm_nt_w128.hip) on the full 256-row tiles of whole rounds, 8-wave kernel
+// (gemm_nt_persist.hip) on the remaining rows (the partial last m-tile and what would be a mostly idle last round, as 128-row tiles) ----
+// The row split is a function of (M, N, K), the CU count and vitk_set_cu_reserve() only: vitk_gemm_nt_colsum_rows() reports the partial
+// rows of both launches.  While another kernel is expected on the chip (cu_reserve > 0: the in-backward all-reduce) everything goes to the
+// 8-wave kernel, whose dynamic tile tickets keep a launch from waiting for CUs it does not get.
+static int ntw_tiles_m(const NtpPlan& q, int64_t M, int64_t N, int64_t K) {
+    const char* e = getenv("VITK_NT_W128");
+    if (!q.ok || (e && e[0] == '0') || vitk_get_cu_reserve() > 0 || !gemm_ntw_serves(M, N, K)) return 0;
+    return gemm_ntw_split(M, N, q.grid);
+}
+static int64_t nt_persist_colsum_rows(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int64_t ldc) {
+    const int tmw = ntw_tiles_m(q, M, N, K);
+    if (tmw == 0) return ntp_colsum_rows(q);
+    const int64_t rest = M - 256LL * tmw;
+    return 2LL * tmw + (rest > 0 ? ntp_colsum_rows(ntp_plan(rest, N, K, ldc, nullptr)) : 0);
+}
+static int nt_persist_dispatch(const NtpPlan& q, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                               int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* csum, unsigned drop_t,
+                               unsigned drop_seed, float inv_keep, void* stream) {
+    const int tmw = ntw_tiles_m(q, M, N, K);
+    // fused dropout lives in the 8-wave kernel; only the epilogue with column sums has to keep the row split (its partial rows are promised)
+    if (tmw == 0 || (drop_t && !(epilogue == VITK_EPI_GELU_BWD && csum)))
+        return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);
+    const int64_t rows_w = 256LL * tmw, rest = M - rows_w;
+    int rc;
+    if (drop_t) {       // the first rows as 256-row tiles of the 8-wave kernel (same partial rows as the four-wave launch would write)
+        NtpPlan q1 = q;
+        q1.tm_main = tmw; q1.tail_tm = 0; q1.n_main = tmw * q1.tiles_n; q1.n_tail = 0;
+        rc = gemm_ntp_launch(q1, A, lda, W, ldw, C, ldc, rows_w, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);
+    } else {
+        if (256LL * (lda > ldw ? lda : ldw) * 2 + K * 2 >= (1LL << 31)) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: row stride too large (lda %lld, ldw %lld)", (long long)lda, (long long)ldw);
+        rc = gemm_ntw_launch(tmw, q.grid, A, lda, W, ldw, C, ldc, N, K, epilogue, bias, resid, aux, csum, 0, 0, stream);
+    }
+    if (rc != 0 || rest <= 0) return rc;
+    const NtpPlan q2 = ntp_plan(rest, N, K, ldc, aux);
+    if (!q2.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: internal: the row split left %lld rows the persistent kernel does not take", (long long)rest);
+    const int64_t csz = epilogue == VITK_EPI_RESID ? 4 : 2;
+    return gemm_ntp_launch(q2, (const char*)A + rows_w * lda * 2, lda, W, ldw, (char*)C + rows_w * ldc * csz, ldc, rest, N, K, epilogue, bias,
+                           resid ? (const float*)((const char*)resid + rows_w * ldc * csz) : nullptr, aux ? (char*)aux + rows_w * ldc * 2 : nullptr,
+                           csum ? csum + 2LL * tmw * N : nullptr, drop_t, drop_seed, inv_keep, stream);
 }
 
 namespace {
@@ -993,12 +1036,12 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
         if (epilogue == VITK_EPI_BIAS_GELU_DG || epilogue == VITK_EPI_MUL_AUX) {       // the gelu'-factor pair (round 4): the persistent kernel only
             if (!q.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: EPI_BIAS_GELU_DG / EPI_MUL_AUX are served by the persistent kernel only (vitk_gemm_nt_plan() says which shapes)");
             if (!aux || drop_t || (epilogue == VITK_EPI_BIAS_GELU_DG && !bias)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS_GELU_DG needs bias and aux, EPI_MUL_AUX aux; no fused dropout");
-            return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, 0u, 0u, 1.0f, stream);
+            return nt_persist_dispatch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, 0u, 0u, 1.0f, stream);
         }
         if (epilogue == VITK_EPI_RESID16) {       // 16-bit forward residual stream (opt-in): the persistent kernel only
             if (!q.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: EPI_RESID16 is served by the persistent kernel only (vitk_gemm_nt_plan() says which shapes)");
             if (!resid || !aligned8(resid) || drop_t) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_RESID16 needs an 8-byte aligned 16-bit resid and no dropout");
-            return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, 0u, 0u, 1.0f, stream);
+            return nt_persist_dispatch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, 0u, 0u, 1.0f, stream);
         }
         if (q.ok && epilogue >= 0 && epilogue <= 4 && (((epis >> epilogue) & 1u) || epilogue == VITK_EPI_GELU_BWD)) {
             switch (epilogue) {
@@ -1011,7 +1054,7 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
             }
             if (drop_t && epilogue != VITK_EPI_RESID && epilogue != VITK_EPI_BIAS_GELU && epilogue != VITK_EPI_GELU_BWD)
                 VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: fused dropout exists for the RESID / BIAS_GELU / GELU_BWD epilogues only");
-            return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);
+            return nt_persist_dispatch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);
         }
     }
     if (ldw == 0) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: a K-blocked W (ldw == 0, vitk_pack_w_nt) is read by the persistent kernel only (vitk_gemm_nt_plan() says which shapes it serves)");

@@ -1,0 +1,117 @@
+// gemm_nt_epi.h -- epilogue helpers shared by the NT GEMM kernels (gemm_nt_persist.hip: 8 waves, 128 x 64 wave tiles;
+// gemm_nt_w128.hip: 4 waves, 128 x 128 wave tiles): uncounted asm loads with exact-count waits, the packed GELU forms, the
+// lane-pair exchange that turns a lane's 4 columns of 2 rows into 8 columns of one row (full 128-byte lines per store).
+#pragma once
+#include "common.h"
+
+namespace {
+
+// ---- epilogue operand loads the compiler does not count (interior tiles) ---------------------------------------------------
+// hipcc waits vmcnt(0) for an ordinary VGPR-destination load whenever an LDS-DMA is in flight -- and in this kernel one always is
+// (the next tile's first K-steps).  CDNA4's vmcnt counts stores too and retires in order, so every use of a residual row (f32
+// residual epilogue) or of a saved pre-activation row (GELU' epilogue) drained the ring AND waited for the completion of every
+// store issued so far: a write round trip per fragment row, 4-8 of them per tile [the ISA showed vmcnt(0) / vmcnt(1) in front of
+// every second row; FF2 + residual: ~26 us of epilogue per 256 x 256 tile against ~9 us of store issue].  Issued here as asm
+// and waited for by an EXACT count: D fragment rows are in flight, and the stores issued after a row's loads may stay in flight.
+// (Form (ii) of the guide's 5.7: "=v" loads, then a wait statement naming every destination "+v"; the epilogue is straight-line
+// code, so no destination is loop-carried; tools/asm_inflight_audit.py checks the .s for compiler accesses in between.)
+#ifndef Q_EPI_ASM_RESID
+#define Q_EPI_ASM_RESID 1        // 0: compiler-counted residual loads (A/B builds)
+#endif
+#ifndef Q_EPI_ASM_PRE
+#define Q_EPI_ASM_PRE 1          // 0: compiler-counted pre-activation loads (A/B builds)
+#endif
+#ifndef Q_EPI_DEPTH_RESID
+#define Q_EPI_DEPTH_RESID 3      // fragment rows of the residual in flight (16 VGPRs each)
+#endif
+#ifndef Q_EPI_DEPTH_PRE
+#define Q_EPI_DEPTH_PRE 2        // fragment rows of the saved pre-activation in flight (8 VGPRs each)
+#endif
+__device__ __forceinline__ void q_gload_f32x4(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void q_gload_bf16x8(bf16x8& d, const __bf16* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// ops issued between the loads of fragment row f and their wait: PER_F loads + PER_F stores per row, D rows of loads in flight
+__host__ __device__ constexpr int q_epi_younger(int f, int fmw, int d, int per_f) {
+    const int last = f + d - 1 < fmw - 1 ? f + d - 1 : fmw - 1;
+    return per_f * ((last - f) + (f < d ? f : d - 1));
+}
+#define Q_WAIT_CASE(n) else if constexpr (N_ == n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+template <int N_, typename T> __device__ __forceinline__ void q_wait_regs4(T& a, T& b, T& c, T& d) {
+    if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
+    Q_WAIT_CASE(4); Q_WAIT_CASE(6); Q_WAIT_CASE(8); Q_WAIT_CASE(10); Q_WAIT_CASE(12); Q_WAIT_CASE(16); Q_WAIT_CASE(20); Q_WAIT_CASE(24);
+    Q_WAIT_CASE(28); Q_WAIT_CASE(32); Q_WAIT_CASE(36); Q_WAIT_CASE(40);
+    else static_assert(N_ < 0, "unsupported vmcnt");
+}
+#define Q_WAIT2_CASE(n) else if constexpr (N_ == n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b) :: "memory")
+template <int N_, typename T> __device__ __forceinline__ void q_wait_regs2(T& a, T& b) {
+    if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) :: "memory");
+    Q_WAIT2_CASE(2); Q_WAIT2_CASE(4); Q_WAIT2_CASE(6); Q_WAIT2_CASE(8); Q_WAIT2_CASE(10); Q_WAIT2_CASE(12);
+    Q_WAIT2_CASE(14); Q_WAIT2_CASE(16); Q_WAIT2_CASE(18); Q_WAIT2_CASE(20);
+    else static_assert(N_ < 0, "unsupported vmcnt");
+}
+
+// 8-wide forms of common.h's gelu_fast2 / gelu_grad_fast2 (same polynomial, same operation order per element): written on
+// 8-vectors so that every Horner step is four INDEPENDENT v_pk_fma_f32 -- the 2-wide form compiled to one dependent chain
+// per pair with a stall slot after every step.
+typedef float q_f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ q_f32x8 q_splat8(float v) { return q_f32x8{v, v, v, v, v, v, v, v}; }
+__device__ __forceinline__ q_f32x8 q_phi8(q_f32x8 x) {
+    q_f32x8 xc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xc[e] = __builtin_amdgcn_fmed3f(x[e], -4.5f, 4.5f);
+    const q_f32x8 u = xc * xc;
+    q_f32x8 q = __builtin_elementwise_fma(u, q_splat8(3.619783835e-11f), q_splat8(-3.842468662e-09f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(1.789582063e-07f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(-4.853476327e-06f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(8.614045158e-05f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(-1.069849927e-03f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(9.707349039e-03f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(-6.620850869e-02f));
+    q = __builtin_elementwise_fma(q, u, q_splat8(3.988530737e-01f));
+    return __builtin_elementwise_fma(xc, q, q_splat8(0.5f));
+}
+__device__ __forceinline__ q_f32x8 q_gelu8(q_f32x8 x) { return x * q_phi8(x); }
+__device__ __forceinline__ q_f32x8 q_gelu_grad8(q_f32x8 x) {
+    const q_f32x8 w = x * x * q_splat8(-0.72134752044448170368f);
+    q_f32x8 e;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(w[i]);
+    return __builtin_elementwise_fma(x * q_splat8(0.39894228040143267794f), e, q_phi8(x));
+}
+// GELU and its derivative of the same 8 values with ONE evaluation of Phi (the BIAS_GELU_DG epilogue: the forward GEMM stores gelu'(pre) for
+// the backward instead of pre, so that the backward's epilogue is a multiplication -- same operations per element as q_gelu8 / q_gelu_grad8)
+__device__ __forceinline__ void q_gelu_both8(q_f32x8 x, q_f32x8& g, q_f32x8& dg) {
+    const q_f32x8 ph = q_phi8(x);
+    const q_f32x8 w = x * x * q_splat8(-0.72134752044448170368f);
+    q_f32x8 e;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(w[i]);
+    g = x * ph;
+    dg = __builtin_elementwise_fma(x * q_splat8(0.39894228040143267794f), e, ph);
+}
+__device__ __forceinline__ q_f32x8 q_widen8(bf16x8 v) {
+    q_f32x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
+    return r;
+}
+__device__ __forceinline__ bf16x8 q_narrow8(q_f32x8 v) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
+    return r;
+}
+
+template <int EPI> __host__ __device__ constexpr bool q_has_bias() {
+    return EPI == VITK_EPI_BIAS || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_GELU_DG || EPI == VITK_EPI_RESID || EPI == VITK_EPI_RESID16;
+}
+
+__device__ __forceinline__ unsigned q_dpp_xor1(unsigned v) {       // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned q_pack2(float a, float b) {
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace
