@@ -98,7 +98,11 @@ def test_plan_uses_both_tile_heights_at_vit_b_sizes():
     p = K.gemm_nt_plan(50432, 768, 3072, 768)
     assert p["persistent"] and p["tiles_m256"] > 0 and p["tiles_m128"] > 0
     assert 256 * p["tiles_m256"] + 128 * p["tiles_m128"] >= 50432
-    assert K.gemm_nt_colsum_rows(50432, 768, 3072, 768) == 2 * (p["tiles_m256"] + p["tiles_m128"])
+    os.environ["VITK_NT_W128"] = "0"          # the 8-wave kernel alone (round 5: the four-wave kernel takes the whole rounds, tests/test_gemm_nt_w128_gpu.py)
+    try:
+        assert K.gemm_nt_colsum_rows(50432, 768, 3072, 768) == 2 * (p["tiles_m256"] + p["tiles_m128"])
+    finally:
+        os.environ.pop("VITK_NT_W128", None)
     assert not K.gemm_nt_plan(512, 768, 768, 768)["persistent"]          # small M stays on the 128-row kernel
 
 

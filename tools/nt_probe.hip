@@ -161,18 +161,28 @@ int main(int argc, char** argv) {
             // ---- ablations of the four-wave launch (all full tiles) ----
             if (epi == VITK_EPI_NONE) {
                 struct Ab { const char* name; int abl, dbg; };
-                const Ab abs[] = {{"all", 0, 0}, {"strict waits after the epilogue", 0, 2}, {"main loop alone (no epilogue)", 0, 1}, {"LDS-DMA only", 6, 1},
-                                  {"MFMA only", 3, 1}, {"fragment reads only", 5, 1}, {"DMA + reads", 4, 1}, {"DMA + MFMA", 2, 1}, {"empty loop", 7, 1},
-                                  {"epilogue only (empty loop + stores)", 7, 0}};
+                const Ab abs[] = {{"all (DMA pieces staggered by wave)", 0, 0}, {"all, pieces of all waves at the same points", 0, 4},
+                                  {"strict waits after the epilogue", 0, 2}, {"main loop alone (no epilogue)", 0, 1},
+                                  {"main loop alone, same points", 0, 5}, {"LDS-DMA only", 6, 1}, {"LDS-DMA only, same points", 6, 5}, {"MFMA only", 3, 1},
+                                  {"fragment reads only", 5, 1}, {"DMA + MFMA", 2, 1}, {"DMA + MFMA, same points", 2, 5}, {"empty loop", 7, 1},
+                                  {"epilogue only (empty loop + stores)", 7, 0}, {"odd workgroups start 2 x 3.4 us late", 0, 2 << 8},
+                                  {"odd workgroups start 3 x 3.4 us late", 0, 3 << 8}, {"odd workgroups start 4 x 3.4 us late", 0, 4 << 8},
+                                  {"odd workgroups start 6 x 3.4 us late", 0, 6 << 8}, {"odd workgroups start 6 late, strict waits", 0, (6 << 8) | 2}};
                 for (const Ab& ab : abs) {
                     std::vector<float> t;
                     for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
-                    printf("      %-38s %7.1f us\n", ab.name, median(t) * 1e3);
+                    printf("      %-42s %7.1f us\n", ab.name, median(t) * 1e3);
                 }
             } else if (epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_MUL_AUX || epi == VITK_EPI_RESID16) {
-                std::vector<float> t, t2;
-                for (int r = 0; r < rounds; ++r) { t.push_back(time_ms([&] { direct(tm_all, 7, 0); }, 10)); t2.push_back(time_ms([&] { direct(tm_all, 0, 2); }, 10)); }
-                printf("      %-38s %7.1f us\n      %-38s %7.1f us\n", "epilogue only (empty loop + epilogue)", median(t) * 1e3, "strict waits after the epilogue", median(t2) * 1e3);
+                struct Ab { const char* name; int abl, dbg; };
+                const Ab abs[] = {{"epilogue only (empty loop + epilogue)", 7, 0}, {"strict waits after the epilogue", 0, 2}, {"pieces of all waves at the same points", 0, 4},
+                                  {"odd workgroups start 3 x 3.4 us late", 0, 3 << 8}, {"odd workgroups start 5 x 3.4 us late", 0, 5 << 8},
+                                  {"odd workgroups start 7 x 3.4 us late", 0, 7 << 8}, {"odd workgroups start 5 late, strict waits", 0, (5 << 8) | 2}};
+                for (const Ab& ab : abs) {
+                    std::vector<float> t;
+                    for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
+                    printf("      %-42s %7.1f us\n", ab.name, median(t) * 1e3);
+                }
             }
         }
         for (Buf* b : {&A, &W, &bias, &aux_in, &r16, &r32, &Wp, &C0, &C1, &X0, &X1, &cs0, &cs1}) CK(hipFree(b->p));

@@ -1,0 +1,18 @@
+#!/bin/bash
+# One GPU call of round 5:  bash tools/r05_shot.sh <tag> <steps...>   (steps: probe tests_nt tests_all bench profile)
+set -u
+tag=$1; shift
+root=$PWD
+export PYTHONPATH=$root
+out=$root/gpurun_out
+mkdir -p $out
+for step in "$@"; do
+  case $step in
+    probe) timeout 600 tools/nt_probe.bin 3 > $out/${tag}_nt_probe.log 2>&1; tail -5 $out/${tag}_nt_probe.log ;;
+    tests_nt) timeout 900 python -m pytest tests/test_gemm_nt_w128_gpu.py tests/test_gemm_persist_gpu.py tests/test_kernels_gpu.py tests/test_headline_extents_gpu.py tests/test_fuzz_ops_gpu.py -m gpu -x -q > $out/${tag}_tests_nt.log 2>&1; tail -3 $out/${tag}_tests_nt.log ;;
+    tests_all) timeout 2400 python -m pytest tests -m gpu -x -q > $out/${tag}_tests_all.log 2>&1; tail -3 $out/${tag}_tests_all.log ;;
+    bench) timeout 400 python bench.py > $out/${tag}_bench.json.log 2> $out/${tag}_bench.err; tail -1 $out/${tag}_bench.json.log | cut -c1-600 ;;
+    bench_ab) for i in 1 2; do VITK_NT_W128=0 timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_old_$i.json.log 2>&1; timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_new_$i.json.log 2>&1; done; grep -h -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_old_*.json.log $out/${tag}_bench_new_*.json.log ;;
+    profile) bash tools/profile_round.sh $tag ;;
+  esac
+done

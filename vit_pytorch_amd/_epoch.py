@@ -62,7 +62,25 @@ def note_grad_mode(enabled: bool) -> None:
 
 
 def caller_grad_mode() -> bool:
-    return getattr(_TLS, "grad", True)
+    """The one-shot note of the module that is about to call a fused Function, AND the mode the enclosing model-level forward was
+    entered in (model_grad_scope): the stages in front of / behind the transformer (patch embedding, head) run before the note is set /
+    after it is reset, and under torch.no_grad() they must not build and cache the backward's transposed weight packs."""
+    return getattr(_TLS, "grad", True) and getattr(_TLS, "model", True)
+
+
+class model_grad_scope:
+    """with model_grad_scope(): ... around a model-level forward (functional.autocast_aware opens it): records torch.is_grad_enabled()
+    for every fused stage the forward runs; nests (the previous value comes back)."""
+
+    def __enter__(self):
+        import torch
+        self.prev = getattr(_TLS, "model", True)
+        _TLS.model = self.prev and torch.is_grad_enabled()
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.model = self.prev
+        return False
 
 
 def reset_grad_mode() -> None:

@@ -997,7 +997,7 @@ static int nt_persist_dispatch(const NtpPlan& q, const void* A, int64_t lda, con
     const int64_t csz = epilogue == VITK_EPI_RESID ? 4 : 2;
     return gemm_ntp_launch(q2, (const char*)A + rows_w * lda * 2, lda, W, ldw, (char*)C + rows_w * ldc * csz, ldc, rest, N, K, epilogue, bias,
                            resid ? (const float*)((const char*)resid + rows_w * ldc * csz) : nullptr, aux ? (char*)aux + rows_w * ldc * 2 : nullptr,
-                           csum ? csum + 2LL * tmw * N : nullptr, drop_t, drop_seed, inv_keep, stream);
+                           csum ? csum + 2LL * tmw * N : nullptr, drop_t, drop_seed, inv_keep, stream, (unsigned)rows_w);
 }
 
 namespace {

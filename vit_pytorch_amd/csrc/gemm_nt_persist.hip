@@ -73,6 +73,7 @@ struct NtpArgs {
     const __bf16* bias; const float* resid; __bf16* aux; float* csum;
     int tiles_n, group_n, tm_main, tail_tm, n_main, n_tail, nt;
     unsigned drop_t, drop_seed; float inv_keep;     // fused nn.Dropout (vit.py:22,24,48): threshold 0 = off
+    unsigned drop_m0;   // row of the dropout pattern that row 0 of this launch is (a launch on the last rows of a split call)
     int tail_first;
     unsigned* tickets;  // DYNAMIC tile tickets: 8 per-XCD counters zeroed before the launch (null: static tile lists) -- see the kernel
     int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone)
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                             const int m = mrow0 + f * 16 + j;
                             f32x4 v = f32x4{acc[0][f][j], acc[1][f][j], acc[2][f][j], acc[3][f][j]} + b4;
                             if (p.drop_t) {       // nn.Dropout on the Linear output, before the residual add (vit.py:24,48 + :80-81)
-                                const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+                                const unsigned hrow = drop_row((unsigned)m + p.drop_m0, p.drop_seed);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = drop_keep(hrow, (unsigned)(ncol4 + e), p.drop_t) ? v[e] * p.inv_keep : 0.f;
                             }
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                             const int m = mrow0 + f * 16 + j;
                             f32x4 v = f32x4{acc[0][f][j], acc[1][f][j], acc[2][f][j], acc[3][f][j]} + b4;
                             if (p.drop_t) {       // nn.Dropout on the Linear output, before the residual add (vit.py:24,48 + :80-81)
-                                const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+                                const unsigned hrow = drop_row((unsigned)m + p.drop_m0, p.drop_seed);
     #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = drop_keep(hrow, (unsigned)(ncol4 + e), p.drop_t) ? v[e] * p.inv_keep : 0.f;
                             }
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                             if (ok) *reinterpret_cast<bf16x8*>(p.aux + o) = v;
                             bf16x8 g8 = q_narrow8(q_gelu8(q_widen8(v)));     // of the ROUNDED pre-activation
                             if (p.drop_t) {       // nn.Dropout after the GELU (vit.py:22): the saved pre-activation stays undropped
-                                const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+                                const unsigned hrow = drop_row((unsigned)m + p.drop_m0, p.drop_seed);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e)
                                     g8[e] = drop_keep(hrow, (unsigned)(ncol8 + e), p.drop_t) ? (__bf16)((float)g8[e] * p.inv_keep) : (__bf16)0.f;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                             const bf16x8 h8 = hpre[f % DP][pr];
                             q_f32x8 g = q_widen8(v) * (EPI == VITK_EPI_MUL_AUX ? q_widen8(h8) : q_gelu_grad8(q_widen8(h8)));
                             if (p.drop_t) {     // factor of the forward's dropout(gelu(pre)) at (m, n): same decision, same 1 / (1 - p)
-                                const unsigned hrow = drop_row((unsigned)m, p.drop_seed);
+                                const unsigned hrow = drop_row((unsigned)m + p.drop_m0, p.drop_seed);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) g[e] *= drop_keep(hrow, (unsigned)(ncol8 + e), p.drop_t) ? p.inv_keep : 0.f;
                             }
@@ -891,9 +892,9 @@ NtpPlan ntp_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) 
 
 int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                     int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* csum, unsigned drop_t,
-                    unsigned drop_seed, float inv_keep, void* stream) {
+                    unsigned drop_seed, float inv_keep, void* stream, unsigned drop_m0) {
     NtpArgs a;
-    a.drop_t = drop_t; a.drop_seed = drop_seed; a.inv_keep = inv_keep;
+    a.drop_t = drop_t; a.drop_seed = drop_seed; a.inv_keep = inv_keep; a.drop_m0 = drop_m0;
     a.A = (const char*)A; a.lda = lda; a.W = (const char*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.bias = (const __bf16*)bias; a.resid = resid; a.aux = (__bf16*)aux; a.csum = csum;

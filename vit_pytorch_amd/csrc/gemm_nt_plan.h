@@ -26,7 +26,7 @@ static inline int64_t ntp_colsum_rows(const NtpPlan& pl) { return 2 * ((int64_t)
 
 int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                     int64_t N, int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* csum, unsigned drop_t, unsigned drop_seed,
-                    float inv_keep, void* stream);
+                    float inv_keep, void* stream, unsigned drop_m0 = 0);
 
 // the four-wave kernel (gemm_nt_w128.hip): full 256-row tiles only, rows [0, 256 tiles_m); `resid` is f32 (EPI_RESID) or 16-bit (EPI_RESID16)
 bool gemm_ntw_serves(int64_t M, int64_t N, int64_t K);

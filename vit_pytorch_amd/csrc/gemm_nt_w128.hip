@@ -56,7 +56,8 @@ struct NtwArgs {
     int M, N, K;
     const __bf16* bias; const void* resid; __bf16* aux; float* csum;
     int tiles_n, group_n, tiles_m, n_tiles, nt;      // FULL interior tiles only: rows [0, 256 tiles_m), N % 256 == 0
-    int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone), bit 1 = strict waits after an epilogue
+    int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone), bit 1 = strict waits after an epilogue, bit 2 = DMA pieces of all
+                        // waves at the same points of a K-step, bits 8..15 = late start of every second workgroup (x s_sleep 127)
 };
 
 template <int OFF> __device__ __forceinline__ bf16x8 v_rd(unsigned lds_addr) {
@@ -73,7 +74,8 @@ template <bool Z> __device__ __forceinline__ void v_mfma(f32x4& c, const bf16x8&
 __device__ __forceinline__ void v_gload_bf16x4(bf16x4& d, const __bf16* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 
 // ABL (experiments, tools/nt_probe.hip): bit 0 no LDS-DMA in the loop, bit 1 no fragment reads, bit 2 no MFMA
-template <int EPI, int ABL>
+// SG: the DMA pieces of the four waves at different points of a K-step (see V_GROUP); 0 = all waves at the same points (A/B builds)
+template <int EPI, int ABL, int SG>
 __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
@@ -87,6 +89,9 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     const int xcd = blockIdx.x & 7, l0 = blockIdx.x >> 3, L = gridDim.x >> 3;
     const int ms = (int)(((long long)xcd * p.n_tiles) >> 3), count = (int)(((long long)(xcd + 1) * p.n_tiles) >> 3) - ms;
     if (l0 >= count) return;
+    // experiments (p.dbg bits 8..15): every second workgroup of an XCD starts that many s_sleep 127 (~3.4 us each) late, i.e. out of phase
+    // with its neighbours -- do epilogue store bursts that fall into other workgroups' main loops pay for the idle start?
+    if ((p.dbg >> 8) && (l0 & 1)) { for (int i = (p.dbg >> 8) & 0xff; i > 0; --i) __builtin_amdgcn_s_sleep(127); }
     auto decode = [&](int idx, int& m0, int& n0, int& mt) {
         int tn;
         v_grouped_tile(ms + idx, p.tiles_m, p.tiles_n, p.group_n, mt, tn);
@@ -168,15 +173,22 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     f32x4 acc[8][8];            // acc[fn][f][j]: row 16 f + 4 fg + j, column 64 (fn >> 2) + 4 fi + (fn & 3) of the wave tile
 
     // one group of a K-step: 4 MFMAs on the current fragments (activation fragment fm x W fragments 4h .. 4h + 3), one fragment of the next
-    // K-step, every second group one DMA piece
+    // K-step, every second group one DMA piece.  WHERE the piece is issued depends on the wave (ST = 0..3; -1 = all waves after the third
+    // MFMA of the odd groups): [measured, tools/nt_probe: LDS-DMA alone 112 us, MFMA alone 111 us, both 160 us] the four waves run in lock
+    // step between barriers and the CU's texture-address unit takes one 1 KiB piece per ~21 cycles, so four pieces issued at the same
+    // MFMA slot queue behind one another and the last wave's matrix pipe runs dry meanwhile; staggered, wave s issues after the second
+    // (s even) or fourth (s odd) MFMA of the groups of parity s >> 1: one piece per two MFMA slots CU-wide.
 #define V_GROUP(G, Z, XC, WC, XN, WN) do { \
         constexpr int fm_ = (G) >> 1, h_ = ((G) & 1) * 4; \
+        constexpr bool mine_ = ST >= 0 && ((G) & 1) == (ST >> 1); \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 0][fm_], XC[fm_], WC[h_ + 0]); \
         if constexpr (!(ABL & 2)) { if constexpr ((G) < 8) XN[(G)] = v_rd<(G) * 1024>(rdA); else WN[(G) - 8] = v_rd<((G) - 8) * 1024>(rdW); } \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 1][fm_], XC[fm_], WC[h_ + 1]); \
+        if constexpr (!(ABL & 1) && mine_ && !(ST & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 2][fm_], XC[fm_], WC[h_ + 2]); \
-        if constexpr (!(ABL & 1) && ((G) & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
+        if constexpr (!(ABL & 1) && ST < 0 && ((G) & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 3][fm_], XC[fm_], WC[h_ + 3]); \
+        if constexpr (!(ABL & 1) && mine_ && (ST & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
     } while (0)
     // one K-step.  WAIT = the counted vmcnt statement: own pieces of K-step t + 2 landed (t + 3, t + 4 fly)
 #define V_STEP(Z, XC, WC, XN, WN, WAIT) do { \
@@ -440,28 +452,39 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
     } while (0)
 
-    for (int idx = l0; idx < count; idx += L) {
-        int m0, n0, mt;
-        decode(idx, m0, n0, mt);
-        // K-steps in pairs (the two fragment sets swap roles); the first K-step writes the accumulators with C = 0
-        V_STEP(true, xa, wa, xb, wb, V_WAITR);
-        V_STEP(false, xb, wb, xa, wa, V_WAITR);
-        for (int kt = 2; kt + 4 < p.nt; kt += 2) {
+    auto tiles = [&](auto st_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_c)::value;
+        for (int idx = l0; idx < count; idx += L) {
+            int m0, n0, mt;
+            decode(idx, m0, n0, mt);
+            // K-steps in pairs (the two fragment sets swap roles); the first K-step writes the accumulators with C = 0
+            V_STEP(true, xa, wa, xb, wb, V_WAITR);
+            V_STEP(false, xb, wb, xa, wa, V_WAITR);
+            for (int kt = 2; kt + 4 < p.nt; kt += 2) {
+                V_STEP(false, xa, wa, xb, wb, V_WAIT16);
+                V_STEP(false, xb, wb, xa, wa, V_WAIT16);
+            }
+            next_src(idx + L);       // the pieces of the last four K-steps are the next tile's first four
             V_STEP(false, xa, wa, xb, wb, V_WAIT16);
             V_STEP(false, xb, wb, xa, wa, V_WAIT16);
+            V_STEP(false, xa, wa, xb, wb, V_WAIT16);
+            V_STEP(false, xb, wb, xa, wa, V_WAIT16);       // reads the NEXT tile's first fragments
+            // the asm MFMAs' results are complete before the compiler's reads of them (it does not see the MFMAs' latency); nothing is
+            // scheduled across the pin
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            V_PIN();
+            epilogue(m0, n0, mt);
+            relax = !(p.dbg & 3);
         }
-        next_src(idx + L);       // the pieces of the last four K-steps are the next tile's first four
-        V_STEP(false, xa, wa, xb, wb, V_WAIT16);
-        V_STEP(false, xb, wb, xa, wa, V_WAIT16);
-        V_STEP(false, xa, wa, xb, wb, V_WAIT16);
-        V_STEP(false, xb, wb, xa, wa, V_WAIT16);       // reads the NEXT tile's first fragments
-        // the asm MFMAs' results are complete before the compiler's reads of them (it does not see the MFMAs' latency); nothing is
-        // scheduled across the pin
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        V_PIN();
-        epilogue(m0, n0, mt);
-        relax = !(p.dbg & 3);
-    }
+    };
+    if constexpr (SG) {        // one copy of the tile loop per wave: the DMA slots are compile-time positions in the asm stream
+        switch (wave) {
+            case 0: tiles(std::integral_constant<int, 0>{}); break;
+            case 1: tiles(std::integral_constant<int, 1>{}); break;
+            case 2: tiles(std::integral_constant<int, 2>{}); break;
+            default: tiles(std::integral_constant<int, 3>{}); break;
+        }
+    } else tiles(std::integral_constant<int, -1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the surplus DMA pieces must not outlive the workgroup's LDS allocation
 #undef V_WAITR
 #undef V_WAIT16
@@ -525,10 +548,11 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
     const int lds_bytes = V_RING + a.tiles_n * 512 + 16;
     hipStream_t st = (hipStream_t)stream;
     if (tiles_m <= 0 || grid < 8) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16 (w128): nothing to do");
-#define NTW_LAUNCH1(E, AB) do { \
-        static const int rc__ = v_set_max_lds(gemm_ntw_kernel<E, AB>, V_LDS_MAX); \
+#define NTW_LAUNCH1(E, AB) do { if (dbg & 4) NTW_LAUNCH2(E, AB, 0); else NTW_LAUNCH2(E, AB, 1); } while (0)
+#define NTW_LAUNCH2(E, AB, SGV) do { \
+        static const int rc__ = v_set_max_lds(gemm_ntw_kernel<E, AB, SGV>, V_LDS_MAX); \
         if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16 (w128): cannot enable %d B of LDS", V_LDS_MAX); \
-        hipLaunchKernelGGL((gemm_ntw_kernel<E, AB>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a); \
+        hipLaunchKernelGGL((gemm_ntw_kernel<E, AB, SGV>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a); \
     } while (0)
 #ifdef NTW_PROBE
 #define NTW_LAUNCH_ALL(E) do { \
@@ -558,6 +582,7 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
 #undef NTW_LAUNCH_ALL
 #undef NTW_LAUNCH
 #undef NTW_LAUNCH1
+#undef NTW_LAUNCH2
     VITK_CHECK_LAUNCH("gemm_nt_bf16 (w128)");
     return 0;
 }

@@ -500,7 +500,7 @@ class TransformerFn(torch.autograd.Function):
                 pair_out = None
                 if f8 is not None:
                     fork.run(lambda: dw(li, q2, g2T, o, 3, dwo, x8=o_8), g2T, o, dwo, q2, o_8)
-                elif not fork.enabled and T in ops.HALF and K.gemm_tn_pair_splits(M, wqkv.shape[0], wqkv.shape[1], wout.shape[0], wout.shape[1]) > 0:
+                elif not fork.enabled and T in ops.HALF and K.gemm_tn_pair_splits(M, wqkv.shape[0], wqkv.shape[1], wout.shape[0], wout.shape[1], T) > 0:
                     # issued together with to_qkv's weight gradient below, ONE launch (ops.linear_dw_pair: 36 tiles x 7 splits instead of
                     # 27 x 9 and 9 x 28 -- half the f32 slabs, a launch and a fold less: 31.55 -> 31.29 ms per step, same box).  Only without
                     # the side stream: beside the dX chain the deferred gradient loses more overlap than the pair saves (+0.5 ms measured).
@@ -591,7 +591,7 @@ class PatchEmbedFn(torch.autograd.Function):
         # Rearrange + LayerNorm(patch_dim) (vit.py:100-101).  16-bit images of 3 channels with 16 x 16 patches: ONE kernel gathers the patch
         # straight from the NCHW image inside the LayerNorm's load (no `patches` tensor, no patchify pass; the backward re-gathers from the
         # image, which is kept instead); everything else: patchify, then LayerNorm.
-        gather = T in ops.HALF and K.patch_ln_serves(img, C, H, W, p1, p2)
+        gather = T in ops.HALF and img.data_ptr() % 16 == 0 and K.patch_ln_serves(img, C, H, W, p1, p2)      # (a misaligned view: patchify + LayerNorm)
         if gather:
             patches = None
             st1 = (ops.empty((Mp,), F32, img), ops.empty((Mp,), F32, img))
@@ -615,6 +615,7 @@ class PatchEmbedFn(torch.autograd.Function):
         ctx.save_for_backward(ln1w, ln1b, w, ln2w, ln2b, *([b] if b is not None else []))
         ctx.inter = (patches if not gather else img, st1, pn, y, st2)
         ctx.gather = (B, C, H, W, p1, p2) if gather else None
+        ctx.img_version = img._version if gather else None       # the backward re-gathers from the caller's image
         ctx.geom = (B, C, H, W, p1, p2)
         ctx.pad = (Pp, w_mm if Pp != P else None)
         ctx.cls_pos = (cls, pos)
@@ -672,6 +673,10 @@ class PatchEmbedFn(torch.autograd.Function):
             dpn = ops.linear_dx(dyp, w, Mp)
         dl1w, dl1b = _grad_buf(ln1w), _grad_buf(ln1b)
         dimg = None
+        if ctx.gather is not None and patches._version != ctx.img_version:
+            # what autograd's saved-tensor check would have said: the backward re-gathers the patches from the caller's image
+            raise RuntimeError("vit_pytorch_amd: the input image was modified in place between forward and backward (the fused patch "
+                               "embedding re-reads it in backward); pass a copy, or modify it after backward")
         if ctx.needs_input_grad[0]:
             # the INPUT requires a gradient (saliency maps, adversarial inputs: the reference differentiates through Rearrange + LayerNorm,
             # vit.py:100-101): LayerNorm(patch_dim) backward with its dx, then the inverse scatter of the Rearrange

@@ -17,6 +17,7 @@ from torch import nn
 from . import kernels as K
 from . import ops
 from ._lib import VitkError
+from ._epoch import model_grad_scope
 
 Tensor = torch.Tensor
 F32 = torch.float32
@@ -70,14 +71,17 @@ class CastParamsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dtype, *params):
         outs = [torch.empty(p.shape, dtype=dtype, device=p.device) for p in params]
-        live = [(p.detach().contiguous(), o) for p, o in zip(params, outs) if p.numel()]
+        def aligned(t):         # vitk_cast_many reads 16-byte vectors: a parameter that is a view at an odd offset of a flat buffer is copied first
+            t = t.detach().contiguous()
+            return t.clone() if t.data_ptr() % 16 else t
+        live = [(aligned(p), o) for p, o in zip(params, outs) if p.numel()]
         K.cast_many([a for a, _ in live], [b for _, b in live])
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gs):
         outs = [None if g is None else torch.empty(g.shape, dtype=F32, device=g.device) for g in gs]
-        live = [(g.contiguous(), o) for g, o in zip(gs, outs) if g is not None and g.numel()]
+        live = [(g.contiguous() if g.data_ptr() % 16 == 0 else g.contiguous().clone(), o) for g, o in zip(gs, outs) if g is not None and g.numel()]
         if live:
             half = {g.dtype for g, _ in live}
             for hd in half:       # (one source dtype per call)
@@ -141,19 +145,28 @@ def autocast_aware(forward):
     import functools
 
     @functools.wraps(forward)
-    def wrapped(self, x, *args, **kwargs):
+    def wrapped(self, *args, **kwargs):      # (every argument may come by keyword: model(img=t), a trainer's model(**batch))
+        with model_grad_scope():             # torch.no_grad() around the call is seen by every fused stage, not just the transformer
+            return inner(self, *args, **kwargs)
+
+    def inner(self, *args, **kwargs):
         dt = _autocast_dtype()
         if dt is None:
-            return forward(self, x, *args, **kwargs)
-        named = [(n, p) for n, p in self.named_parameters() if p.dtype == F32 and p.is_cuda]
+            return forward(self, *args, **kwargs)
+        # remove_duplicate=False: every alias of a tied / shared parameter is swapped, not just the first name
+        named = [(n, p) for n, p in self.named_parameters(remove_duplicate=False) if p.dtype == F32 and p.is_cuda]
         if not named:
             with torch.autocast("cuda", enabled=False):
-                return forward(self, x, *args, **kwargs)
-        cast_all = CastParamsFn.apply(dt, *[p for _, p in named])
+                return forward(self, *args, **kwargs)
+        uniq = {}
+        for _, p in named:
+            uniq.setdefault(id(p), p)
+        cast_all = CastParamsFn.apply(dt, *uniq.values())
         for c in cast_all:
             c._vitk_weight = True            # ops.is_weight: these get the K-blocked / transposed copies a Parameter gets
-        swap = {n: c for (n, _), c in zip(named, cast_all)}
-        for n, b in self.named_buffers():
+        by_id = dict(zip(uniq.keys(), cast_all))
+        swap = {n: by_id[id(p)] for n, p in named}
+        for n, b in self.named_buffers(remove_duplicate=False):
             if b.dtype == F32 and b.is_cuda and b.is_floating_point():
                 swap[n] = _to(b, dt)
 
@@ -164,13 +177,17 @@ def autocast_aware(forward):
                 return type(v)(conv(u) for u in v)
             return v
 
+        args = tuple(conv(a) for a in args)
+        kwargs = {k: conv(v) for k, v in kwargs.items()}
+        # (the swap is in place for the duration of the call: concurrent forwards of ONE module from several threads would see each
+        # other's 16-bit tensors -- like torch.func.functional_call, not thread-safe per module)
         with torch.autocast("cuda", enabled=False):
             try:
                 from torch.nn.utils.stateless import _reparametrize_module
             except ImportError:       # public route: re-enters __call__ (hooks on the top-level module then fire twice)
-                return torch.func.functional_call(self, swap, (conv(x), *args), kwargs, strict=False)
+                return torch.func.functional_call(self, swap, args, kwargs, strict=False)
             with _reparametrize_module(self, swap, strict=False):
-                return forward(self, conv(x), *args, **kwargs)
+                return forward(self, *args, **kwargs)
 
     return wrapped
 

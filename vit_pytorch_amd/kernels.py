@@ -136,8 +136,14 @@ def gemm_nt_bf16_drop(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: 
                                                    _p(partials), drop_p, drop_seed & 0xffffffff, _stream()), "gemm_nt_bf16_drop")
 
 
-def gemm_nt_colsum_rows(M: int, N: int, K: int, ldc: int) -> int:
-    return int(L.load().vitk_gemm_nt_colsum_rows(M, N, K, ldc))
+def _lib_of(dtype):
+    """The library flavour that will serve operands of `dtype` (None / anything but float16: the bfloat16 library).  The schedule
+    queries below depend on per-library state (vitk_set_cu_reserve), so they must ask the library that will run the GEMM."""
+    return L.load_f16() if dtype == torch.float16 else L.load()
+
+
+def gemm_nt_colsum_rows(M: int, N: int, K: int, ldc: int, dtype=None) -> int:
+    return int(_lib_of(dtype).vitk_gemm_nt_colsum_rows(M, N, K, ldc))
 
 
 def gemm_nt_plan(M: int, N: int, K: int, ldc: int) -> dict:
@@ -176,8 +182,8 @@ def set_cu_reserve(cus: int, dtype=None):
     check(lib.vitk_set_cu_reserve(int(cus)), "set_cu_reserve")
 
 
-def gemm_tn_splits(M: int, N: int, K: int) -> int:
-    return int(L.load().vitk_gemm_tn_splits(M, N, K))
+def gemm_tn_splits(M: int, N: int, K: int, dtype=None) -> int:
+    return int(_lib_of(dtype).vitk_gemm_tn_splits(M, N, K))
 
 
 def gemm_tn_bf16(dY: Tensor, ldy: int, X: Tensor, ldx: int, dW: Tensor, ldo: int, M: int, N: int, K: int,
@@ -186,8 +192,10 @@ def gemm_tn_bf16(dY: Tensor, ldy: int, X: Tensor, ldx: int, dW: Tensor, ldo: int
                                      _p(ws), splits, _stream()), "gemm_tn_bf16")
 
 
-def gemm_tn_pair_splits(M: int, N0: int, K0: int, N1: int, K1: int) -> int:
-    return int(L.load().vitk_gemm_tn_pair_splits(M, N0, K0, N1, K1))
+def gemm_tn_pair_splits(M: int, N0: int, K0: int, N1: int, K1: int, dtype=None) -> int:
+    """Split count of the paired weight-gradient launch, from the library that will run it: the count depends on that library's
+    vitk_set_cu_reserve() and vitk_gemm_tn_bf16_pair insists on its own answer."""
+    return int(_lib_of(dtype).vitk_gemm_tn_pair_splits(M, N0, K0, N1, K1))
 
 
 def gemm_tn_bf16_pair(dY0: Tensor, ldy0: int, X0: Tensor, ldx0: int, dW0: Tensor, dY1: Tensor, ldy1: int, X1: Tensor, ldx1: int, dW1: Tensor,

@@ -365,7 +365,7 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
             raise L.VitkError("linear_dx: gelu_dg goes without gelu_pre / dropout and with a shape gelu_dg_ok accepts")
         dx = empty((M, Kd), T, dy)
         Wt, ldt = nt_weight(W, M, True)
-        R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
+        R = K.gemm_nt_colsum_rows(M, Kd, N, Kd, T)
         part = empty((R * Kd,), F32, dy) if db is not None else None
         K.gemm_nt_bf16_mul_aux_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_dg, part)
         if db is not None:
@@ -381,7 +381,7 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
     if T in HALF and N % 32 == 0 and Kd % 4 == 0:
         Wt, ldt = nt_weight(W, M, True)  # W^T (K, N): makes dX an NT GEMM with reduction dim N contiguous (K-blocked copy or plain transpose)
         if drop is not None:        # backward of dropout(gelu(pre)): same keep decisions, fused with GELU' (and db)
-            R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
+            R = K.gemm_nt_colsum_rows(M, Kd, N, Kd, T)
             if gelu_pre is None or R == 0:
                 raise L.VitkError("linear_dx: fused dropout backward needs gelu_pre and a shape served by the 256-row kernel")
             part = empty((R * Kd,), F32, dy) if db is not None else None
@@ -391,7 +391,7 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
                 return dx, True
             return dx
         if gelu_pre is not None and db is not None:
-            R = K.gemm_nt_colsum_rows(M, Kd, N, Kd)
+            R = K.gemm_nt_colsum_rows(M, Kd, N, Kd, T)
             if R > 0:
                 part = empty((R * Kd,), F32, dy)
                 K.gemm_nt_bf16_gelu_bwd_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_pre, part)
@@ -424,7 +424,7 @@ def linear_dw(dy: Tensor, x: Tensor, M: int, dW: Tensor, db: Optional[Tensor] = 
         ws = empty((splits * N * Kd,), F32, dy)
         K.gemm_tn_bf16(y6, N, x6, Kd, dW, Kd, 6 * M, N, Kd, ws, splits)
     elif dy.dtype in HALF and N % 8 == 0 and Kd % 8 == 0 and ldy % 8 == 0 and ldx % 8 == 0:
-        splits = K.gemm_tn_splits(M, N, Kd)
+        splits = K.gemm_tn_splits(M, N, Kd, dy.dtype)
         ws = empty((splits * N * Kd,), F32, dy)
         K.gemm_tn_bf16(dy, ldy, x, ldx, dW, Kd, M, N, Kd, ws, splits)
     else:
@@ -440,7 +440,7 @@ def linear_dw_pair(dy0: Tensor, x0: Tensor, dW0: Tensor, dy1: Tensor, x1: Tensor
     and 9 x 28, i.e. half the f32 slabs, one launch and one fold less; otherwise two linear_dw calls."""
     (N0, K0), (N1, K1) = dW0.shape, dW1.shape
     if dy0.dtype in HALF and dy1.dtype == dy0.dtype and dW0.dtype == dW1.dtype and dW0.dtype in HALF + (F32,):
-        splits = K.gemm_tn_pair_splits(M, N0, K0, N1, K1)
+        splits = K.gemm_tn_pair_splits(M, N0, K0, N1, K1, dy0.dtype)
         if splits > 0:
             ws = empty((splits * (N0 * K0 + N1 * K1),), F32, dy0)
             K.gemm_tn_bf16_pair(dy0, N0, x0, K0, dW0, dy1, N1, x1, K1, dW1, M, ws, splits)
