@@ -727,118 +727,6 @@ __global__ __launch_bounds__(512) void gemm_nt256pp_kernel(
     }
 }
 
-// TN 256 x 256 output tile, 64 token rows per step, register-staged into padded rows (544 B:
-// 8 consecutive rows hit 8 disjoint 32-byte bank windows for the transpose reads).
-constexpr int LT_BKM = 64;
-constexpr int LT_LD = 544;
-constexpr int LT_TILE_BYTES = LT_BKM * LT_LD;       // 34,816
-constexpr int LT_STAGE_BYTES = 2 * LT_TILE_BYTES;
-constexpr int LT_LDS_BYTES = 2 * LT_STAGE_BYTES;    // 139,264
-
-__device__ __forceinline__ bf16x8 tr_frag_ld(const char* tile, int off, int ld) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off + 16 * ld));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-__global__ __launch_bounds__(512) void gemm_tn256_kernel(
-    const __bf16* __restrict__ dY, long long ldy, const __bf16* __restrict__ X, long long ldx,
-    float* __restrict__ ws, int M, int N, int K, int rows_per_split, int tiles_k, int nwg) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wn = wave >> 2, wk = wave & 3;   // wave tile: 128 (n) x 64 (k)
-    // XCD-aware order over (split, tile) JOINTLY, split-major: each XCD gets a contiguous run of tiles of (mostly)
-    // ONE M-split, i.e. workgroups that read the same dY / X rows at the same time, so a 64-row slice is fetched
-    // from HBM once per XCD and shared through its L2 (measured before: 40% L2 hits, ~1 GB fabric reads / call).
-    const int lin = xcd_swizzle(blockIdx.x, (int)gridDim.x);
-    const int split = lin / nwg;
-    const int wg = lin % nwg;
-    const int tn = wg / tiles_k, tk = wg % tiles_k;
-    const int n0 = tn * 256, k0 = tk * 256;
-    const int mbeg = split * rows_per_split;
-    int mend = mbeg + rows_per_split; mend = mend < M ? mend : M;
-
-    int srow[4], scol[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = tid + 512 * j; srow[j] = c >> 5; scol[j] = (c & 31) * 8; }
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    bf16x8 ry[4], rx[4];
-    auto gload = [&](int mb) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = mb + srow[j];
-            const bool mv = m < mend;
-            ry[j] = (mv && n0 + scol[j] < N) ? *reinterpret_cast<const bf16x8*>(dY + (long long)m * ldy + n0 + scol[j]) : zero8;
-            rx[j] = (mv && k0 + scol[j] < K) ? *reinterpret_cast<const bf16x8*>(X + (long long)m * ldx + k0 + scol[j]) : zero8;
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* base = lds + buf * LT_STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<bf16x8*>(base + srow[j] * LT_LD + scol[j] * 2) = ry[j];
-            *reinterpret_cast<bf16x8*>(base + LT_TILE_BYTES + srow[j] * LT_LD + scol[j] * 2) = rx[j];
-        }
-    };
-
-    const int fi = lane & 15, fg = lane >> 4;
-    const int tr_off = (4 * fg + (fi >> 2)) * LT_LD + (fi & 3) * 8;
-    const int y_off = tr_off + wn * 256;                     // + fn*32 bytes ; + ks*32 rows
-    const int x_off = LT_TILE_BYTES + tr_off + wk * 128;     // + fk*32 bytes
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nsteps = (mend - mbeg + LT_BKM - 1) / LT_BKM;
-    if (nsteps > 0) {
-        gload(mbeg);
-        lstore(0);
-        __syncthreads();
-        for (int t = 0; t < nsteps; ++t) {
-            if (t + 1 < nsteps) gload(mbeg + (t + 1) * LT_BKM);
-            const char* base = lds + (t & 1) * LT_STAGE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xf[4];
-#pragma unroll
-                for (int f = 0; f < 4; ++f) xf[f] = tr_frag_ld(base, x_off + ks * 32 * LT_LD + f * 32, LT_LD);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    bf16x8 yf[4];
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) yf[f] = tr_frag_ld(base, y_off + ks * 32 * LT_LD + (h * 4 + f) * 32, LT_LD);
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-#pragma unroll
-                        for (int fk = 0; fk < 4; ++fk)
-                            acc[h * 4 + f][fk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[f], xf[fk], acc[h * 4 + f][fk], 0, 0, 0);
-                }
-            }
-            if (t + 1 < nsteps) lstore((t + 1) & 1);
-            __syncthreads();
-        }
-    }
-    float* out = ws + (long long)split * N * K;
-#pragma unroll
-    for (int fn = 0; fn < 8; ++fn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn * 128 + fn * 16 + 4 * fg + r;
-            if (n >= N) continue;
-#pragma unroll
-            for (int fk = 0; fk < 4; ++fk) {
-                const int k = k0 + wk * 64 + fk * 16 + fi;
-                if (k < K) out[(long long)n * K + k] = acc[fn][fk][r];
-            }
-        }
-}
-
 template <typename Kern>
 int set_max_lds(Kern kernel, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1127,9 +1015,6 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 }
 }  // namespace
 
-// gemm_tn_dma.hip: the LDS-DMA / ping-pong kernel that serves the large shapes
-int gemm_tn_dma_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* ws, int64_t M, int64_t N, int64_t K,
-                       int64_t splits, void* stream);
 
 bool gemm_tn_w128_serves(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx, int64_t splits);
 int gemm_tn_w128_launch2(const void* dY0, int64_t ldy0, const void* X0, int64_t ldx0, int64_t N0, int64_t K0, const void* dY1, int64_t ldy1,
@@ -1137,7 +1022,7 @@ int gemm_tn_w128_launch2(const void* dY0, int64_t ldy0, const void* X0, int64_t 
 int gemm_tn_w128_launch(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* ws, int64_t M, int64_t N, int64_t K,
                         int64_t splits, void* stream);
 
-static bool tn_large(int64_t M, int64_t N, int64_t K) { return M >= 4096 && N >= 256 && K >= 256 && !getenv("VITK_NO_256"); }
+static bool tn_large(int64_t M, int64_t N, int64_t K) { return M >= 4096 && N >= 256 && K >= 256; }
 
 // CUs to leave to OTHER kernels (an RCCL collective overlapping the backward): the weight-gradient GEMM launches one (tile, M-split)
 // job per workgroup and every job needs a whole CU -- with c CUs taken, c of ~250 jobs of a full-chip launch run as a second
@@ -1178,27 +1063,12 @@ extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int
     if ((ldy & 7) || (ldx & 7) || (ldo & 3) || !aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(ws))
         VITK_FAIL(VITK_E_ALIGN, "gemm_tn_bf16: ldy/ldx %% 8, ldo %% 4 and 16-byte aligned pointers required");
     hipStream_t st = (hipStream_t)stream;
-    // gemm_tn_dma.hip (LDS-DMA ring, ping-pong slots) and gemm_tn256_kernel (register staging) measure level -- 0.975x .. 1.037x box to
-    // box (tools/tn_ab.py): both are bound by the ds_read_b64_tr_b16 issue rate, not by how the tiles reach LDS.  The register-staged
-    // kernel stays the default; VITK_TN_DMA=1 selects the other.
-    // gemm_tn_w128.hip (round 4: four waves, 128 x 128 wave tiles, pinned asm MFMAs, double-buffered fragments) is the default for the
-    // large shapes: x1.3-1.5 over the two 8-wave kernels below (tools/tn_probe.hip); VITK_TN_W128=0 falls back to them for A/B runs.
-    const bool w128_off = getenv("VITK_TN_W128") && atoi(getenv("VITK_TN_W128")) == 0;
-    if (tn_large(M, N, K) && !w128_off && gemm_tn_w128_serves(M, N, K, ldy, ldx, splits)) {
+    // gemm_tn_w128.hip (round 4: four waves, 128 x 128 wave tiles, pinned asm MFMAs, double-buffered fragments) serves the large shapes;
+    // the two 8-wave kernels it replaced (x1.3-1.5 slower: gemm_tn256_kernel, register-staged, rounds 1-3, and gemm_tn_dma.hip) left the
+    // tree in round 5.  Everything else -- small extents, splits whose 32-bit descriptor offsets would overflow -- runs the 128 x 128 kernel.
+    if (tn_large(M, N, K) && gemm_tn_w128_serves(M, N, K, ldy, ldx, splits)) {
         const int rc = gemm_tn_w128_launch(dY, ldy, X, ldx, ws, M, N, K, splits, stream);
         if (rc != 0) return rc;
-    } else if (tn_large(M, N, K) && getenv("VITK_TN_DMA") && atoi(getenv("VITK_TN_DMA"))) {
-        const int rc = gemm_tn_dma_launch(dY, ldy, X, ldx, ws, M, N, K, splits, stream);
-        if (rc != 0) return rc;
-    } else if (tn_large(M, N, K)) {
-        const int tiles_n = (int)((N + 255) / 256), tiles_k = (int)((K + 255) / 256);
-        const int nwg = tiles_n * tiles_k;
-        long long rps = (M + splits - 1) / splits;
-        rps = (rps + LT_BKM - 1) / LT_BKM * LT_BKM;
-        static const int rc__ = set_max_lds(gemm_tn256_kernel, LT_LDS_BYTES);
-        if (rc__ != 0) VITK_FAIL(rc__, "gemm_tn_bf16: cannot enable %d B of LDS", LT_LDS_BYTES);
-        hipLaunchKernelGGL(gemm_tn256_kernel, dim3((unsigned)(nwg * splits)), dim3(512), LT_LDS_BYTES, st, (const __bf16*)dY,
-                           (long long)ldy, (const __bf16*)X, (long long)ldx, ws, (int)M, (int)N, (int)K, (int)rps, tiles_k, nwg);
     } else {
         const int tiles_n = (int)((N + BN - 1) / BN), tiles_k = (int)((K + BM - 1) / BM);
         const int nwg = tiles_n * tiles_k;
@@ -1220,7 +1090,6 @@ extern "C" int vitk_gemm_tn_bf16(const void* dY, int64_t ldy, const void* X, int
 // splits for the pair (0: not served -- call vitk_gemm_tn_bf16 twice): both problems large, the kernel's 32-bit offsets hold
 extern "C" int64_t vitk_gemm_tn_pair_splits(int64_t M, int64_t N0, int64_t K0, int64_t N1, int64_t K1) {
     if (!tn_large(M, N0, K0) || !tn_large(M, N1, K1) || (N0 & 7) || (K0 & 7) || (N1 & 7) || (K1 & 7)) return 0;
-    if (getenv("VITK_TN_W128") && atoi(getenv("VITK_TN_W128")) == 0) return 0;
     // VITK_TN_PAIR=0 switches it off.  [measured, profiles/r04_tn_pair_ab.log, r04_dw_stream_ab.log] with the launches of a step serialized (the
     // default since round 4) the pair is worth 0.2-0.3 ms of the ViT-B/16 step; beside a side stream it LOSES 0.5 ms (the deferred gradient no
     // longer overlaps the attention backward) -- engine.TransformerFn pairs only when its side stream is off.

@@ -56,8 +56,8 @@ struct NtwArgs {
     int M, N, K;
     const __bf16* bias; const void* resid; __bf16* aux; float* csum;
     int tiles_n, group_n, tiles_m, n_tiles, nt;      // FULL interior tiles only: rows [0, 256 tiles_m), N % 256 == 0
-    int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone), bit 1 = strict waits after an epilogue, bit 2 = DMA pieces of all
-                        // waves at the same points of a K-step, bits 8..15 = late start of every second workgroup (x s_sleep 127)
+    int dbg;            // experiments: bit 0 = skip the epilogue (main loop alone), bit 1 = strict waits after an epilogue,
+                        // bits 8..15 = late start of every second workgroup (x s_sleep 127)
 };
 
 template <int OFF> __device__ __forceinline__ bf16x8 v_rd(unsigned lds_addr) {
@@ -74,8 +74,7 @@ template <bool Z> __device__ __forceinline__ void v_mfma(f32x4& c, const bf16x8&
 __device__ __forceinline__ void v_gload_bf16x4(bf16x4& d, const __bf16* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 
 // ABL (experiments, tools/nt_probe.hip): bit 0 no LDS-DMA in the loop, bit 1 no fragment reads, bit 2 no MFMA
-// SG: the DMA pieces of the four waves at different points of a K-step (see V_GROUP); 0 = all waves at the same points (A/B builds)
-template <int EPI, int ABL, int SG>
+template <int EPI, int ABL>
 __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
@@ -173,22 +172,17 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     f32x4 acc[8][8];            // acc[fn][f][j]: row 16 f + 4 fg + j, column 64 (fn >> 2) + 4 fi + (fn & 3) of the wave tile
 
     // one group of a K-step: 4 MFMAs on the current fragments (activation fragment fm x W fragments 4h .. 4h + 3), one fragment of the next
-    // K-step, every second group one DMA piece.  WHERE the piece is issued depends on the wave (ST = 0..3; -1 = all waves after the third
-    // MFMA of the odd groups): [measured, tools/nt_probe: LDS-DMA alone 112 us, MFMA alone 111 us, both 160 us] the four waves run in lock
-    // step between barriers and the CU's texture-address unit takes one 1 KiB piece per ~21 cycles, so four pieces issued at the same
-    // MFMA slot queue behind one another and the last wave's matrix pipe runs dry meanwhile; staggered, wave s issues after the second
-    // (s even) or fourth (s odd) MFMA of the groups of parity s >> 1: one piece per two MFMA slots CU-wide.
+    // K-step, every second group one DMA piece.  [measured, tools/nt_probe, FF1 shape: LDS-DMA alone 112 us, MFMA alone 111 us, both 160-166 us:
+    // the wave's matrix pipe runs dry while a DMA instruction waits to issue.  NOT the waves queueing behind one another at the texture-address
+    // unit: with the four waves' pieces at four different MFMA slots (one piece per two slots CU-wide) the loop ran 165.9 vs 164.9 us.]
 #define V_GROUP(G, Z, XC, WC, XN, WN) do { \
         constexpr int fm_ = (G) >> 1, h_ = ((G) & 1) * 4; \
-        constexpr bool mine_ = ST >= 0 && ((G) & 1) == (ST >> 1); \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 0][fm_], XC[fm_], WC[h_ + 0]); \
         if constexpr (!(ABL & 2)) { if constexpr ((G) < 8) XN[(G)] = v_rd<(G) * 1024>(rdA); else WN[(G) - 8] = v_rd<((G) - 8) * 1024>(rdW); } \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 1][fm_], XC[fm_], WC[h_ + 1]); \
-        if constexpr (!(ABL & 1) && mine_ && !(ST & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 2][fm_], XC[fm_], WC[h_ + 2]); \
-        if constexpr (!(ABL & 1) && ST < 0 && ((G) & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
+        if constexpr (!(ABL & 1) && ((G) & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 3][fm_], XC[fm_], WC[h_ + 3]); \
-        if constexpr (!(ABL & 1) && mine_ && (ST & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
     } while (0)
     // one K-step.  WAIT = the counted vmcnt statement: own pieces of K-step t + 2 landed (t + 3, t + 4 fly)
 #define V_STEP(Z, XC, WC, XN, WN, WAIT) do { \
@@ -231,6 +225,7 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
         asm volatile("" : "+v"(fi), "+v"(fg), "+s"(ewm), "+s"(ewn));
         const int mrow0 = m0 + ewm * 128 + 4 * fg;              // + 16 f + j
         const int ncolw = n0 + ewn * 128;                       // first column of the wave tile
+        const long long obase4 = (long long)mrow0 * p.ldc + ncolw + 4 * fi;      // element (row mrow0, the lane's 4 columns of block 0)
         f32x4 b4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if constexpr (q_has_bias<EPI>()) {
 #pragma unroll
@@ -247,7 +242,9 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
             f32x4 r[D][4];
             auto fetch = [&](int rr_, f32x4 (&dst)[4]) __attribute__((always_inline)) {
                 const int f = rr_ >> 1, qq = rr_ & 1;
-                const float* rp = Rf + (long long)(mrow0 + f * 16) * p.ldc + ncolw + qq * 64 + 4 * fi;
+                long long orow = obase4 + (long long)(f * 16) * p.ldc + qq * 64;
+                asm volatile("" : "+v"(orow));
+                const float* rp = Rf + orow;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) q_gload_f32x4(dst[j], rp + (long long)j * p.ldc);
             };
@@ -262,7 +259,9 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
                 asm volatile("" : "+a"(acc[4 * qq + 0][f]), "+a"(acc[4 * qq + 1][f]), "+a"(acc[4 * qq + 2][f]), "+a"(acc[4 * qq + 3][f]));
                 f32x4 (&rr)[4] = r[R_ % D];
                 q_wait_regs4<q_epi_younger(R_, NR, D, 4)>(rr[0], rr[1], rr[2], rr[3]);
-                float* cp = Cf + (long long)(mrow0 + f * 16) * p.ldc + ncolw + qq * 64 + 4 * fi;
+                long long ocp = obase4 + (long long)(f * 16) * p.ldc + qq * 64;
+                asm volatile("" : "+v"(ocp));
+                float* cp = Cf + ocp;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = f32x4{acc[4 * qq + 0][f][j], acc[4 * qq + 1][f][j], acc[4 * qq + 2][f][j], acc[4 * qq + 3][f][j]} + b4[qq];
@@ -284,7 +283,9 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
             bf16x4 r[D][4];
             auto fetch = [&](int rr_, bf16x4 (&dst)[4]) __attribute__((always_inline)) {
                 const int f = rr_ >> 1, qq = rr_ & 1;
-                const __bf16* rp = Rb + (long long)(mrow0 + f * 16) * p.ldc + ncolw + qq * 64 + 4 * fi;
+                long long orow = obase4 + (long long)(f * 16) * p.ldc + qq * 64;
+                asm volatile("" : "+v"(orow));
+                const __bf16* rp = Rb + orow;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v_gload_bf16x4(dst[j], rp + (long long)j * p.ldc);
             };
@@ -299,7 +300,9 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
                 asm volatile("" : "+a"(acc[4 * qq + 0][f]), "+a"(acc[4 * qq + 1][f]), "+a"(acc[4 * qq + 2][f]), "+a"(acc[4 * qq + 3][f]));
                 bf16x4 (&rr)[4] = r[R_ % D];
                 q_wait_regs4<q_epi_younger(R_, NR, D, 4)>(rr[0], rr[1], rr[2], rr[3]);
-                __bf16* cp = Cb + (long long)(mrow0 + f * 16) * p.ldc + ncolw + qq * 64 + 4 * fi;
+                long long ocp = obase4 + (long long)(f * 16) * p.ldc + qq * 64;
+                asm volatile("" : "+v"(ocp));
+                __bf16* cp = Cb + ocp;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = f32x4{acc[4 * qq + 0][f][j], acc[4 * qq + 1][f][j], acc[4 * qq + 2][f][j], acc[4 * qq + 3][f][j]} + b4[qq];
@@ -317,12 +320,15 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
             // after the pair exchange: even lanes own row r = mrow0 + 16 f + 2 pr, odd lanes row r + 1, columns ncol8 .. + 7 of the block
             const int odd = fi & 1;
             __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
+            const long long obase = (long long)(mrow0 + odd) * p.ldc + ncolw + 8 * (fi >> 1);      // + 16 f ldc + 64 qq + 2 pr ldc
             constexpr bool AUX_IN = (EPI == VITK_EPI_GELU_BWD || EPI == VITK_EPI_MUL_AUX);      // an (M, N) 16-bit operand read in the epilogue
             constexpr int DP = 6;
             bf16x8 hpre[DP][2];
             auto fetch_pre = [&](int rr_, bf16x8 (&dst)[2]) __attribute__((always_inline)) {
                 const int f = rr_ >> 1, qq = rr_ & 1;
-                const __bf16* ap = p.aux + (long long)(mrow0 + f * 16 + odd) * p.ldc + ncolw + qq * 64 + 8 * (fi >> 1);
+                long long oa = obase + (long long)(f * 16) * p.ldc + qq * 64;
+                asm volatile("" : "+v"(oa));        // (opaque: hipcc otherwise forms the addresses of all 16 rows at the top of the epilogue -- 256 VGPRs)
+                const __bf16* ap = p.aux + oa;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) q_gload_bf16x8(dst[pr], ap + (long long)(2 * pr) * p.ldc);
             };
@@ -341,7 +347,8 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
                 V_PIN();
                 asm volatile("" : "+a"(acc[4 * qq + 0][f]), "+a"(acc[4 * qq + 1][f]), "+a"(acc[4 * qq + 2][f]), "+a"(acc[4 * qq + 3][f]));
                 if constexpr (AUX_IN) q_wait_regs2<q_epi_younger(R_, NR, DP, 2)>(hpre[R_ % DP][0], hpre[R_ % DP][1]);
-                const long long o0 = (long long)(mrow0 + f * 16 + odd) * p.ldc + ncolw + qq * 64 + 8 * (fi >> 1);
+                long long o0 = obase + (long long)(f * 16) * p.ldc + qq * 64;
+                asm volatile("" : "+v"(o0));
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     // rows j0 = 2 pr and j0 + 1 of this lane's 4 columns, rounded to the 16-bit type
@@ -452,39 +459,28 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
     } while (0)
 
-    auto tiles = [&](auto st_c) __attribute__((always_inline)) {
-        constexpr int ST = decltype(st_c)::value;
-        for (int idx = l0; idx < count; idx += L) {
-            int m0, n0, mt;
-            decode(idx, m0, n0, mt);
-            // K-steps in pairs (the two fragment sets swap roles); the first K-step writes the accumulators with C = 0
-            V_STEP(true, xa, wa, xb, wb, V_WAITR);
-            V_STEP(false, xb, wb, xa, wa, V_WAITR);
-            for (int kt = 2; kt + 4 < p.nt; kt += 2) {
-                V_STEP(false, xa, wa, xb, wb, V_WAIT16);
-                V_STEP(false, xb, wb, xa, wa, V_WAIT16);
-            }
-            next_src(idx + L);       // the pieces of the last four K-steps are the next tile's first four
+    for (int idx = l0; idx < count; idx += L) {
+        int m0, n0, mt;
+        decode(idx, m0, n0, mt);
+        // K-steps in pairs (the two fragment sets swap roles); the first K-step writes the accumulators with C = 0
+        V_STEP(true, xa, wa, xb, wb, V_WAITR);
+        V_STEP(false, xb, wb, xa, wa, V_WAITR);
+        for (int kt = 2; kt + 4 < p.nt; kt += 2) {
             V_STEP(false, xa, wa, xb, wb, V_WAIT16);
             V_STEP(false, xb, wb, xa, wa, V_WAIT16);
-            V_STEP(false, xa, wa, xb, wb, V_WAIT16);
-            V_STEP(false, xb, wb, xa, wa, V_WAIT16);       // reads the NEXT tile's first fragments
-            // the asm MFMAs' results are complete before the compiler's reads of them (it does not see the MFMAs' latency); nothing is
-            // scheduled across the pin
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-            V_PIN();
-            epilogue(m0, n0, mt);
-            relax = !(p.dbg & 3);
         }
-    };
-    if constexpr (SG) {        // one copy of the tile loop per wave: the DMA slots are compile-time positions in the asm stream
-        switch (wave) {
-            case 0: tiles(std::integral_constant<int, 0>{}); break;
-            case 1: tiles(std::integral_constant<int, 1>{}); break;
-            case 2: tiles(std::integral_constant<int, 2>{}); break;
-            default: tiles(std::integral_constant<int, 3>{}); break;
-        }
-    } else tiles(std::integral_constant<int, -1>{});
+        next_src(idx + L);       // the pieces of the last four K-steps are the next tile's first four
+        V_STEP(false, xa, wa, xb, wb, V_WAIT16);
+        V_STEP(false, xb, wb, xa, wa, V_WAIT16);
+        V_STEP(false, xa, wa, xb, wb, V_WAIT16);
+        V_STEP(false, xb, wb, xa, wa, V_WAIT16);       // reads the NEXT tile's first fragments
+        // the asm MFMAs' results are complete before the compiler's reads of them (it does not see the MFMAs' latency); nothing is
+        // scheduled across the pin
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        V_PIN();
+        epilogue(m0, n0, mt);
+        relax = !(p.dbg & 3);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the surplus DMA pieces must not outlive the workgroup's LDS allocation
 #undef V_WAITR
 #undef V_WAIT16
@@ -548,11 +544,10 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
     const int lds_bytes = V_RING + a.tiles_n * 512 + 16;
     hipStream_t st = (hipStream_t)stream;
     if (tiles_m <= 0 || grid < 8) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16 (w128): nothing to do");
-#define NTW_LAUNCH1(E, AB) do { if (dbg & 4) NTW_LAUNCH2(E, AB, 0); else NTW_LAUNCH2(E, AB, 1); } while (0)
-#define NTW_LAUNCH2(E, AB, SGV) do { \
-        static const int rc__ = v_set_max_lds(gemm_ntw_kernel<E, AB, SGV>, V_LDS_MAX); \
+#define NTW_LAUNCH1(E, AB) do { \
+        static const int rc__ = v_set_max_lds(gemm_ntw_kernel<E, AB>, V_LDS_MAX); \
         if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16 (w128): cannot enable %d B of LDS", V_LDS_MAX); \
-        hipLaunchKernelGGL((gemm_ntw_kernel<E, AB, SGV>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a); \
+        hipLaunchKernelGGL((gemm_ntw_kernel<E, AB>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a); \
     } while (0)
 #ifdef NTW_PROBE
 #define NTW_LAUNCH_ALL(E) do { \
@@ -582,7 +577,6 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
 #undef NTW_LAUNCH_ALL
 #undef NTW_LAUNCH
 #undef NTW_LAUNCH1
-#undef NTW_LAUNCH2
     VITK_CHECK_LAUNCH("gemm_nt_bf16 (w128)");
     return 0;
 }
