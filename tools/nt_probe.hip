@@ -4,7 +4,8 @@
 //   tools/nt_probe.bin [rounds]          (run from the repo root)
 //
 // Kernel under test: vit_pytorch_amd/csrc/gemm_nt_w128.hip (included here with its ablation instances: the product library builds
-// only ABL = 0) -- four waves x 128 x 128 wave tiles, asm-pinned MFMAs, two fragment sets, buffer-descriptor LDS-DMA -- against the
+// only ABL = 0) -- asm-pinned MFMAs, two fragment sets, buffer-descriptor LDS-DMA; four waves x 128 x 128 wave tiles or eight waves x
+// 128 x 64 on the same hand-ordered stream -- against the
 // 8-wave persistent kernel of rounds 2-4 (libvitk.so with VITK_NT_W128=0), at the ViT-B/16 batch-256 shapes (M = 50,432).
 //   * parity: the product path (four-wave launch on the whole rounds + 8-wave launch on the remaining rows) must be BIT-IDENTICAL to the
 //     8-wave kernel alone, per epilogue;
@@ -155,19 +156,19 @@ int main(int argc, char** argv) {
                 if (r) { t_old.push_back(a); t_new.push_back(b); t_dir.push_back(c); }
             }
             const float mo = median(t_old), mn = median(t_new), md = median(t_dir);
-            printf("  %-13s 8-wave %7.1f us %7.1f TF/s | product path %7.1f us %7.1f TF/s (x%.3f) | four-wave alone, all %d m-tiles %7.1f us %7.1f TF/s\n",
+            printf("  %-13s r4 8-wave %7.1f us %7.1f TF/s | product path %7.1f us %7.1f TF/s (x%.3f) | new kernel alone, all %d m-tiles %7.1f us %7.1f TF/s\n",
                    epi_name[epi], mo * 1e3, flop / mo / 1e9, mn * 1e3, flop / mn / 1e9, mo / mn, tm_all, md * 1e3, 2.0 * 256 * tm_all * N * K / md / 1e9);
             if (epi == sh.epis[0] || epi == VITK_EPI_RESID16 || epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_MUL_AUX) { sum_old += mo; sum_new += mn; }
             // ---- ablations of the four-wave launch (all full tiles) ----
             if (epi == VITK_EPI_NONE) {
                 struct Ab { const char* name; int abl, dbg; };
-                const Ab abs[] = {{"all (DMA pieces staggered by wave)", 0, 0}, {"all, pieces of all waves at the same points", 0, 4},
-                                  {"strict waits after the epilogue", 0, 2}, {"main loop alone (no epilogue)", 0, 1},
-                                  {"main loop alone, same points", 0, 5}, {"LDS-DMA only", 6, 1}, {"LDS-DMA only, same points", 6, 5}, {"MFMA only", 3, 1},
-                                  {"fragment reads only", 5, 1}, {"DMA + MFMA", 2, 1}, {"DMA + MFMA, same points", 2, 5}, {"empty loop", 7, 1},
-                                  {"epilogue only (empty loop + stores)", 7, 0}, {"odd workgroups start 2 x 3.4 us late", 0, 2 << 8},
-                                  {"odd workgroups start 3 x 3.4 us late", 0, 3 << 8}, {"odd workgroups start 4 x 3.4 us late", 0, 4 << 8},
-                                  {"odd workgroups start 6 x 3.4 us late", 0, 6 << 8}, {"odd workgroups start 6 late, strict waits", 0, (6 << 8) | 2}};
+                const Ab abs[] = {{"8 waves: all", 0, 0}, {"8 waves: strict waits after the epilogue", 0, 2}, {"8 waves: main loop alone (no epilogue)", 0, 1},
+                                  {"8 waves: LDS-DMA only", 6, 1}, {"8 waves: MFMA only", 3, 1}, {"8 waves: fragment reads only", 5, 1},
+                                  {"8 waves: DMA + MFMA", 2, 1}, {"8 waves: reads + MFMA", 1, 1}, {"8 waves: empty loop", 7, 1},
+                                  {"8 waves: epilogue only (empty loop + stores)", 7, 0},
+                                  {"4 waves: all", 0, 4}, {"4 waves: strict waits after the epilogue", 0, 6}, {"4 waves: main loop alone (no epilogue)", 0, 5},
+                                  {"4 waves: LDS-DMA only", 6, 5}, {"4 waves: MFMA only", 3, 5}, {"4 waves: DMA + MFMA", 2, 5}, {"4 waves: reads + MFMA", 1, 5},
+                                  {"4 waves: epilogue only (empty loop + stores)", 7, 4}};
                 for (const Ab& ab : abs) {
                     std::vector<float> t;
                     for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
@@ -175,9 +176,8 @@ int main(int argc, char** argv) {
                 }
             } else if (epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_MUL_AUX || epi == VITK_EPI_RESID16) {
                 struct Ab { const char* name; int abl, dbg; };
-                const Ab abs[] = {{"epilogue only (empty loop + epilogue)", 7, 0}, {"strict waits after the epilogue", 0, 2}, {"pieces of all waves at the same points", 0, 4},
-                                  {"odd workgroups start 3 x 3.4 us late", 0, 3 << 8}, {"odd workgroups start 5 x 3.4 us late", 0, 5 << 8},
-                                  {"odd workgroups start 7 x 3.4 us late", 0, 7 << 8}, {"odd workgroups start 5 late, strict waits", 0, (5 << 8) | 2}};
+                const Ab abs[] = {{"8 waves: epilogue only (empty loop + epilogue)", 7, 0}, {"8 waves: strict waits after the epilogue", 0, 2},
+                                  {"4 waves: all", 0, 4}, {"4 waves: epilogue only (empty loop + epilogue)", 7, 4}, {"4 waves: strict waits after the epilogue", 0, 6}};
                 for (const Ab& ab : abs) {
                     std::vector<float> t;
                     for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
