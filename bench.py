@@ -424,6 +424,8 @@ def main():
             c["ms"] += kms_ * kn_; c["flops"] += kfl_ * kn_; c["launches"] += kn_
             c["inst"].append(((cls, n_, k_), kms_, kfl_, kn_))
 
+        balance = round(peak * 1e12 / 6.3e12, 1)
+
         def inst_entry(key, kms_, kfl_, kn_):
             tr, alg, src = (None, None, None) if args.fp8 else pmc_traffic_bytes(key)
             ach_ = kfl_ / (kms_ * 1e-3) / 1e12
@@ -431,13 +433,16 @@ def main():
                  "avg_launch_ms": round(kms_, 4), "launches_per_step": kn_, "traffic": tr, "algorithmic_bytes": alg, "traffic_source": src}
             if alg and kfl_:       # which roof the bytes say: FLOP per algorithmic byte against the machine balance (peak / 6.3 TB/s)
                 e["flop_per_byte"] = round(kfl_ / alg, 1)
+                if e["flop_per_byte"] < balance:        # a balanced / HBM-side instance is priced against BOTH roofs
+                    e["hbm_frac"] = round(alg / (kms_ * 1e-3) / 6.3e12, 4)
             return e
 
         ranked = sorted(classes.items(), key=lambda kv: -kv[1]["ms"])
         dom_cls, dom = ranked[0]
         dkey, dms_, dfl_, dn_ = max(dom["inst"], key=lambda t: t[1] * t[3])
         dent = inst_entry(dkey, dms_, dfl_, dn_)
-        balance = round(peak * 1e12 / 6.3e12, 1)
+        dom_ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12          # the CLASS: all its launches of the step (not its best instance)
+        dom_avg_ms = dom["ms"] / dom["launches"]
         others = []
         for cls, c in ranked:
             ach_c = c["flops"] / (c["ms"] * 1e-3) / 1e12
@@ -476,10 +481,15 @@ def main():
                       "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
                       **({"frac_note": "whole-step fraction is of the bf16 peak 2516.6 TF/s (the number comparable with the bf16 line); of the fp8 roof named in `roof` it is "
                                        + str(round(value / world * gf / 1e3 / peak, 4))} if args.fp8 else {})},
-            "roofline": {"bound": "mfma", "kernel": CLASS_NAMES.get(dom_cls, dom_cls) + f": heaviest class of the step ({round(dom['ms'] / ms * 100, 1)} % of it), "
-                                                      f"timed instance {dent['shape']}",
-                         "achieved": dent["achieved"], "peak": peak, "unit": "TFLOP/s", "roof": roof_name, "frac": dent["frac"],
-                         "avg_launch_ms": dent["avg_launch_ms"], "launches_timed": dent["launches_per_step"] * 3,
+            "roofline": {"bound": "mfma", "kernel": CLASS_NAMES.get(dom_cls, dom_cls) + f": heaviest class of the step ({round(dom['ms'] / ms * 100, 1)} % of it); "
+                                                      f"achieved / frac / avg_launch_ms are the CLASS's (algorithmic flops of all its launches / their summed durations), "
+                                                      f"heaviest_instance is {dent['shape']}",
+                         "achieved": round(dom_ach, 2), "peak": peak, "unit": "TFLOP/s", "roof": roof_name, "frac": round(dom_ach / peak, 4),
+                         "avg_launch_ms": round(dom_avg_ms, 4), "launches_timed": dom["launches"] * 3,
+                         "heaviest_instance": dent,
+                         "worst_class": (lambda wc: {"class": wc["class"], "frac": wc["frac"], "achieved": wc["achieved"], "ms_per_step": wc["ms_per_step"],
+                                                     **({"hbm_frac": wc["heaviest_instance"]["hbm_frac"]} if "hbm_frac" in wc["heaviest_instance"] else {})})(
+                                            min(others, key=lambda o: o["frac"])),
                          "timed_in": "3 extra steps after the timed region, weight-gradient side stream off (serialized launches); a class's share_of_step = its "
                                      "serialized kernel time per step / the measured step",
                          "traffic": dent["traffic"], "algorithmic_bytes": dent["algorithmic_bytes"], "traffic_source": dent["traffic_source"],

@@ -284,14 +284,9 @@ def test_gemm_nt_rejects_bad_shapes():
 
 @pytest.mark.parametrize("M,N,Kd", [(4096, 256, 256), (5000, 768, 768), (6304, 2304, 768), (4500, 264, 520), (64, 128, 128), (1000, 768, 768), (197 * 16, 2304, 768), (333, 136, 72), (197 * 8, 768, 3072), (5000, 64, 256)])
 @pytest.mark.parametrize("odt", [BF, F32])
-@pytest.mark.parametrize("variant", ["default", "w128_off", "VITK_TN_DMA"])
-def test_gemm_tn(M, N, Kd, odt, variant, monkeypatch):
-    """variant: the default (large shapes: gemm_tn_w128.hip, four waves with 128 x 128 wave tiles), the register-staged 8-wave kernel
-    (VITK_TN_W128=0) or gemm_tn_dma.hip (8 waves, LDS-DMA ring)."""
-    if variant != "default":
-        monkeypatch.setenv("VITK_TN_W128", "0")
-    if variant == "VITK_TN_DMA":
-        monkeypatch.setenv("VITK_TN_DMA", "1")
+def test_gemm_tn(M, N, Kd, odt):
+    """Large shapes: gemm_tn_w128.hip (four waves with 128 x 128 wave tiles); the rest: the 128 x 128 kernel.  (The two 8-wave kernels of
+    rounds 1-3 that VITK_TN_W128=0 / VITK_TN_DMA=1 used to select left the tree in round 5.)"""
     dY = rnd(M, N, dtype=BF, seed=51) * (M ** -0.5); X = rnd(M, Kd, dtype=BF, seed=52)
     ref = dY.double().t() @ X.double()
     splits = K.gemm_tn_splits(M, N, Kd)

@@ -4,8 +4,7 @@
 //   tools/nt_probe.bin [rounds]          (run from the repo root)
 //
 // Kernel under test: vit_pytorch_amd/csrc/gemm_nt_w128.hip (included here with its ablation instances: the product library builds
-// only ABL = 0) -- asm-pinned MFMAs, two fragment sets, buffer-descriptor LDS-DMA; four waves x 128 x 128 wave tiles or eight waves x
-// 128 x 64 on the same hand-ordered stream -- against the
+// only ABL = 0) -- four waves x 128 x 128 wave tiles, asm-pinned MFMAs, two fragment sets, buffer-descriptor LDS-DMA -- against the
 // 8-wave persistent kernel of rounds 2-4 (libvitk.so with VITK_NT_W128=0), at the ViT-B/16 batch-256 shapes (M = 50,432).
 //   * parity: the product path (four-wave launch on the whole rounds + 8-wave launch on the remaining rows) must be BIT-IDENTICAL to the
 //     8-wave kernel alone, per epilogue;
@@ -87,7 +86,7 @@ int main(int argc, char** argv) {
         const int64_t R = 2 * ((M + 127) / 128) + 8;
         Buf cs0 = dalloc(R * N * 4), cs1 = dalloc(R * N * 4);
         const double flop = 2.0 * M * N * K;
-        const int tm_all = (int)(M / 256), tm_split = probe_ntw_split(M, N, grid);
+        const int tm_all = (int)(M / 256), tm_split = probe_ntw_split(M, N, K, grid);
         printf("\n== %s: %d full m-tiles x %lld n-tiles = %.2f rounds; product split: four-wave %d m-tiles, 8-wave %lld rows ==\n", sh.name, tm_all,
                (long long)(N / 256), (double)tm_all * (N / 256) / grid, tm_split, (long long)(M - 256LL * tm_split));
         for (int epi : sh.epis) {
@@ -162,22 +161,31 @@ int main(int argc, char** argv) {
             // ---- ablations of the four-wave launch (all full tiles) ----
             if (epi == VITK_EPI_NONE) {
                 struct Ab { const char* name; int abl, dbg; };
-                const Ab abs[] = {{"8 waves: all", 0, 0}, {"8 waves: strict waits after the epilogue", 0, 2}, {"8 waves: main loop alone (no epilogue)", 0, 1},
-                                  {"8 waves: LDS-DMA only", 6, 1}, {"8 waves: MFMA only", 3, 1}, {"8 waves: fragment reads only", 5, 1},
-                                  {"8 waves: DMA + MFMA", 2, 1}, {"8 waves: reads + MFMA", 1, 1}, {"8 waves: empty loop", 7, 1},
-                                  {"8 waves: epilogue only (empty loop + stores)", 7, 0},
-                                  {"4 waves: all", 0, 4}, {"4 waves: strict waits after the epilogue", 0, 6}, {"4 waves: main loop alone (no epilogue)", 0, 5},
-                                  {"4 waves: LDS-DMA only", 6, 5}, {"4 waves: MFMA only", 3, 5}, {"4 waves: DMA + MFMA", 2, 5}, {"4 waves: reads + MFMA", 1, 5},
-                                  {"4 waves: epilogue only (empty loop + stores)", 7, 4}};
+                const Ab abs[] = {{"all", 0, 0}, {"strict waits after the epilogue", 0, 2}, {"main loop alone (no epilogue)", 0, 1},
+                                  {"LDS-DMA only", 6, 1}, {"MFMA only", 3, 1}, {"fragment reads only", 5, 1}, {"DMA + MFMA", 2, 1}, {"reads + MFMA", 1, 1},
+                                  {"empty loop", 7, 1}, {"epilogue only (empty loop + stores)", 7, 0}};
                 for (const Ab& ab : abs) {
                     std::vector<float> t;
                     for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
                     printf("      %-42s %7.1f us\n", ab.name, median(t) * 1e3);
                 }
+                // the same launches on ZERO operands: same instruction stream and addresses, no toggling in the matrix cores / data paths -- what
+                // the chip's power management (DVFS) takes from the random-data numbers above
+                Buf Az = dalloc(M * K * 2), Wz = dalloc(vitk_pack_w_nt_bytes(N, K));
+                CK(hipMemset(Az.p, 0, Az.n)); CK(hipMemset(Wz.p, 0, Wz.n));
+                auto direct_z = [&](int abl, int dbg) {
+                    VK(probe_ntw_launch(tm_all, grid, Az.p, K, Wz.p, 0, C1.p, N, N, K, epi, nullptr, nullptr, nullptr, nullptr, abl, dbg, nullptr));
+                };
+                const Ab zs[] = {{"ZERO operands: all", 0, 0}, {"ZERO operands: main loop alone", 0, 1}, {"ZERO operands: MFMA only", 3, 1}, {"ZERO operands: DMA + MFMA", 2, 1}};
+                for (const Ab& ab : zs) {
+                    std::vector<float> t;
+                    for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct_z(ab.abl, ab.dbg); }, 10));
+                    printf("      %-42s %7.1f us\n", ab.name, median(t) * 1e3);
+                }
+                CK(hipFree(Az.p)); CK(hipFree(Wz.p));
             } else if (epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_MUL_AUX || epi == VITK_EPI_RESID16) {
                 struct Ab { const char* name; int abl, dbg; };
-                const Ab abs[] = {{"8 waves: epilogue only (empty loop + epilogue)", 7, 0}, {"8 waves: strict waits after the epilogue", 0, 2},
-                                  {"4 waves: all", 0, 4}, {"4 waves: epilogue only (empty loop + epilogue)", 7, 4}, {"4 waves: strict waits after the epilogue", 0, 6}};
+                const Ab abs[] = {{"epilogue only (empty loop + epilogue)", 7, 0}, {"strict waits after the epilogue", 0, 2}};
                 for (const Ab& ab : abs) {
                     std::vector<float> t;
                     for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));

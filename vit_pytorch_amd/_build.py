@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitk.so")
 LIB_F16 = os.path.join(HERE, "libvitk_f16.so")
-SOURCES = ["elementwise.hip", "layernorm.hip", "gemm_bf16.hip", "gemm_nt_persist.hip", "gemm_nt_w128.hip", "gemm_tn_dma.hip", "gemm_tn_w128.hip", "gemm_tn_fp8.hip", "gemm_generic.hip", "attention.hip", "attention_pipe.hip", "attention_varlen.hip", "comm.hip"]
+SOURCES = ["elementwise.hip", "layernorm.hip", "gemm_bf16.hip", "gemm_nt_persist.hip", "gemm_nt_w128.hip", "gemm_tn_w128.hip", "gemm_tn_fp8.hip", "gemm_generic.hip", "attention.hip", "attention_pipe.hip", "attention_varlen.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_nt_plan.h"), os.path.join(CSRC, "gemm_nt_epi.h"), os.path.join(CSRC, "attention_pipe.h"), os.path.join(CSRC, "attention_frag.h"), os.path.join(os.path.dirname(HERE), "include", "vitk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -854,7 +854,7 @@ extern "C" int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, cons
 static int ntw_tiles_m(const NtpPlan& q, int64_t M, int64_t N, int64_t K) {
     const char* e = getenv("VITK_NT_W128");
     if (!q.ok || (e && e[0] == '0') || vitk_get_cu_reserve() > 0 || !gemm_ntw_serves(M, N, K)) return 0;
-    return gemm_ntw_split(M, N, q.grid);
+    return gemm_ntw_split(M, N, K, q.grid);
 }
 static int64_t nt_persist_colsum_rows(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int64_t ldc) {
     const int tmw = ntw_tiles_m(q, M, N, K);

@@ -30,6 +30,6 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
 
 // the four-wave kernel (gemm_nt_w128.hip): full 256-row tiles only, rows [0, 256 tiles_m); `resid` is f32 (EPI_RESID) or 16-bit (EPI_RESID16)
 bool gemm_ntw_serves(int64_t M, int64_t N, int64_t K);
-int gemm_ntw_split(int64_t M, int64_t N, int grid);
+int gemm_ntw_split(int64_t M, int64_t N, int64_t K, int grid);
 int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                     int64_t N, int64_t K, int epilogue, const void* bias, const void* resid, void* aux, float* csum, int abl, int dbg, void* stream);

@@ -74,24 +74,14 @@ template <bool Z> __device__ __forceinline__ void v_mfma(f32x4& c, const bf16x8&
 __device__ __forceinline__ void v_gload_bf16x4(bf16x4& d, const __bf16* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 
 // ABL (experiments, tools/nt_probe.hip): bit 0 no LDS-DMA in the loop, bit 1 no fragment reads, bit 2 no MFMA
-// NW: 4 waves (one per SIMD, wave tile 128 x 128: 256 accumulator registers, the 512-register budget) or 8 waves (two per SIMD, wave tile
-// 128 x 64: 128 accumulator registers, 256-register budget) running the SAME hand-ordered stream.  [measured, tools/nt_probe, 4 waves: the
-// matrix pipe of a SIMD idles while its only wave waits to issue an LDS-DMA instruction (~70 cycles each, 8 per 64 MFMAs: LDS-DMA alone 112 us,
-// MFMA alone 111 us, both 165 us at the FF1 shape) -- with two waves per SIMD the partner's MFMAs fill those gaps, and the epilogue's VALU work
-// issues at twice the rate.]
-template <int EPI, int ABL, int NW>
-__device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
+template <int EPI, int ABL>
+__global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
-    constexpr int NB = NW == 4 ? 2 : 1;         // 64-column blocks per wave
-    constexpr int FN = 4 * NB;                  // W fragments per wave
-    constexpr int PA = 16 / NW;                 // DMA pieces of each operand per wave and K-step
-    constexpr int PW = 2 * PA;                  // DMA pieces per wave and K-step
-    constexpr bool REREAD = NW == 8 && (EPI == VITK_EPI_GELU_BWD || EPI == VITK_EPI_MUL_AUX);      // see the tile loop
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? (wave & 1) : (wave & 3);
+    const int wm = wave >> 1, wn = wave & 1;
 
     // ---- this workgroup's tiles (gemm_nt_persist.hip's static lists): XCD x owns a contiguous run of the main list and of the tail
     //      list; its workgroups take every L-th tile of the concatenation ----
@@ -114,12 +104,11 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
     // block are then 4 consecutive output columns); K-blocked W (ldw == 0) IS that image, block (n-tile, K-step) after block.
     const int srow = lane >> 2, spos = lane & 3;
     const int schunk = spos ^ v_swz(lane >> 4);
-    int avo[PA], wvo[PA];
+    int avo[4], wvo[4];
 #pragma unroll
-    for (int j = 0; j < PA; ++j) {
-        const int pi = PA * wave + j;       // piece = LDS rows 16 pi .. 16 pi + 15 of the operand tile
-        avo[j] = (int)(((long long)(16 * pi + srow) * p.lda + schunk * 8) * 2);
-        wvo[j] = p.ldw == 0 ? pi * 1024 + lane * 16 : (int)(((long long)(64 * (pi >> 2) + 4 * srow + (pi & 3)) * p.ldw + schunk * 8) * 2);
+    for (int j = 0; j < 4; ++j) {
+        avo[j] = (int)(((long long)(64 * wave + 16 * j + srow) * p.lda + schunk * 8) * 2);
+        wvo[j] = p.ldw == 0 ? (4 * wave + j) * 1024 + lane * 16 : (int)(((long long)(64 * wave + 4 * srow + j) * p.ldw + schunk * 8) * 2);
     }
     const int w_kstride = p.ldw == 0 ? V_TILE : 64;     // bytes between consecutive K-steps
     __amdgpu_buffer_rsrc_t a_rs, w_rs;
@@ -137,12 +126,11 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
         }
         a_so = 0; w_so = 0;
     };
-    // piece q (0 .. PW - 1) of the producer's K-step into stage `stg`: q < PA activation piece PA w + q, else W piece PA w + q - PA
+    // piece q of the producer's K-step into stage `stg`: q < 4 activation piece 4w + q, else W piece 4w + q - 4
     auto dma = [&](int stg, int q) __attribute__((always_inline)) {
-        const int j = q < PA ? q : q - PA;
-        char* dst = lds + stg * V_STAGE + (q >= PA ? V_TILE : 0) + (wave * PA + j) * 1024;
-        if (q < PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (void __attribute__((address_space(3)))*)dst, 16, avo[j], a_so, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (void __attribute__((address_space(3)))*)dst, 16, wvo[j], w_so, 0, 0);
+        char* dst = lds + stg * V_STAGE + (q >= 4 ? V_TILE : 0) + (wave * 4 + (q & 3)) * 1024;
+        if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (void __attribute__((address_space(3)))*)dst, 16, avo[q & 3], a_so, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (void __attribute__((address_space(3)))*)dst, 16, wvo[q & 3], w_so, 0, 0);
     };
     // after the 8 pieces of a K-step.  The producer changes tile at a FIXED point of the consumer's tile (before its K-step nt - 4: the stream
     // runs four K-steps ahead), so no K-step carries a tile-switch test.  Past the end of the tile list the descriptors have range 0: the
@@ -161,7 +149,7 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
     const char* bias_lds = lds + V_RING;
     if constexpr (q_has_bias<EPI>()) {
         const int ncols = p.tiles_n * 256;
-        for (int i = tid * 8; i < ncols; i += NW * 64 * 8) {
+        for (int i = tid * 8; i < ncols; i += 256 * 8) {
             bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (p.bias && i < p.N) v = *reinterpret_cast<const bf16x8*>(p.bias + i);
             *reinterpret_cast<bf16x8*>(lds + V_RING + i * 2) = v;
@@ -176,23 +164,25 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
         const int fi = lane & 15, fg = lane >> 4;
         const int fpos = fg ^ v_swz(fi >> 2);
         a_rd = lds_base + (wm * 128 + fi) * 64 + fpos * 16;
-        w_rd = lds_base + V_TILE + (wn * 64 * NB + fi) * 64 + fpos * 16;
+        w_rd = lds_base + V_TILE + (wn * 128 + fi) * 64 + fpos * 16;
     }
 
     int stg = 0;                // K-step counter mod 4: the stage whose fragments are in registers (the DMA of this K-step refills it)
-    bf16x8 xa[8], wa[FN], xb[8], wb[FN];
-    f32x4 acc[FN][8];           // acc[fn][f][j]: row 16 f + 4 fg + j, column 64 (fn >> 2) + 4 fi + (fn & 3) of the wave tile
+    bf16x8 xa[8], wa[8], xb[8], wb[8];
+    f32x4 acc[8][8];            // acc[fn][f][j]: row 16 f + 4 fg + j, column 64 (fn >> 2) + 4 fi + (fn & 3) of the wave tile
 
     // one group of a K-step: 4 MFMAs on the current fragments (activation fragment fm x W fragments 4h .. 4h + 3), one fragment of the next
     // K-step, every second group one DMA piece.  [measured, tools/nt_probe, FF1 shape: LDS-DMA alone 112 us, MFMA alone 111 us, both 160-166 us:
     // the wave's matrix pipe runs dry while a DMA instruction waits to issue.  NOT the waves queueing behind one another at the texture-address
-    // unit: with the four waves' pieces at four different MFMA slots (one piece per two slots CU-wide) the loop ran 165.9 vs 164.9 us.]
+    // unit: with the four waves' pieces at four different MFMA slots (one piece per two slots CU-wide) the loop ran 165.9 vs 164.9 us.  NOR
+    // the lone wave of a SIMD being stuck at the issue: the same stream on EIGHT waves (two per SIMD, 128 x 64 wave tiles, the partner's MFMAs
+    // in the gaps) ran 169 vs 165 us, its epilogues level too (profiles/r05c_nt_probe_8wave_vs_4wave.log; the flavour was not kept).  What is
+    // left is the chip: matrix cores and the LDS-DMA feed at full rate together draw more than either alone (DVFS, MI355X_MICROARCH.md).]
 #define V_GROUP(G, Z, XC, WC, XN, WN) do { \
-        constexpr int fm_ = NW == 4 ? (G) >> 1 : (G), h_ = NW == 4 ? ((G) & 1) * 4 : 0; \
+        constexpr int fm_ = (G) >> 1, h_ = ((G) & 1) * 4; \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 0][fm_], XC[fm_], WC[h_ + 0]); \
         if constexpr (!(ABL & 2)) { if constexpr ((G) < 8) XN[(G)] = v_rd<(G) * 1024>(rdA); else WN[(G) - 8] = v_rd<((G) - 8) * 1024>(rdW); } \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 1][fm_], XC[fm_], WC[h_ + 1]); \
-        if constexpr (!(ABL & 2) && NW == 8 && (G) < 4) WN[(G)] = v_rd<(G) * 1024>(rdW); \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 2][fm_], XC[fm_], WC[h_ + 2]); \
         if constexpr (!(ABL & 1) && ((G) & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
         if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 3][fm_], XC[fm_], WC[h_ + 3]); \
@@ -204,10 +194,8 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
         __builtin_amdgcn_s_setprio(1); \
         V_GROUP(0, Z, XC, WC, XN, WN); V_GROUP(1, Z, XC, WC, XN, WN); V_GROUP(2, Z, XC, WC, XN, WN); V_GROUP(3, Z, XC, WC, XN, WN); \
         V_GROUP(4, Z, XC, WC, XN, WN); V_GROUP(5, Z, XC, WC, XN, WN); V_GROUP(6, Z, XC, WC, XN, WN); V_GROUP(7, Z, XC, WC, XN, WN); \
-        if constexpr (NW == 4) { \
-            V_GROUP(8, Z, XC, WC, XN, WN); V_GROUP(9, Z, XC, WC, XN, WN); V_GROUP(10, Z, XC, WC, XN, WN); V_GROUP(11, Z, XC, WC, XN, WN); \
-            V_GROUP(12, Z, XC, WC, XN, WN); V_GROUP(13, Z, XC, WC, XN, WN); V_GROUP(14, Z, XC, WC, XN, WN); V_GROUP(15, Z, XC, WC, XN, WN); \
-        } \
+        V_GROUP(8, Z, XC, WC, XN, WN); V_GROUP(9, Z, XC, WC, XN, WN); V_GROUP(10, Z, XC, WC, XN, WN); V_GROUP(11, Z, XC, WC, XN, WN); \
+        V_GROUP(12, Z, XC, WC, XN, WN); V_GROUP(13, Z, XC, WC, XN, WN); V_GROUP(14, Z, XC, WC, XN, WN); V_GROUP(15, Z, XC, WC, XN, WN); \
         __builtin_amdgcn_s_setprio(0); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the next K-step's fragments are in registers */ \
         if constexpr (!(ABL & 1)) { WAIT; } \
@@ -217,17 +205,17 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
         if constexpr (!(ABL & 1)) advance(); \
         stg = (stg + 1) & 3; \
     } while (0)
-#define V_WAIT16 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory")      /* two K-steps of own pieces may fly */
+#define V_WAIT16 asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
 
     // ---- epilogue of one tile: registers -> global, full lines, stores not waited for ----
     // the 8-wave kernel's, over the wave's two 64-column blocks: "row" r = 2 f + qq covers fragment row f (4 output rows per lane) of
     // block qq.  Every tile is interior (the launch takes full tiles only), so operand rows come by uncounted asm loads D rows ahead
     // and are waited for by exact counts (gemm_nt_epi.h).
     auto epilogue = [&](int m0, int n0, int mt) __attribute__((always_inline)) {
-        constexpr int NR = 8 * NB;          // rows: r = 2 f + qq (4 waves), r = f (8 waves)
+        constexpr int NR = 16;
         if ((p.dbg & 1) || (ABL & 8)) {
 #pragma unroll
-            for (int i = 0; i < FN; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) asm volatile("" :: "a"(acc[i][j]));
             return;
@@ -239,12 +227,12 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
         int fi = elane & 15, fg = elane >> 4, ewm = wm, ewn = wn;
         asm volatile("" : "+v"(fi), "+v"(fg), "+s"(ewm), "+s"(ewn));
         const int mrow0 = m0 + ewm * 128 + 4 * fg;              // + 16 f + j
-        const int ncolw = n0 + ewn * (64 * NB);                 // first column of the wave tile
+        const int ncolw = n0 + ewn * 128;                       // first column of the wave tile
         const long long obase4 = (long long)mrow0 * p.ldc + ncolw + 4 * fi;      // element (row mrow0, the lane's 4 columns of block 0)
-        f32x4 b4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};     // [qq]
+        f32x4 b4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if constexpr (q_has_bias<EPI>()) {
 #pragma unroll
-            for (int qq = 0; qq < NB; ++qq) {
+            for (int qq = 0; qq < 2; ++qq) {
                 const bf16x4 bb = *reinterpret_cast<const bf16x4*>(bias_lds + (ncolw + qq * 64 + 4 * fi) * 2);
                 b4[qq] = f32x4{(float)bb[0], (float)bb[1], (float)bb[2], (float)bb[3]};
             }
@@ -253,10 +241,10 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
             // lane: rows mrow0 + 16 f + j, 4 consecutive f32 columns: 16 lanes = 256 contiguous bytes of a row
             float* Cf = reinterpret_cast<float*>(p.C);
             const float* Rf = reinterpret_cast<const float*>(p.resid);
-            constexpr int D = NW == 4 ? 4 : 2;          // fragment rows of the residual in flight (16 VGPRs each)
+            constexpr int D = 4;
             f32x4 r[D][4];
             auto fetch = [&](int rr_, f32x4 (&dst)[4]) __attribute__((always_inline)) {
-                const int f = NB == 2 ? rr_ >> 1 : rr_, qq = NB == 2 ? rr_ & 1 : 0;
+                const int f = rr_ >> 1, qq = rr_ & 1;
                 long long orow = obase4 + (long long)(f * 16) * p.ldc + qq * 64;
                 asm volatile("" : "+v"(orow));
                 const float* rp = Rf + orow;
@@ -267,7 +255,7 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
             for (int i = 0; i < D; ++i) fetch(i, r[i]);
             auto row = [&](auto rc) __attribute__((always_inline)) {
                 constexpr int R_ = decltype(rc)::value;
-                constexpr int f = NB == 2 ? R_ >> 1 : R_, qq = NB == 2 ? R_ & 1 : 0;
+                constexpr int f = R_ >> 1, qq = R_ & 1;
                 // hipcc places the AGPR -> VGPR copy of an asm output right behind its DEFINITION (here: the last MFMAs, inside their latency,
                 // all 256 of them live through the epilogue, ~90 registers of it in scratch): re-define the row's accumulators here
                 V_PIN();
@@ -287,19 +275,17 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
             };
             row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
             row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
-            if constexpr (NR == 16) {
-                row(std::integral_constant<int, 8>{}); row(std::integral_constant<int, 9>{}); row(std::integral_constant<int, 10>{}); row(std::integral_constant<int, 11>{});
-                row(std::integral_constant<int, 12>{}); row(std::integral_constant<int, 13>{}); row(std::integral_constant<int, 14>{}); row(std::integral_constant<int, 15>{});
-            }
+            row(std::integral_constant<int, 8>{}); row(std::integral_constant<int, 9>{}); row(std::integral_constant<int, 10>{}); row(std::integral_constant<int, 11>{});
+            row(std::integral_constant<int, 12>{}); row(std::integral_constant<int, 13>{}); row(std::integral_constant<int, 14>{}); row(std::integral_constant<int, 15>{});
         } else if constexpr (EPI == VITK_EPI_RESID16) {
             // the residual epilogue with the stream in the 16-bit type: lane -> (row, 4 columns), 8-byte loads and stores (16 lanes = 128
             // contiguous bytes of a row); the sum is formed in f32 and rounded once
             __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
             const __bf16* Rb = reinterpret_cast<const __bf16*>(p.resid);
-            constexpr int D = NW == 4 ? 6 : 4;          // (8 VGPRs each)
+            constexpr int D = 6;
             bf16x4 r[D][4];
             auto fetch = [&](int rr_, bf16x4 (&dst)[4]) __attribute__((always_inline)) {
-                const int f = NB == 2 ? rr_ >> 1 : rr_, qq = NB == 2 ? rr_ & 1 : 0;
+                const int f = rr_ >> 1, qq = rr_ & 1;
                 long long orow = obase4 + (long long)(f * 16) * p.ldc + qq * 64;
                 asm volatile("" : "+v"(orow));
                 const __bf16* rp = Rb + orow;
@@ -310,7 +296,7 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
             for (int i = 0; i < D; ++i) fetch(i, r[i]);
             auto row = [&](auto rc) __attribute__((always_inline)) {
                 constexpr int R_ = decltype(rc)::value;
-                constexpr int f = NB == 2 ? R_ >> 1 : R_, qq = NB == 2 ? R_ & 1 : 0;
+                constexpr int f = R_ >> 1, qq = R_ & 1;
                 // hipcc places the AGPR -> VGPR copy of an asm output right behind its DEFINITION (here: the last MFMAs, inside their latency,
                 // all 256 of them live through the epilogue, ~90 registers of it in scratch): re-define the row's accumulators here
                 V_PIN();
@@ -331,20 +317,18 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
             };
             row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
             row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
-            if constexpr (NR == 16) {
-                row(std::integral_constant<int, 8>{}); row(std::integral_constant<int, 9>{}); row(std::integral_constant<int, 10>{}); row(std::integral_constant<int, 11>{});
-                row(std::integral_constant<int, 12>{}); row(std::integral_constant<int, 13>{}); row(std::integral_constant<int, 14>{}); row(std::integral_constant<int, 15>{});
-            }
+            row(std::integral_constant<int, 8>{}); row(std::integral_constant<int, 9>{}); row(std::integral_constant<int, 10>{}); row(std::integral_constant<int, 11>{});
+            row(std::integral_constant<int, 12>{}); row(std::integral_constant<int, 13>{}); row(std::integral_constant<int, 14>{}); row(std::integral_constant<int, 15>{});
         } else {
             // after the pair exchange: even lanes own row r = mrow0 + 16 f + 2 pr, odd lanes row r + 1, columns ncol8 .. + 7 of the block
             const int odd = fi & 1;
             __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
             const long long obase = (long long)(mrow0 + odd) * p.ldc + ncolw + 8 * (fi >> 1);      // + 16 f ldc + 64 qq + 2 pr ldc
             constexpr bool AUX_IN = (EPI == VITK_EPI_GELU_BWD || EPI == VITK_EPI_MUL_AUX);      // an (M, N) 16-bit operand read in the epilogue
-            constexpr int DP = NW == 4 ? 6 : (EPI == VITK_EPI_GELU_BWD ? 2 : 3);         // (8 VGPRs each)
+            constexpr int DP = 6;
             bf16x8 hpre[DP][2];
             auto fetch_pre = [&](int rr_, bf16x8 (&dst)[2]) __attribute__((always_inline)) {
-                const int f = NB == 2 ? rr_ >> 1 : rr_, qq = NB == 2 ? rr_ & 1 : 0;
+                const int f = rr_ >> 1, qq = rr_ & 1;
                 long long oa = obase + (long long)(f * 16) * p.ldc + qq * 64;
                 asm volatile("" : "+v"(oa));        // (opaque: hipcc otherwise forms the addresses of all 16 rows at the top of the epilogue -- 256 VGPRs)
                 const __bf16* ap = p.aux + oa;
@@ -360,7 +344,7 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
             for (int e = 0; e < 8; ++e) { cs[0][e] = 0.f; cs[1][e] = 0.f; }
             auto frow = [&](auto rc) __attribute__((always_inline)) {
                 constexpr int R_ = decltype(rc)::value;
-                constexpr int f = NB == 2 ? R_ >> 1 : R_, qq = NB == 2 ? R_ & 1 : 0;
+                constexpr int f = R_ >> 1, qq = R_ & 1;
                 // hipcc places the AGPR -> VGPR copy of an asm output right behind its DEFINITION (here: the last MFMAs, inside their latency,
                 // all 256 of them live through the epilogue, ~90 registers of it in scratch): re-define the row's accumulators here
                 V_PIN();
@@ -408,16 +392,14 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
             };
             frow(std::integral_constant<int, 0>{}); frow(std::integral_constant<int, 1>{}); frow(std::integral_constant<int, 2>{}); frow(std::integral_constant<int, 3>{});
             frow(std::integral_constant<int, 4>{}); frow(std::integral_constant<int, 5>{}); frow(std::integral_constant<int, 6>{}); frow(std::integral_constant<int, 7>{});
-            if constexpr (NR == 16) {
-                frow(std::integral_constant<int, 8>{}); frow(std::integral_constant<int, 9>{}); frow(std::integral_constant<int, 10>{}); frow(std::integral_constant<int, 11>{});
-                frow(std::integral_constant<int, 12>{}); frow(std::integral_constant<int, 13>{}); frow(std::integral_constant<int, 14>{}); frow(std::integral_constant<int, 15>{});
-            }
+            frow(std::integral_constant<int, 8>{}); frow(std::integral_constant<int, 9>{}); frow(std::integral_constant<int, 10>{}); frow(std::integral_constant<int, 11>{});
+            frow(std::integral_constant<int, 12>{}); frow(std::integral_constant<int, 13>{}); frow(std::integral_constant<int, 14>{}); frow(std::integral_constant<int, 15>{});
             if constexpr (AUX_IN) {
                 if (p.csum) {
                     // bias gradient by-product: the 8 lanes (c ^ 1, 4 row groups) that own the same 8 columns are summed in
                     // registers; one partial row per (m-tile, wm)
 #pragma unroll
-                    for (int qq = 0; qq < NB; ++qq) {
+                    for (int qq = 0; qq < 2; ++qq) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             float v = cs[qq][e];
@@ -446,10 +428,10 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int q = 0; q < PW; ++q) dma(s, q);
+            for (int q = 0; q < 8; ++q) dma(s, q);
             advance();
         }
-        V_WAIT16;
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     }
     V_PIN();
     __builtin_amdgcn_s_barrier();           // also publishes the bias image
@@ -459,7 +441,7 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
         xa[0] = v_rd<0 * 1024>(rdA); xa[1] = v_rd<1 * 1024>(rdA); xa[2] = v_rd<2 * 1024>(rdA); xa[3] = v_rd<3 * 1024>(rdA);
         xa[4] = v_rd<4 * 1024>(rdA); xa[5] = v_rd<5 * 1024>(rdA); xa[6] = v_rd<6 * 1024>(rdA); xa[7] = v_rd<7 * 1024>(rdA);
         wa[0] = v_rd<0 * 1024>(rdW); wa[1] = v_rd<1 * 1024>(rdW); wa[2] = v_rd<2 * 1024>(rdW); wa[3] = v_rd<3 * 1024>(rdW);
-        if constexpr (NW == 4) { wa[4] = v_rd<4 * 1024>(rdW); wa[5] = v_rd<5 * 1024>(rdW); wa[6] = v_rd<6 * 1024>(rdW); wa[7] = v_rd<7 * 1024>(rdW); }
+        wa[4] = v_rd<4 * 1024>(rdW); wa[5] = v_rd<5 * 1024>(rdW); wa[6] = v_rd<6 * 1024>(rdW); wa[7] = v_rd<7 * 1024>(rdW);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     V_PIN();
@@ -467,17 +449,20 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
     V_PIN();
     if constexpr (ABL & 2) {
 #pragma unroll
-        for (int f = 0; f < 8; ++f) { xb[f] = xa[f]; if (f < FN) wb[f] = wa[f]; }
+        for (int f = 0; f < 8; ++f) { xb[f] = xa[f]; wb[f] = wa[f]; }
     }
 
     // the first two K-steps after an epilogue: its stores may stay in flight behind the two K-steps' worth of DMA pieces the wait is
     // about (vmcnt retires in order and counts to 63); the first tile has nothing but DMA pieces in flight
     constexpr int ST_ROW = (F32OUT || EPI == VITK_EPI_RESID16 || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_GELU_DG) ? 4 : 2;   // stores per epilogue row
-    constexpr int VM_RELAX = 2 * PW + 8 * NB * ST_ROW > 63 ? 63 : 2 * PW + 8 * NB * ST_ROW;
+    constexpr int VM_RELAX = 16 + 16 * ST_ROW > 63 ? 63 : 16 + 16 * ST_ROW;
+    // [measured, tools/nt_probe, strict vs exact-count waits: plain 16-bit stores (QKV) 155 vs 151 us; every epilogue that also READS rows
+    //  or stores two tensors is level or better strict (FF1 shape 216 vs 231, dFF1 271 vs 275, out-projection 69.9 vs 76.6)]
+    constexpr bool RELAX_OK = (EPI == VITK_EPI_NONE || EPI == VITK_EPI_BIAS);
     bool relax = false;
 #define V_WAITR do { \
         if (relax) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_RELAX) : "memory"); \
-        else V_WAIT16; \
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
     } while (0)
 
     for (int idx = l0; idx < count; idx += L) {
@@ -500,16 +485,7 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         V_PIN();
         epilogue(m0, n0, mt);
-        relax = !(p.dbg & 3);
-        if constexpr (REREAD) {
-            // 8 waves, an (M, N) operand read in the epilogue: 128 VGPRs do not hold the next tile's first fragments (48) beside the epilogue's
-            // prefetched rows; they are read again here (their stage is refilled only by the K-step that follows) instead of living in scratch
-            const unsigned rdA = a_rd + stg * V_STAGE, rdW = w_rd + stg * V_STAGE;
-            xa[0] = v_rd<0 * 1024>(rdA); xa[1] = v_rd<1 * 1024>(rdA); xa[2] = v_rd<2 * 1024>(rdA); xa[3] = v_rd<3 * 1024>(rdA);
-            xa[4] = v_rd<4 * 1024>(rdA); xa[5] = v_rd<5 * 1024>(rdA); xa[6] = v_rd<6 * 1024>(rdA); xa[7] = v_rd<7 * 1024>(rdA);
-            wa[0] = v_rd<0 * 1024>(rdW); wa[1] = v_rd<1 * 1024>(rdW); wa[2] = v_rd<2 * 1024>(rdW); wa[3] = v_rd<3 * 1024>(rdW);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        relax = RELAX_OK && !(p.dbg & 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the surplus DMA pieces must not outlive the workgroup's LDS allocation
 #undef V_WAITR
@@ -518,29 +494,9 @@ __device__ __forceinline__ void gemm_ntw_body(const NtwArgs& p) {
 #undef V_GROUP
 }
 
-// (two entry points: hipcc emits no host stub for a kernel template whose __launch_bounds__ depends on a template parameter)
-template <int EPI, int ABL> __global__ __launch_bounds__(256) void gemm_ntw4_kernel(const NtwArgs p) { gemm_ntw_body<EPI, ABL, 4>(p); }
-template <int EPI, int ABL> __global__ __launch_bounds__(512) void gemm_ntw8_kernel(const NtwArgs p) { gemm_ntw_body<EPI, ABL, 8>(p); }
-
 template <typename Kern>
 int v_set_max_lds(Kern kernel, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-
-// one instance per (epilogue, ablation, waves); the GELU' epilogue exists on four waves only (see gemm_ntw_launch)
-template <int E, int AB, int NWV>
-int v_launch(const NtwArgs& a, int grid, int lds_bytes, hipStream_t st) {
-    if constexpr (NWV == 8 && E == VITK_EPI_GELU_BWD) return VITK_E_ARG;
-    else if constexpr (NWV == 8) {
-        static const int rc = v_set_max_lds(gemm_ntw8_kernel<E, AB>, V_LDS_MAX);
-        if (rc != 0) return rc;
-        hipLaunchKernelGGL((gemm_ntw8_kernel<E, AB>), dim3((unsigned)grid), dim3(512), lds_bytes, st, a);
-    } else {
-        static const int rc = v_set_max_lds(gemm_ntw4_kernel<E, AB>, V_LDS_MAX);
-        if (rc != 0) return rc;
-        hipLaunchKernelGGL((gemm_ntw4_kernel<E, AB>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
-    }
-    return 0;
 }
 
 }  // namespace
@@ -554,18 +510,21 @@ bool gemm_ntw_serves(int64_t M, int64_t N, int64_t K) {
 }
 
 // how many of the floor(M / 256) full m-tiles go to the four-wave launch.  Rounds = tiles / resident workgroups; a last round that is
-// mostly idle is cheaper as 128-row tiles of the 8-wave kernel (cost model in units of one 256-row tile of the four-wave kernel:
-// a 128-row tile of the 8-wave kernel ~0.6, plus ~0.15 of a tile for the second launch).
-int gemm_ntw_split(int64_t M, int64_t N, int grid) {
+// mostly idle is cheaper as 128-row tiles of the 8-wave kernel -- if a tile is long enough to pay for the second launch.  Cost model in
+// units of one 256-row tile of the four-wave kernel (~0.72 us per K-step + 6 us): a 128-row tile of the 8-wave kernel ~0.6, the second
+// launch ~14 us [measured, tools/nt_probe: FF1 (K = 768, 9.23 rounds) 216 us in one launch vs 230 split; FF2 (K = 3072, 2.31 rounds) 226 vs
+// 220; the out-projection (K = 768, 2.31 rounds) 70.0 vs 72.1].
+int gemm_ntw_split(int64_t M, int64_t N, int64_t K, int grid) {
     const long long tiles_n = N / 256;
     // the rows left over go to the 8-wave persistent kernel, which takes M >= 1024: none, or at least 1024
     const long long tm_cap = (M % 256 == 0) ? M / 256 : (M - 1024) / 256;
     if (tm_cap <= 0) return 0;
+    const double second_launch = 14.0 / (0.72 * (double)(K / 32) + 6.0);
     auto legal = [&](long long tm) { const long long rest = M - 256 * tm; return tm > 0 && tm <= tm_cap && (rest == 0 || rest >= 1024); };
     auto cost = [&](long long tm) -> double {
         const long long rest = M - 256 * tm;
         double c = (double)((tm * tiles_n + grid - 1) / grid);
-        if (rest > 0) c += 0.15 + 0.6 * (double)((((rest + 127) / 128) * tiles_n + grid - 1) / grid);
+        if (rest > 0) c += second_launch + 0.6 * (double)((((rest + 127) / 128) * tiles_n + grid - 1) / grid);
         return c;
     };
     long long best_tm = 0;
@@ -581,8 +540,6 @@ int gemm_ntw_split(int64_t M, int64_t N, int grid) {
 
 int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                     int64_t N, int64_t K, int epilogue, const void* bias, const void* resid, void* aux, float* csum, int abl, int dbg, void* stream) {
-    // dbg bit 2: the four-wave flavour (also the GELU' epilogue's: its polynomial + exponential do not fit 128 VGPRs beside the prefetched rows)
-    const int waves = ((dbg & 4) || epilogue == VITK_EPI_GELU_BWD) ? 4 : 8;
     NtwArgs a;
     a.A = (const char*)A; a.lda = lda; a.W = (const char*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
     a.M = 256 * tiles_m; a.N = (int)N; a.K = (int)K;
@@ -597,8 +554,9 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
     hipStream_t st = (hipStream_t)stream;
     if (tiles_m <= 0 || grid < 8) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16 (w128): nothing to do");
 #define NTW_LAUNCH1(E, AB) do { \
-        const int rc__ = waves == 8 ? v_launch<E, AB, 8>(a, grid, lds_bytes, st) : v_launch<E, AB, 4>(a, grid, lds_bytes, st); \
+        static const int rc__ = v_set_max_lds(gemm_ntw_kernel<E, AB>, V_LDS_MAX); \
         if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16 (w128): cannot enable %d B of LDS", V_LDS_MAX); \
+        hipLaunchKernelGGL((gemm_ntw_kernel<E, AB>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a); \
     } while (0)
 #ifdef NTW_PROBE
 #define NTW_LAUNCH_ALL(E) do { \
