@@ -31,7 +31,7 @@ sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from oracle.params import (CASES, NAVIT_CASES, NAVIT_WIDE_CASES, VARIANT_CASES, WIDE_CASES, make_params_for, make_images, make_navit_images, make_navit_params, make_params,  # noqa: E402
+from oracle.params import (CASES, NAVIT_BENCH_CASES, NAVIT_CASES, NAVIT_WIDE_CASES, navit_bench_sizes, VARIANT_CASES, WIDE_CASES, make_params_for, make_images, make_navit_images, make_navit_params, make_params,  # noqa: E402
                            sample_index)
 from oracle.vit_oracle import loss_fn  # noqa: E402
 
@@ -188,9 +188,49 @@ def main_navit_wide():
         print(f"{name}: logits {tuple(out.shape)} {len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def main_navit_bench():
+    """NaViT on the BENCH workload's image draw (oracle/params.py::NAVIT_BENCH_CASES): a flat list of 65 images, grouped by the
+    reference itself (group_images=True, group_max_seq_len=4096); compact golden, f32 and the reference's own bf16 run."""
+    import gc
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    mod = load_ref("na_vit")
+    for name, case in NAVIT_BENCH_CASES.items():
+        if ONLY and name not in ONLY:
+            continue
+        sizes = navit_bench_sizes()
+        params = make_navit_params(case["cfg"], case["seed"])
+        images = make_navit_images(case["cfg"], [sizes], case["seed"] + 1000)[0]        # one flat list
+        res = {}
+        for dtype in (torch.float32, torch.bfloat16):
+            model = mod.NaViT(**case["cfg"])
+            model.load_state_dict(params, strict=True)
+            model = model.to(dtype).eval()
+            out = model([im.to(dtype) for im in images], group_images=True, group_max_seq_len=case["group_max_seq_len"])
+            loss_fn(out.float()).backward()
+            res[dtype] = (out.detach().float(), {k: p.grad.detach().float() for k, p in model.named_parameters()})
+            del model, out
+            gc.collect()
+        out, grads = res[torch.float32]
+        out16, grads16 = res[torch.bfloat16]
+        blob = {"logits": out.numpy(), "bf16::logits": out16.numpy(), "sizes": np.asarray(sizes, dtype=np.int64)}
+        for k, g in grads.items():
+            idx = sample_index(g.numel(), case["sample"])
+            blob["gnorm::" + k] = np.float64(g.double().norm().item())
+            blob["gsample::" + k] = g.flatten().numpy()[idx]
+            blob["bf16::gsample::" + k] = grads16[k].flatten().numpy()[idx]
+        path = os.path.join(outdir, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(f"{name}: {len(sizes)} images, logits {tuple(out.shape)} {len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 if __name__ == "__main__":
+    if ONLY and all(n in NAVIT_BENCH_CASES for n in ONLY):
+        main_navit_bench()
+        sys.exit(0)
     main()
     main_navit()
     main_wide()
     main_variants()
     main_navit_wide()
+    main_navit_bench()

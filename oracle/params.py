@@ -282,6 +282,29 @@ NAVIT_CASES = {
 # BASELINE config 4 at its real width (dim 1024, 16 heads, mlp 4096, patch 16), depth 2: ONE pack of exactly 4,096 tokens from 32
 # images of mixed resolutions (256, 128, 64, 16 and 32 patches).  Compact golden (logits + norms and samples of every gradient),
 # reference in f32 and the reference's own bf16 run (make_golden.main_navit_wide).
+def navit_bench_sizes():
+    """The image sizes of bench.py --config navit (BASELINE config 4's bench workload): a*16 x b*16 px with a, b ~ U{4..40} from
+    numpy default_rng(0) until >= 32,768 tokens: 65 images, grouped into 9 packs of <= 4,096 tokens by group_images (na_vit.py:38-77)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    sizes, tok = [], 0
+    while tok < 32768:
+        a, b = rng.integers(4, 41, 2)
+        sizes.append((int(a) * 16, int(b) * 16)); tok += int(a) * int(b)
+    return sizes
+
+
+# The BENCH workload of config 4 (the 65-image / 9-pack draw) through the reference at config 4's width -- at depth 1: the reference's
+# masked attention materialises (packs, heads, 4096, 4096) f32 scores and keeps ~3 of them per layer for backward, ~30 GB per layer for
+# this draw, so the depth-24 run the bench times needs ~700 GB of host memory (this container has 62).  What depth 1 pins is everything
+# that is specific to the bench workload: the greedy grouping of the flat list, nine ragged packs at once, the per-image attention
+# pooling and the factorised positions at sizes up to 640 px; depth is pinned by the full-depth ViT goldens on the same kernels.
+NAVIT_BENCH_CASES = {
+    "navit_bench_draw_d12": dict(
+        seed=43, sample=1024, flat=True, group_max_seq_len=4096,
+        cfg=dict(image_size=1024, patch_size=16, num_classes=1000, dim=1024, depth=12, heads=16, mlp_dim=4096)),
+}
+
 NAVIT_WIDE_CASES = {
     "navit_cfg4_width": dict(
         seed=41, sample=1024,

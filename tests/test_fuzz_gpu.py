@@ -6,7 +6,9 @@ kernels, the 16-bit stream's shape rule, ...).  Every draw below lands somewhere
 (numpy RandomState(seed)), so a failure names a configuration that can be re-run alone.
 
 Tolerances (floating point): f32 mode <= 1e-3 relative L2 on logits and on the concatenated gradient (north star); bf16 mode by
-the rule of test_parity_gpu.py -- at most 1.5x the error of the oracle's own pure-bf16 run on the same inputs, + 1e-3."""
+the rule of test_parity_gpu.py -- at most 1.5x the error of the oracle's own pure-bf16 run on the same inputs, + 1e-3 -- AND an absolute
+cap of 2e-2 on the concatenated gradient (ABS_CAP): the reference's own bf16 gradient error grows with M (2e-1 at the headline batch), where
+the relative rule alone would pass almost anything; the drop-in accumulates in f32 everywhere and is held to the cap."""
 import numpy as np
 import pytest
 import torch
@@ -21,6 +23,7 @@ from vit_pytorch_amd.na_vit import NaViT  # noqa: E402
 
 DEV = "cuda"
 N_DRAWS = 40
+ABS_CAP = 2e-2          # concatenated bf16 gradient vs the f32 oracle, beside the 1.5x-of-reference-bf16 rule
 
 
 def rel(a, b):
@@ -84,7 +87,7 @@ def test_random_configuration_f32_and_bf16_vs_oracle(seed):
     e, e_ref = rel(out, ref_out), rel(bf_out, ref_out)
     g, g_ref = rel(cat(grads), cat(ref_g)), rel(cat(bf_g), cat(ref_g))
     print(f"draw {seed}: {kind} {cfg} batch {batch}: bf16 logits {e:.2e} (reference-bf16 {e_ref:.2e}), grads {g:.2e} ({g_ref:.2e})")
-    assert e <= 1.5 * e_ref + 1e-3 and g <= 1.5 * g_ref + 1e-3, ("bf16", kind, cfg, batch, e, e_ref, g, g_ref)
+    assert e <= 1.5 * e_ref + 1e-3 and g <= min(1.5 * g_ref + 1e-3, ABS_CAP), ("bf16", kind, cfg, batch, e, e_ref, g, g_ref)
 
 
 def draw_navit(seed: int):
@@ -124,7 +127,7 @@ def test_random_navit_packs_vs_oracle(seed):
         else:
             e_ref, g_ref = rel(bf_out, ref_out), rel(cat(bf_g), cat(ref_g))
             print(f"navit draw {seed}: {cfg} {packs}: bf16 logits {e:.2e} ({e_ref:.2e}), grads {g:.2e} ({g_ref:.2e})")
-            assert e <= 1.5 * e_ref + 1e-3 and g <= 1.5 * g_ref + 1e-3, ("bf16", cfg, packs, e, e_ref, g, g_ref)
+            assert e <= 1.5 * e_ref + 1e-3 and g <= min(1.5 * g_ref + 1e-3, ABS_CAP), ("bf16", cfg, packs, e, e_ref, g, g_ref)
 
 
 # ---- the same draws through the other modes of the drop-in -------------------------------------------------------------------------
@@ -179,7 +182,7 @@ def test_random_configuration_op_by_op_path(seed):
     e, g, e_ref, g_ref = _errors(kind, cfg, batch, seed, runner)
     assert len(seen) == cfg["depth"]
     assert all(torch.allclose(s, torch.ones_like(s), atol=2e-2) for s in seen)
-    assert e <= 1.5 * e_ref + 1e-3 and g <= 1.5 * g_ref + 1e-3, (kind, cfg, batch, e, e_ref, g, g_ref)
+    assert e <= 1.5 * e_ref + 1e-3 and g <= min(1.5 * g_ref + 1e-3, ABS_CAP), (kind, cfg, batch, e, e_ref, g, g_ref)
 
 
 @pytest.mark.parametrize("seed", range(0, N_DRAWS, 4))
@@ -205,12 +208,12 @@ def test_random_configuration_inference_modes(seed):
     assert all(p.grad is not None for p in m.parameters() if p.numel())
 
 
-@pytest.mark.parametrize("seed", [2, 4, 7, 12, 19, 29, 31, 35])
+@pytest.mark.parametrize("seed", [2, 4, 7, 12, 19, 29, 31, 35, 42, 46, 70, 87, 92, 117, 154, 160, 161, 177, 190])
 def test_random_configuration_fp8_operands(seed):
     """enable_fp8 on draws whose token count reaches the large-M kernels (the fp8 GEMMs serve K % 64 == 0 shapes on the 256-row
-    kernel; everything else of such a model stays on the 16-bit kernels -- of these eight seeds only draw 7 engages the fp8 GEMMs
-    (ops.fp8_gemm_ok); the other engaging draws below 200 -- 42, 46, 70, 87, 92, 117, 154, 160, 161, 177, 190 -- run through the host logic
-    with the doubles in tests/test_fuzz_host_logic.py and are the next seeds to add here once a GPU run has seen them).  Gate: the self-stated fp8 tolerance of
+    kernel; everything else of such a model stays on the 16-bit kernels).  Of the first eight seeds only draw 7 engages the fp8 GEMMs
+    (ops.fp8_gemm_ok); seeds 42, 46, 70, 87, 92, 117, 154, 160, 161, 177, 190 are the other draws below 200 that do (the same draws run through the
+    host logic with the kernel doubles in tests/test_fuzz_host_logic.py).  Gate: the self-stated fp8 tolerance of
     test_fp8_gpu.py -- 3e-2 logits / 5e-2 concatenated gradient against the f32 oracle (no north-star figure exists for fp8)."""
     from vit_pytorch_amd.fp8 import enable_fp8
     kind, cfg, batch = draw(seed)
@@ -278,7 +281,7 @@ def test_random_configuration_under_engine_switches(seed, flags, monkeypatch):
         monkeypatch.setenv(k, v)
     kind, cfg, batch = draw(seed)
     e, g, e_ref, g_ref = _errors(kind, cfg, batch, seed, run_mine)
-    assert e <= 1.5 * e_ref + 1e-3 and g <= 1.5 * g_ref + 1e-3, (_FLAG_SETS[flags], kind, cfg, batch, e, e_ref, g, g_ref)
+    assert e <= 1.5 * e_ref + 1e-3 and g <= min(1.5 * g_ref + 1e-3, ABS_CAP), (_FLAG_SETS[flags], kind, cfg, batch, e, e_ref, g, g_ref)
 
 
 @pytest.mark.parametrize("seed", range(8, 20))
