@@ -294,11 +294,12 @@ def navit_bench_sizes():
     return sizes
 
 
-# The BENCH workload of config 4 (the 65-image / 9-pack draw) through the reference at config 4's width -- at depth 1: the reference's
-# masked attention materialises (packs, heads, 4096, 4096) f32 scores and keeps ~3 of them per layer for backward, ~30 GB per layer for
-# this draw, so the depth-24 run the bench times needs ~700 GB of host memory (this container has 62).  What depth 1 pins is everything
-# that is specific to the bench workload: the greedy grouping of the flat list, nine ragged packs at once, the per-image attention
-# pooling and the factorised positions at sizes up to 640 px; depth is pinned by the full-depth ViT goldens on the same kernels.
+# The BENCH workload of config 4 (the 65-image / 9-pack draw of bench.py --config navit, ~33 k tokens) through the reference at config 4's
+# width -- at depth 12, half of the depth the bench times: the reference's masked attention keeps (packs, heads, 4096, 4096) score tensors for
+# the backward, 44 GiB peak at depth 12 in f32 on this container's 62 GiB (depth 16 did not fit).  It pins what is specific to the bench
+# workload -- the greedy grouping of the flat list, nine ragged packs at once, per-image attention pooling, factorised positions at sizes up to
+# 640 px -- at a depth where 16-bit error has accumulated over twelve layers; the remaining depth is pinned by the 24-layer ViT-L/16 golden on
+# the same kernels.
 NAVIT_BENCH_CASES = {
     "navit_bench_draw_d12": dict(
         seed=43, sample=1024, flat=True, group_max_seq_len=4096,

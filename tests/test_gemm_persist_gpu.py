@@ -10,7 +10,6 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-os.environ["VITK_NTP_EPIS"] = "31"      # every epilogue on the persistent kernel (the default leaves plain stores on the per-tile one)
 
 from vit_pytorch_amd import kernels as K  # noqa: E402
 from vit_pytorch_amd import _lib as L  # noqa: E402
@@ -54,17 +53,6 @@ def _all_epilogues(M, N, Kd, A, W, bias, resid, h):
     K.gemm_nt_bf16_gelu_bwd_colsum(A, Kd, W, Kd, C2, N, M, N, Kd, h, part)
     out["gbwd"] = C2; out["part"] = part.view(R, N)
     return out
-
-
-def test_slot_main_loop_in_a_subprocess():
-    """The R/M-slot flavour of the main loop (VITK_NTP_PIPE=0 is read once per process): same checks on two shapes."""
-    import subprocess, sys
-    code = ("import os, tests.test_gemm_persist_gpu as t\n"
-            "for s in [(12608, 768, 768), (9000, 1000, 32), (4100, 2304, 128)]: t.test_persistent_nt_against_float64(*s)\nprint('slot-ok')")
-    env = dict(os.environ, VITK_NTP_PIPE="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "slot-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("M,N,Kd", SHAPES)

@@ -12,7 +12,6 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-os.environ.setdefault("VITK_NTP_EPIS", "31")
 
 from vit_pytorch_amd import kernels as K  # noqa: E402
 from vit_pytorch_amd import _lib as L  # noqa: E402

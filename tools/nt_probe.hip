@@ -163,7 +163,8 @@ int main(int argc, char** argv) {
                 struct Ab { const char* name; int abl, dbg; };
                 const Ab abs[] = {{"all", 0, 0}, {"strict waits after the epilogue", 0, 2}, {"main loop alone (no epilogue)", 0, 1},
                                   {"LDS-DMA only", 6, 1}, {"MFMA only", 3, 1}, {"fragment reads only", 5, 1}, {"DMA + MFMA", 2, 1}, {"reads + MFMA", 1, 1},
-                                  {"empty loop", 7, 1}, {"epilogue only (empty loop + stores)", 7, 0}};
+                                  {"empty loop", 7, 1}, {"epilogue only (empty loop + stores)", 7, 0},
+                                  {"32x32x16 MFMAs (timing only): main loop", 8, 1}, {"32x32x16 MFMAs: DMA + MFMA", 10, 1}, {"32x32x16 MFMAs: MFMA only", 11, 1}};
                 for (const Ab& ab : abs) {
                     std::vector<float> t;
                     for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
@@ -176,7 +177,8 @@ int main(int argc, char** argv) {
                 auto direct_z = [&](int abl, int dbg) {
                     VK(probe_ntw_launch(tm_all, grid, Az.p, K, Wz.p, 0, C1.p, N, N, K, epi, nullptr, nullptr, nullptr, nullptr, abl, dbg, nullptr));
                 };
-                const Ab zs[] = {{"ZERO operands: all", 0, 0}, {"ZERO operands: main loop alone", 0, 1}, {"ZERO operands: MFMA only", 3, 1}, {"ZERO operands: DMA + MFMA", 2, 1}};
+                const Ab zs[] = {{"ZERO operands: all", 0, 0}, {"ZERO operands: main loop alone", 0, 1}, {"ZERO operands: MFMA only", 3, 1}, {"ZERO operands: DMA + MFMA", 2, 1},
+                                 {"ZERO operands: 32x32x16 main loop", 8, 1}};
                 for (const Ab& ab : zs) {
                     std::vector<float> t;
                     for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct_z(ab.abl, ab.dbg); }, 10));

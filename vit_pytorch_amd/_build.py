@@ -63,9 +63,14 @@ def _build_one(lib: str, bdir: str, extra, force: bool, verbose: bool) -> str:
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
-    """libvitk.so (16-bit type = bfloat16) and libvitk_f16.so (same sources, 16-bit type = IEEE half)."""
-    _build_one(LIB_F16, os.path.join(CSRC, "build", "f16"), ["-DVITK_HALF_IS_F16=1"], force, verbose)
-    return _build_one(LIB, os.path.join(CSRC, "build"), [], force, verbose)
+    """libvitk.so (16-bit type = bfloat16) and libvitk_f16.so (same sources, 16-bit type = IEEE half).
+
+    VITK_BUILD_EXPERIMENTS=1 compiles the experiment knobs in (vitk_exp() in csrc/common.h: tile orders, cost-model constants, debug
+    stamps -- what the tools/ scripts of rounds 2-4 switch); the product build reads only the switches README.md lists."""
+    exp = ["-DVITK_EXPERIMENTS=1"] if os.environ.get("VITK_BUILD_EXPERIMENTS", "0") not in ("0", "") else []
+    sub = "exp" if exp else ""
+    _build_one(LIB_F16, os.path.join(CSRC, "build", sub, "f16"), ["-DVITK_HALF_IS_F16=1", *exp], force, verbose)
+    return _build_one(LIB, os.path.join(CSRC, "build", sub), exp, force, verbose)
 
 
 if __name__ == "__main__":

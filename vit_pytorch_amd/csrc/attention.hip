@@ -586,7 +586,7 @@ int attn_shape_check(const char* name, int64_t B, int64_t H, int64_t N, int64_t 
 // chains in flight (112 VGPRs, two workgroups per CU still fit).  Backward: one -- two tiles need 158 / 218 VGPRs, which
 // halves the occupancy and measured slower (ViT-B shapes: 0.259 ms vs 0.276 / 0.283 ms).  VITK_ATTN_R_* override (tests).
 int tiles_per_wave(const char* env, bool prefer2, int64_t N) {
-    if (const char* e = getenv(env)) return atoi(e) == 2 ? 2 : 1;
+    if (const char* e = vitk_switch(env)) return atoi(e) == 2 ? 2 : 1;
     return prefer2 && (N + 15) / 16 > AT_WAVES ? 2 : 1;
 }
 #define ATTN_LAUNCH(KERNEL, name, r, grid, lds, st, ...) do { \

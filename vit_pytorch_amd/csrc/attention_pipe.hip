@@ -1121,7 +1121,7 @@ template <int NS> int launch_fwd(const AttnPipeFwd& p, hipStream_t st) {
     FwdArgs<NS> a;
     for (int t = 0; t < NS; ++t) { a.q[t] = tnd(p.q[t]); a.k[t] = tnd(p.k[t]); a.v[t] = tnd(p.v[t]); }
     a.o = ond(p.o); a.lse = p.lse; a.H = (int)p.H; a.N = (int)p.N; a.nitems = (int)(p.B * p.H);
-    a.dbg = getenv("VITK_ATTN_DBG") ? atoi(getenv("VITK_ATTN_DBG")) : 0;
+    a.dbg = vitk_exp("VITK_ATTN_DBG") ? atoi(vitk_exp("VITK_ATTN_DBG")) : 0;
     a.c = p.scale * LOG2E; a.drop_t = drop_thresh(p.drop_p); a.drop_seed = p.drop_seed; a.inv_keep = 1.0f / (1.0f - p.drop_p);
     const int nks = (int)((p.N + 31) / 32);
     const int lds = NS * 2 * nks * 32 * 128;
@@ -1148,7 +1148,7 @@ template <int NS> int launch_bwd(const AttnPipeBwd& p, hipStream_t st, int which
     if (grid > nitems) grid = nitems;
     const unsigned drop_t = drop_thresh(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
-    const int dbg = getenv("VITK_ATTN_DBG") ? atoi(getenv("VITK_ATTN_DBG")) : 0;
+    const int dbg = vitk_exp("VITK_ATTN_DBG") ? atoi(vitk_exp("VITK_ATTN_DBG")) : 0;
     if (which & 1) {
         DqArgs<NS> a;
         a.dbg = dbg;
@@ -1191,7 +1191,7 @@ int launch_fused(const AttnPipeBwd& p, hipStream_t st) {
     a.q = tnd(p.q[0]); a.k = tnd(p.k[0]); a.v = tnd(p.v[0]); a.dout = tnd(p.dout[0]); a.o = tnd(p.o);
     a.lse = p.lse; a.delta = p.delta; a.dq = ond(p.dq); a.dk = ond(p.dk); a.dv = ond(p.dv);
     a.H = (int)p.H; a.N = (int)p.N; a.nitems = (int)(p.B * p.H); a.scale = p.scale;
-    a.dbg = getenv("VITK_ATTN_DBG") ? atoi(getenv("VITK_ATTN_DBG")) : 0;
+    a.dbg = vitk_exp("VITK_ATTN_DBG") ? atoi(vitk_exp("VITK_ATTN_DBG")) : 0;
     int grid = num_cus();
     if (grid > a.nitems) grid = a.nitems;
     AP_SET_LDS(attn_bwd_fused_kernel<1>, "attn_bwd (fused)");
@@ -1209,7 +1209,7 @@ int attn_pipe_bwd_fused(const AttnPipeBwd& a, void* stream) { return launch_fuse
 // averages, pipelined vs one-workgroup-per-head] forward 89 vs 81 us, dQ 110 vs 118 us, dK/dV 150 vs 143 us: only the dQ kernel -- the
 // one whose per-wave rows are prefetched a whole item ahead -- gains, so only it is on.  VITK_ATTN_PIPE=<mask> overrides (tests: 7).
 int attn_pipe_mask() {
-    const char* e = getenv("VITK_ATTN_PIPE");
+    const char* e = vitk_switch("VITK_ATTN_PIPE");
     if (e) return atoi(e);
     // the pipelined kernels are resident workgroups with STATIC item lists and a CU each: while another kernel is expected on the chip
     // (vitk_set_cu_reserve > 0: a collective overlapping the backward) the per-head kernels run instead -- their 3,072 independent

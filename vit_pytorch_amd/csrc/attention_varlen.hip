@@ -638,7 +638,7 @@ bool hnd_ok(vitk_hnd t) { return t.p && aligned16(t.p) && (t.s_h % 8 == 0) && (t
 // experiments (VITK_VL_DBG): bit 0 = no LDS-DMA after the first chunk, bit 1 = no arithmetic, bit 2 = no barrier after the first (results are wrong)
 // bits 8..: order of the workgroups (vl_block_of), VITK_VL_ORDER
 int vl_dbg() {
-    static const int g = [] { const char* e = getenv("VITK_VL_DBG"); const char* o = getenv("VITK_VL_ORDER");
+    static const int g = [] { const char* e = vitk_exp("VITK_VL_DBG"); const char* o = vitk_exp("VITK_VL_ORDER");
                               return (e ? atoi(e) & 255 : 0) | ((o ? atoi(o) : 2) << 8); }();
     return g;
 }
@@ -648,7 +648,7 @@ unsigned vl_grid(int64_t nblk, int64_t H) { return (unsigned)((nblk * H + 7) / 8
 // in the backward (2,339 vs 2,482 us at batch 256) and level in the forward; d = 64 (NaViT mix): (1, 8) is 6 % ahead in the forward and
 // level in the backward.  VITK_ATTN_VL = 1 / 2 overrides (A/B runs).
 int vl_geometry(int64_t d) {
-    static const int g = [] { const char* e = getenv("VITK_ATTN_VL"); return e ? atoi(e) : 0; }();
+    static const int g = [] { const char* e = vitk_exp("VITK_ATTN_VL"); return e ? atoi(e) : 0; }();
     return g == 1 || g == 2 ? g : (d > 64 ? 2 : 1);
 }
 

@@ -27,6 +27,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // ---- error plumbing (host) -------------------------------------------------------------
 void vitk_set_error(const char* fmt, ...);
+
+// ---- runtime switches (host) -------------------------------------------------------------
+// vitk_switch(NAME): the handful of environment switches the product build reads (README "Switches"): kernel-selection hooks the test
+// suite and tools/nt_probe use to hold two production kernels against each other (VITK_NT_W128, VITK_ATTN_PIPE, VITK_ATTN_R_*,
+// VITK_NTP_STATIC / _DYNAMIC, VITK_TN_PAIR).  vitk_exp(NAME): experiment knobs (tile orders, cost-model constants, debug stamps, ablations) --
+// compiled out of the product build; `VITK_BUILD_EXPERIMENTS=1 python -m vit_pytorch_amd._build` brings them back for the tools/ scripts.
+const char* vitk_switch(const char* name);
+#ifdef VITK_EXPERIMENTS
+#define vitk_exp(name) vitk_switch(name)
+#else
+#define vitk_exp(name) (static_cast<const char*>(nullptr))
+#endif
 #define VITK_FAIL(code, ...) do { vitk_set_error(__VA_ARGS__); return (code); } while (0)
 #define VITK_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); \
     if (e__ != hipSuccess) { vitk_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return (int)e__; } } while (0)

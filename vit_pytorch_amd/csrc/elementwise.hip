@@ -1,6 +1,7 @@
 // elementwise.hip -- data movement and element-wise kernels (HBM-bound), plus version / error API.
 #include <cmath>
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 // ---- error string (thread-local) ---------------------------------------------------------
@@ -11,6 +12,7 @@ void vitk_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+const char* vitk_switch(const char* name) { return getenv(name); }
 extern "C" int vitk_half_type(void) {
 #ifdef VITK_HALF_IS_F16
     return VITK_F16;

@@ -738,7 +738,7 @@ namespace {
 struct NtPlan { bool large; int fm; };
 NtPlan nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
     NtPlan pl;
-    pl.large = (K % L_BK == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux)) && !getenv("VITK_NO_256");
+    pl.large = (K % L_BK == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux));
     // Tile height: 256 rows (8 m-fragments per wave) or 224 (7).  One workgroup per CU, so the grid is
     // quantised in rounds of 256 tiles: pick the height whose (rounds x height) is smaller -- e.g. M = 50,432,
     // N = 768: 591 tiles of 256 rows need 3 rounds for 2.31 rounds of work, 678 tiles of 224 rows need 3
@@ -749,7 +749,6 @@ NtPlan nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
         const long long t8 = ((M + 255) / 256) * tn_, t7 = ((M + 223) / 224) * tn_;
         const long long cost8 = ((t8 + 255) / 256) * 8, cost7 = ((t7 + 255) / 256) * 7;
         if (cost7 * 10 <= cost8 * 9) pl.fm = 7;   // only when it buys >= 10 %: the shorter tile re-uses each W fragment 7x instead of 8x
-        if (getenv("VITK_NT_FM")) pl.fm = atoi(getenv("VITK_NT_FM")) == 7 ? 7 : 8;
     }
     return pl;
 }
@@ -852,7 +851,7 @@ extern "C" int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, cons
 // rows of both launches.  While another kernel is expected on the chip (cu_reserve > 0: the in-backward all-reduce) everything goes to the
 // 8-wave kernel, whose dynamic tile tickets keep a launch from waiting for CUs it does not get.
 static int ntw_tiles_m(const NtpPlan& q, int64_t M, int64_t N, int64_t K) {
-    const char* e = getenv("VITK_NT_W128");
+    const char* e = vitk_switch("VITK_NT_W128");
     if (!q.ok || (e && e[0] == '0') || vitk_get_cu_reserve() > 0 || !gemm_ntw_serves(M, N, K)) return 0;
     return gemm_ntw_split(M, N, K, q.grid);
 }
@@ -920,7 +919,7 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
         // the persistent kernel is the fastest setting: 40.17 ms/step vs 40.95 (plain stores per-tile) vs 41.60 (all per-tile).
         // VITK_NTP_EPIS = bit mask over VITK_EPI_* overrides (GELU_BWD always: its column-sum rows follow the persistent plan).
         const NtpPlan q = ntp_plan(M, N, K, ldc, aux);
-        const unsigned epis = getenv("VITK_NTP_EPIS") ? (unsigned)atoi(getenv("VITK_NTP_EPIS")) : 0x1fu;
+        const unsigned epis = vitk_exp("VITK_NTP_EPIS") ? (unsigned)atoi(vitk_exp("VITK_NTP_EPIS")) : 0x1fu;
         if (epilogue == VITK_EPI_BIAS_GELU_DG || epilogue == VITK_EPI_MUL_AUX) {       // the gelu'-factor pair (round 4): the persistent kernel only
             if (!q.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: EPI_BIAS_GELU_DG / EPI_MUL_AUX are served by the persistent kernel only (vitk_gemm_nt_plan() says which shapes)");
             if (!aux || drop_t || (epilogue == VITK_EPI_BIAS_GELU_DG && !bias)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS_GELU_DG needs bias and aux, EPI_MUL_AUX aux; no fused dropout");
@@ -960,7 +959,7 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     hipStream_t st = (hipStream_t)stream;
     int group_n = tiles_n;                                  // n-tiles per group of the grouped tile order
     if (large && tiles_n > 8) group_n = (tiles_n + (tiles_n + 5) / 6 - 1) / ((tiles_n + 5) / 6);
-    if (getenv("VITK_GROUP_N")) group_n = atoi(getenv("VITK_GROUP_N")) > 0 ? atoi(getenv("VITK_GROUP_N")) : tiles_n;
+    if (vitk_exp("VITK_GROUP_N")) group_n = atoi(vitk_exp("VITK_GROUP_N")) > 0 ? atoi(vitk_exp("VITK_GROUP_N")) : tiles_n;
     if (group_n > tiles_n) group_n = tiles_n;
 #define NT_LAUNCH_F8(E, F, FK) do { \
             static const int rc8__ = set_max_lds(gemm_nt256pp_kernel<E, F, 1, FK>, P_LDS_BYTES); \
@@ -1093,7 +1092,7 @@ extern "C" int64_t vitk_gemm_tn_pair_splits(int64_t M, int64_t N0, int64_t K0, i
     // VITK_TN_PAIR=0 switches it off.  [measured, profiles/r04_tn_pair_ab.log, r04_dw_stream_ab.log] with the launches of a step serialized (the
     // default since round 4) the pair is worth 0.2-0.3 ms of the ViT-B/16 step; beside a side stream it LOSES 0.5 ms (the deferred gradient no
     // longer overlaps the attention backward) -- engine.TransformerFn pairs only when its side stream is off.
-    if (getenv("VITK_TN_PAIR") && atoi(getenv("VITK_TN_PAIR")) == 0) return 0;
+    if (vitk_switch("VITK_TN_PAIR") && atoi(vitk_switch("VITK_TN_PAIR")) == 0) return 0;
     const int64_t tiles = ((N0 + 255) / 256) * ((K0 + 255) / 256) + ((N1 + 255) / 256) * ((K1 + 255) / 256);
     const int reserve = g_cu_reserve.load();
     int64_t s = reserve ? (256 - reserve) / tiles : (256 + tiles / 2) / tiles;

@@ -97,16 +97,14 @@ template <int N_> __device__ __forceinline__ void q_wait_vm() {
 }
 
 
-template <int EPI, bool PIPE, bool DYN>
+template <int EPI, bool DYN>
 __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
-    static_assert(PIPE || !DYN, "dynamic tickets exist in the software-pipelined flavour only");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const bool grp_b = wave >= 4;
 
     // ---- this workgroup's tiles: XCD x owns a contiguous run of the main list and of the tail list; its workgroups take
     //      every L-th tile of the concatenation, so the tiles an XCD works on at one time are neighbours in the grouped order
@@ -122,7 +120,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     int ms, cm, ts, ct;
     q_geom(xcd, ms, cm, ts, ct);
     const int count = cm + ct;
-    // DYNAMIC TICKETS (PIPE flavour, K >= 256): instead of the static list l0, l0 + L, ... every workgroup draws its next tile from
+    // DYNAMIC TICKETS (K >= 256): instead of the static list l0, l0 + L, ... every workgroup draws its next tile from
     // its XCD's counter (and, once that queue is dry, from the other XCDs').  Why: each workgroup needs a whole CU (128+ KiB of
     // LDS, 512 x 256 registers).  If another kernel -- an RCCL collective of the data-parallel step -- holds c CUs, c workgroups
     // of a static launch start only when others have FINISHED their whole lists: a second round, up to 2x the launch time.  With
@@ -229,30 +227,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
         }
     };
     const int w_kstride = p.ldw == 0 ? Q_TILE_BYTES : 64;      // bytes between consecutive K-steps of a W row group
-    auto issue_a = [&]() {
-        if (!p_more) return;
-        char* base = lds + (p_g & 3) * Q_STAGE_BYTES + wave * 2048;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a_src[j] + p_kt * 64),
-                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
-    };
-    auto issue_w = [&]() {
-        if (!p_more) return;
-        char* base = lds + (p_g & 3) * Q_STAGE_BYTES + Q_TILE_BYTES + wave * 2048;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(w_src[j] + p_kt * w_kstride),
-                                             (void __attribute__((address_space(3)))*)(base + j * 1024), 16, 0, 0);
-        ++p_g;
-        if (++p_kt == p.nt) {
-            p_kt = 0;
-            p_idx += L;
-            if (p_idx < count) setup_src(p_idx); else p_more = false;
-        }
-    };
-
-    // PIPE: the four DMA instructions of a K-step as straight-line code (their block also holds MFMAs and must stay one basic
+    // the four DMA instructions of a K-step as straight-line code (their block also holds MFMAs and must stay one basic
     // block).  Issued on EVERY K-step: when the tile list is exhausted the producer stays on its last K-step and re-loads it
     // into a stage nobody reads again, which keeps the counted waits uniform (always vmcnt(8)); the kernel drains before it ends.
     auto issue4 = [&]() __attribute__((always_inline)) {
@@ -297,20 +272,6 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     const int w_off = Q_TILE_BYTES + (wn * 64 + fi) * 64 + fpos * 16;    // + fn * 1024
 
     int c_g = 0;            // global K-step counter of this workgroup
-    // counted wait at the end of K-step c_g: the DMA of K-step c_g + 1 has landed; the DMA of K-steps c_g + 2 and c_g + 3
-    // (4 instructions each) may stay in flight.  After an epilogue this also waits for that epilogue's stores (they are older
-    // than the DMA of K-step c_g + 3): allowing for them with an exact count (vmcnt(8 + stores), legal because vmcnt
-    // retires in order) measured equal or slower -- whatever is queued behind a CU's stores waits for them anyway.
-    auto wait_next = [&]() {
-        const int rem = total_steps - (c_g + 2);
-        if (rem >= 2) q_wait_vm<8>();
-        else if (rem == 1) q_wait_vm<4>();
-        else q_wait_vm<0>();
-    };
-
-    const bool stamp_on = p.stamps && blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == 4);
-    long long* my_stamps = p.stamps ? p.stamps + (wave == 4 ? 1024 : 0) : nullptr;
-#define Q_STAMP(slot) do { if (stamp_on && c_g >= 8 && c_g < 40) my_stamps[(c_g - 8) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
     // Q_TIMELINE builds (tools/nt_timeline.py: -DQ_TIMELINE=1, a separate libvitk_tl.so): s_memtime stamps of ONE wave of one workgroup along
     // the software-pipelined loop -- K-step starts, epilogue start, epilogue stores issued -- kept in LDS above the bias image (ds_write:
     // the lgkmcnt domain, so the exact vmcnt counts of the DMA ring stay exact) and copied to p.stamps when the workgroup ends.
@@ -331,7 +292,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
 #pragma unroll
             for (int j = 0; j < FMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        if constexpr (PIPE) {
+        {
             // ---- software-pipelined main loop: no R slots.  The ds_reads of the NEXT fragments and the DMA issue sit between the
             //      MFMAs of the wave (its partner on the SIMD fills the bubbles), one barrier B(g) per K-step: "stage g + 1 is
             //      visible to everyone and stage g has been read by everyone" -- after it the DMA of K-step g + 4 may refill stage g.
@@ -414,57 +375,6 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
             int kt = 0;
             for (; kt + 1 < p.nt; kt += 2) { kstep(f0w, f0x, f1w, f1x); kstep(f1w, f1x, f0w, f0x); }
             if (kt < p.nt) kstep(f0w, f0x, f1w, f1x);
-        } else {
-        for (int kt = 0; kt < p.nt; ++kt) {
-                const char* base = lds + (c_g & 3) * Q_STAGE_BYTES;
-                bf16x8 wf[4], xf[4];
-                Q_STAMP(0);
-                // ---- R0 ----
-    #pragma unroll
-                for (int f = 0; f < 4; ++f) wf[f] = *reinterpret_cast<const bf16x8*>(base + w_off + f * 1024);
-    #pragma unroll
-                for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + f * 1024);
-                Q_STAMP(1);
-                issue_a();
-                if constexpr (FMW == 4) { issue_w(); wait_next(); }
-                Q_STAMP(2);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                Q_STAMP(3);
-                QQ_BARRIER();
-                Q_STAMP(4);
-                // ---- M0 ----
-                __builtin_amdgcn_s_setprio(1);
-    #pragma unroll
-                for (int fn = 0; fn < 4; ++fn)
-    #pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        acc[fn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][f], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                Q_STAMP(5);
-                QQ_BARRIER();
-                Q_STAMP(6);
-                if constexpr (FMW == 8) {
-                    // ---- R1 ----
-    #pragma unroll
-                    for (int f = 0; f < 4; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(base + a_off + (4 + f) * 1024);
-                    issue_w();
-                    wait_next();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    Q_STAMP(7);
-                    QQ_BARRIER();
-                    // ---- M1 ----
-                    __builtin_amdgcn_s_setprio(1);
-    #pragma unroll
-                    for (int fn = 0; fn < 4; ++fn)
-    #pragma unroll
-                        for (int f = 0; f < 4; ++f)
-                            acc[fn][4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[f], wf[fn], acc[fn][4 + f], 0, 0, 0);
-                    __builtin_amdgcn_s_setprio(0);
-                    QQ_BARRIER();
-                }
-                ++c_g;
-            }
-    
         }
 
         // ---- epilogue: registers -> global, full lines, stores not waited for ----
@@ -724,20 +634,10 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
     }
     // ---- prologue: K-steps 0..2 in flight, K-step 0 landed ----
     setup_src(p_idx);
-    if constexpr (PIPE) {
-        // four stages in flight: B(g) frees stage g half a step before its next use
-        issue4(); advance4(); issue4(); advance4(); issue4(); advance4(); issue4(); advance4();
-        q_wait_vm<12>();
-    } else {
-        issue_a(); issue_w();
-        issue_a(); issue_w();
-        issue_a(); issue_w();
-        if (total_steps > 2) q_wait_vm<8>();
-        else if (total_steps > 1) q_wait_vm<4>();
-        else q_wait_vm<0>();
-    }
+    // four stages in flight: B(g) frees stage g half a step before its next use
+    issue4(); advance4(); issue4(); advance4(); issue4(); advance4(); issue4(); advance4();
+    q_wait_vm<12>();
     QQ_BARRIER();              // also publishes the bias image
-    if (!PIPE && grp_b) QQ_BARRIER();   // group B runs one slot behind group A
 
     if (dyn) {
         int n = 0;
@@ -760,8 +660,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
             else run_tile(std::integral_constant<int, 8>{}, m0, n0, mt);
         }
     }
-    if (!PIPE && !grp_b) QQ_BARRIER();  // pairs with group B's extra barrier
-    if constexpr (PIPE) q_wait_vm<0>();  // the surplus DMAs of the last K-steps must not outlive the workgroup's LDS allocation
+    q_wait_vm<0>();  // the surplus DMAs of the last K-steps must not outlive the workgroup's LDS allocation
 #ifdef Q_TIMELINE
     if (tl_on) {
         p.stamps[0] = tl_n;
@@ -834,7 +733,7 @@ long long q_makespan(int n_main, int n_tail, int L, long long c_full, long long 
 NtpPlan ntp_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) {
     NtpPlan pl{};
     pl.ok = (K % 32 == 0) && M >= 1024 && N >= 256 && (N % 8 == 0) && (ldc % 8 == 0) && (!aux || aligned16(aux)) &&
-            M < (1 << 30) && N <= 16128 /* bias image + ticket words: 32 KiB of LDS above the ring */ && !getenv("VITK_NO_256") && !getenv("VITK_NO_PERSIST");
+            M < (1 << 30) && N <= 16128 /* bias image + ticket words: 32 KiB of LDS above the ring */ && !vitk_exp("VITK_NO_PERSIST");
     if (!pl.ok) return pl;
     struct Key { int64_t m, n, k; bool operator==(const Key& o) const { return m == o.m && n == o.n && k == o.k; } };
     struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.m * 1000003 + k.n * 10007 + k.k); } };
@@ -849,14 +748,14 @@ NtpPlan ntp_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) 
     pl.tiles_n = (int)((N + 255) / 256);
     pl.group_n = pl.tiles_n;
     if (pl.tiles_n > 8) pl.group_n = (pl.tiles_n + (pl.tiles_n + 5) / 6 - 1) / ((pl.tiles_n + 5) / 6);
-    if (getenv("VITK_GROUP_N")) pl.group_n = atoi(getenv("VITK_GROUP_N")) > 0 ? atoi(getenv("VITK_GROUP_N")) : pl.tiles_n;
+    if (vitk_exp("VITK_GROUP_N")) pl.group_n = atoi(vitk_exp("VITK_GROUP_N")) > 0 ? atoi(vitk_exp("VITK_GROUP_N")) : pl.tiles_n;
     if (pl.group_n > pl.tiles_n) pl.group_n = pl.tiles_n;
     pl.nt = (int)(K / 32);
     pl.grid = q_num_cus() / 8 * 8;
     const int L = pl.grid / 8;
     // cost of a tile in barrier slots: 4 (2) per K-step of a 256-row (128-row) tile plus the epilogue
-    const long long e_full = getenv("VITK_NTP_EFULL") ? atoll(getenv("VITK_NTP_EFULL")) : 16;
-    const long long e_half = getenv("VITK_NTP_EHALF") ? atoll(getenv("VITK_NTP_EHALF")) : 12;
+    const long long e_full = vitk_exp("VITK_NTP_EFULL") ? atoll(vitk_exp("VITK_NTP_EFULL")) : 16;
+    const long long e_half = vitk_exp("VITK_NTP_EHALF") ? atoll(vitk_exp("VITK_NTP_EHALF")) : 12;
     const long long c_full = 4LL * pl.nt + e_full, c_half = 2LL * pl.nt + e_half;
     const int full_tm = (int)(M / 256);
     // candidate 0: no tail (every tile 256 rows, the last m-tile partial)
@@ -871,8 +770,8 @@ NtpPlan ntp_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, const void* aux) 
         const long long c = q_makespan(tm_main * pl.tiles_n, tail_tm * pl.tiles_n, L, c_full, c_half);
         if (c < best) { best = c; best_tm = tm_main; best_tail = tail_tm; }
     }
-    if (getenv("VITK_NTP_TAIL")) {      // experiments: number of 256-row m-tiles moved to the tail
-        const int d = atoi(getenv("VITK_NTP_TAIL"));
+    if (vitk_exp("VITK_NTP_TAIL")) {      // experiments: number of 256-row m-tiles moved to the tail
+        const int d = atoi(vitk_exp("VITK_NTP_TAIL"));
         if (d < 0) { best_tm = (int)((M + 255) / 256); best_tail = 0; }
         else {
             best_tm = full_tm - d < 0 ? 0 : full_tm - d;
@@ -904,42 +803,37 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     // rest of the launch, tail LAST keeps the sharers of an activation panel in step: [measured, profiles/r04_nt_tile_order_knobs_*] the FF1
     // GEMM (N = 3072: twelve n-tiles per panel, two 16-bit outputs) fetches 373 instead of 530 MB with the tail last and runs 3.97 instead of
     // 4.12 ms per step; every other epilogue is level or slightly better tail-first.  VITK_NTP_TAIL_LAST = 1 / 0 forces one order for all.
-    static const int tail_env = getenv("VITK_NTP_TAIL_LAST") ? (atoi(getenv("VITK_NTP_TAIL_LAST")) ? 0 : 1) : -1;
+    static const int tail_env = vitk_exp("VITK_NTP_TAIL_LAST") ? (atoi(vitk_exp("VITK_NTP_TAIL_LAST")) ? 0 : 1) : -1;
     a.tail_first = tail_env >= 0 ? tail_env : ((epilogue == VITK_EPI_BIAS_GELU || epilogue == VITK_EPI_BIAS_GELU_DG) ? 0 : 1);
-    // main-loop flavour: software-pipelined (default) or the R/M slot ping-pong (VITK_NTP_PIPE=0).  [measured] kernel by kernel the
-    // pipelined loop is ~5 % ahead (8-shape sum 1.688 vs 1.783 ms), inside the training step the two are level (42.7-43.1 vs
-    // 43.0-43.2 ms on the same box).
-    static const bool pipe = !(getenv("VITK_NTP_PIPE") && atoi(getenv("VITK_NTP_PIPE")) == 0);
     // dynamic tile tickets (see the kernel): K >= 256 so that a ticket drawn two tiles ahead is always there in time.  WHEN: while
     // other kernels are expected on the chip -- vitk_set_cu_reserve(c > 0), which parallel.FlatGradSink opens around every
     // in-backward all-reduce -- or VITK_NTP_DYNAMIC=1.  Not by default: [measured, ViT-B/16 batch 256, no other kernel on the
     // chip] tickets cost the eight NT GEMMs of a layer 1.632 -> 1.664 ms (the N = 768 shapes, 2.6 tiles per workgroup, lose 6-18 us
     // each to the static plan's makespan-optimal lists; FF1 gains 14 us) and the training step 0.8 ms; with 16-64 CUs held by
     // another kernel they save 19-25 % (tools/cu_contention.py).  VITK_NTP_STATIC=1 forces the static lists.
-    const char* st_env = getenv("VITK_NTP_STATIC");
-    const char* dy_env = getenv("VITK_NTP_DYNAMIC");
+    const char* st_env = vitk_switch("VITK_NTP_STATIC");
+    const char* dy_env = vitk_switch("VITK_NTP_DYNAMIC");
     const bool want_dyn = (dy_env && dy_env[0] == '1') || vitk_get_cu_reserve() > 0;
-    a.tickets = (pipe && pl.nt >= 8 && want_dyn && !(st_env && st_env[0] == '1')) ? q_ticket_slot((hipStream_t)stream) : nullptr;
+    a.tickets = (pl.nt >= 8 && want_dyn && !(st_env && st_env[0] == '1')) ? q_ticket_slot((hipStream_t)stream) : nullptr;
     // queue order under tickets: the 256-row tiles first, the 128-row tiles last (longest-processing-time rule; [measured] sums of the
     // eight shapes: 1.664 ms vs 1.73 ms with the static lists' tail-first order or a half-and-half split).  VITK_NTP_DYN_ORDER = 0 / 1 / 2
-    if (a.tickets) a.tail_first = getenv("VITK_NTP_DYN_ORDER") ? atoi(getenv("VITK_NTP_DYN_ORDER")) : 0;
-    a.dbg = getenv("VITK_NTP_DBG") ? atoi(getenv("VITK_NTP_DBG")) : 0;
-    a.stamps = getenv("VITK_NTP_STAMPS") ? (long long*)strtoull(getenv("VITK_NTP_STAMPS"), nullptr, 0) : nullptr;
+    if (a.tickets) a.tail_first = vitk_exp("VITK_NTP_DYN_ORDER") ? atoi(vitk_exp("VITK_NTP_DYN_ORDER")) : 0;
+    a.dbg = vitk_exp("VITK_NTP_DBG") ? atoi(vitk_exp("VITK_NTP_DBG")) : 0;
+    a.stamps = vitk_exp("VITK_NTP_STAMPS") ? (long long*)strtoull(vitk_exp("VITK_NTP_STAMPS"), nullptr, 0) : nullptr;
 #ifdef Q_TIMELINE
     const int lds_bytes = Q_LDS_MAX;
 #else
     const int lds_bytes = Q_LDS_BYTES + pl.tiles_n * 512 + 16;      // ring + bias image (tiles_n * 256 columns of 2 bytes) + 4 ticket words
 #endif
     hipStream_t st = (hipStream_t)stream;
-#define NTP_LAUNCH1(E, P, Dn) do { \
-            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, P, Dn>, Q_LDS_MAX); \
+#define NTP_LAUNCH1(E, Dn) do { \
+            static const int rc__ = q_set_max_lds(gemm_ntp_kernel<E, Dn>, Q_LDS_MAX); \
             if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16: cannot enable %d B of LDS", Q_LDS_MAX); \
-            hipLaunchKernelGGL((gemm_ntp_kernel<E, P, Dn>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
+            hipLaunchKernelGGL((gemm_ntp_kernel<E, Dn>), dim3((unsigned)pl.grid), dim3(512), lds_bytes, st, a); \
         } while (0)
 #define NTP_LAUNCH(E) do { \
-        if (pipe && a.tickets) NTP_LAUNCH1(E, true, true); \
-        else if (pipe) NTP_LAUNCH1(E, true, false); \
-        else NTP_LAUNCH1(E, false, false); \
+        if (a.tickets) NTP_LAUNCH1(E, true); \
+        else NTP_LAUNCH1(E, false); \
     } while (0)
     switch (epilogue) {
         case VITK_EPI_NONE: NTP_LAUNCH(VITK_EPI_NONE); break;

@@ -65,6 +65,19 @@ template <int OFF> __device__ __forceinline__ bf16x8 v_rd(unsigned lds_addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
     return v;
 }
+#ifdef NTW_PROBE
+// experiments (ABL bit 3, timing only, results are wrong): the same stream with v_mfma_f32_32x32x16 -- twice the flops per instruction
+// and per operand register read -- on the fragments the 16 x 16 x 32 form reads; accumulators as 16 tuples of 16 registers
+typedef float v_f32x16 __attribute__((ext_vector_type(16)));
+#ifdef VITK_HALF_IS_F16
+#define NTW_MFMA32_ASM "v_mfma_f32_32x32x16_f16"
+#else
+#define NTW_MFMA32_ASM "v_mfma_f32_32x32x16_bf16"
+#endif
+__device__ __forceinline__ void v_mfma32(v_f32x16& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("" NTW_MFMA32_ASM " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+#endif
 // MFMA as asm with the accumulator pinned to AGPRs; the Z form writes A.B (C = 0): the first K-step of a tile
 template <bool Z> __device__ __forceinline__ void v_mfma(f32x4& c, const bf16x8& a, const bf16x8& b) {
     if constexpr (Z) asm volatile("" NTW_MFMA_ASM " %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
@@ -170,6 +183,13 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     int stg = 0;                // K-step counter mod 4: the stage whose fragments are in registers (the DMA of this K-step refills it)
     bf16x8 xa[8], wa[8], xb[8], wb[8];
     f32x4 acc[8][8];            // acc[fn][f][j]: row 16 f + 4 fg + j, column 64 (fn >> 2) + 4 fi + (fn & 3) of the wave tile
+#ifdef NTW_PROBE
+    v_f32x16 acc32[16];
+    if constexpr (ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc32[i] = v_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
+#endif
 
     // one group of a K-step: 4 MFMAs on the current fragments (activation fragment fm x W fragments 4h .. 4h + 3), one fragment of the next
     // K-step, every second group one DMA piece.  [measured, tools/nt_probe, FF1 shape: LDS-DMA alone 112 us, MFMA alone 111 us, both 160-166 us:
@@ -178,14 +198,21 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     // the lone wave of a SIMD being stuck at the issue: the same stream on EIGHT waves (two per SIMD, 128 x 64 wave tiles, the partner's MFMAs
     // in the gaps) ran 169 vs 165 us, its epilogues level too (profiles/r05c_nt_probe_8wave_vs_4wave.log; the flavour was not kept).  What is
     // left is the chip: matrix cores and the LDS-DMA feed at full rate together draw more than either alone (DVFS, MI355X_MICROARCH.md).]
+#ifdef NTW_PROBE
+#define V_MFMA32(G, I_, XC, WC) do { if constexpr (!(ABL & 4) && (ABL & 8)) v_mfma32(acc32[(2 * (G) + (I_)) & 15], XC[(G) >> 1], WC[((G) & 1) * 4 + (I_)]); } while (0)
+#else
+#define V_MFMA32(G, I_, XC, WC) do { } while (0)
+#endif
 #define V_GROUP(G, Z, XC, WC, XN, WN) do { \
         constexpr int fm_ = (G) >> 1, h_ = ((G) & 1) * 4; \
-        if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 0][fm_], XC[fm_], WC[h_ + 0]); \
+        if constexpr (!(ABL & 4) && !(ABL & 8)) v_mfma<Z>(acc[h_ + 0][fm_], XC[fm_], WC[h_ + 0]); \
+        V_MFMA32(G, 0, XC, WC); \
         if constexpr (!(ABL & 2)) { if constexpr ((G) < 8) XN[(G)] = v_rd<(G) * 1024>(rdA); else WN[(G) - 8] = v_rd<((G) - 8) * 1024>(rdW); } \
-        if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 1][fm_], XC[fm_], WC[h_ + 1]); \
-        if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 2][fm_], XC[fm_], WC[h_ + 2]); \
+        if constexpr (!(ABL & 4) && !(ABL & 8)) v_mfma<Z>(acc[h_ + 1][fm_], XC[fm_], WC[h_ + 1]); \
+        if constexpr (!(ABL & 4) && !(ABL & 8)) v_mfma<Z>(acc[h_ + 2][fm_], XC[fm_], WC[h_ + 2]); \
         if constexpr (!(ABL & 1) && ((G) & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
-        if constexpr (!(ABL & 4)) v_mfma<Z>(acc[h_ + 3][fm_], XC[fm_], WC[h_ + 3]); \
+        V_MFMA32(G, 1, XC, WC); \
+        if constexpr (!(ABL & 4) && !(ABL & 8)) v_mfma<Z>(acc[h_ + 3][fm_], XC[fm_], WC[h_ + 3]); \
     } while (0)
     // one K-step.  WAIT = the counted vmcnt statement: own pieces of K-step t + 2 landed (t + 3, t + 4 fly)
 #define V_STEP(Z, XC, WC, XN, WN, WAIT) do { \
@@ -213,7 +240,14 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     // and are waited for by exact counts (gemm_nt_epi.h).
     auto epilogue = [&](int m0, int n0, int mt) __attribute__((always_inline)) {
         constexpr int NR = 16;
-        if ((p.dbg & 1) || (ABL & 8)) {
+#ifdef NTW_PROBE
+        if constexpr (ABL & 8) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" :: "a"(acc32[i]));
+            return;
+        }
+#endif
+        if (p.dbg & 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -492,6 +526,7 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
 #undef V_WAIT16
 #undef V_STEP
 #undef V_GROUP
+#undef V_MFMA32
 }
 
 template <typename Kern>
@@ -534,7 +569,7 @@ int gemm_ntw_split(int64_t M, int64_t N, int64_t K, int grid) {
     if (M % 256 == 0 && tm_cap > 4) consider(tm_cap - 4);
     const long long k = (tm_cap * tiles_n) / grid;          // whole rounds
     if (k >= 1) { long long tm = (k * grid) / tiles_n; consider(tm); while (tm > 0 && !legal(tm)) --tm; consider(tm); }
-    if (getenv("VITK_NTW_TM")) { const long long v = atoll(getenv("VITK_NTW_TM")); if (v == 0 || legal(v)) best_tm = v; }    // experiments
+    if (vitk_exp("VITK_NTW_TM")) { const long long v = atoll(vitk_exp("VITK_NTW_TM")); if (v == 0 || legal(v)) best_tm = v; }    // experiments
     return (int)best_tm;
 }
 
@@ -548,7 +583,7 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
     // grouped tile order of the 8-wave kernel: groups of <= 8 n-tiles, m fastest inside a group's n-tiles
     a.group_n = a.tiles_n;
     if (a.tiles_n > 8) a.group_n = (a.tiles_n + (a.tiles_n + 5) / 6 - 1) / ((a.tiles_n + 5) / 6);
-    if (getenv("VITK_GROUP_N")) { const int g = atoi(getenv("VITK_GROUP_N")); a.group_n = g > 0 && g < a.tiles_n ? g : a.tiles_n; }
+    if (vitk_exp("VITK_GROUP_N")) { const int g = atoi(vitk_exp("VITK_GROUP_N")); a.group_n = g > 0 && g < a.tiles_n ? g : a.tiles_n; }
     a.dbg = dbg;
     const int lds_bytes = V_RING + a.tiles_n * 512 + 16;
     hipStream_t st = (hipStream_t)stream;
@@ -563,6 +598,7 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
         switch (abl) { \
             case 0: NTW_LAUNCH1(E, 0); break; case 1: NTW_LAUNCH1(E, 1); break; case 2: NTW_LAUNCH1(E, 2); break; case 3: NTW_LAUNCH1(E, 3); break; \
             case 4: NTW_LAUNCH1(E, 4); break; case 5: NTW_LAUNCH1(E, 5); break; case 6: NTW_LAUNCH1(E, 6); break; case 7: NTW_LAUNCH1(E, 7); break; \
+            case 8: NTW_LAUNCH1(E, 8); break; case 10: NTW_LAUNCH1(E, 10); break; case 11: NTW_LAUNCH1(E, 11); break; \
             default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16 (w128): bad ablation %d", abl); \
         } } while (0)
 #define NTW_LAUNCH(E) do { if (abl == 0) NTW_LAUNCH1(E, 0); else if (abl == 7) NTW_LAUNCH1(E, 7); else VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16 (w128): ablation %d exists for EPI_NONE only", abl); } while (0)

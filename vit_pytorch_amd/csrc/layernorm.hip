@@ -778,7 +778,7 @@ int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* m
     // 16-bit rows of 768 / 1024 / 1280 elements with identity maps and nothing fused: two rows per wave, 16-byte accesses (ln_fwd16_kernel);
     // VITK_LN_FWD16=0 keeps the general kernel (A/B)
     if constexpr (std::is_same<XT, __bf16>::value && std::is_same<YT, __bf16>::value && std::is_same<WT, __bf16>::value) {
-        static const bool off16 = getenv("VITK_LN_FWD16") && atoi(getenv("VITK_LN_FWD16")) == 0;
+        static const bool off16 = vitk_exp("VITK_LN_FWD16") && atoi(vitk_exp("VITK_LN_FWD16")) == 0;
         const int cpl = D / 256;
         if (!off16 && D % 256 == 0 && cpl >= 3 && cpl <= 5 && rows >= 1024 && im.group <= 0 && om.group <= 0 && !add && !f8.p && !f8.amax && aligned16(w) && (!b || aligned16(b))) {
 #define LN_FWD16_LAUNCH(CPL_, HB_) do { \
@@ -800,7 +800,7 @@ int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* m
     }
     // nontemporal row loads (VITK_LN_FWD_NT=1): [measured, round 3] no gain here, unlike the backward -- two interleaved bench runs
     // 39.2-39.5 ms with the hint vs 39.2-39.3 without (the forward's rows are re-read soon, by the residual epilogue); left opt-in
-    const char* nt_env = getenv("VITK_LN_FWD_NT");
+    const char* nt_env = vitk_exp("VITK_LN_FWD_NT");
     const bool nt = rows >= 4096 && nt_env && nt_env[0] == '1';
     // grid = the blocks that are resident at once (occupancy x CUs, asked once per instantiation): every wave then walks its rows with
     // the next one in flight; VITK_LN_FWD_BLOCKS overrides the cap
@@ -809,7 +809,7 @@ int launch_ln_fwd(const void* x, const void* w, const void* b, void* y, float* m
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, LN_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 4; \
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; \
             return (long long)per_cu * cus; }(); \
-        long long cap = getenv("VITK_LN_FWD_BLOCKS") ? atoll(getenv("VITK_LN_FWD_BLOCKS")) : resident; \
+        long long cap = vitk_exp("VITK_LN_FWD_BLOCKS") ? atoll(vitk_exp("VITK_LN_FWD_BLOCKS")) : resident; \
         if (cap < 1) cap = 1; \
         const long long nb = blocks < cap ? blocks : cap; \
         hipLaunchKernelGGL(KERNEL, dim3((unsigned)nb), dim3(LN_THREADS), 0, st, (const XT*)x, (const WT*)w, (const WT*)b, (YT*)y, mean, rstd, \
@@ -856,15 +856,15 @@ int launch_ln_bwd(const void* dy, const void* x, const void* w, const float* mea
         return 0;
         }
     }
-    static const int no_fast = getenv("VITK_LNB_FAST") ? !atoi(getenv("VITK_LNB_FAST")) : 0;
+    static const int no_fast = vitk_exp("VITK_LNB_FAST") ? !atoi(vitk_exp("VITK_LNB_FAST")) : 0;
     if (!no_fast && gin && (dxf || !F32_STREAM) && dxt && colsum_dx && dm.group <= 0 && xm.group <= 0 && om.group <= 0 && (D == 768 || D == 1024 || D == 1280)) {
         // nontemporal loads of the three row streams: 123 -> 99 us at 50432 x 768 (6.3 TB/s); prefetching the next row (PIPE) on
         // top of them costs 10 us, so it stays a switch
 #define LN_BWD_FAST(MC, NWV, WPE, NTL, PIPE, DROP) hipLaunchKernelGGL((ln_bwd_fast_kernel<DYT, XT, WT, DXT, GT, MC, NWV, WPE, NTL, PIPE, DROP>), \
         dim3((unsigned)blocks), dim3(NWV * WAVE), 0, st, \
         (const DYT*)dy, (const XT*)x, (const WT*)w, mean, rstd, gin, dxf, (DXT*)dxt, partials, rows, drop_t, drop_seed, inv_keep)
-        static const int fnt = getenv("VITK_LNB_NT") ? atoi(getenv("VITK_LNB_NT")) : 1;
-        static const int fpipe = getenv("VITK_LNB_PIPE") ? atoi(getenv("VITK_LNB_PIPE")) : 0;
+        static const int fnt = vitk_exp("VITK_LNB_NT") ? atoi(vitk_exp("VITK_LNB_NT")) : 1;
+        static const int fpipe = vitk_exp("VITK_LNB_PIPE") ? atoi(vitk_exp("VITK_LNB_PIPE")) : 0;
 #define LN_BWD_FAST_D(MC, NWV, WPE) \
         if (drop_t) LN_BWD_FAST(MC, NWV, WPE, true, false, true); \
         else if (fnt && fpipe) LN_BWD_FAST(MC, NWV, WPE, true, true, false); \
@@ -929,7 +929,7 @@ extern "C" int vitk_layernorm_fwd_fp8(const void* x, int xdt, const void* w, con
 
 // ---- fused patch gather + LayerNorm(patch_dim) (see patch_ln_fwd16_kernel) ----
 extern "C" int vitk_patch_ln_serves(int dt, int64_t C, int64_t H, int64_t W, int64_t p1, int64_t p2) {
-    return dt == VITK_BF16 && C == 3 && p1 == 16 && p2 == 16 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && !getenv("VITK_NO_PATCH_LN");
+    return dt == VITK_BF16 && C == 3 && p1 == 16 && p2 == 16 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && !vitk_exp("VITK_NO_PATCH_LN");
 }
 extern "C" int64_t vitk_patch_ln_bwd_blocks(int64_t rows) {
     int64_t nb = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES);
