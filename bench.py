@@ -384,6 +384,12 @@ def main():
     mid = sorted(range(len(dts)), key=dts.__getitem__)[len(dts) // 2]
     dt = dts[mid]
     assert torch.isfinite(loss).item(), "loss is not finite"
+    comm_stats = None
+    if world > 1:       # one more step with the collectives timed (HIP events on the communication stream) -- after the timed region
+        dp.sink.enable_timing(True)
+        step()
+        comm_stats = dp.sink.timing_stats()
+        dp.sink.enable_timing(False)
     taps = time_gemm_classes(step)      # every rank: the steps contain the collectives
 
     # one step with every weight-derived cache invalidated (= what each step of a real training loop pays) vs a steady step
@@ -477,6 +483,10 @@ def main():
             "per_gpu_images_per_s": round(value / world, 2),
             "per_rank_images_per_s": [round(batch * args.steps / d, 2) for d in rank_dts[mid]],       # each rank's own clock, the reported window
             "device_count": torch.cuda.device_count(), "rccl_version": rccl_version(),
+            **({"comm": {**comm_stats, "process_group_world": dist.get_world_size(),
+                         "note": "one extra step after the timed region: bytes and event-timed duration of each gradient all-reduce on the "
+                                 "communication stream, and exposed_ms = how long the main stream waited for it at the end of backward"}}
+               if comm_stats else {}),
             "model": {"gflop_per_image_fwd_bwd": round(gf, 3), "tflops_per_gpu": round(value / world * gf / 1e3, 2),
                       "frac_of_mfma_peak": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
                       **({"frac_note": "whole-step fraction is of the bf16 peak 2516.6 TF/s (the number comparable with the bf16 line); of the fp8 roof named in `roof` it is "

@@ -170,7 +170,8 @@ def test_navit_bench_workload_draw_vs_reference_golden(name, dtype):
     """BASELINE config 4's BENCH workload (bench.py --config navit: the 65-image draw of a*16 x b*16 px images, ~33 k tokens, grouped into
     nine packs of <= 4,096 tokens by the model itself) at config 4's width against outputs of /root/reference/vit_pytorch/na_vit.py on
     the same images and weights (oracle/make_golden.py::main_navit_bench; the depth the host's memory allows -- see oracle/params.py).
-    f32: 1e-3; bf16 (what the bench runs): 1.5x the reference's own bf16 error + 1e-3, gradient samples also under the absolute 2e-2."""
+    f32: 1e-3; bf16 (what the bench runs): logits and gradient samples no further from the reference's f32 outputs than the reference's own
+    bf16 run is (+ 1e-3) -- [measured] 1.7e-2 / 6.4e-2 against 2.6e-2 / 9.7e-2."""
     case = NAVIT_BENCH_CASES[name]
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     sizes = navit_bench_sizes()
@@ -194,7 +195,9 @@ def test_navit_bench_workload_draw_vs_reference_golden(name, dtype):
     if dtype == torch.float32:
         assert e <= 1e-3 and g <= 1e-3, (e, g)
     else:
-        assert e <= 1.5 * e16 + 1e-3 and g <= min(1.5 * g16 + 1e-3, 2e-2), (e, e16, g, g16)
+        # twelve layers of dim 1024 on randn-scale weights: the REFERENCE's own bf16 run is 2.6e-2 / 9.7e-2 off its f32 run here, so the absolute
+        # 2e-2 cap of the shallow cases cannot apply; the drop-in (f32 accumulation everywhere) must simply not be worse than the reference-bf16
+        assert e <= 1.0 * e16 + 1e-3 and g <= 1.0 * g16 + 1e-3, (e, e16, g, g16)
 
 
 @pytest.mark.parametrize("name", list(NAVIT_CASES))

@@ -222,9 +222,40 @@ class FlatGradSink:
         else:
             self._allreduce(seg)
 
+    # ---- instrumentation (bench.py --gpus N: what the collective costs, and how much of it the step waits for) ----
+    def enable_timing(self, on: bool = True):
+        """Record, per collective of a step, its bytes and a HIP-event pair on the stream it is enqueued on, and around finish_step's
+        wait for the communication stream an event pair on the main stream (the EXPOSED part).  timing_stats() reads them."""
+        self._timing = [] if (on and self.device.type == "cuda") else None
+        self._exposed = None
+
+    def timing_stats(self):
+        """{"world", "collectives": [{"bytes", "ms"}...], "comm_ms", "exposed_ms", "cu_reserve", "layers_per_chunk"} of the LAST step
+        (synchronises the device); None when timing is off."""
+        if getattr(self, "_timing", None) is None:
+            return None
+        torch.cuda.synchronize(self.device)
+        cols = [{"bytes": b, "ms": round(e0.elapsed_time(e1), 4)} for b, e0, e1 in self._timing]
+        exposed = round(self._exposed[0].elapsed_time(self._exposed[1]), 4) if self._exposed else 0.0
+        return {"world": self.world, "collectives": cols, "comm_ms": round(sum(c["ms"] for c in cols), 4), "exposed_ms": exposed,
+                "cu_reserve": self.cu_reserve, "layers_per_chunk": self.layers_per_chunk}
+
     def _allreduce(self, seg: torch.Tensor):
         if self.log is not None:
             self.log.append(((seg.data_ptr() - self.flat.data_ptr()) // seg.element_size(), seg.numel()))
+        timing = getattr(self, "_timing", None)
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+            try:
+                self._allreduce_raw(seg)
+            finally:
+                e1.record(torch.cuda.current_stream(self.device))
+                timing.append((seg.numel() * seg.element_size(), e0, e1))
+            return
+        self._allreduce_raw(seg)
+
+    def _allreduce_raw(self, seg: torch.Tensor):
         if self.average and dist.get_backend(self.group) == "nccl":
             dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)
         else:
@@ -234,6 +265,9 @@ class FlatGradSink:
 
     # ---- step-facing ----------------------------------------------------------------------------
     def begin_step(self):
+        if getattr(self, "_timing", None) is not None:
+            self._timing = []
+            self._exposed = None
         self._filled.clear()
         self._multi.clear()
         self._cursor = 0
@@ -263,7 +297,14 @@ class FlatGradSink:
         if self.world > 1:
             early_was, late_was = self._early_launched, self._late_launched
             if self.side is not None:
-                torch.cuda.current_stream(self.device).wait_stream(self.side)
+                if getattr(self, "_timing", None) is not None:       # how long the main stream stands still for the communication stream
+                    x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    x0.record(torch.cuda.current_stream(self.device))
+                    torch.cuda.current_stream(self.device).wait_stream(self.side)
+                    x1.record(torch.cuda.current_stream(self.device))
+                    self._exposed = (x0, x1)
+                else:
+                    torch.cuda.current_stream(self.device).wait_stream(self.side)
             if not early_was and not late_was and self._cursor == 0:
                 self._allreduce(self.flat)                       # nothing went out during backward: one collective
             else:
