@@ -139,7 +139,7 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
     return {key: (sum(e0.elapsed_time(e1) for e0, e1, _ in tl) / len(tl), tl[0][2], len(tl) // nsteps) for key, tl in taps.items()}
 
 
-TRAFFIC_FILES = ("r04h_pmc_traffic.json", "r04d_pmc_traffic.json", "r04c_pmc_traffic.json", "r04b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04h_pmc_traffic.json", "r04d_pmc_traffic.json", "r04c_pmc_traffic.json", "r04b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 # (class, N, K) of a ViT-B/16 GEMM -> the label tools/kprof.py / tools/pmc_traffic_json.py give its launch group
 TRAFFIC_LABELS = {("tn", 3072, 768): "dW ff1", ("tn", 2304, 768): "dW qkv", ("ff1", 3072, 768): "FF1 bias+GELU", ("dff1", 3072, 768): "dFF1 GELU'",
                   ("nt", 2304, 768): "QKV", ("nt_resid", 768, 3072): "FF2 +", ("nt_resid", 768, 768): "out-proj +", ("nt", 768, 3072): "dX of FF1"}
@@ -418,12 +418,13 @@ def main():
         # GEMM classes by their share of the step (kernel time per step / measured step time); the roofline kernel is the heaviest
         # INSTANCE (one shape) of the heaviest class
         CLASS_NAMES = {"tn": "gemm_tn_w128_kernel + tn_reduce_kernel (weight gradients dW = dY^T X: four waves, 128 x 128 wave tiles)",
-                       "ff1": "gemm_ntp_kernel<EPI_BIAS_GELU_DG> (persistent NT GEMM, FF1: bias + GELU, stores the gelu' factor for the backward)",
-                       "dff1": "gemm_ntp_kernel<EPI_MUL_AUX> (dFF1: x the stored gelu' factor + bias-gradient column sums)",
-                       "nt_resid": "gemm_ntp_kernel<EPI_RESID16 / EPI_RESID> (out-projection, FF2: + bias + residual)",
-                       "nt": "gemm_ntp_kernel<EPI_NONE / EPI_BIAS> (QKV and the three dX GEMMs)"}
+                       "ff1": "gemm_ntw_kernel<EPI_BIAS_GELU_DG> (four-wave persistent NT GEMM, FF1: bias + GELU, stores the gelu' factor for the backward) "
+                              "[+ gemm_ntp_kernel on the rows the row split leaves]",
+                       "dff1": "gemm_ntw_kernel<EPI_MUL_AUX> (dFF1: x the stored gelu' factor + bias-gradient column sums) [+ gemm_ntp_kernel on the remaining rows]",
+                       "nt_resid": "gemm_ntw_kernel<EPI_RESID16 / EPI_RESID> + gemm_ntp_kernel on the remaining rows (out-projection, FF2: + bias + residual)",
+                       "nt": "gemm_ntw_kernel<EPI_NONE / EPI_BIAS> + gemm_ntp_kernel on the remaining rows (QKV and the three dX GEMMs)"}
         if args.fp8:
-            CLASS_NAMES = {k: v.replace("gemm_ntp_kernel", "gemm_nt256pp_kernel (fp8 operands)").replace("gemm_tn_w128_kernel", "gemm_tn_fp8") for k, v in CLASS_NAMES.items()}
+            CLASS_NAMES = {k: v.replace("gemm_ntw_kernel", "gemm_nt256pp_kernel (fp8 operands)").replace("gemm_ntp_kernel", "gemm_nt256pp_kernel (fp8 operands)").replace("gemm_tn_w128_kernel", "gemm_tn_fp8") for k, v in CLASS_NAMES.items()}
         classes = {}
         for (cls, n_, k_), (kms_, kfl_, kn_) in taps.items():
             c = classes.setdefault(cls, {"ms": 0.0, "flops": 0.0, "launches": 0, "inst": []})

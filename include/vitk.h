@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 134
+#define VITK_VERSION 135
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -398,6 +398,12 @@ int vitk_cast(const void* x, int xdt, void* y, int ydt, int64_t n, void* stream)
  * torch.autocast does to the weights of a float32 model once per forward (the reference under `torch.autocast`, or accelerate's
  * mixed precision, train_vit_decorr.py:74) and to their gradients on the way back.  float32 tensors 16-byte aligned, 16-bit 8-byte. */
 int vitk_cast_many(const void* const* src, void* const* dst, const int64_t* numel, int64_t count, int xdt, int ydt, void* stream);
+/* `count` folds of partial rows in ceil(count / 40) launches: dst_j[c] = (flags_j & 1 ? dst_j[c] : 0) + sum_{p < nparts_j} src_j[p * ld_j + c],
+ * c < cols_j; dst dtype tag in flags_j >> 4 (VITK_F32 / VITK_BF16 = "T").  What vitk_colsum_partials / vitk_layernorm_bwd_finalize do one
+ * job at a time (same order of additions, bit-identical): the bias gradients of nn.Linear (vit.py:20,23,47) and the weight / bias
+ * gradients of nn.LayerNorm (vit.py:19,39,69) of a whole transformer layer's backward in one launch.  Host tables, like vitk_cast_many. */
+int vitk_fold_many(const float* const* src, void* const* dst, const int64_t* nparts, const int64_t* ld, const int64_t* cols,
+                   const int32_t* flags, int64_t count, void* stream);
 /* x[b, 0:ncls, :] = cls[0:ncls, :] + pos[0:ncls, :] for every b (vit.py:122-127); x f32 or T   */
 int vitk_write_cls_rows(void* x, int xdt, const void* cls, const void* pos, int pdt,
                         int64_t B, int64_t N, int64_t D, int64_t ncls, void* stream);

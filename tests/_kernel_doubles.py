@@ -281,6 +281,12 @@ def colsum_partials(partials, nparts, ld, cols, out, accumulate=False):
     out.copy_(r + (out.float() if accumulate else 0))
 
 
+def fold_many(jobs):
+    """K.fold_many: the queued folds of a fused backward (ops.deferred_folds), one job at a time."""
+    for part, nparts, ld, cols, out, acc in jobs:
+        colsum_partials(part, nparts, ld, cols, out, acc)
+
+
 def colsum(x, rows, cols, ld, out, ws, accumulate=False):
     r = x.reshape(rows, ld)[:, :cols].float().sum(0)
     o = out.view(-1)                        # (cols,) however the caller shapes it ((N, D) for the positional-table gradient)
@@ -519,7 +525,7 @@ def require_device(*ts):
 _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_nt_bf16_gelu_bwd_colsum, gemm_nt_bf16_mul_aux_colsum=gemm_nt_bf16_mul_aux_colsum, gemm_nt_fp8_v2=gemm_nt_fp8_v2,
                   gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_bf16_pair=gemm_tn_bf16_pair, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
-                  fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials,
+                  fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials, fold_many=fold_many,
                   colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, cast_many=cast_many, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify, unpatchify=unpatchify, patch_ln_fwd=patch_ln_fwd, patch_ln_bwd_params=patch_ln_bwd_params,
                   copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, concat_tokens=concat_tokens, hnd=hnd, attn_varlen_fwd_bf16=attn_varlen_fwd_bf16, attn_varlen_bwd_bf16=attn_varlen_bwd_bf16,
                   patchify_cpp=patchify_cpp, gather_add2=gather_add2, csr_rowsum=csr_rowsum,

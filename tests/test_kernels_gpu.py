@@ -794,3 +794,60 @@ def test_gemm_tn_pair(M, N0, K0, N1, K1, odt, monkeypatch):
     K.gemm_tn_bf16_pair(dY0, N0, X0, K0, dW0, dY1, N1, X1, K1, dW1, M, ws, splits, accumulate0=True)
     assert rel(dW0, 2 * (dY0.double().t() @ X0.double())) < 2 * tol
     assert rel(dW1, dY1.double().t() @ X1.double()) < tol
+
+
+def test_fold_many_equals_the_one_job_folds_bit_for_bit():
+    """vitk_fold_many (round 5: the LayerNorm finalizes and bias-gradient column sums of a layer's backward in one launch) against
+    vitk_colsum_partials job by job: same additions in the same order, so the results are bit-identical -- float32 and 16-bit outputs,
+    accumulate, a strided partial slab, more jobs than one launch holds (40), one-column and ragged widths."""
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    jobs, want = [], []
+    shapes = [(404, 3072, 3072), (394, 768, 768), (197, 768, 768), (1, 8, 8), (33, 100, 72), (16, 64, 64), (17, 1, 1)] * 7       # 49 jobs: two launches
+    for i, (nparts, ld, cols) in enumerate(shapes):
+        part = torch.randn(nparts * ld, generator=g).to(DEV)
+        odt = F32 if i % 3 == 0 else BF
+        acc = i % 4 == 1
+        init = torch.randn(cols, generator=g).to(odt).to(DEV)
+        a, b = init.clone(), init.clone()
+        K.colsum_partials(part, nparts, ld, cols, a, acc)
+        want.append(a)
+        jobs.append((part, nparts, ld, cols, b, acc))
+    K.fold_many(jobs)
+    for i, (j, w) in enumerate(zip(jobs, want)):
+        assert torch.equal(j[4], w), (i, shapes[i])
+    # the three slabs of a LayerNorm backward's partials as three jobs == vitk_layernorm_bwd_finalize
+    nblk, D = 200, 768
+    partials = torch.randn(3 * nblk * D, generator=g).to(DEV)
+    dw0, db0, dc0 = (torch.empty(D, dtype=BF, device=DEV) for _ in range(3))
+    K.layernorm_bwd_finalize(partials, nblk, D, dw0, db0, dc0, K.dt(dw0))
+    outs = [torch.empty(D, dtype=BF, device=DEV) for _ in range(3)]
+    K.fold_many([(partials[i * nblk * D:], nblk, D, D, outs[i], False) for i in range(3)])
+    assert torch.equal(outs[0], dw0) and torch.equal(outs[1], db0) and torch.equal(outs[2], dc0)
+    with pytest.raises(L.VitkError):
+        K.fold_many([(partials.to(BF), nblk, D, D, outs[0], False)])
+
+
+def test_fused_backward_with_deferred_folds_equals_immediate_folds():
+    """engine.TransformerFn.backward queues its folds (ops.deferred_folds) and flushes once per layer; with the queue switched off (every
+    fold its own launch, as in rounds 1-4) the gradients must be bit-identical."""
+    from vit_pytorch_amd import ViT, ops as OPS
+    torch.manual_seed(0)
+    m = ViT(image_size=64, patch_size=8, num_classes=10, dim=256, depth=3, heads=4, mlp_dim=512).to(DEV, dtype=BF)
+    img = torch.randn(24, 3, 64, 64, device=DEV).to(BF)
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        m(img).float().square().mean().backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    g1 = grads()
+    real = OPS.deferred_folds
+    class off:              # a deferred_folds that defers nothing
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+    OPS.deferred_folds = off
+    try:
+        g0 = grads()
+    finally:
+        OPS.deferred_folds = real
+    assert all(torch.equal(a, b) for a, b in zip(g1, g0))

@@ -19,10 +19,21 @@ def groups(root, counter):
                 continue
             rows.append((int(r["Dispatch_Id"]), n, float(r["Counter_Value"])))
     rows.sort()
-    out = []
+    # a CALL of the NT entry point may be two dispatches since round 5: gemm_ntw_kernel<EPI, ..> on the whole rounds, then gemm_ntp_kernel<EPI, ..>
+    # on the remaining rows -- their counters are summed
+    calls = []
     for _, n, v in rows:
         m = re.search(r"(gemm_\w+)(<[^>]*>)?", n)
-        key = m.group(1) + (m.group(2) or "")
+        name, targs = m.group(1), (m.group(2) or "")
+        epi = targs.strip("<>").split(",")[0].strip() if targs else ""
+        if (name == "gemm_ntp_kernel" and calls and calls[-1][2] == ("gemm_ntw_kernel", epi) and not calls[-1][3]):
+            calls[-1][1] += v
+            calls[-1][0] += " + gemm_ntp_kernel" + targs
+            calls[-1][3] = True
+        else:
+            calls.append([name + targs, v, (name, epi), False])
+    out = []
+    for key, v, _, _ in calls:
         if out and out[-1][0] == key and len(out[-1][1]) < 3:
             out[-1][1].append(v)
         else:

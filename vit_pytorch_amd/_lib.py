@@ -16,7 +16,7 @@ LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit t
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD, EPI_RESID16, EPI_BIAS_GELU_DG, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6, 7
-VITK_VERSION = 134
+VITK_VERSION = 135
 
 
 class RowMap(C.Structure):
@@ -120,6 +120,7 @@ SIGNATURES = {
     "vitk_add_rows": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i64, _vp]),
     "vitk_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
     "vitk_cast_many": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "vitk_fold_many": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vitk_write_cls_rows": (_i, [_vp, _i, _vp, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
     "vitk_mean_pool_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),
     "vitk_mean_pool_bwd": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),

@@ -555,7 +555,7 @@ int gemm_ntw_split(int64_t M, int64_t N, int64_t K, int grid) {
     const long long tm_cap = (M % 256 == 0) ? M / 256 : (M - 1024) / 256;
     if (tm_cap <= 0) return 0;
     double second_launch = 14.0 / (0.72 * (double)(K / 32) + 6.0);
-    if (const char* e = vitk_switch("VITK_NTW_SPLIT")) second_launch = e[0] == 'r' ? 0.15 : (e[0] == 'n' ? 100.0 : second_launch);      // A/B: rounds / none
+    if (const char* e = vitk_exp("VITK_NTW_SPLIT")) second_launch = e[0] == 'r' ? 0.15 : (e[0] == 'n' ? 100.0 : second_launch);      // A/B: rounds / none
     auto legal = [&](long long tm) { const long long rest = M - 256 * tm; return tm > 0 && tm <= tm_cap && (rest == 0 || rest >= 1024); };
     auto cost = [&](long long tm) -> double {
         const long long rest = M - 256 * tm;
@@ -586,7 +586,7 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
     if (a.tiles_n > 8) a.group_n = (a.tiles_n + (a.tiles_n + 5) / 6 - 1) / ((a.tiles_n + 5) / 6);
     if (vitk_exp("VITK_GROUP_N")) { const int g = atoi(vitk_exp("VITK_GROUP_N")); a.group_n = g > 0 && g < a.tiles_n ? g : a.tiles_n; }
     a.dbg = dbg;
-    if (const char* e = vitk_switch("VITK_NTW_RELAX")) a.dbg |= e[0] == 'a' ? 16 : (e[0] == 'n' ? 2 : 0);      // A/B: all / none
+    if (const char* e = vitk_exp("VITK_NTW_RELAX")) a.dbg |= e[0] == 'a' ? 16 : (e[0] == 'n' ? 2 : 0);      // A/B: all / none
     const int lds_bytes = V_RING + a.tiles_n * 512 + 16;
     hipStream_t st = (hipStream_t)stream;
     if (tiles_m <= 0 || grid < 8) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16 (w128): nothing to do");

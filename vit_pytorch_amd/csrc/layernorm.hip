@@ -611,6 +611,42 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
     }
 }
 
+// Many folds in one launch (round 5): the backward of a layer ends in ~4 tiny fold launches -- two LayerNorm finalizes (3 slabs each), the
+// FeedForward bias-gradient column sums -- each 4-11 us of launch latency around a few MB of reads; their outputs are parameter gradients
+// nobody reads before the optimizer / the all-reduce, so the engine queues them and folds a layer's worth in ONE launch.  Job j:
+// dst[c] = (accumulate ? dst[c] : 0) + sum_p src[p * ld + c], c < cols, p < nparts -- the SAME order of additions as the kernels above
+// (16 phases strided over the partial rows, then the 16 phase sums in order), so results are bit-identical to the one-job launches.
+constexpr int FM_MAX = 40;
+struct FoldMany { const float* src[FM_MAX]; void* dst[FM_MAX]; int nparts[FM_MAX]; int ld[FM_MAX]; int cols[FM_MAX]; int flags[FM_MAX]; int blk0[FM_MAX + 1]; int count; };
+__global__ __launch_bounds__(1024) void fold_many_kernel(const FoldMany a) {
+    __shared__ float red[16][64];
+    int lo = 0, hi = a.count;                  // uniform binary search: blk0[lo] <= blockIdx.x < blk0[lo + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= a.blk0[mid]) lo = mid; else hi = mid; }
+    const float* __restrict__ src = a.src[lo];
+    const int nparts = a.nparts[lo], cols = a.cols[lo], flags = a.flags[lo];
+    const long long ld = a.ld[lo];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - a.blk0[lo]) * 64 + cx;
+    float s = 0.f;
+    if (c < cols) for (int p = ph; p < nparts; p += 16) s += src[(long long)p * ld + c];
+    red[ph][cx] = s;
+    __syncthreads();
+    if (ph == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        if ((flags >> 4) == VITK_F32) {
+            float* o = (float*)a.dst[lo];
+            if (flags & 1) t += o[c];
+            o[c] = t;
+        } else {
+            __bf16* o = (__bf16*)a.dst[lo];
+            if (flags & 1) t += (float)o[c];
+            o[c] = (__bf16)t;
+        }
+    }
+}
+
 // LayerNorm-backward finalize: reduce the 2 or 3 partial slabs of one ln_bwd launch in ONE kernel
 // (1024 threads = 64 columns x 16 partial phases; dw/db in the parameter dtype, dcol in f32).
 template <typename OT>
@@ -1051,6 +1087,31 @@ extern "C" int vitk_colsum_partials(const float* partials, int64_t nparts, int64
     VITK_DISPATCH_DT(odt, OT, hipLaunchKernelGGL((colsum_partials_kernel<OT>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream,
                                                   partials, (long long)nparts, (long long)ld, (long long)cols, (OT*)out, accumulate));
     VITK_CHECK_LAUNCH("colsum_partials");
+    return 0;
+}
+
+extern "C" int vitk_fold_many(const float* const* src, void* const* dst, const int64_t* nparts, const int64_t* ld, const int64_t* cols,
+                              const int32_t* flags, int64_t count, void* stream) {
+    if (count <= 0) return 0;
+    if (!src || !dst || !nparts || !ld || !cols || !flags) VITK_FAIL(VITK_E_ARG, "fold_many: null table");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t t = 0;
+    while (t < count) {
+        FoldMany a;
+        a.count = 0; a.blk0[0] = 0;
+        while (t < count && a.count < FM_MAX) {
+            if (!src[t] || !dst[t]) VITK_FAIL(VITK_E_ARG, "fold_many: null pointer in the table");
+            if (nparts[t] <= 0 || cols[t] <= 0 || ld[t] < cols[t] || nparts[t] > 0x7fffffff || ld[t] > 0x7fffffff) VITK_FAIL(VITK_E_SHAPE, "fold_many: bad job %lld", (long long)t);
+            const int dt_ = flags[t] >> 4;
+            if ((flags[t] & ~0x31) || (dt_ != VITK_F32 && dt_ != VITK_BF16)) VITK_FAIL(VITK_E_DTYPE, "fold_many: bad flags / dtype tag in job %lld", (long long)t);
+            const int k = a.count;
+            a.src[k] = src[t]; a.dst[k] = dst[t]; a.nparts[k] = (int)nparts[t]; a.ld[k] = (int)ld[t]; a.cols[k] = (int)cols[t]; a.flags[k] = flags[t];
+            a.blk0[k + 1] = a.blk0[k] + (int)((cols[t] + 63) / 64);
+            ++a.count; ++t;
+        }
+        hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)a.blk0[a.count]), dim3(1024), 0, st, a);
+        VITK_CHECK_LAUNCH("fold_many");
+    }
     return 0;
 }
 

@@ -338,6 +338,11 @@ class TransformerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with ops.deferred_folds():          # the LayerNorm finalizes and bias-gradient column sums of a layer go out as one launch
+            return TransformerFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         heads, dim_head, depth, B, N, D, in_dtype = ctx.meta
         drop_p, drop_seed = ctx.drop
         site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
@@ -394,7 +399,7 @@ class TransformerFn(torch.autograd.Function):
             K.gemm_nt_fp8_v2(dy8, Nw, w8t, Nw, dx, Kd, M, Kd, Nw, epi, a_kind=K.A_E5M2, aux=pre, partials=part,
                              alpha_a=sc[1:], alpha_w=wsc[1:], c8=c8b, c8_scale=c8s, c8_amax64=c8a, k128=f8.k128 and Nw % 128 == 0)
             if db is not None:
-                K.colsum_partials(part, R, Kd, Kd, db)
+                ops.fold(part, R, Kd, Kd, db)
             return dx
 
         def dw(li, q, dyT, x, xslot, dW, db=None, x8=None):
@@ -537,6 +542,7 @@ class TransformerFn(torch.autograd.Function):
             grads[base + 0], grads[base + 1] = dl1w, dl1b
             g, gb = g1, g1b
             del g2, g2b, da1
+            ops.flush_folds()                    # this layer's parameter-gradient folds: one launch, before the sink may send them
             sk = _sink()
             if sk is not None:
                 tick = getattr(sk, "layer_tick", None)
@@ -545,6 +551,7 @@ class TransformerFn(torch.autograd.Function):
             if sk is not None and sk.wants_layer(li):
                 fork.join()                      # this layer's weight gradients (side stream) are part of the chunk
                 sk.stage_done("layer", li)
+        ops.flush_folds()
         fork.join()
         if f8 is not None:
             f8.end_of_backward()

@@ -111,6 +111,26 @@ def colsum_partials(partials: Tensor, nparts: int, ld: int, cols: int, out: Tens
           "colsum_partials")
 
 
+def fold_many(jobs):
+    """jobs: [(partials, nparts, ld, cols, out, accumulate)]: out[c] = (accumulate ? out[c] : 0) + sum_p partials[p * ld + c] for every job
+    in ceil(len / 40) launches (vitk_fold_many) -- the colsum_partials / layernorm_bwd_finalize of a whole layer's backward at once."""
+    import ctypes
+    if not jobs:
+        return
+    n = len(jobs)
+    for part, nparts, ld, cols, out, _ in jobs:
+        if part.dtype != torch.float32 or not out.is_contiguous() or out.numel() < cols:
+            raise L.VitkError("fold_many: float32 partial rows and a contiguous output of at least `cols` elements are required")
+    src = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+    dst = (ctypes.c_void_p * n)(*[j[4].data_ptr() for j in jobs])
+    npar = (ctypes.c_int64 * n)(*[int(j[1]) for j in jobs])
+    lds = (ctypes.c_int64 * n)(*[int(j[2]) for j in jobs])
+    cls = (ctypes.c_int64 * n)(*[int(j[3]) for j in jobs])
+    flg = (ctypes.c_int32 * n)(*[(1 if j[5] else 0) | (dt(j[4]) << 4) for j in jobs])
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    check(_lib_for(*[j[4] for j in jobs]).vitk_fold_many(cv(src), cv(dst), cv(npar), cv(lds), cv(cls), cv(flg), n, _stream()), "fold_many")
+
+
 def colsum_ws_floats(rows: int, cols: int) -> int:
     return int(L.load().vitk_colsum_ws_floats(rows, cols))
 

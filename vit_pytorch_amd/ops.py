@@ -66,7 +66,57 @@ def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, rows: i
         K.layernorm_bwd(dy, x, w, mean, rstd, gin, dx_f32, dx_t, partials, dcol is not None, rows, D, dymap, xmap, dxmap,
                         *(drop if drop else (0.0, 0)))
     assert dcol is None or dcol.dtype in (F32, w.dtype)
-    K.layernorm_bwd_finalize(partials, nblk, D, dw, db, dcol, K.dt(w))
+    if folds_deferred():        # a fused backward is collecting its folds: the three slabs join the layer's one launch (flush_folds)
+        for i, out in enumerate((dw, db, dcol)):
+            if out is not None:
+                fold(partials[i * nblk * D:], nblk, D, D, out)
+    else:
+        K.layernorm_bwd_finalize(partials, nblk, D, dw, db, dcol, K.dt(w))
+
+
+# ---- deferred folds ---------------------------------------------------------------------------------------------------------
+# The backward of a transformer layer ends in ~4 tiny fold launches (two LayerNorm finalizes, the FeedForward bias-gradient column sums)
+# whose outputs are parameter gradients nobody reads before the optimizer / the all-reduce.  Inside `with deferred_folds():` they are
+# queued (the partial rows stay referenced) and go out as ONE vitk_fold_many launch per flush_folds() -- per layer in engine.TransformerFn,
+# before the data-parallel sink is told the layer is done.  Same additions in the same order: bit-identical gradients.
+import threading as _threading
+
+_FOLDS = _threading.local()
+
+
+def folds_deferred() -> bool:
+    return getattr(_FOLDS, "q", None) is not None
+
+
+def flush_folds():
+    q = getattr(_FOLDS, "q", None)
+    if q:
+        K.fold_many(q)
+        del q[:]
+
+
+class deferred_folds:
+    def __enter__(self):
+        self.prev = getattr(_FOLDS, "q", None)
+        _FOLDS.q = []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            if exc_type is None:
+                flush_folds()
+        finally:
+            _FOLDS.q = self.prev
+        return False
+
+
+def fold(part: Tensor, nparts: int, ld: int, cols: int, out: Tensor, accumulate: bool = False):
+    """out[c] (+)= sum_p part[p * ld + c]: K.colsum_partials now, or a job of the enclosing deferred_folds() block."""
+    q = getattr(_FOLDS, "q", None)
+    if q is None:
+        K.colsum_partials(part, nparts, ld, cols, out, accumulate)
+    else:
+        q.append((part, nparts, ld, cols, out, accumulate))
 
 
 def grad_stream_16() -> bool:
@@ -369,7 +419,7 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
         part = empty((R * Kd,), F32, dy) if db is not None else None
         K.gemm_nt_bf16_mul_aux_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_dg, part)
         if db is not None:
-            K.colsum_partials(part, R, Kd, Kd, db)
+            fold(part, R, Kd, Kd, db)
             return dx, True
         return dx
     if drop is None and _f32_nt_ok(dy, M, Kd, N):
@@ -387,7 +437,7 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
             part = empty((R * Kd,), F32, dy) if db is not None else None
             K.gemm_nt_bf16_drop(dy, N, Wt, ldt, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, drop[0], drop[1], aux=gelu_pre, partials=part)
             if db is not None:
-                K.colsum_partials(part, R, Kd, Kd, db)
+                fold(part, R, Kd, Kd, db)
                 return dx, True
             return dx
         if gelu_pre is not None and db is not None:
@@ -395,7 +445,7 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
             if R > 0:
                 part = empty((R * Kd,), F32, dy)
                 K.gemm_nt_bf16_gelu_bwd_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_pre, part)
-                K.colsum_partials(part, R, Kd, Kd, db)
+                fold(part, R, Kd, Kd, db)
                 return dx, True
         if gelu_pre is not None:
             K.gemm_nt_bf16(dy, N, Wt, ldt, dx, Kd, M, Kd, N, L.EPI_GELU_BWD, aux=gelu_pre)
