@@ -127,7 +127,9 @@ def test_random_navit_packs_vs_oracle(seed):
         else:
             e_ref, g_ref = rel(bf_out, ref_out), rel(cat(bf_g), cat(ref_g))
             print(f"navit draw {seed}: {cfg} {packs}: bf16 logits {e:.2e} ({e_ref:.2e}), grads {g:.2e} ({g_ref:.2e})")
-            assert e <= 1.5 * e_ref + 1e-3 and g <= min(1.5 * g_ref + 1e-3, ABS_CAP), ("bf16", cfg, packs, e, e_ref, g, g_ref)
+            # (NaViT's q / k RMSNorm and attention pool make small random models noisy in bf16: the REFERENCE's own bf16 gradients are up to
+            #  4e-2 off here, so the absolute cap applies unless the reference-bf16 itself is beyond it -- then "not worse than the reference")
+            assert e <= 1.5 * e_ref + 1e-3 and g <= min(1.5 * g_ref + 1e-3, max(ABS_CAP, g_ref + 1e-3)), ("bf16", cfg, packs, e, e_ref, g, g_ref)
 
 
 # ---- the same draws through the other modes of the drop-in -------------------------------------------------------------------------

@@ -16,6 +16,8 @@ for step in "$@"; do
     tests_new) timeout 1200 python -m pytest tests/test_gemm_nt_w128_gpu.py tests/test_gemm_persist_gpu.py tests/test_kernels_gpu.py tests/test_navit_gpu.py tests/test_fuzz_gpu.py -m gpu -x -q > $out/${tag}_tests_new.log 2>&1; tail -3 $out/${tag}_tests_new.log ;;
     bench_ab4) for v in "default::" "r05d:rounds:all" "split_rounds:rounds:" "relax_all::all" "default2::"; do n=${v%%:*}; r=${v#*:}; sp=${r%%:*}; rx=${r#*:}; VITK_NTW_SPLIT=$sp VITK_NTW_RELAX=$rx timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_$n.json.log 2>&1; echo $n $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_$n.json.log | head -1); done ;;
     tree_ab) for i in 1 2; do (cd _ab_r05d && PYTHONPATH=$PWD timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_oldtree_$i.json.log 2>&1); echo oldtree $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_oldtree_$i.json.log | head -1); timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_newtree_$i.json.log 2>&1; echo newtree $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_newtree_$i.json.log | head -1); done ;;
+    fold_ab) for i in 1 2; do VITK_FOLD_DEFER=0 timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_nofold_$i.json.log 2>&1; echo nofold $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_nofold_$i.json.log | head -1); timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_fold_$i.json.log 2>&1; echo fold $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_fold_$i.json.log | head -1); done ;;
+    mask_ab) for i in 1 2; do for m in 0 0x23 0xff; do VITK_NT_W128=$m timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_mask${m}_$i.json.log 2>&1; echo mask $m $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_mask${m}_$i.json.log | head -1); done; done ;;
     profile) bash tools/profile_round.sh $tag ;;
   esac
 done

@@ -850,13 +850,17 @@ extern "C" int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, cons
 // The row split is a function of (M, N, K), the CU count and vitk_set_cu_reserve() only: vitk_gemm_nt_colsum_rows() reports the partial
 // rows of both launches.  While another kernel is expected on the chip (cu_reserve > 0: the in-backward all-reduce) everything goes to the
 // 8-wave kernel, whose dynamic tile tickets keep a launch from waiting for CUs it does not get.
-static int ntw_tiles_m(const NtpPlan& q, int64_t M, int64_t N, int64_t K) {
+// VITK_NT_W128 = bit mask over VITK_EPI_* of the epilogues the four-wave kernel serves (0 = none: the 8-wave kernel alone; unset = NTW_EPIS)
+constexpr unsigned NTW_EPIS = 0xffu;
+static int ntw_tiles_m(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int epilogue) {
     const char* e = vitk_switch("VITK_NT_W128");
-    if (!q.ok || (e && e[0] == '0') || vitk_get_cu_reserve() > 0 || !gemm_ntw_serves(M, N, K)) return 0;
+    const unsigned mask = e ? (unsigned)strtoul(e, nullptr, 0) : NTW_EPIS;
+    if (!q.ok || !((mask >> epilogue) & 1u) || vitk_get_cu_reserve() > 0 || !gemm_ntw_serves(M, N, K)) return 0;
     return gemm_ntw_split(M, N, K, q.grid);
 }
 static int64_t nt_persist_colsum_rows(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int64_t ldc) {
-    const int tmw = ntw_tiles_m(q, M, N, K);
+    // (the two epilogues with column sums, GELU_BWD and MUL_AUX, are switched together: one row count serves both entry points)
+    const int tmw = ntw_tiles_m(q, M, N, K, VITK_EPI_MUL_AUX);
     if (tmw == 0) return ntp_colsum_rows(q);
     const int64_t rest = M - 256LL * tmw;
     return 2LL * tmw + (rest > 0 ? ntp_colsum_rows(ntp_plan(rest, N, K, ldc, nullptr)) : 0);
@@ -864,7 +868,7 @@ static int64_t nt_persist_colsum_rows(const NtpPlan& q, int64_t M, int64_t N, in
 static int nt_persist_dispatch(const NtpPlan& q, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
                                int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* csum, unsigned drop_t,
                                unsigned drop_seed, float inv_keep, void* stream) {
-    const int tmw = ntw_tiles_m(q, M, N, K);
+    const int tmw = ntw_tiles_m(q, M, N, K, epilogue == VITK_EPI_GELU_BWD ? VITK_EPI_MUL_AUX : epilogue);
     // fused dropout lives in the 8-wave kernel; only the epilogue with column sums has to keep the row split (its partial rows are promised)
     if (tmw == 0 || (drop_t && !(epilogue == VITK_EPI_GELU_BWD && csum)))
         return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);

@@ -98,7 +98,7 @@ def flush_folds():
 class deferred_folds:
     def __enter__(self):
         self.prev = getattr(_FOLDS, "q", None)
-        _FOLDS.q = []
+        _FOLDS.q = [] if os.environ.get("VITK_FOLD_DEFER", "1") != "0" else None       # =0: every fold its own launch (A/B runs)
         return self
 
     def __exit__(self, exc_type, exc, tb):
