@@ -85,7 +85,7 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
       ff1       NT GEMM with the fused bias + GELU epilogue       dff1   NT GEMM with the GELU' + bias-gradient column sums epilogue
       nt_resid  NT GEMM + bias + residual (out-projection, FF2)    nt     NT GEMM, plain / bias epilogue (QKV, the three dX GEMMs)"""
     from vit_pytorch_amd import _lib as L, kernels as K
-    orig = {n: getattr(K, n) for n in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum", "gemm_nt_bf16_mul_aux_colsum", "gemm_nt_fp8_v2", "gemm_tn_bf16",
+    orig = {n: getattr(K, n) for n in ("gemm_nt_bf16", "gemm_nt_bf16_gelu_bwd_colsum", "gemm_nt_bf16_mul_aux_colsum", "gemm_nt_bf16_mul_aux8_colsum", "gemm_nt_fp8_v2", "gemm_tn_bf16",
                                        "gemm_tn_bf16_pair")}
     taps = {}
 
@@ -98,7 +98,7 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
         taps.setdefault(key, []).append((e0, e1, flops))
         return r
 
-    nt_class = {L.EPI_BIAS_GELU: "ff1", L.EPI_BIAS_GELU_DG: "ff1", L.EPI_GELU_BWD: "dff1", L.EPI_MUL_AUX: "dff1", L.EPI_RESID: "nt_resid", L.EPI_RESID16: "nt_resid"}
+    nt_class = {L.EPI_BIAS_GELU: "ff1", L.EPI_BIAS_GELU_DG: "ff1", L.EPI_BIAS_GELU_DG8: "ff1", L.EPI_MUL_AUX8: "dff1", L.EPI_GELU_BWD: "dff1", L.EPI_MUL_AUX: "dff1", L.EPI_RESID: "nt_resid", L.EPI_RESID16: "nt_resid"}
 
     def tapped_nt(*a, **kw):
         epi = a[9] if len(a) > 9 else kw.get("epilogue", L.EPI_NONE)
@@ -118,6 +118,10 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
 
     K.gemm_nt_bf16, K.gemm_nt_bf16_gelu_bwd_colsum, K.gemm_nt_fp8_v2, K.gemm_tn_bf16 = tapped_nt, tapped_bwd, tapped_f8, tapped_tn
     K.gemm_nt_bf16_mul_aux_colsum = tapped_mul
+
+    def tapped_mul8(*a, **kw):
+        return bracket(("dff1", a[7], a[8]), 2.0 * a[6] * a[7] * a[8], orig["gemm_nt_bf16_mul_aux8_colsum"], a, kw)
+    K.gemm_nt_bf16_mul_aux8_colsum = tapped_mul8
 
     def tapped_pair(*a, **kw):          # (dY0, ldy0, X0, ldx0, dW0, dY1, ldy1, X1, ldx1, dW1, M, ws, splits): two weight gradients, one launch
         (n0, k0), (n1, k1) = a[4].shape, a[9].shape
@@ -418,9 +422,9 @@ def main():
         # GEMM classes by their share of the step (kernel time per step / measured step time); the roofline kernel is the heaviest
         # INSTANCE (one shape) of the heaviest class
         CLASS_NAMES = {"tn": "gemm_tn_w128_kernel + tn_reduce_kernel (weight gradients dW = dY^T X: four waves, 128 x 128 wave tiles)",
-                       "ff1": "gemm_ntw_kernel<EPI_BIAS_GELU_DG> (four-wave persistent NT GEMM, FF1: bias + GELU, stores the gelu' factor for the backward) "
+                       "ff1": "gemm_ntw_kernel<EPI_BIAS_GELU_DG8> (four-wave persistent NT GEMM, FF1: bias + GELU, stores the gelu' factor for the backward as 8-bit codes) "
                               "[+ gemm_ntp_kernel on the rows the row split leaves]",
-                       "dff1": "gemm_ntw_kernel<EPI_MUL_AUX> (dFF1: x the stored gelu' factor + bias-gradient column sums) [+ gemm_ntp_kernel on the remaining rows]",
+                       "dff1": "gemm_ntw_kernel<EPI_MUL_AUX8> (dFF1: x the stored gelu' factor + bias-gradient column sums) [+ gemm_ntp_kernel on the remaining rows]",
                        "nt_resid": "gemm_ntw_kernel<EPI_RESID16 / EPI_RESID> + gemm_ntp_kernel on the remaining rows (out-projection, FF2: + bias + residual)",
                        "nt": "gemm_ntw_kernel<EPI_NONE / EPI_BIAS> + gemm_ntp_kernel on the remaining rows (QKV and the three dX GEMMs)"}
         if args.fp8:
@@ -506,7 +510,7 @@ def main():
                          "traffic": dent["traffic"], "algorithmic_bytes": dent["algorithmic_bytes"], "traffic_source": dent["traffic_source"],
                          "machine_balance_flop_per_byte": balance,
                          "bound_note": "MFMA roof; an instance whose flop_per_byte is below machine_balance_flop_per_byte (peak / 6.3 TB/s) is balanced or HBM-side by its bytes "
-                                       "(FF1 at K = 768 with two 16-bit outputs: 339 FLOP/B against 399)",
+                                       "(FF1 at K = 768 with a 16-bit and an 8-bit output: 435 FLOP/B against 399; with two 16-bit outputs it was 339)",
                          "classes": others},
         }
         if world == 1 and not args.no_cpu_baseline:

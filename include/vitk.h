@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 135
+#define VITK_VERSION 136
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -133,6 +133,11 @@ int vitk_colsum(const void* x, int xdt, int64_t rows, int64_t cols, int64_t ld,
                                   instead of a second polynomial + exponential per element; persistent kernel only, no fused dropout */
 #define VITK_EPI_MUL_AUX 7     /* C = acc * aux[m][n]  (aux = the gelu' factor BIAS_GELU_DG stored); column sums as with GELU_BWD
                                   (vitk_gemm_nt_bf16_mul_aux_colsum); persistent kernel only */
+#define VITK_EPI_BIAS_GELU_DG8 8 /* BIAS_GELU_DG with the factor stored in 8 bits: aux is M x ldc BYTES, code = rne(200 gelu'(pre)) + 27 (gelu' lies in
+                                  [-0.129, 1.129]: codes 1 .. 253), i.e. fixed point with |error| <= 0.0025 -- a bf16 of the same value is off by up to
+                                  0.0039 in [1, 1.13) -- and 0, 0.5, 1 exact; halves the bytes of FF1's second output and of dFF1's second input, both
+                                  of which run at the memory system's rate; persistent kernel only, ldc % 8 == 0 */
+#define VITK_EPI_MUL_AUX8 9    /* C = acc * 0.005 (aux8[m][n] - 27): VITK_EPI_MUL_AUX on the codes BIAS_GELU_DG8 stored (vitk_gemm_nt_bf16_mul_aux8_colsum) */
 
 /* C[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  A, W bf16, K-contiguous ("NT").
  * Requirements: K % 32 == 0; lda, ldw % 8 == 0; N % 4 == 0; pointers 16-byte aligned.
@@ -150,6 +155,9 @@ int64_t vitk_gemm_nt_colsum_rows(int64_t M, int64_t N, int64_t K, int64_t ldc);
 /* The same with VITK_EPI_MUL_AUX: C = (A . W^T) * aux, aux = the gelu' factor a VITK_EPI_BIAS_GELU_DG forward stored. */
 int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                      int64_t M, int64_t N, int64_t K, const void* aux, float* colsum_partials, void* stream);
+/* The same on the 8-bit codes of a VITK_EPI_BIAS_GELU_DG8 forward (aux8: M x ldc bytes). */
+int vitk_gemm_nt_bf16_mul_aux8_colsum(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                      int64_t M, int64_t N, int64_t K, const void* aux8, float* colsum_partials, void* stream);
 /* Tile schedule of the persistent NT kernel for (M, N, K) (tests, tuning): out[0] = 1 when the shape is served by it,
  * out[1] = 256-row m-tiles, out[2] = 128-row m-tiles of the tail region, out[3] = resident workgroups, out[4] = n-tiles. */
 int vitk_gemm_nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, int32_t* out5);

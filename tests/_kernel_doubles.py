@@ -53,8 +53,21 @@ def _w_plain(W, ldw, N, Kd):
 
 
 def _epilogue(acc, C, M, N, epilogue, bias, resid, aux, partials=None):
-    if epilogue in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_BIAS_GELU_DG, L.EPI_RESID, L.EPI_RESID16) and bias is not None:
+    if epilogue in (L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_BIAS_GELU_DG, L.EPI_BIAS_GELU_DG8, L.EPI_RESID, L.EPI_RESID16) and bias is not None:
         acc = acc + bias.float()
+    if epilogue == L.EPI_BIAS_GELU_DG8:                             # aux = 8-bit codes of gelu'(pre): rne(200 f) + 27 (include/vitk.h)
+        assert aux.dtype == torch.uint8
+        pre = acc.to(C.dtype).float()
+        aux.view(M, N).copy_((torch.round(O.gelu_bwd(torch.ones_like(pre), pre) * 200.0) + 27.0).clamp_(0, 255).to(torch.uint8))
+        C.view(M, N).copy_(O.gelu_fwd(pre))
+        return
+    if epilogue == L.EPI_MUL_AUX8:
+        assert aux.dtype == torch.uint8
+        C.view(M, N).copy_(acc * ((aux.view(M, N).float() - 27.0) * 0.005))
+        if partials is not None:
+            partials.zero_()
+            partials[:N] = C.view(M, N).float().sum(0)
+        return
     if epilogue == L.EPI_BIAS_GELU_DG:                              # aux = gelu'(pre) of the pre-activation rounded to T
         pre = acc.to(aux.dtype).float()
         aux.view(M, N).copy_(O.gelu_bwd(torch.ones_like(pre), pre))
@@ -516,13 +529,16 @@ def gelu_fwd(x, y):
 
 def gelu_bwd(dy, x, dx):
     dx.copy_(O.gelu_bwd(dy.float(), x.float()))
+def gemm_nt_bf16_mul_aux8_colsum(A, lda, W, ldw, C, ldc, M, N, Kd, aux8, partials):
+    CALLS.append(("gemm_nt_bf16_mul_aux8_colsum", (M, N, Kd)))
+    _epilogue(A.reshape(M, Kd).float() @ _w_plain(W, ldw, N, Kd).t(), C, M, N, L.EPI_MUL_AUX8, None, None, aux8, partials)
 
 
 def require_device(*ts):
     return None
 
 
-_K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_nt_bf16_gelu_bwd_colsum, gemm_nt_bf16_mul_aux_colsum=gemm_nt_bf16_mul_aux_colsum, gemm_nt_fp8_v2=gemm_nt_fp8_v2,
+_K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_nt_bf16_gelu_bwd_colsum, gemm_nt_bf16_mul_aux_colsum=gemm_nt_bf16_mul_aux_colsum, gemm_nt_bf16_mul_aux8_colsum=gemm_nt_bf16_mul_aux8_colsum, gemm_nt_fp8_v2=gemm_nt_fp8_v2,
                   gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_bf16_pair=gemm_tn_bf16_pair, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials, fold_many=fold_many,

@@ -268,7 +268,7 @@ def test_model_surgery_takes_the_module_path_and_pristine_models_the_fused_one(k
 
 
 @pytest.mark.parametrize("flags", [{"VITK_RECOMPUTE": "1"}, {"VITK_FWD_STREAM": "f32", "VITK_GRAD_STREAM": "f32"}, {"VITK_FWD_STREAM": "16"},
-                                   {"VITK_GELU_DG": "0"}, {"VITK_RECOMPUTE": "1", "VITK_GRAD_STREAM": "f32"}])
+                                   {"VITK_GELU_DG": "0"}, {"VITK_GELU_DG": "16"}, {"VITK_RECOMPUTE": "1", "VITK_GRAD_STREAM": "f32"}])
 @pytest.mark.parametrize("seed", [2, 4, 9, 19, 21, 29])
 def test_fuzz_draw_under_engine_switches_bf16_host_logic(seed, flags, monkeypatch):
     """The engine's switches (recompute, stream dtypes, FeedForward pair) change WHICH tensors the host code allocates, saves and hands to

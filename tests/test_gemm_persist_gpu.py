@@ -209,14 +209,20 @@ def test_gelu_factor_epilogue_pair(M, N, Kd):
     # the pre-activation itself carries the f32-accumulation error of one rounding step on a few elements: compare where both agree
     same = pre0.double() == pre
     assert same.double().mean().item() > 0.99
-    assert (dg.double() - dref)[same].abs().max().item() <= 2 ** -8 * 1.2 + 1e-4
+    # the stored factor: 8-bit fixed-point codes (the default: |error| <= 0.0025 over the whole range) or the 16-bit type (VITK_GELU_DG=16)
+    if dg.dtype == torch.uint8:
+        dgv = (dg.double() - 27.0) * 0.005
+        assert (dgv - dref)[same].abs().max().item() <= 0.0025 + 1e-4
+    else:
+        dgv = dg.double()
+        assert (dgv - dref)[same].abs().max().item() <= 2 ** -8 * 1.2 + 1e-4
     # backward: dY (M, N2) . W2 (N2, N) * factor, N2 = Kd
     dY = (torch.randn(M, Kd, device=DEV) * 0.5).to(BF); W2 = (torch.randn(Kd, N, device=DEV) * Kd ** -0.5).to(BF)
     db = torch.empty(N, dtype=BF, device=DEV); db0 = torch.empty(N, dtype=BF, device=DEV)
     dx, done = ops.linear_dx(dY, W2, M, gelu_dg=dg, db=db)
     dx0, done0 = ops.linear_dx(dY, W2, M, gelu_pre=pre0, db=db0)
     assert done and done0
-    ref = (dY.double() @ W2.double()) * dg.double()
+    ref = (dY.double() @ W2.double()) * dgv
     assert rel(dx, ref) < 4e-3
     assert rel(db, dx.double().sum(0)) < 4e-3              # column sums of the ROUNDED output, like GELU_BWD
     assert rel(dx, dx0.double()) < 6e-3                     # vs the pair it replaces: one more rounding of the factor

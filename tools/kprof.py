@@ -28,15 +28,21 @@ def run(label, n, k, epi):
         alg += 4 * M * n                                   # 16-bit residual read + 16-bit write
     else:
         C = torch.empty(M, n, dtype=BF, device=dev); resid = None; aux = torch.randn(M, n, device=dev).to(BF)
-        alg += 2 * M * n * (2 if epi in (L.EPI_BIAS_GELU, L.EPI_GELU_BWD) else 1)   # + pre-activation written (FF1) / read (dFF1)
+        alg += 2 * M * n
     dg = not os.environ.get("KPROF_NO_DG")      # round 4 default: FF1 stores the gelu' factor (EPI_BIAS_GELU_DG), dFF1 multiplies (EPI_MUL_AUX)
+    dg8 = dg and not os.environ.get("KPROF_DG16")       # round 5 default: the factor as 8-bit codes (EPI_BIAS_GELU_DG8 / EPI_MUL_AUX8)
+    if epi in (L.EPI_BIAS_GELU, L.EPI_GELU_BWD):
+        alg += (1 if dg8 else 2) * M * n           # + the factor / pre-activation written (FF1) / read (dFF1)
+        if dg8:
+            aux = torch.randint(1, 254, (M, n), dtype=torch.uint8, device=dev)
     for _ in range(ITERS):
         if epi == L.EPI_GELU_BWD:
             rows = K.gemm_nt_colsum_rows(M, n, k, n)
             cs = torch.empty(rows * n, device=dev)
-            (K.gemm_nt_bf16_mul_aux_colsum if dg else K.gemm_nt_bf16_gelu_bwd_colsum)(A, k, W, ldw, C, n, M, n, k, aux, cs)
+            (K.gemm_nt_bf16_mul_aux8_colsum if dg8 else K.gemm_nt_bf16_mul_aux_colsum if dg else K.gemm_nt_bf16_gelu_bwd_colsum)(A, k, W, ldw, C, n, M, n, k, aux, cs)
         else:
-            K.gemm_nt_bf16(A, k, W, ldw, C, n, M, n, k, L.EPI_BIAS_GELU_DG if (dg and epi == L.EPI_BIAS_GELU) else epi, bias=bias, resid=resid, aux=aux)
+            e = (L.EPI_BIAS_GELU_DG8 if dg8 else L.EPI_BIAS_GELU_DG) if (dg and epi == L.EPI_BIAS_GELU) else epi
+            K.gemm_nt_bf16(A, k, W, ldw, C, n, M, n, k, e, bias=bias, resid=resid, aux=aux)
     torch.cuda.synchronize()
     LABELS.append((label, n, k, alg))
 

@@ -66,13 +66,14 @@ int main(int argc, char** argv) {
 
     struct Shape { const char* name; int64_t N, K; std::vector<int> epis; };
     const std::vector<Shape> shapes = {
-        {"FF1   (N 3072, K  768)", 3072, 768, {VITK_EPI_NONE, VITK_EPI_BIAS_GELU_DG, VITK_EPI_MUL_AUX, VITK_EPI_BIAS_GELU, VITK_EPI_GELU_BWD}},
+        {"FF1   (N 3072, K  768)", 3072, 768, {VITK_EPI_NONE, VITK_EPI_BIAS_GELU_DG, VITK_EPI_BIAS_GELU_DG8, VITK_EPI_MUL_AUX, VITK_EPI_MUL_AUX8, VITK_EPI_BIAS_GELU, VITK_EPI_GELU_BWD}},
         {"FF2   (N  768, K 3072)", 768, 3072, {VITK_EPI_NONE, VITK_EPI_RESID16, VITK_EPI_RESID, VITK_EPI_BIAS}},
         {"QKV   (N 2304, K  768)", 2304, 768, {VITK_EPI_NONE}},
         {"out   (N  768, K  768)", 768, 768, {VITK_EPI_NONE, VITK_EPI_RESID16}},
         {"dXqkv (N  768, K 2304)", 768, 2304, {VITK_EPI_NONE}},
     };
-    const char* epi_name[8] = {"NONE", "BIAS", "BIAS_GELU", "RESID(f32)", "GELU_BWD", "RESID16", "BIAS_GELU_DG", "MUL_AUX"};
+    const char* epi_name[10] = {"NONE", "BIAS", "BIAS_GELU", "RESID(f32)", "GELU_BWD", "RESID16", "BIAS_GELU_DG", "MUL_AUX", "BIAS_GELU_DG8", "MUL_AUX8"};
+    const bool quick = argc > 2 && atoi(argv[2]) == 1;      // no ablations
     double sum_old = 0, sum_new = 0;
     for (const Shape& sh : shapes) {
         const int64_t N = sh.N, K = sh.K;
@@ -91,14 +92,16 @@ int main(int argc, char** argv) {
                (long long)(N / 256), (double)tm_all * (N / 256) / grid, tm_split, (long long)(M - 256LL * tm_split));
         for (int epi : sh.epis) {
             const bool f32out = epi == VITK_EPI_RESID;
-            const bool aux_is_in = epi == VITK_EPI_GELU_BWD || epi == VITK_EPI_MUL_AUX;
-            const bool aux_is_out = epi == VITK_EPI_BIAS_GELU || epi == VITK_EPI_BIAS_GELU_DG;
+            const bool aux_is_in = epi == VITK_EPI_GELU_BWD || epi == VITK_EPI_MUL_AUX || epi == VITK_EPI_MUL_AUX8;
+            const bool aux_is_out = epi == VITK_EPI_BIAS_GELU || epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_BIAS_GELU_DG8;
+            const size_t aux_sz = (epi == VITK_EPI_BIAS_GELU_DG8 || epi == VITK_EPI_MUL_AUX8) ? 1 : 2;
             const bool has_bias = epi == VITK_EPI_BIAS || aux_is_out || epi == VITK_EPI_RESID16 || epi == VITK_EPI_RESID;
             const void* resid = epi == VITK_EPI_RESID ? r32.p : (epi == VITK_EPI_RESID16 ? r16.p : nullptr);
             const size_t cbytes = (size_t)M * N * (f32out ? 4 : 2);
             auto api = [&](Buf& C, Buf& X, Buf& cs) {
                 void* aux = aux_is_in ? aux_in.p : (aux_is_out ? X.p : nullptr);
                 if (epi == VITK_EPI_MUL_AUX) VK(vitk_gemm_nt_bf16_mul_aux_colsum(A.p, K, Wp.p, 0, C.p, N, M, N, K, aux, (float*)cs.p, nullptr));
+                else if (epi == VITK_EPI_MUL_AUX8) VK(vitk_gemm_nt_bf16_mul_aux8_colsum(A.p, K, Wp.p, 0, C.p, N, M, N, K, aux, (float*)cs.p, nullptr));
                 else if (epi == VITK_EPI_GELU_BWD) VK(vitk_gemm_nt_bf16_gelu_bwd_colsum(A.p, K, Wp.p, 0, C.p, N, M, N, K, aux, (float*)cs.p, nullptr));
                 else VK(vitk_gemm_nt_bf16(A.p, K, Wp.p, 0, C.p, N, M, N, K, epi, has_bias ? bias.p : nullptr, (const float*)resid, aux, nullptr));
             };
@@ -124,7 +127,7 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < cbytes; ++i) if (h0[i] != h1[i]) { if (!bad) first_bad = i; ++bad; }
             size_t badx = 0;
             if (aux_is_out) {
-                std::vector<unsigned char> x0((size_t)M * N * 2), x1((size_t)M * N * 2);
+                std::vector<unsigned char> x0((size_t)M * N * aux_sz), x1((size_t)M * N * aux_sz);
                 CK(hipMemcpy(x0.data(), X0.p, x0.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(x1.data(), X1.p, x1.size(), hipMemcpyDeviceToHost));
                 for (size_t i = 0; i < x0.size(); ++i) badx += x0[i] != x1[i];
             }
@@ -157,7 +160,8 @@ int main(int argc, char** argv) {
             const float mo = median(t_old), mn = median(t_new), md = median(t_dir);
             printf("  %-13s r4 8-wave %7.1f us %7.1f TF/s | product path %7.1f us %7.1f TF/s (x%.3f) | new kernel alone, all %d m-tiles %7.1f us %7.1f TF/s\n",
                    epi_name[epi], mo * 1e3, flop / mo / 1e9, mn * 1e3, flop / mn / 1e9, mo / mn, tm_all, md * 1e3, 2.0 * 256 * tm_all * N * K / md / 1e9);
-            if (epi == sh.epis[0] || epi == VITK_EPI_RESID16 || epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_MUL_AUX) { sum_old += mo; sum_new += mn; }
+            if (epi == sh.epis[0] || epi == VITK_EPI_RESID16 || epi == VITK_EPI_BIAS_GELU_DG8 || epi == VITK_EPI_MUL_AUX8) { sum_old += mo; sum_new += mn; }
+            if (quick) continue;
             // ---- ablations of the four-wave launch (all full tiles) ----
             if (epi == VITK_EPI_NONE) {
                 struct Ab { const char* name; int abl, dbg; };
@@ -185,7 +189,7 @@ int main(int argc, char** argv) {
                     printf("      %-42s %7.1f us\n", ab.name, median(t) * 1e3);
                 }
                 CK(hipFree(Az.p)); CK(hipFree(Wz.p));
-            } else if (epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_MUL_AUX || epi == VITK_EPI_RESID16) {
+            } else if (epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_MUL_AUX || epi == VITK_EPI_RESID16 || epi == VITK_EPI_BIAS_GELU_DG8 || epi == VITK_EPI_MUL_AUX8) {
                 struct Ab { const char* name; int abl, dbg; };
                 const Ab abs[] = {{"epilogue only (empty loop + epilogue)", 7, 0}, {"strict waits after the epilogue", 0, 2}};
                 for (const Ab& ab : abs) {

@@ -16,7 +16,8 @@ LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit t
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD, EPI_RESID16, EPI_BIAS_GELU_DG, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6, 7
-VITK_VERSION = 135
+EPI_BIAS_GELU_DG8, EPI_MUL_AUX8 = 8, 9       # the gelu' factor as 8-bit codes (include/vitk.h)
+VITK_VERSION = 136
 
 
 class RowMap(C.Structure):
@@ -81,6 +82,7 @@ SIGNATURES = {
     "vitk_pack_w_nt": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_nt_bf16_gelu_bwd_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_nt_bf16_mul_aux_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "vitk_gemm_nt_bf16_mul_aux8_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_tn_splits": (_i64, [_i64, _i64, _i64]),
     "vitk_set_cu_reserve": (_i, [_i]),
     "vitk_get_cu_reserve": (_i, []),

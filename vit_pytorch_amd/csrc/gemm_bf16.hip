@@ -845,6 +845,14 @@ extern "C" int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, cons
     return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, VITK_EPI_MUL_AUX, nullptr, nullptr, const_cast<void*>(aux), colsum_partials, stream);
 }
 
+extern "C" int vitk_gemm_nt_bf16_mul_aux8_colsum(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                                 int64_t N, int64_t K, const void* aux8, float* colsum_partials, void* stream) {
+    if (!aux8) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16_mul_aux8_colsum: null pointer");
+    if (colsum_partials && vitk_gemm_nt_colsum_rows(M, N, K, ldc) == 0)
+        VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16_mul_aux8_colsum: shape not served by the persistent kernel (vitk_gemm_nt_colsum_rows() == 0)");
+    return gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, VITK_EPI_MUL_AUX8, nullptr, nullptr, const_cast<void*>(aux8), colsum_partials, stream);
+}
+
 // ---- the persistent NT kernels: four-wave kernel (gemm_nt_w128.hip) on the full 256-row tiles of whole rounds, 8-wave kernel
 // (gemm_nt_persist.hip) on the remaining rows (the partial last m-tile and what would be a mostly idle last round, as 128-row tiles) ----
 // The row split is a function of (M, N, K), the CU count and vitk_set_cu_reserve() only: vitk_gemm_nt_colsum_rows() reports the partial
@@ -853,6 +861,9 @@ extern "C" int vitk_gemm_nt_bf16_mul_aux_colsum(const void* A, int64_t lda, cons
 // VITK_NT_W128 = bit mask over VITK_EPI_* of the epilogues the four-wave kernel serves (0 = none: the 8-wave kernel alone; unset = NTW_EPIS)
 constexpr unsigned NTW_EPIS = 0xffu;
 static int ntw_tiles_m(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int epilogue) {
+    // (the 8-bit-factor pair follows the switches of its 16-bit twins)
+    if (epilogue == VITK_EPI_BIAS_GELU_DG8) epilogue = VITK_EPI_BIAS_GELU_DG;
+    if (epilogue == VITK_EPI_MUL_AUX8) epilogue = VITK_EPI_MUL_AUX;
     const char* e = vitk_switch("VITK_NT_W128");
     const unsigned mask = e ? (unsigned)strtoul(e, nullptr, 0) : NTW_EPIS;
     if (!q.ok || !((mask >> epilogue) & 1u) || vitk_get_cu_reserve() > 0 || !gemm_ntw_serves(M, N, K)) return 0;
@@ -869,6 +880,7 @@ static int nt_persist_dispatch(const NtpPlan& q, const void* A, int64_t lda, con
                                int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* csum, unsigned drop_t,
                                unsigned drop_seed, float inv_keep, void* stream) {
     const int tmw = ntw_tiles_m(q, M, N, K, epilogue == VITK_EPI_GELU_BWD ? VITK_EPI_MUL_AUX : epilogue);
+    const int64_t asz = (epilogue == VITK_EPI_BIAS_GELU_DG8 || epilogue == VITK_EPI_MUL_AUX8) ? 1 : 2;      // bytes per element of aux
     // fused dropout lives in the 8-wave kernel; only the epilogue with column sums has to keep the row split (its partial rows are promised)
     if (tmw == 0 || (drop_t && !(epilogue == VITK_EPI_GELU_BWD && csum)))
         return gemm_ntp_launch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);
@@ -887,7 +899,7 @@ static int nt_persist_dispatch(const NtpPlan& q, const void* A, int64_t lda, con
     if (!q2.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: internal: the row split left %lld rows the persistent kernel does not take", (long long)rest);
     const int64_t csz = epilogue == VITK_EPI_RESID ? 4 : 2;
     return gemm_ntp_launch(q2, (const char*)A + rows_w * lda * 2, lda, W, ldw, (char*)C + rows_w * ldc * csz, ldc, rest, N, K, epilogue, bias,
-                           resid ? (const float*)((const char*)resid + rows_w * ldc * csz) : nullptr, aux ? (char*)aux + rows_w * ldc * 2 : nullptr,
+                           resid ? (const float*)((const char*)resid + rows_w * ldc * csz) : nullptr, aux ? (char*)aux + rows_w * ldc * asz : nullptr,
                            csum ? csum + 2LL * tmw * N : nullptr, drop_t, drop_seed, inv_keep, stream, (unsigned)rows_w);
 }
 
@@ -924,9 +936,10 @@ int gemm_nt_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
         // VITK_NTP_EPIS = bit mask over VITK_EPI_* overrides (GELU_BWD always: its column-sum rows follow the persistent plan).
         const NtpPlan q = ntp_plan(M, N, K, ldc, aux);
         const unsigned epis = vitk_exp("VITK_NTP_EPIS") ? (unsigned)atoi(vitk_exp("VITK_NTP_EPIS")) : 0x1fu;
-        if (epilogue == VITK_EPI_BIAS_GELU_DG || epilogue == VITK_EPI_MUL_AUX) {       // the gelu'-factor pair (round 4): the persistent kernel only
-            if (!q.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: EPI_BIAS_GELU_DG / EPI_MUL_AUX are served by the persistent kernel only (vitk_gemm_nt_plan() says which shapes)");
-            if (!aux || drop_t || (epilogue == VITK_EPI_BIAS_GELU_DG && !bias)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS_GELU_DG needs bias and aux, EPI_MUL_AUX aux; no fused dropout");
+        const bool dg_out = epilogue == VITK_EPI_BIAS_GELU_DG || epilogue == VITK_EPI_BIAS_GELU_DG8;
+        if (dg_out || epilogue == VITK_EPI_MUL_AUX || epilogue == VITK_EPI_MUL_AUX8) {       // the gelu'-factor pairs (round 4; 8-bit factor: round 5): the persistent kernel only
+            if (!q.ok) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: EPI_BIAS_GELU_DG(8) / EPI_MUL_AUX(8) are served by the persistent kernel only (vitk_gemm_nt_plan() says which shapes)");
+            if (!aux || drop_t || (dg_out && !bias)) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: EPI_BIAS_GELU_DG(8) needs bias and aux, EPI_MUL_AUX(8) aux; no fused dropout");
             return nt_persist_dispatch(q, A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, resid, aux, csum, 0u, 0u, 1.0f, stream);
         }
         if (epilogue == VITK_EPI_RESID16) {       // 16-bit forward residual stream (opt-in): the persistent kernel only

@@ -503,15 +503,25 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                 __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
                 // GELU_BWD: saved pre-activations, fetched DP fragment rows ahead.  Interior tiles: uncounted asm loads + exact-count
                 // waits (see q_gload_f32x4); per fragment row 2 loads and 2 stores
-                constexpr bool AUX_IN = (EPI == VITK_EPI_GELU_BWD || EPI == VITK_EPI_MUL_AUX);      // an (M, N) 16-bit operand read in the epilogue
+                constexpr bool AUX_IN = q_aux_in<EPI>();      // an (M, N) operand read in the epilogue (16-bit; MUL_AUX8: 8-bit codes)
+                constexpr bool AUX8 = (EPI == VITK_EPI_MUL_AUX8);
                 constexpr bool ASM_PRE = AUX_IN && INT && Q_EPI_ASM_PRE;
                 constexpr int DP = ASM_PRE ? Q_EPI_DEPTH_PRE : 2;
-                bf16x8 hpre[DP][2];
-                auto fetch_pre = [&](int f, bf16x8 (&dst)[2]) {
+                using HPre = std::conditional_t<AUX8, q_u32x2, bf16x8>;
+                HPre hpre[DP][2];
+                auto fetch_pre = [&](int f, HPre (&dst)[2]) {
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         int m = mrow0 + f * 16 + 2 * pr + odd;
-                        if constexpr (ASM_PRE) q_gload_bf16x8(dst[pr], p.aux + (long long)m * p.ldc + ncol8);
+                        if constexpr (AUX8) {
+                            const unsigned char* a8 = reinterpret_cast<const unsigned char*>(p.aux);
+                            if constexpr (ASM_PRE) q_gload_u32x2(dst[pr], a8 + (long long)m * p.ldc + ncol8);
+                            else {
+                                if (!INT) m = m < p.M ? m : p.M - 1;
+                                dst[pr] = q_u32x2{0u, 0u};
+                                if (colok) dst[pr] = *reinterpret_cast<const q_u32x2*>(a8 + (long long)m * p.ldc + ncol8);
+                            }
+                        } else if constexpr (ASM_PRE) q_gload_bf16x8(dst[pr], p.aux + (long long)m * p.ldc + ncol8);
                         else {
                             if (!INT) m = m < p.M ? m : p.M - 1;
                             dst[pr] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -557,14 +567,21 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                                     g8[e] = drop_keep(hrow, (unsigned)(ncol8 + e), p.drop_t) ? (__bf16)((float)g8[e] * p.inv_keep) : (__bf16)0.f;
                             }
                             if (ok) *reinterpret_cast<bf16x8*>(Cb + o) = g8;
-                        } else if constexpr (EPI == VITK_EPI_BIAS_GELU_DG) {
+                        } else if constexpr (EPI == VITK_EPI_BIAS_GELU_DG || EPI == VITK_EPI_BIAS_GELU_DG8) {
                             q_f32x8 gl, dgl;
                             q_gelu_both8(q_widen8(v), gl, dgl);              // of the ROUNDED pre-activation, like BIAS_GELU
-                            if (ok) *reinterpret_cast<bf16x8*>(p.aux + o) = q_narrow8(dgl);
+                            if constexpr (EPI == VITK_EPI_BIAS_GELU_DG8) {
+                                if (ok) *reinterpret_cast<q_u32x2*>(reinterpret_cast<unsigned char*>(p.aux) + o) = q_dg_encode8(dgl);
+                            } else {
+                                if (ok) *reinterpret_cast<bf16x8*>(p.aux + o) = q_narrow8(dgl);
+                            }
                             if (ok) *reinterpret_cast<bf16x8*>(Cb + o) = q_narrow8(gl);
                         } else if constexpr (AUX_IN) {
-                            const bf16x8 h8 = hpre[f % DP][pr];
-                            q_f32x8 g = q_widen8(v) * (EPI == VITK_EPI_MUL_AUX ? q_widen8(h8) : q_gelu_grad8(q_widen8(h8)));
+                            q_f32x8 fac;
+                            if constexpr (AUX8) fac = q_dg_decode8(hpre[f % DP][pr]);
+                            else if constexpr (EPI == VITK_EPI_MUL_AUX) fac = q_widen8(hpre[f % DP][pr]);
+                            else fac = q_gelu_grad8(q_widen8(hpre[f % DP][pr]));
+                            q_f32x8 g = q_widen8(v) * fac;
                             if (p.drop_t) {     // factor of the forward's dropout(gelu(pre)) at (m, n): same decision, same 1 / (1 - p)
                                 const unsigned hrow = drop_row((unsigned)m + p.drop_m0, p.drop_seed);
 #pragma unroll
@@ -804,7 +821,7 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
     // GEMM (N = 3072: twelve n-tiles per panel, two 16-bit outputs) fetches 373 instead of 530 MB with the tail last and runs 3.97 instead of
     // 4.12 ms per step; every other epilogue is level or slightly better tail-first.  VITK_NTP_TAIL_LAST = 1 / 0 forces one order for all.
     static const int tail_env = vitk_exp("VITK_NTP_TAIL_LAST") ? (atoi(vitk_exp("VITK_NTP_TAIL_LAST")) ? 0 : 1) : -1;
-    a.tail_first = tail_env >= 0 ? tail_env : ((epilogue == VITK_EPI_BIAS_GELU || epilogue == VITK_EPI_BIAS_GELU_DG) ? 0 : 1);
+    a.tail_first = tail_env >= 0 ? tail_env : ((epilogue == VITK_EPI_BIAS_GELU || epilogue == VITK_EPI_BIAS_GELU_DG || epilogue == VITK_EPI_BIAS_GELU_DG8) ? 0 : 1);
     // dynamic tile tickets (see the kernel): K >= 256 so that a ticket drawn two tiles ahead is always there in time.  WHEN: while
     // other kernels are expected on the chip -- vitk_set_cu_reserve(c > 0), which parallel.FlatGradSink opens around every
     // in-backward all-reduce -- or VITK_NTP_DYNAMIC=1.  Not by default: [measured, ViT-B/16 batch 256, no other kernel on the
@@ -843,6 +860,8 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
         case VITK_EPI_GELU_BWD: NTP_LAUNCH(VITK_EPI_GELU_BWD); break;
         case VITK_EPI_BIAS_GELU_DG: NTP_LAUNCH(VITK_EPI_BIAS_GELU_DG); break;
         case VITK_EPI_MUL_AUX: NTP_LAUNCH(VITK_EPI_MUL_AUX); break;
+        case VITK_EPI_BIAS_GELU_DG8: NTP_LAUNCH(VITK_EPI_BIAS_GELU_DG8); break;
+        case VITK_EPI_MUL_AUX8: NTP_LAUNCH(VITK_EPI_MUL_AUX8); break;
         case VITK_EPI_RESID16: NTP_LAUNCH(VITK_EPI_RESID16); break;
         default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16: bad epilogue %d", epilogue);
     }

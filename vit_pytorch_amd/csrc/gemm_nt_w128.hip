@@ -358,16 +358,20 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
             const int odd = fi & 1;
             __bf16* Cb = reinterpret_cast<__bf16*>(p.C);
             const long long obase = (long long)(mrow0 + odd) * p.ldc + ncolw + 8 * (fi >> 1);      // + 16 f ldc + 64 qq + 2 pr ldc
-            constexpr bool AUX_IN = (EPI == VITK_EPI_GELU_BWD || EPI == VITK_EPI_MUL_AUX);      // an (M, N) 16-bit operand read in the epilogue
-            constexpr int DP = 6;
-            bf16x8 hpre[DP][2];
-            auto fetch_pre = [&](int rr_, bf16x8 (&dst)[2]) __attribute__((always_inline)) {
+            constexpr bool AUX_IN = q_aux_in<EPI>();      // an (M, N) operand read in the epilogue (16-bit; MUL_AUX8: 8-bit codes)
+            constexpr bool AUX8 = (EPI == VITK_EPI_MUL_AUX8);
+            constexpr int DP = AUX8 ? 4 : 6;
+            using HPre = std::conditional_t<AUX8, q_u32x2, bf16x8>;
+            HPre hpre[DP][2];
+            auto fetch_pre = [&](int rr_, HPre (&dst)[2]) __attribute__((always_inline)) {
                 const int f = rr_ >> 1, qq = rr_ & 1;
                 long long oa = obase + (long long)(f * 16) * p.ldc + qq * 64;
                 asm volatile("" : "+v"(oa));        // (opaque: hipcc otherwise forms the addresses of all 16 rows at the top of the epilogue -- 256 VGPRs)
-                const __bf16* ap = p.aux + oa;
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) q_gload_bf16x8(dst[pr], ap + (long long)(2 * pr) * p.ldc);
+                for (int pr = 0; pr < 2; ++pr) {
+                    if constexpr (AUX8) q_gload_u32x2(dst[pr], reinterpret_cast<const unsigned char*>(p.aux) + oa + (long long)(2 * pr) * p.ldc);
+                    else q_gload_bf16x8(dst[pr], p.aux + oa + (long long)(2 * pr) * p.ldc);
+                }
             };
             if constexpr (AUX_IN) {
 #pragma unroll
@@ -406,14 +410,18 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
                     } else if constexpr (EPI == VITK_EPI_BIAS_GELU) {
                         *reinterpret_cast<bf16x8*>(p.aux + o) = v;
                         *reinterpret_cast<bf16x8*>(Cb + o) = q_narrow8(q_gelu8(q_widen8(v)));     // of the ROUNDED pre-activation
-                    } else if constexpr (EPI == VITK_EPI_BIAS_GELU_DG) {
+                    } else if constexpr (EPI == VITK_EPI_BIAS_GELU_DG || EPI == VITK_EPI_BIAS_GELU_DG8) {
                         q_f32x8 gl, dgl;
                         q_gelu_both8(q_widen8(v), gl, dgl);              // of the ROUNDED pre-activation, like BIAS_GELU
-                        *reinterpret_cast<bf16x8*>(p.aux + o) = q_narrow8(dgl);
+                        if constexpr (EPI == VITK_EPI_BIAS_GELU_DG8) *reinterpret_cast<q_u32x2*>(reinterpret_cast<unsigned char*>(p.aux) + o) = q_dg_encode8(dgl);
+                        else *reinterpret_cast<bf16x8*>(p.aux + o) = q_narrow8(dgl);
                         *reinterpret_cast<bf16x8*>(Cb + o) = q_narrow8(gl);
                     } else if constexpr (AUX_IN) {
-                        const bf16x8 h8 = hpre[R_ % DP][pr];
-                        const q_f32x8 g = q_widen8(v) * (EPI == VITK_EPI_MUL_AUX ? q_widen8(h8) : q_gelu_grad8(q_widen8(h8)));
+                        q_f32x8 fac;
+                        if constexpr (AUX8) fac = q_dg_decode8(hpre[R_ % DP][pr]);
+                        else if constexpr (EPI == VITK_EPI_MUL_AUX) fac = q_widen8(hpre[R_ % DP][pr]);
+                        else fac = q_gelu_grad8(q_widen8(hpre[R_ % DP][pr]));
+                        const q_f32x8 g = q_widen8(v) * fac;
                         const bf16x8 g8 = q_narrow8(g);
                         *reinterpret_cast<bf16x8*>(Cb + o) = g8;
 #pragma unroll
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
 
     // the first two K-steps after an epilogue: its stores may stay in flight behind the two K-steps' worth of DMA pieces the wait is
     // about (vmcnt retires in order and counts to 63); the first tile has nothing but DMA pieces in flight
-    constexpr int ST_ROW = (F32OUT || EPI == VITK_EPI_RESID16 || EPI == VITK_EPI_BIAS_GELU || EPI == VITK_EPI_BIAS_GELU_DG) ? 4 : 2;   // stores per epilogue row
+    constexpr int ST_ROW = (F32OUT || EPI == VITK_EPI_RESID16 || q_two_outputs<EPI>()) ? 4 : 2;   // stores per epilogue row
     constexpr int VM_RELAX = 16 + 16 * ST_ROW > 63 ? 63 : 16 + 16 * ST_ROW;
     // [measured, tools/nt_probe, strict vs exact-count waits: plain 16-bit stores (QKV) 155 vs 151 us; every epilogue that also READS rows
     //  or stores two tensors is level or better strict (FF1 shape 216 vs 231, dFF1 271 vs 275, out-projection 69.9 vs 76.6)]
@@ -617,6 +625,8 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
         case VITK_EPI_GELU_BWD: NTW_LAUNCH(VITK_EPI_GELU_BWD); break;
         case VITK_EPI_BIAS_GELU_DG: NTW_LAUNCH(VITK_EPI_BIAS_GELU_DG); break;
         case VITK_EPI_MUL_AUX: NTW_LAUNCH(VITK_EPI_MUL_AUX); break;
+        case VITK_EPI_BIAS_GELU_DG8: NTW_LAUNCH(VITK_EPI_BIAS_GELU_DG8); break;
+        case VITK_EPI_MUL_AUX8: NTW_LAUNCH(VITK_EPI_MUL_AUX8); break;
         case VITK_EPI_RESID16: NTW_LAUNCH(VITK_EPI_RESID16); break;
 #endif
         default: VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16 (w128): bad epilogue %d", epilogue);

@@ -196,6 +196,16 @@ def gemm_nt_bf16_mul_aux_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Ten
                                                      _stream()), "gemm_nt_bf16_mul_aux_colsum")
 
 
+def gemm_nt_bf16_mul_aux8_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
+                                 aux8: Tensor, partials: Optional[Tensor]):
+    """C = (A . W^T) * 0.005 (aux8 - 27) (EPI_MUL_AUX8: aux8 = the 8-bit codes of the gelu' factor an EPI_BIAS_GELU_DG8 forward stored) + column
+    sums of C."""
+    if aux8.dtype != torch.uint8:
+        raise L.VitkError("gemm_nt_bf16_mul_aux8_colsum: aux8 must be uint8")
+    check(_lib_for(A, W, C).vitk_gemm_nt_bf16_mul_aux8_colsum(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, _p(aux8), _p(partials),
+                                                              _stream()), "gemm_nt_bf16_mul_aux8_colsum")
+
+
 def set_cu_reserve(cus: int, dtype=None):
     """CUs the weight-gradient GEMMs leave to other kernels (vitk_set_cu_reserve; process-wide per library flavour)."""
     lib = L.load_f16() if dtype == torch.float16 else L.load()

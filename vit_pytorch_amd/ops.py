@@ -247,9 +247,18 @@ def gelu_dg_ok(T, M: int, Fh: int, D: int) -> bool:
     """The FeedForward pair FF1 (M, Fh) = a (M, D) . W1^T and dFF1 (M, Fh) = dy (M, D) . W2 can store / consume the gelu' FACTOR instead of
     the pre-activation (EPI_BIAS_GELU_DG / EPI_MUL_AUX: both on the persistent NT kernel).  Round 4: FF1's epilogue holds Phi(pre) anyway,
     one exp2 more per element gives gelu'(pre); the backward GEMM's epilogue then multiplies instead of evaluating the polynomial and the
-    exponential again (it was the slowest NT kernel of the step, VALU-bound in its epilogue).  VITK_GELU_DG=0 switches it off."""
+    exponential again (it was the slowest NT kernel of the step, VALU-bound in its epilogue).  VITK_GELU_DG=0 switches it off.
+    Round 5: the factor is stored as 8-bit fixed-point codes (EPI_BIAS_GELU_DG8 / EPI_MUL_AUX8, include/vitk.h: |error| <= 0.0025 over
+    gelu''s whole range [-0.129, 1.129], a bf16 is off by up to 0.0039 at the top of it) -- both epilogues run at the memory system's
+    rate and the factor was a third of their bytes; bfloat16 models only (float16's 11-bit factor is finer than the codes); VITK_GELU_DG=16
+    keeps the 16-bit factor."""
     return (T in HALF and os.environ.get("VITK_GELU_DG", "1") != "0" and D % 32 == 0 and Fh % 32 == 0 and _persistent_nt(M, Fh, D)
             and K.gemm_nt_colsum_rows(M, Fh, D, Fh) > 0)
+
+
+def gelu_dg_bits() -> int:
+    """Storage of the gelu' factor between FF1 and dFF1: 8 (fixed-point codes, the default) or 16 (the model's 16-bit type)."""
+    return 16 if os.environ.get("VITK_GELU_DG", "1") == "16" else 8
 
 
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bool = False,
@@ -266,8 +275,12 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], M: int, *, gelu: bo
             raise L.VitkError("linear_fwd: save_dg needs gelu, a bias, no dropout and a shape gelu_dg_ok accepts")
         Wn, ldw = nt_weight(W, M, False)
         act = empty((M, N), T, x)
-        dg = empty((M, N), T, x)
-        K.gemm_nt_bf16(x, Kd, Wn, ldw, act, N, M, N, Kd, L.EPI_BIAS_GELU_DG, bias=bias, aux=dg)
+        if gelu_dg_bits() == 8 and T == BF16 and N % 8 == 0:      # (a float16 model keeps its 11-bit factor: the codes are at a bfloat16's accuracy)
+            dg = empty((M, N), torch.uint8, x)
+            K.gemm_nt_bf16(x, Kd, Wn, ldw, act, N, M, N, Kd, L.EPI_BIAS_GELU_DG8, bias=bias, aux=dg)
+        else:
+            dg = empty((M, N), T, x)
+            K.gemm_nt_bf16(x, Kd, Wn, ldw, act, N, M, N, Kd, L.EPI_BIAS_GELU_DG, bias=bias, aux=dg)
         return act, dg
     if drop is not None and not fused_dropout_ok(T, M, N, Kd):
         raise L.VitkError("linear_fwd: fused dropout needs a shape served by the 256-row kernel (caller must check fused_dropout_ok)")
@@ -417,7 +430,10 @@ def linear_dx(dy: Tensor, W: Tensor, M: int, *, gelu_pre: Optional[Tensor] = Non
         Wt, ldt = nt_weight(W, M, True)
         R = K.gemm_nt_colsum_rows(M, Kd, N, Kd, T)
         part = empty((R * Kd,), F32, dy) if db is not None else None
-        K.gemm_nt_bf16_mul_aux_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_dg, part)
+        if gelu_dg.dtype == torch.uint8:        # the codes an EPI_BIAS_GELU_DG8 forward stored
+            K.gemm_nt_bf16_mul_aux8_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_dg, part)
+        else:
+            K.gemm_nt_bf16_mul_aux_colsum(dy, N, Wt, ldt, dx, Kd, M, Kd, N, gelu_dg, part)
         if db is not None:
             fold(part, R, Kd, Kd, db)
             return dx, True
