@@ -90,8 +90,8 @@ def main():
         name = m.group(1)
         if flt not in name:
             continue
-        end = txt.index("s_endpgm", m.end())
-        body = txt[m.end():end + 8].split("\n")
+        end = txt.index(".Lfunc_end", m.end())          # the whole function (a kernel may hold more than one s_endpgm: early exits)
+        body = txt[m.end():end].split("\n")
         if not any("ASMSTART" in l for l in body):
             continue
         total += audit(name, body)
