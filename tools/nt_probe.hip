@@ -64,6 +64,38 @@ int main(int argc, char** argv) {
     const int grid = cus / 8 * 8;
     printf("nt_probe: M = %lld, %d CUs, grid %d, rounds %d\n", (long long)M, cus, grid, rounds);
 
+    if (argc > 2 && atoi(argv[2]) == 2) {
+        // mode 2: why is FF1 slower inside the training step than in this bench?  The same launch (a) on ONE pair of output buffers, as
+        // everywhere below, (b) rotating over NB pairs (fresh output memory every launch, like the step: 15 GB of saved activations),
+        // (c) many launches back to back (sustained load); each with the plain-store epilogue and the FF1 epilogue.
+        const int64_t N = 3072, K = 768;
+        Buf A = rand_bf16(M * K, 1.0f, 1), W = rand_bf16(N * K, 0.05f, 2), bias = rand_bf16(N, 0.5f, 3);
+        Buf Wp = dalloc(vitk_pack_w_nt_bytes(N, K));
+        VK(vitk_pack_w_nt(W.p, K, N, K, Wp.p, nullptr, nullptr));
+        const int NB = 16;
+        std::vector<Buf> Cs, Xs;
+        for (int i = 0; i < NB; ++i) { Cs.push_back(dalloc(M * N * 2)); Xs.push_back(dalloc(M * N * 2)); }
+        const int epis[3] = {VITK_EPI_NONE, VITK_EPI_BIAS_GELU_DG8, VITK_EPI_BIAS_GELU_DG};
+        if (argc > 3) {     // sustained load: seconds of the FF1 launch back to back, 500 launches per line
+            for (int blk = 0; blk < atoi(argv[3]); ++blk)
+                printf("  sustained FF1 (epilogue 8), launches %5d ..: %7.1f us\n", blk * 500, 1e3 * time_ms([&] {
+                    VK(vitk_gemm_nt_bf16(A.p, K, Wp.p, 0, Cs[0].p, N, M, N, K, VITK_EPI_BIAS_GELU_DG8, bias.p, nullptr, Xs[0].p, nullptr)); }, 500));
+            return 0;
+        }
+        for (int epi : epis) {
+            for (int nb : {1, NB}) {
+                for (int iters : {10, 200}) {
+                    int it = 0;
+                    std::vector<float> t;
+                    for (int r = 0; r < rounds; ++r)
+                        t.push_back(time_ms([&] { const int b = (it++) % nb;
+                            VK(vitk_gemm_nt_bf16(A.p, K, Wp.p, 0, Cs[b].p, N, M, N, K, epi, epi ? bias.p : nullptr, nullptr, epi ? Xs[b].p : nullptr, nullptr)); }, iters));
+                    printf("  epilogue %d  output buffers %2d  launches back to back %3d: %7.1f us\n", epi, nb, iters, median(t) * 1e3);
+                }
+            }
+        }
+        return 0;
+    }
     struct Shape { const char* name; int64_t N, K; std::vector<int> epis; };
     const std::vector<Shape> shapes = {
         {"FF1   (N 3072, K  768)", 3072, 768, {VITK_EPI_NONE, VITK_EPI_BIAS_GELU_DG, VITK_EPI_BIAS_GELU_DG8, VITK_EPI_MUL_AUX, VITK_EPI_MUL_AUX8, VITK_EPI_BIAS_GELU, VITK_EPI_GELU_BWD}},

@@ -50,7 +50,9 @@ def main():
     rn, re_ = ("f32 residual", 3) if f32s else ("16-bit residual", 5)
     for lab, n, k, epi in (("QKV", 3 * D, D, 0), ("FF1 bias+GELU", F, D, 2), (f"out-proj + {rn}", D, D, re_), (f"FF2 + {rn}", D, F, re_),
                            ("dFF1 GELU' + column sums", F, D, 4), ("dX of FF1 (K=3072)", D, F, 0)):
-        alg = 2 * (M * k + n * k) + (8 * M * n if epi == 3 else 4 * M * n if epi == 5 else 2 * M * n * (2 if epi in (2, 4) else 1))
+        # FF1 / dFF1: the second (M, N) tensor is the gelu' factor -- 8-bit codes since round 5 (KPROF_DG16 / KPROF_NO_DG: 16-bit values)
+        aux_b = (2 if (os.environ.get("KPROF_DG16") or os.environ.get("KPROF_NO_DG")) else 1) if epi in (2, 4) else 0
+        alg = 2 * (M * k + n * k) + (8 * M * n if epi == 3 else 4 * M * n if epi == 5 else (2 + aux_b) * M * n)
         labels.append((lab, n, k, alg))
     for lab, n, k in (("dW qkv", 3 * D, D), ("dW ff1", F, D)):
         labels.append((lab, n, k, 2 * (M * n + M * k + n * k)))
