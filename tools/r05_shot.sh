@@ -12,6 +12,7 @@ for step in "$@"; do
     dg_ab) for i in 1 2; do VITK_GELU_DG=16 timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_dg16_$i.json.log 2>&1; echo dg16 $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_dg16_$i.json.log | head -1); timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_dg8_$i.json.log 2>&1; echo dg8 $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_dg8_$i.json.log | head -1); done ;;
     parity_log) timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -s -x > $out/${tag}_parity_dg8.log 2>&1; tail -2 $out/${tag}_parity_dg8.log; VITK_GELU_DG=16 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -s -x > $out/${tag}_parity_dg16.log 2>&1; tail -2 $out/${tag}_parity_dg16.log ;;
     probe_instep) timeout 600 tools/nt_probe.bin 3 2 > $out/${tag}_nt_probe_instep.log 2>&1; cat $out/${tag}_nt_probe_instep.log ;;
+    r04_ab) for i in 1 2; do (cd _ab_r04 && PYTHONPATH=$PWD timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_r04tree_$i.json.log 2>&1); echo r04tree $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_r04tree_$i.json.log | head -1); timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_r05tree_$i.json.log 2>&1; echo r05tree $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_r05tree_$i.json.log | head -1); done ;;
     probe) timeout 600 tools/nt_probe.bin 3 > $out/${tag}_nt_probe.log 2>&1; tail -5 $out/${tag}_nt_probe.log ;;
     tests_nt) timeout 900 python -m pytest tests/test_gemm_nt_w128_gpu.py tests/test_gemm_persist_gpu.py tests/test_kernels_gpu.py tests/test_headline_extents_gpu.py tests/test_fuzz_ops_gpu.py -m gpu -x -q > $out/${tag}_tests_nt.log 2>&1; tail -3 $out/${tag}_tests_nt.log ;;
     tests_all) timeout 2400 python -m pytest tests -m gpu -x -q > $out/${tag}_tests_all.log 2>&1; tail -3 $out/${tag}_tests_all.log ;;
