@@ -444,8 +444,7 @@ def main():
                  "avg_launch_ms": round(kms_, 4), "launches_per_step": kn_, "traffic": tr, "algorithmic_bytes": alg, "traffic_source": src}
             if alg and kfl_:       # which roof the bytes say: FLOP per algorithmic byte against the machine balance (peak / 6.3 TB/s)
                 e["flop_per_byte"] = round(kfl_ / alg, 1)
-                if e["flop_per_byte"] < balance:        # a balanced / HBM-side instance is priced against BOTH roofs
-                    e["hbm_frac"] = round(alg / (kms_ * 1e-3) / 6.3e12, 4)
+                e["hbm_frac"] = round(alg / (kms_ * 1e-3) / 6.3e12, 4)      # every instance is priced against BOTH roofs (6.3 TB/s achievable)
             return e
 
         ranked = sorted(classes.items(), key=lambda kv: -kv[1]["ms"])
