@@ -13,6 +13,8 @@ for step in "$@"; do
     parity_log) timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -s -x > $out/${tag}_parity_dg8.log 2>&1; tail -2 $out/${tag}_parity_dg8.log; VITK_GELU_DG=16 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -s -x > $out/${tag}_parity_dg16.log 2>&1; tail -2 $out/${tag}_parity_dg16.log ;;
     probe_instep) timeout 600 tools/nt_probe.bin 3 2 > $out/${tag}_nt_probe_instep.log 2>&1; cat $out/${tag}_nt_probe_instep.log ;;
     r04_ab) for i in 1 2; do (cd _ab_r04 && PYTHONPATH=$PWD timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_r04tree_$i.json.log 2>&1); echo r04tree $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_r04tree_$i.json.log | head -1); timeout 300 python bench.py --no-cpu-baseline > $out/${tag}_bench_r05tree_$i.json.log 2>&1; echo r05tree $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_r05tree_$i.json.log | head -1); done ;;
+    group_sweep) for i in 1 2; do for g in default 3 4 6 9 12; do if [ $g = default ]; then unset VITK_GROUP_N; else export VITK_GROUP_N=$g; fi; timeout 300 python bench.py --no-cpu-baseline --repeats 2 > $out/${tag}_bench_group${g}_$i.json.log 2>&1; echo group_n $g $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_group${g}_$i.json.log | head -1); done; unset VITK_GROUP_N; for sp in r n; do VITK_NTW_SPLIT=$sp timeout 300 python bench.py --no-cpu-baseline --repeats 2 > $out/${tag}_bench_split${sp}_$i.json.log 2>&1; echo split $sp $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_split${sp}_$i.json.log | head -1); done; done ;;   # needs the VITK_BUILD_EXPERIMENTS=1 library
+    group_confirm) for i in 1 2 3; do for v in "default::" "group4:4:" "splitn::n" "both:4:n" "group3:3:" "g3n:3:n"; do n=${v%%:*}; r=${v#*:}; g=${r%%:*}; sp=${r#*:}; if [ -z "$g" ]; then unset VITK_GROUP_N; else export VITK_GROUP_N=$g; fi; if [ -z "$sp" ]; then unset VITK_NTW_SPLIT; else export VITK_NTW_SPLIT=$sp; fi; timeout 300 python bench.py --no-cpu-baseline --repeats 2 > $out/${tag}_bench_${n}_$i.json.log 2>&1; echo $n $(grep -o '"ms_per_step": [0-9.]*' $out/${tag}_bench_${n}_$i.json.log | head -1); done; done; unset VITK_GROUP_N VITK_NTW_SPLIT ;;   # needs the VITK_BUILD_EXPERIMENTS=1 library
     probe) timeout 600 tools/nt_probe.bin 3 > $out/${tag}_nt_probe.log 2>&1; tail -5 $out/${tag}_nt_probe.log ;;
     tests_nt) timeout 900 python -m pytest tests/test_gemm_nt_w128_gpu.py tests/test_gemm_persist_gpu.py tests/test_kernels_gpu.py tests/test_headline_extents_gpu.py tests/test_fuzz_ops_gpu.py -m gpu -x -q > $out/${tag}_tests_nt.log 2>&1; tail -3 $out/${tag}_tests_nt.log ;;
     tests_all) timeout 2400 python -m pytest tests -m gpu -x -q > $out/${tag}_tests_all.log 2>&1; tail -3 $out/${tag}_tests_all.log ;;

@@ -589,9 +589,13 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
     a.M = 256 * tiles_m; a.N = (int)N; a.K = (int)K;
     a.bias = (const __bf16*)bias; a.resid = resid; a.aux = (__bf16*)aux; a.csum = csum;
     a.tiles_n = (int)(N / 256); a.tiles_m = tiles_m; a.n_tiles = a.tiles_m * a.tiles_n; a.nt = (int)(K / 32);
-    // grouped tile order of the 8-wave kernel: groups of <= 8 n-tiles, m fastest inside a group's n-tiles
+    // grouped tile order (the 8-wave kernel's scheme): one group up to 8 n-tiles, beyond that groups of 4 (K <= 768) or balanced groups of <= 6; n fastest inside a group
+    // [measured on the whole step, round 5, two boxes x 2-3 interleaved runs (profiles/r05g_group_sweep.log): groups of 4 n-tiles for the
+    //  9- and 12-tile shapes (QKV, FF1, dFF1) 30.83 ms against 30.97 with the 8-wave kernel's balanced groups of <= 6; 3: 31.05; 9 / 12: level]
+    //  With longer rows the balanced groups stay: ViT-L/16 (K = 1024) 52.44 ms with 6 against 52.58 with 4, ViT-H/14 (K = 1280) 664.5 ms with 5
+    //  against 682.8 with 4 (profiles/r05g_group_sweep.log).]
     a.group_n = a.tiles_n;
-    if (a.tiles_n > 8) a.group_n = (a.tiles_n + (a.tiles_n + 5) / 6 - 1) / ((a.tiles_n + 5) / 6);
+    if (a.tiles_n > 8) a.group_n = K <= 768 ? 4 : (a.tiles_n + (a.tiles_n + 5) / 6 - 1) / ((a.tiles_n + 5) / 6);
     if (vitk_exp("VITK_GROUP_N")) { const int g = atoi(vitk_exp("VITK_GROUP_N")); a.group_n = g > 0 && g < a.tiles_n ? g : a.tiles_n; }
     a.dbg = dbg;
     if (const char* e = vitk_exp("VITK_NTW_RELAX")) a.dbg |= e[0] == 'a' ? 16 : (e[0] == 'n' ? 2 : 0);      // A/B: all / none
