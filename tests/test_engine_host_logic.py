@@ -92,6 +92,35 @@ def test_16bit_forward_stream_option(x, monkeypatch):
     print(f"16-bit forward stream vs f32 oracle: out {rel(y, y_ref):.2e} (f32 stream {rel(y32, y_ref):.2e}), worst grad {worst_grad(g, g_ref):.2e} ({worst_grad(g32, g_ref):.2e})")
 
 
+@pytest.mark.parametrize("dtype,env,codes", [(torch.bfloat16, None, True), (torch.bfloat16, "16", False), (torch.float16, None, False), (torch.bfloat16, "0", None)])
+def test_gelu_factor_storage_between_ff1_and_dff1(x, dtype, env, codes, monkeypatch):
+    """What FF1 leaves for dFF1 (ops.linear_fwd(save_dg=True) / ops.linear_dx(gelu_dg=...)): 8-bit fixed-point codes of gelu'(pre) in a
+    bfloat16 model (EPI_BIAS_GELU_DG8 -> vitk_gemm_nt_bf16_mul_aux8_colsum), the 16-bit factor in a float16 model or under VITK_GELU_DG=16
+    (EPI_BIAS_GELU_DG -> _mul_aux_colsum), the pre-activation under VITK_GELU_DG=0 (EPI_BIAS_GELU -> _gelu_bwd_colsum).  The three agree
+    with the oracle to the same gates."""
+    if env is None:
+        monkeypatch.delenv("VITK_GELU_DG", raising=False)
+    else:
+        monkeypatch.setenv("VITK_GELU_DG", env)
+    m, params = build(dtype)
+    y_ref, dx_ref, g_ref = reference(params, x)
+    with KD.installed() as calls:
+        y, dx, g = run(m, x)
+    epis = [c[1][3] for c in calls if c[0] == "gemm_nt_bf16"]
+    names = [c[0] for c in calls]
+    if codes is None:
+        assert epis.count(L.EPI_BIAS_GELU) == DEPTH and L.EPI_BIAS_GELU_DG not in epis and L.EPI_BIAS_GELU_DG8 not in epis
+        assert names.count("gemm_nt_bf16_gelu_bwd_colsum") == DEPTH
+    elif codes:
+        assert epis.count(L.EPI_BIAS_GELU_DG8) == DEPTH and L.EPI_BIAS_GELU_DG not in epis and L.EPI_BIAS_GELU not in epis
+        assert names.count("gemm_nt_bf16_mul_aux8_colsum") == DEPTH and "gemm_nt_bf16_mul_aux_colsum" not in names
+    else:
+        assert epis.count(L.EPI_BIAS_GELU_DG) == DEPTH and L.EPI_BIAS_GELU_DG8 not in epis
+        assert names.count("gemm_nt_bf16_mul_aux_colsum") == DEPTH and "gemm_nt_bf16_mul_aux8_colsum" not in names
+    # (float16: this loss leaves gradients of 1e-7, below the format's normal range -- the gates are the bfloat16 ones)
+    assert rel(y, y_ref) < 2e-2 and rel(dx, dx_ref) < 4e-2 and worst_grad(g, g_ref) < 9e-2, (rel(y, y_ref), rel(dx, dx_ref), worst_grad(g, g_ref))
+
+
 def fp8_calls(calls):
     return [c[1] for c in calls if c[0] == "gemm_nt_fp8_v2"]
 
