@@ -65,12 +65,17 @@ def _build_one(lib: str, bdir: str, extra, force: bool, verbose: bool) -> str:
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     """libvitk.so (16-bit type = bfloat16) and libvitk_f16.so (same sources, 16-bit type = IEEE half).
 
-    VITK_BUILD_EXPERIMENTS=1 compiles the experiment knobs in (vitk_exp() in csrc/common.h: tile orders, cost-model constants, debug
-    stamps -- what the tools/ scripts of rounds 2-4 switch); the product build reads only the switches README.md lists."""
-    exp = ["-DVITK_EXPERIMENTS=1"] if os.environ.get("VITK_BUILD_EXPERIMENTS", "0") not in ("0", "") else []
-    sub = "exp" if exp else ""
-    _build_one(LIB_F16, os.path.join(CSRC, "build", sub, "f16"), ["-DVITK_HALF_IS_F16=1", *exp], force, verbose)
-    return _build_one(LIB, os.path.join(CSRC, "build", sub), exp, force, verbose)
+    VITK_BUILD_EXPERIMENTS=1 builds the EXPERIMENTS flavour instead -- the knobs of vitk_exp() in csrc/common.h compiled in (tile orders,
+    cost-model constants, debug stamps: what the tools/ scripts switch) -- under its own names, libvitk_exp.so / libvitk_f16_exp.so, from its
+    own object directory: the product libraries are never overwritten by it (a later product build used to see nothing stale and keep the
+    experiments flavour under the product name).  Load it with VITK_LIB=.../libvitk_exp.so (and VITK_LIB_F16)."""
+    exp = os.environ.get("VITK_BUILD_EXPERIMENTS", "0") not in ("0", "")
+    if exp:
+        flags = ["-DVITK_EXPERIMENTS=1"]
+        _build_one(LIB_F16.replace(".so", "_exp.so"), os.path.join(CSRC, "build", "exp", "f16"), ["-DVITK_HALF_IS_F16=1", *flags], force, verbose)
+        return _build_one(LIB.replace(".so", "_exp.so"), os.path.join(CSRC, "build", "exp"), flags, force, verbose)
+    _build_one(LIB_F16, os.path.join(CSRC, "build", "f16"), ["-DVITK_HALF_IS_F16=1"], force, verbose)
+    return _build_one(LIB, os.path.join(CSRC, "build"), [], force, verbose)
 
 
 if __name__ == "__main__":

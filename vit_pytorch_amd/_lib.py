@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITK_LIB") or os.path.join(HERE, "libvitk.so")     # VITK_LIB: A/B against another build of the library (tools)
-LIB_PATH_F16 = os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit type is IEEE half (model.half())
+LIB_PATH_F16 = os.environ.get("VITK_LIB_F16") or os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit type is IEEE half (model.half())
 
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2
