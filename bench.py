@@ -27,6 +27,13 @@ Extra objects in the line:
                 step right after `invalidate_weight_caches()` (what every step of a real run pays), measured after the timed
                 region: `ms_per_step + weight_cache_rebuild_ms` is the fwd+bwd time inside a training loop.
   model         whole-step algorithmic TFLOP/s (105.383 GF/img for ViT-B/16) and its fraction of peak.
+  box           a ~60 ms calibration of THIS box before the timed region, with plain torch ops (not the product): a bf16 torch.mm
+                (hipBLASLt) of 8192^3 on random data in TFLOP/s, a 1 GiB fill and a 1 GiB copy in TB/s.  The pool's boxes differ by +-5 % on the
+                same tree; these three numbers let a driver line from a slow box be read.  `value` is NOT normalised by them.
+  fp16          the same model and kernels with IEEE-half parameters (libvitk_f16.so): images/s measured here (N = 1 only), and the
+                parity numbers of both 16-bit types against the reference's float32 run on the headline configuration itself
+                (static: profiles/r06_headline_parity.json, written by the GPU parity test of the batch-256 golden).  bfloat16 -- the
+                dtype BASELINE.json quotes the metric in -- lands at the reference-bf16's own 9e-3; float16 meets the north star's 1e-3.
   cpu_baseline  the CPU oracle (oracle/vit_oracle.py, kind "port") timed on this host's cores on a bounded
                 sample of the same workload (same model, f32, batch 32, best of a thread sweep), rank 0 at N = 1 only.
 
@@ -262,6 +269,64 @@ def bench_navit(args, dev):
     }), flush=True)
 
 
+def box_calibration(dev):
+    """Plain torch ops, outside the timed region: how fast is THIS box?  (bf16 matmul on random data, a fill, a copy.)"""
+    def timed(fn, iters):
+        fn(); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+    try:
+        n = 8192
+        a = torch.randn(n, n, device=dev).to(torch.bfloat16); b = torch.randn(n, n, device=dev).to(torch.bfloat16)
+        c = torch.empty(n, n, device=dev, dtype=torch.bfloat16)
+        t_mm = timed(lambda: torch.mm(a, b, out=c), 20)
+        x = torch.empty(1 << 30, device=dev, dtype=torch.uint8); y = torch.empty_like(x)
+        t_fill = timed(lambda: x.fill_(1), 10)
+        t_copy = timed(lambda: y.copy_(x), 10)
+        del a, b, c, x, y
+        return {"torch_mm_bf16_8192_tflops": round(2.0 * n ** 3 / t_mm / 1e12, 1), "fill_1gib_tb_s": round((1 << 30) / t_fill / 1e12, 2),
+                "copy_1gib_tb_s": round(2.0 * (1 << 30) / t_copy / 1e12, 2),
+                "note": "plain torch ops (hipBLASLt matmul on random data, fill_, copy_: read + write bytes), timed before the benchmark; not part of the product, not used to normalise `value`"}
+    except Exception as e:       # a calibration failure must not cost the benchmark line
+        return {"error": repr(e)}
+
+
+def fp16_leg(cfg, batch, dev, steps: int = 10):
+    """The same step with IEEE-half parameters (libvitk_f16.so: the same sources, the 16-bit type switched); N = 1 only."""
+    from vit_pytorch_amd import ViT
+    torch.manual_seed(0)
+    m = ViT(**cfg).to(dev, dtype=torch.float16)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    img = torch.randn(batch, 3, cfg["image_size"], cfg["image_size"], device=dev, generator=g).to(torch.float16)
+    labels = torch.randint(0, cfg["num_classes"], (batch,), device=dev, generator=g)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m(img).float(), labels)
+        (loss * 1024.0).backward()       # a constant loss scale, as any float16 training uses
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    out = {"images_per_s": round(batch / dt, 2), "ms_per_step": round(dt * 1e3, 3), "loss_finite": bool(torch.isfinite(loss).item())}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_headline_parity.json")) as f:
+            out["parity_vs_reference_f32"] = json.load(f)
+    except Exception:
+        out["parity_vs_reference_f32"] = None
+    del m
+    return out
+
+
 def rccl_version():
     try:
         return ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -363,6 +428,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    box = box_calibration(dev) if rank == 0 else None
     for _ in range(args.warmup):
         step()
     # Shared GPU boxes show occasional multi-x slow phases (clock / power state; one measured run: 100.9, 39.6, 39.6 ms);
@@ -472,6 +538,8 @@ def main():
             "ms_per_step": round(ms, 3), "ms_per_step_all": [round(d / args.steps * 1e3, 3) for d in dts],
             "weight_cache_rebuild_ms": round(weight_cache_rebuild_ms, 3),
             "train_loop_ms_per_step": round(ms + weight_cache_rebuild_ms, 3),      # fwd+bwd inside a loop whose optimizer changes the weights every step
+            "train_loop_images_per_s": round(batch * world / ((ms + weight_cache_rebuild_ms) * 1e-3), 2),
+            "box": box,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": prec, "data": "synthetic (randn images, randint labels, random-init weights)",
             **({"dtype_detail": "e4m3 x e4m3 forward GEMMs (QKV, out-projection, FF1, FF2), e5m2 gradients x e4m3 weights^T for the four dX GEMMs, "
@@ -512,6 +580,10 @@ def main():
                                        "(FF1 at K = 768 with a 16-bit and an 8-bit output: 435 FLOP/B against 399; with two 16-bit outputs it was 339)",
                          "classes": others},
         }
+        if world == 1 and args.config == "vit_b16" and not args.fp8 and not args.batch:
+            del dp, model
+            torch.cuda.empty_cache()
+            line["fp16"] = fp16_leg(cfg, batch, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

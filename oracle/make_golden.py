@@ -105,6 +105,41 @@ def main_wide():
         print(f"{name}: logits {tuple(out.shape)} loss {float(loss):.6f} {len(grads)} grads -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+AUTOCAST_CASES = ("vit_b16_width", "vit_b16_full", "vit_b16_full_b256")       # (the last: ~40 GiB of host memory, the headline run itself)
+
+
+def main_autocast():
+    """The reference under torch.autocast (what `accelerate`'s mixed precision runs, train_vit_decorr.py:74-78): float32 master parameters,
+    Linear / matmul in bfloat16, LayerNorm / softmax / the residual stream in float32.  For the WIDE_CASES named in AUTOCAST_CASES the
+    unmodified reference is executed inside torch.autocast("cpu", dtype=torch.bfloat16) on the same parameters and images as the float32
+    golden; logits and the same gradient samples go to tests/golden/<case>__autocast.npz.  The drop-in's autocast route is gated against
+    THESE numbers (tests/test_autocast_parity_gpu.py): at most 1.5x the reference-autocast's own distance from the float32 run + 1e-3."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    outdir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name in AUTOCAST_CASES:
+        if ONLY and name + "__autocast" not in ONLY:
+            continue
+        case = WIDE_CASES[name]
+        params = make_params(case["kind"], case["cfg"], case["seed"])
+        img = make_images(case["cfg"], case["batch"], case["seed"] + 1000)
+        mod = load_ref("vit" if case["kind"] == "vit" else "simple_vit")
+        model = (mod.ViT if case["kind"] == "vit" else mod.SimpleViT)(**case["cfg"])
+        model.load_state_dict(params, strict=True)
+        model.train()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = model(img)
+        loss = loss_fn(out.float())
+        loss.backward()
+        blob = {"autocast::logits": out.detach().float().numpy(), "autocast::logits_dtype": np.frombuffer(str(out.dtype).encode(), dtype=np.uint8)}
+        for k, p_ in model.named_parameters():
+            g = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+            idx = sample_index(g.numel(), case.get("sample", 4096))
+            blob["autocast::gsample::" + k] = g.detach().float().flatten().numpy()[idx]
+        path = os.path.join(outdir, name + "__autocast.npz")
+        np.savez_compressed(path, **blob)
+        print(f"{name} under autocast(bf16): logits {tuple(out.shape)} {out.dtype} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main_variants():
     """The sibling variants (oracle/params.py::VARIANT_CASES): reference in eval mode (dropouts off), f32; the golden also records
     the reference's state_dict keys and shapes, which the drop-in's module must reproduce."""
@@ -228,9 +263,13 @@ if __name__ == "__main__":
     if ONLY and all(n in NAVIT_BENCH_CASES for n in ONLY):
         main_navit_bench()
         sys.exit(0)
+    if ONLY and all(n.endswith("__autocast") for n in ONLY):
+        main_autocast()
+        sys.exit(0)
     main()
     main_navit()
     main_wide()
     main_variants()
     main_navit_wide()
     main_navit_bench()
+    main_autocast()

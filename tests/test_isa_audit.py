@@ -40,7 +40,8 @@ def test_four_wave_nt_gemm_keeps_its_registers_and_its_in_flight_loads(tmp_path)
         [measured in round 5] a variant that spilled computed wrong column blocks;
       * not let the compiler touch a register between an uncounted asm load of it and the counted wait that names it
         (tools/asm_inflight_audit.py: residual / gelu'-factor rows prefetched in the epilogue);
-      * issue its K-step exactly as written: 64 MFMAs, 16 fragment reads, 8 LDS-DMA pieces between two barriers."""
+      * issue its K-step exactly as written: 64 MFMAs, 16 fragment reads, 8 LDS-DMA pieces between two barriers -- in both feeds of the
+        activation operand (round 6: 128-byte rows, a K-step pair per instruction; round 5: 64-byte pieces, VITK_NTW_A128=0)."""
     import re
     asm = tmp_path / "gemm_nt_w128.s"
     src = os.path.join(ROOT, "vit_pytorch_amd", "csrc", "gemm_nt_w128.hip")
@@ -51,17 +52,18 @@ def test_four_wave_nt_gemm_keeps_its_registers_and_its_in_flight_loads(tmp_path)
     recs = re.findall(r"Function Name: (\S+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, flags=re.S)
     recs = [(n, int(a), int(s)) for n, a, s in recs if "gemm_ntw_kernel" in n]
     names = [n for n, _, _ in recs]
-    assert len(recs) == 10, recs
+    assert len(recs) == 20, recs       # 10 epilogues x 2 activation feeds
     assert all(s == 0 for _, _, s in recs), recs
     assert all(a == 256 for _, a, _ in recs), recs
     a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_inflight_audit.py"), str(asm)], capture_output=True, text=True)
     assert a.returncode == 0, a.stderr[-2000:]
     lines = [l for l in a.stdout.strip().splitlines() if "gemm_ntw_kernel" in l]
-    assert len(lines) == 10 and all(": 0 compiler instruction(s)" in l for l in lines), a.stdout[-3000:]
+    assert len(lines) == 20 and all(": 0 compiler instruction(s)" in l for l in lines), a.stdout[-3000:]
     # the steady-state K-step of the plain epilogue's instance: the instructions between two consecutive barriers of the inner loop
     text = open(asm).read()
-    body = text[text.index("gemm_ntw_kernelILi0ELi0E"):]
-    body = body[:body.index(".Lfunc_end")]
-    steps = body.split("s_barrier")
-    counts = [(seg.count("v_mfma_f32_16x16x32"), seg.count("ds_read_b128"), seg.count("buffer_load_dwordx4")) for seg in steps]
-    assert counts.count((64, 16, 8)) >= 8, counts
+    for feed in ("Li1E", "Li0E"):
+        body = text[text.index("gemm_ntw_kernelILi0ELi0E" + feed):]
+        body = body[:body.index(".Lfunc_end")]
+        steps = body.split("s_barrier")
+        counts = [(seg.count("v_mfma_f32_16x16x32"), seg.count("ds_read_b128"), seg.count("buffer_load_dwordx4")) for seg in steps]
+        assert counts.count((64, 16, 8)) >= 8, (feed, counts)

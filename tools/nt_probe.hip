@@ -56,6 +56,7 @@ template <typename F> static float time_ms(F&& fn, int iters) {
 static float median(std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);      // (a GPU fault must not take the last lines with it)
     const int rounds = argc > 1 ? atoi(argv[1]) : 3;
     const int64_t M = 50432;
     int dev = 0, cus = 0;
@@ -179,19 +180,36 @@ int main(int argc, char** argv) {
             if (aux_is_out) printf(", aux %s (%zu)", badx ? "MISMATCH" : "bit-identical", badx);
             if (aux_is_in) printf(", colsum rows %lld vs %lld, rel diff of the sums %.2e", (long long)rows_old, (long long)rows_new, cs_err);
             printf("\n");
+            {   // round 5's feed must agree with round 6's, bit for bit (C only: same code beyond the feed)
+                CK(hipMemset(C0.p, 0xdd, cbytes));
+                setenv("VITK_NTW_A128", "0", 1);
+                api(C0, X0, cs0);
+                unsetenv("VITK_NTW_A128");
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(h0.data(), C0.p, cbytes, hipMemcpyDeviceToHost));
+                size_t bad5 = 0;
+                for (size_t i = 0; i < cbytes; ++i) bad5 += h0[i] != h1[i];
+                printf("  %-13s 64-byte vs 128-byte activation feed: C %s (%zu bytes differ)\n", epi_name[epi], bad5 ? "MISMATCH" : "bit-identical", bad5);
+            }
             // ---- A/B timing, interleaved rounds ----
-            std::vector<float> t_old, t_new, t_dir;
+            std::vector<float> t_old, t_new, t_dir, t_r5, t_dir5;
             for (int r = 0; r <= rounds; ++r) {
                 setenv("VITK_NT_W128", "0", 1);
                 const float a = time_ms([&] { api(C0, X0, cs0); }, 10);
                 unsetenv("VITK_NT_W128");
                 const float b = time_ms([&] { api(C1, X1, cs1); }, 10);
                 const float c = time_ms([&] { direct(tm_all, 0, 0); }, 10);
-                if (r) { t_old.push_back(a); t_new.push_back(b); t_dir.push_back(c); }
+                setenv("VITK_NTW_A128", "0", 1);        // round 5's feed: the activation operand as 64-byte row pieces
+                const float d = time_ms([&] { api(C1, X1, cs1); }, 10);
+                const float e = time_ms([&] { direct(tm_all, 0, 0); }, 10);
+                unsetenv("VITK_NTW_A128");
+                if (r) { t_old.push_back(a); t_new.push_back(b); t_dir.push_back(c); t_r5.push_back(d); t_dir5.push_back(e); }
             }
-            const float mo = median(t_old), mn = median(t_new), md = median(t_dir);
-            printf("  %-13s r4 8-wave %7.1f us %7.1f TF/s | product path %7.1f us %7.1f TF/s (x%.3f) | new kernel alone, all %d m-tiles %7.1f us %7.1f TF/s\n",
+            const float mo = median(t_old), mn = median(t_new), md = median(t_dir), m5 = median(t_r5), md5 = median(t_dir5);
+            printf("  %-13s r4 8-wave %7.1f us %7.1f TF/s | product path %7.1f us %7.1f TF/s (x%.3f) | four-wave kernel alone, all %d m-tiles %7.1f us %7.1f TF/s\n",
                    epi_name[epi], mo * 1e3, flop / mo / 1e9, mn * 1e3, flop / mn / 1e9, mo / mn, tm_all, md * 1e3, 2.0 * 256 * tm_all * N * K / md / 1e9);
+            printf("  %-13s    with round 5's 64-byte activation pieces (VITK_NTW_A128=0): product path %7.1f us (128-byte rows x%.3f) | four-wave kernel alone %7.1f us (x%.3f)\n",
+                   epi_name[epi], m5 * 1e3, m5 / mn, md5 * 1e3, md5 / md);
             if (epi == sh.epis[0] || epi == VITK_EPI_RESID16 || epi == VITK_EPI_BIAS_GELU_DG8 || epi == VITK_EPI_MUL_AUX8) { sum_old += mo; sum_new += mn; }
             if (quick) continue;
             // ---- ablations of the four-wave launch (all full tiles) ----
@@ -202,9 +220,14 @@ int main(int argc, char** argv) {
                                   {"empty loop", 7, 1}, {"epilogue only (empty loop + stores)", 7, 0},
                                   {"32x32x16 MFMAs (timing only): main loop", 8, 1}, {"32x32x16 MFMAs: DMA + MFMA", 10, 1}, {"32x32x16 MFMAs: MFMA only", 11, 1}};
                 for (const Ab& ab : abs) {
-                    std::vector<float> t;
-                    for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
-                    printf("      %-42s %7.1f us\n", ab.name, median(t) * 1e3);
+                    std::vector<float> t, t5;
+                    for (int r = 0; r < rounds; ++r) {
+                        t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
+                        setenv("VITK_NTW_A128", "0", 1);
+                        t5.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
+                        unsetenv("VITK_NTW_A128");
+                    }
+                    printf("      %-42s %7.1f us   (64-byte activation pieces: %7.1f us)\n", ab.name, median(t) * 1e3, median(t5) * 1e3);
                 }
                 // the same launches on ZERO operands: same instruction stream and addresses, no toggling in the matrix cores / data paths -- what
                 // the chip's power management (DVFS) takes from the random-data numbers above
@@ -216,18 +239,32 @@ int main(int argc, char** argv) {
                 const Ab zs[] = {{"ZERO operands: all", 0, 0}, {"ZERO operands: main loop alone", 0, 1}, {"ZERO operands: MFMA only", 3, 1}, {"ZERO operands: DMA + MFMA", 2, 1},
                                  {"ZERO operands: 32x32x16 main loop", 8, 1}};
                 for (const Ab& ab : zs) {
-                    std::vector<float> t;
-                    for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct_z(ab.abl, ab.dbg); }, 10));
-                    printf("      %-42s %7.1f us\n", ab.name, median(t) * 1e3);
+                    std::vector<float> t, t5;
+                    for (int r = 0; r < rounds; ++r) {
+                        t.push_back(time_ms([&] { direct_z(ab.abl, ab.dbg); }, 10));
+                        setenv("VITK_NTW_A128", "0", 1);
+                        t5.push_back(time_ms([&] { direct_z(ab.abl, ab.dbg); }, 10));
+                        unsetenv("VITK_NTW_A128");
+                    }
+                    printf("      %-42s %7.1f us   (64-byte activation pieces: %7.1f us)\n", ab.name, median(t) * 1e3, median(t5) * 1e3);
                 }
                 CK(hipFree(Az.p)); CK(hipFree(Wz.p));
             } else if (epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_MUL_AUX || epi == VITK_EPI_RESID16 || epi == VITK_EPI_BIAS_GELU_DG8 || epi == VITK_EPI_MUL_AUX8) {
                 struct Ab { const char* name; int abl, dbg; };
-                const Ab abs[] = {{"epilogue only (empty loop + epilogue)", 7, 0}, {"strict waits after the epilogue", 0, 2}};
+                const Ab abs[] = {{"epilogue only (empty loop + epilogue)", 7, 0}, {"strict waits after the epilogue", 0, 2},
+                                  {"epilogue only, no GELU arithmetic (DG epilogues)", 7, 32}, {"epilogue only, no stores (DG / MUL_AUX epilogues)", 7, 64},
+                                  {"all, no GELU arithmetic (DG epilogues)", 0, 32}, {"all, no stores (DG / MUL_AUX epilogues)", 0, 64},
+                                  {"main loop alone (no epilogue)", 0, 1}};
                 for (const Ab& ab : abs) {
-                    std::vector<float> t;
-                    for (int r = 0; r < rounds; ++r) t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
-                    printf("      %-42s %7.1f us\n", ab.name, median(t) * 1e3);
+                    if ((ab.dbg & 96) && !aux_is_out) continue;      // the GELU / store ablations exist in the DG epilogues (exact-count waits elsewhere)
+                    std::vector<float> t, t5;
+                    for (int r = 0; r < rounds; ++r) {
+                        t.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
+                        setenv("VITK_NTW_A128", "0", 1);
+                        t5.push_back(time_ms([&] { direct(tm_all, ab.abl, ab.dbg); }, 10));
+                        unsetenv("VITK_NTW_A128");
+                    }
+                    printf("      %-42s %7.1f us   (round 5's feed and epilogue: %7.1f us)\n", ab.name, median(t) * 1e3, median(t5) * 1e3);
                 }
             }
         }

@@ -14,6 +14,12 @@
 //     epilogue of tile n, its first fragments are read under the last MFMAs of tile n); the first K-step of a tile writes the
 //     accumulators with C = 0 (no zeroing pass); the first two K-steps after an epilogue wait with an exact count that lets
 //     that epilogue's stores stay in flight (vmcnt retires in order: the DMA pieces they need are older than the stores).
+// Round 6 (AW = 1, the default): the ACTIVATION operand arrives as full 128-byte lines.  The feed is bound by cache-line REQUESTS, not bytes
+// (DESIGN_HISTORY, round 2), and a 64-byte row piece of a row-major activation matrix is HALF a line whose other half is requested a K-step
+// later: an instruction now fetches 8 rows x 128 bytes = the slices of TWO K-steps (8 full lines instead of 16 half lines), into a ring of
+// three 32 KiB activation slots of 128-byte rows (chunk position s of LDS row R holds logical chunk s ^ ((R >> 1) & 7): conflict-free
+// ds_read_b128), beside the four 16 KiB stages of the K-blocked W image (already contiguous KiB pieces).  Same pieces per wave and K-step
+// (4 + 4), same counted waits, same fragments, same MFMA order: bit-identical results.  AW = 0 is round 5's feed (VITK_NTW_A128=0).
 // The epilogue is the 8-wave kernel's, over two 64-column blocks per wave; operand rows it reads (16-bit residual, gelu' factor,
 // f32 residual) come by uncounted asm loads a few fragment rows ahead -- one wave per SIMD has the registers for a deeper prefetch.
 #include "common.h"
@@ -34,6 +40,10 @@ constexpr int V_TILE = 256 * 64;                    // one operand, one K-step: 
 constexpr int V_STAGE = 2 * V_TILE;                 // 32 KiB
 constexpr int V_RING = 4 * V_STAGE;                 // 128 KiB
 constexpr int V_LDS_MAX = V_RING + 32768;           // + bias image
+// AW = 1: three activation slots (a K-step PAIR each: 256 rows of 128 bytes) + four W stages; the bias comes from global memory
+constexpr int X_ASLOT = 256 * 128;                  // 32 KiB
+constexpr int X_WBASE = 3 * X_ASLOT;                // 96 KiB
+constexpr int X_LDS = X_WBASE + 4 * V_TILE;         // 160 KiB: the whole LDS of a CU
 
 #define V_PIN() __builtin_amdgcn_sched_barrier(0)
 
@@ -87,7 +97,7 @@ template <bool Z> __device__ __forceinline__ void v_mfma(f32x4& c, const bf16x8&
 __device__ __forceinline__ void v_gload_bf16x4(bf16x4& d, const __bf16* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 
 // ABL (experiments, tools/nt_probe.hip): bit 0 no LDS-DMA in the loop, bit 1 no fragment reads, bit 2 no MFMA
-template <int EPI, int ABL>
+template <int EPI, int ABL, int AW>
 __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool F32OUT = (EPI == VITK_EPI_RESID);
@@ -115,30 +125,47 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     // the bank swizzle sits in the SOURCE offset: position s of LDS row R holds logical 16-byte chunk s ^ v_swz(R >> 2).  Activation tile:
     // LDS row R = tile row R.  W tile: LDS row R = 64 q + 16 fn + c holds W row 64 q + 4 c + fn (a lane's four B fragments of a 64-column
     // block are then 4 consecutive output columns); K-blocked W (ldw == 0) IS that image, block (n-tile, K-step) after block.
+    // AW = 1, activation tile: an instruction fills 8 LDS rows of 128 bytes (a K-step pair); wave w owns pieces 8w .. 8w + 7 of a slot, piece i =
+    // rows 64 w + 8 i + (lane >> 3).  LDS row R, position s holds logical chunk s ^ ((R >> 1) & 7) = s ^ (4 (i & 1) + (lane >> 4)): one lane
+    // offset for even pieces, one for odd ones; the row offset of piece i (8 i rows) rides in the scalar offset.
     const int srow = lane >> 2, spos = lane & 3;
     const int schunk = spos ^ v_swz(lane >> 4);
     int avo[4], wvo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        avo[j] = (int)(((long long)(64 * wave + 16 * j + srow) * p.lda + schunk * 8) * 2);
+        if constexpr (AW) avo[j] = (int)(((long long)(64 * wave + (lane >> 3)) * p.lda + (((lane & 7) ^ (4 * (j & 1) + (lane >> 4))) * 8)) * 2);      // j & 1 = piece parity
+        else avo[j] = (int)(((long long)(64 * wave + 16 * j + srow) * p.lda + schunk * 8) * 2);
         wvo[j] = p.ldw == 0 ? (4 * wave + j) * 1024 + lane * 16 : (int)(((long long)(64 * wave + 4 * srow + j) * p.ldw + schunk * 8) * 2);
     }
+    const int a_rows8 = (int)(p.lda * 16);              // AW = 1: bytes between the rows of consecutive pieces (8 rows)
     const int w_kstride = p.ldw == 0 ? V_TILE : 64;     // bytes between consecutive K-steps
     __amdgpu_buffer_rsrc_t a_rs, w_rs;
     int a_so = 0, w_so = 0;                             // scalar byte offsets of the producer's K-step
-    auto setup_src = [&](int idx) {
-        int m0, n0, mt;
-        decode(idx, m0, n0, mt);
-        const long long abytes = (255LL * p.lda + p.K) * 2;       // up to the last element of the tile's last row
-        a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda * 2), 0, (int)abytes, 0x00020000);
-        if (p.ldw == 0) {
-            w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)(n0 >> 8) * p.nt * V_TILE), 0, p.nt * V_TILE, 0x00020000);
-        } else {
-            const long long wbytes = (255LL * p.ldw + p.K) * 2;
-            w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.ldw * 2), 0, (int)wbytes, 0x00020000);
-        }
-        a_so = 0; w_so = 0;
+    // (AW = 1: the two operands change tile at different K-steps -- the activation stream runs up to three K-step PAIRS ahead, the W stream
+    //  four K-steps -- hence one setup per operand; past the end of the tile list the descriptor has range 0)
+    auto setup_a = [&](int idx) __attribute__((always_inline)) {
+        if (idx < count) {
+            int m0, n0, mt;
+            decode(idx, m0, n0, mt);
+            const long long abytes = (255LL * p.lda + p.K) * 2;       // up to the last element of the tile's last row
+            a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda * 2), 0, (int)abytes, 0x00020000);
+        } else a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+        a_so = 0;
     };
+    auto setup_w = [&](int idx) __attribute__((always_inline)) {
+        if (idx < count) {
+            int m0, n0, mt;
+            decode(idx, m0, n0, mt);
+            if (p.ldw == 0) {
+                w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)(n0 >> 8) * p.nt * V_TILE), 0, p.nt * V_TILE, 0x00020000);
+            } else {
+                const long long wbytes = (255LL * p.ldw + p.K) * 2;
+                w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.ldw * 2), 0, (int)wbytes, 0x00020000);
+            }
+        } else w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0, 0x00020000);
+        w_so = 0;
+    };
+    auto setup_src = [&](int idx) { setup_a(idx); setup_w(idx); };
     // piece q of the producer's K-step into stage `stg`: q < 4 activation piece 4w + q, else W piece 4w + q - 4
     auto dma = [&](int stg, int q) __attribute__((always_inline)) {
         char* dst = lds + stg * V_STAGE + (q >= 4 ? V_TILE : 0) + (wave * 4 + (q & 3)) * 1024;
@@ -149,18 +176,20 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     // runs four K-steps ahead), so no K-step carries a tile-switch test.  Past the end of the tile list the descriptors have range 0: the
     // pieces still count (the waits stay uniform) but fetch nothing and write zeros into stages nobody reads.
     auto advance = [&]() __attribute__((always_inline)) { a_so += 64; w_so += w_kstride; };
-    auto next_src = [&](int idx) __attribute__((always_inline)) {
-        if (idx < count) setup_src(idx);
-        else {
-            a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
-            w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0, 0x00020000);
-            a_so = 0; w_so = 0;
-        }
+    auto next_src = [&](int idx) __attribute__((always_inline)) { setup_src(idx); };
+    // AW = 1: activation piece i (0..7) of the producer's K-step pair into slot `slot`; W piece j (0..3) of the producer's K-step into stage `stg`
+    auto dma_a = [&](int slot, int i) __attribute__((always_inline)) {
+        char* dst = lds + slot * X_ASLOT + (wave * 8 + i) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (void __attribute__((address_space(3)))*)dst, 16, avo[i & 1], a_so + i * a_rows8, 0, 0);
+    };
+    auto dma_w = [&](int stg, int j) __attribute__((always_inline)) {
+        char* dst = lds + X_WBASE + stg * V_TILE + (wave * 4 + j) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (void __attribute__((address_space(3)))*)dst, 16, wvo[j], w_so, 0, 0);
     };
 
     // ---- bias -> LDS (above the ring), once ----
     const char* bias_lds = lds + V_RING;
-    if constexpr (q_has_bias<EPI>()) {
+    if constexpr (q_has_bias<EPI>() && !AW) {
         const int ncols = p.tiles_n * 256;
         for (int i = tid * 8; i < ncols; i += 256 * 8) {
             bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -172,13 +201,23 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
 
     // ---- consumer ----
     const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds);
-    unsigned a_rd, w_rd;                                 // + f * 1024 / + fn * 1024, + stage
+    unsigned a_rd, w_rd;                                 // + f * 1024 / + fn * 1024, + stage  (AW = 1: + f * 2048, + slot; first K-step of a pair)
+    unsigned a_rd1 = 0;                                  // AW = 1: the second K-step of a pair (logical chunks 4..7: position ^ 4)
     {
         const int fi = lane & 15, fg = lane >> 4;
         const int fpos = fg ^ v_swz(fi >> 2);
-        a_rd = lds_base + (wm * 128 + fi) * 64 + fpos * 16;
-        w_rd = lds_base + V_TILE + (wn * 128 + fi) * 64 + fpos * 16;
+        if constexpr (AW) {
+            const int xpos = fg ^ ((fi >> 1) & 7);
+            a_rd = lds_base + (wm * 128 + fi) * 128 + xpos * 16;
+            a_rd1 = lds_base + (wm * 128 + fi) * 128 + (xpos ^ 4) * 16;
+            w_rd = lds_base + X_WBASE + (wn * 128 + fi) * 64 + fpos * 16;
+        } else {
+            a_rd = lds_base + (wm * 128 + fi) * 64 + fpos * 16;
+            w_rd = lds_base + V_TILE + (wn * 128 + fi) * 64 + fpos * 16;
+        }
     }
+    constexpr int A_FRAG = AW ? 2048 : 1024;             // bytes between the activation fragments of a wave (16 rows)
+    int sp = 0;                 // AW = 1: K-step pair counter mod 3: the slot of the pair the MFMAs are in
 
     int stg = 0;                // K-step counter mod 4: the stage whose fragments are in registers (the DMA of this K-step refills it)
     bf16x8 xa[8], wa[8], xb[8], wb[8];
@@ -207,17 +246,24 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
         constexpr int fm_ = (G) >> 1, h_ = ((G) & 1) * 4; \
         if constexpr (!(ABL & 4) && !(ABL & 8)) v_mfma<Z>(acc[h_ + 0][fm_], XC[fm_], WC[h_ + 0]); \
         V_MFMA32(G, 0, XC, WC); \
-        if constexpr (!(ABL & 2)) { if constexpr ((G) < 8) XN[(G)] = v_rd<(G) * 1024>(rdA); else WN[(G) - 8] = v_rd<((G) - 8) * 1024>(rdW); } \
+        if constexpr (!(ABL & 2)) { if constexpr ((G) < 8) XN[(G)] = v_rd<(G) * A_FRAG>(rdA); else WN[(G) - 8] = v_rd<((G) - 8) * 1024>(rdW); } \
         if constexpr (!(ABL & 4) && !(ABL & 8)) v_mfma<Z>(acc[h_ + 1][fm_], XC[fm_], WC[h_ + 1]); \
         if constexpr (!(ABL & 4) && !(ABL & 8)) v_mfma<Z>(acc[h_ + 2][fm_], XC[fm_], WC[h_ + 2]); \
-        if constexpr (!(ABL & 1) && ((G) & 1)) { V_PIN(); dma(stg, (G) >> 1); V_PIN(); } \
+        if constexpr (!(ABL & 1) && ((G) & 1)) { V_PIN(); if constexpr (AW) { if constexpr ((G) < 8) dma_a(dslot_, di0_ + ((G) >> 1)); else dma_w(stg, ((G) >> 1) - 4); } else dma(stg, (G) >> 1); V_PIN(); } \
         V_MFMA32(G, 1, XC, WC); \
         if constexpr (!(ABL & 4) && !(ABL & 8)) v_mfma<Z>(acc[h_ + 3][fm_], XC[fm_], WC[h_ + 3]); \
     } while (0)
     // one K-step.  WAIT = the counted vmcnt statement: own pieces of K-step t + 2 landed (t + 3, t + 4 fly)
-#define V_STEP(Z, XC, WC, XN, WN, WAIT) do { \
-        const unsigned soff_ = ((stg + 1) & 3) * V_STAGE; \
-        const unsigned rdA = a_rd + soff_, rdW = w_rd + soff_; \
+    // AW = 1, H = the K-step's place in its pair P.  H = 0: reads the pair's second K-step (slot sp, positions ^ 4), issues the second half of
+    // pair P + 2 into slot sp + 2; H = 1: reads the first K-step of pair P + 1 (slot sp + 1), issues the first half of pair P + 3 into slot sp
+    // (read by everyone as of the previous barrier).  Either way the W pieces of K-step t + 4 go into stage stg.
+#define V_STEP(Z, XC, WC, XN, WN, WAIT, H) do { \
+        const unsigned soff_ = ((stg + 1) & 3) * (AW ? V_TILE : V_STAGE); \
+        const int sp1_ = sp == 2 ? 0 : sp + 1; \
+        const int dslot_ = (H) ? sp : (sp == 0 ? 2 : sp - 1); \
+        constexpr int di0_ = (H) ? 0 : 4; \
+        const unsigned rdA = AW ? ((H) ? a_rd + sp1_ * X_ASLOT : a_rd1 + sp * X_ASLOT) : a_rd + soff_; \
+        const unsigned rdW = w_rd + soff_; \
         __builtin_amdgcn_s_setprio(1); \
         V_GROUP(0, Z, XC, WC, XN, WN); V_GROUP(1, Z, XC, WC, XN, WN); V_GROUP(2, Z, XC, WC, XN, WN); V_GROUP(3, Z, XC, WC, XN, WN); \
         V_GROUP(4, Z, XC, WC, XN, WN); V_GROUP(5, Z, XC, WC, XN, WN); V_GROUP(6, Z, XC, WC, XN, WN); V_GROUP(7, Z, XC, WC, XN, WN); \
@@ -229,15 +275,16 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
         V_PIN(); \
         __builtin_amdgcn_s_barrier();           /* stage t + 2 visible to all, stage t + 1 read by all */ \
         V_PIN(); \
-        if constexpr (!(ABL & 1)) advance(); \
+        if constexpr (!(ABL & 1)) { if constexpr (AW) { w_so += w_kstride; if constexpr (!(H)) a_so += 128; } else advance(); } \
+        if constexpr (AW && (H)) sp = sp1_; \
         stg = (stg + 1) & 3; \
     } while (0)
 #define V_WAIT16 asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
-
     // ---- epilogue of one tile: registers -> global, full lines, stores not waited for ----
     // the 8-wave kernel's, over the wave's two 64-column blocks: "row" r = 2 f + qq covers fragment row f (4 output rows per lane) of
     // block qq.  Every tile is interior (the launch takes full tiles only), so operand rows come by uncounted asm loads D rows ahead
     // and are waited for by exact counts (gemm_nt_epi.h).
+    bf16x4 bq[2] = {bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}};      // AW = 1: the lane's bias values of the tile, loaded at the tile's first K-step
     auto epilogue = [&](int m0, int n0, int mt) __attribute__((always_inline)) {
         constexpr int NR = 16;
 #ifdef NTW_PROBE
@@ -265,9 +312,12 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
         const long long obase4 = (long long)mrow0 * p.ldc + ncolw + 4 * fi;      // element (row mrow0, the lane's 4 columns of block 0)
         f32x4 b4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if constexpr (q_has_bias<EPI>()) {
+            if constexpr (AW) asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));       // (asm loads of ~nt K-steps ago: every counted wait since covered them)
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
-                const bf16x4 bb = *reinterpret_cast<const bf16x4*>(bias_lds + (ncolw + qq * 64 + 4 * fi) * 2);
+                bf16x4 bb;
+                if constexpr (AW) bb = bq[qq];
+                else bb = *reinterpret_cast<const bf16x4*>(bias_lds + (ncolw + qq * 64 + 4 * fi) * 2);
                 b4[qq] = f32x4{(float)bb[0], (float)bb[1], (float)bb[2], (float)bb[3]};
             }
         }
@@ -412,7 +462,14 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
                         *reinterpret_cast<bf16x8*>(Cb + o) = q_narrow8(q_gelu8(q_widen8(v)));     // of the ROUNDED pre-activation
                     } else if constexpr (EPI == VITK_EPI_BIAS_GELU_DG || EPI == VITK_EPI_BIAS_GELU_DG8) {
                         q_f32x8 gl, dgl;
+#ifdef NTW_PROBE
+                        // experiments (timing only): p.dbg bit 5 = no GELU arithmetic (the stores alone), bit 6 = no stores (the arithmetic alone)
+                        if (p.dbg & 32) { gl = q_widen8(v); dgl = gl; } else
+#endif
                         q_gelu_both8(q_widen8(v), gl, dgl);              // of the ROUNDED pre-activation, like BIAS_GELU
+#ifdef NTW_PROBE
+                        if (p.dbg & 64) { const bf16x8 t0 = q_narrow8(gl); const q_u32x2 t1 = q_dg_encode8(dgl); asm volatile("" :: "v"(t0), "v"(t1)); continue; }
+#endif
                         if constexpr (EPI == VITK_EPI_BIAS_GELU_DG8) *reinterpret_cast<q_u32x2*>(reinterpret_cast<unsigned char*>(p.aux) + o) = q_dg_encode8(dgl);
                         else *reinterpret_cast<bf16x8*>(p.aux + o) = q_narrow8(dgl);
                         *reinterpret_cast<bf16x8*>(Cb + o) = q_narrow8(gl);
@@ -423,6 +480,9 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
                         else fac = q_gelu_grad8(q_widen8(hpre[R_ % DP][pr]));
                         const q_f32x8 g = q_widen8(v) * fac;
                         const bf16x8 g8 = q_narrow8(g);
+#ifdef NTW_PROBE
+                        if (p.dbg & 64) asm volatile("" :: "v"(g8)); else       // experiments (timing only): bit 6 = no stores
+#endif
                         *reinterpret_cast<bf16x8*>(Cb + o) = g8;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) cs[qq][e] += (float)g8[e];     // of the ROUNDED values: what colsum(C) would read
@@ -467,21 +527,40 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     // ---- prologue: K-steps 0..3 in flight, 0 and 1 landed, the fragments of K-step 0 in registers ----
     setup_src(l0);
     if constexpr (!(ABL & 1)) {
+        if constexpr (AW) {
+            // pairs 0, 1 and the first half of pair 2; W K-steps 0..3.  In issue order: pair 0, W 0, W 1 | pair 1, W 2, W 3 | half of pair 2
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+            for (int pr = 0; pr < 2; ++pr) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dma(s, q);
-            advance();
+                for (int i = 0; i < 8; ++i) dma_a(pr, i);
+                a_so += 128;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dma_w(2 * pr + k, j);
+                    w_so += w_kstride;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma_a(2, i);
+            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");       // pair 0, W 0, W 1 landed
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dma(s, q);
+                advance();
+            }
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     }
     V_PIN();
     __builtin_amdgcn_s_barrier();           // also publishes the bias image
     V_PIN();
     {
         const unsigned rdA = a_rd, rdW = w_rd;
-        xa[0] = v_rd<0 * 1024>(rdA); xa[1] = v_rd<1 * 1024>(rdA); xa[2] = v_rd<2 * 1024>(rdA); xa[3] = v_rd<3 * 1024>(rdA);
-        xa[4] = v_rd<4 * 1024>(rdA); xa[5] = v_rd<5 * 1024>(rdA); xa[6] = v_rd<6 * 1024>(rdA); xa[7] = v_rd<7 * 1024>(rdA);
+        xa[0] = v_rd<0 * A_FRAG>(rdA); xa[1] = v_rd<1 * A_FRAG>(rdA); xa[2] = v_rd<2 * A_FRAG>(rdA); xa[3] = v_rd<3 * A_FRAG>(rdA);
+        xa[4] = v_rd<4 * A_FRAG>(rdA); xa[5] = v_rd<5 * A_FRAG>(rdA); xa[6] = v_rd<6 * A_FRAG>(rdA); xa[7] = v_rd<7 * A_FRAG>(rdA);
         wa[0] = v_rd<0 * 1024>(rdW); wa[1] = v_rd<1 * 1024>(rdW); wa[2] = v_rd<2 * 1024>(rdW); wa[3] = v_rd<3 * 1024>(rdW);
         wa[4] = v_rd<4 * 1024>(rdW); wa[5] = v_rd<5 * 1024>(rdW); wa[6] = v_rd<6 * 1024>(rdW); wa[7] = v_rd<7 * 1024>(rdW);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -500,7 +579,7 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     constexpr int VM_RELAX = 16 + 16 * ST_ROW > 63 ? 63 : 16 + 16 * ST_ROW;
     // [measured, tools/nt_probe, strict vs exact-count waits: plain 16-bit stores (QKV) 155 vs 151 us; every epilogue that also READS rows
     //  or stores two tensors is level or better strict (FF1 shape 216 vs 231, dFF1 271 vs 275, out-projection 69.9 vs 76.6)]
-    constexpr bool RELAX_OK = (EPI == VITK_EPI_NONE || EPI == VITK_EPI_BIAS);
+    constexpr bool RELAX_OK = (EPI == VITK_EPI_NONE || (EPI == VITK_EPI_BIAS && !AW));      // (AW = 1: the bias loads of a tile sit behind the stores)
     bool relax = false;
 #define V_WAITR do { \
         if (relax) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_RELAX) : "memory"); \
@@ -510,18 +589,40 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     for (int idx = l0; idx < count; idx += L) {
         int m0, n0, mt;
         decode(idx, m0, n0, mt);
-        // K-steps in pairs (the two fragment sets swap roles); the first K-step writes the accumulators with C = 0
-        V_STEP(true, xa, wa, xb, wb, V_WAITR);
-        V_STEP(false, xb, wb, xa, wa, V_WAITR);
-        for (int kt = 2; kt + 4 < p.nt; kt += 2) {
-            V_STEP(false, xa, wa, xb, wb, V_WAIT16);
-            V_STEP(false, xb, wb, xa, wa, V_WAIT16);
+        if constexpr (AW && q_has_bias<EPI>()) {
+            if (p.bias) {       // the lane's 2 x 4 bias values of this tile (older than every piece issued from here on: the counted waits cover them)
+                const __bf16* bp = p.bias + n0 + wn * 128 + 4 * (lane & 15);
+                v_gload_bf16x4(bq[0], bp);
+                v_gload_bf16x4(bq[1], bp + 64);
+            }
         }
-        next_src(idx + L);       // the pieces of the last four K-steps are the next tile's first four
-        V_STEP(false, xa, wa, xb, wb, V_WAIT16);
-        V_STEP(false, xb, wb, xa, wa, V_WAIT16);
-        V_STEP(false, xa, wa, xb, wb, V_WAIT16);
-        V_STEP(false, xb, wb, xa, wa, V_WAIT16);       // reads the NEXT tile's first fragments
+        // K-steps in pairs (the two fragment sets swap roles); the first K-step writes the accumulators with C = 0
+        V_STEP(true, xa, wa, xb, wb, V_WAITR, 0);
+        V_STEP(false, xb, wb, xa, wa, V_WAITR, 1);
+        if constexpr (AW) {
+            for (int kt = 2; kt + 6 < p.nt; kt += 2) {
+                V_STEP(false, xa, wa, xb, wb, V_WAIT16, 0);
+                V_STEP(false, xb, wb, xa, wa, V_WAIT16, 1);
+            }
+            V_STEP(false, xa, wa, xb, wb, V_WAIT16, 0);     // K-step nt - 6: completes the tile's last pair
+            setup_a(idx + L);                               // the next three pairs are the next tile's first three ...
+            V_STEP(false, xb, wb, xa, wa, V_WAIT16, 1);
+            setup_w(idx + L);                               // ... and the W pieces of the last four K-steps its first four
+            V_STEP(false, xa, wa, xb, wb, V_WAIT16, 0);
+            V_STEP(false, xb, wb, xa, wa, V_WAIT16, 1);
+            V_STEP(false, xa, wa, xb, wb, V_WAIT16, 0);
+            V_STEP(false, xb, wb, xa, wa, V_WAIT16, 1);       // reads the NEXT tile's first fragments
+        } else {
+            for (int kt = 2; kt + 4 < p.nt; kt += 2) {
+                V_STEP(false, xa, wa, xb, wb, V_WAIT16, 0);
+                V_STEP(false, xb, wb, xa, wa, V_WAIT16, 1);
+            }
+            next_src(idx + L);       // the pieces of the last four K-steps are the next tile's first four
+            V_STEP(false, xa, wa, xb, wb, V_WAIT16, 0);
+            V_STEP(false, xb, wb, xa, wa, V_WAIT16, 1);
+            V_STEP(false, xa, wa, xb, wb, V_WAIT16, 0);
+            V_STEP(false, xb, wb, xa, wa, V_WAIT16, 1);       // reads the NEXT tile's first fragments
+        }
         // the asm MFMAs' results are complete before the compiler's reads of them (it does not see the MFMAs' latency); nothing is
         // scheduled across the pin
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -602,10 +703,19 @@ int gemm_ntw_launch(int tiles_m, int grid, const void* A, int64_t lda, const voi
     const int lds_bytes = V_RING + a.tiles_n * 512 + 16;
     hipStream_t st = (hipStream_t)stream;
     if (tiles_m <= 0 || grid < 8) VITK_FAIL(VITK_E_ARG, "gemm_nt_bf16 (w128): nothing to do");
+    // the activation feed: 128-byte rows (round 6) unless VITK_NTW_A128=0 asks for round 5's 64-byte pieces (the same-box A/B of the two feeds)
+    const char* aw_e = vitk_switch("VITK_NTW_A128");
+    const bool a128 = !(aw_e && aw_e[0] == '0');
 #define NTW_LAUNCH1(E, AB) do { \
-        static const int rc__ = v_set_max_lds(gemm_ntw_kernel<E, AB>, V_LDS_MAX); \
-        if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16 (w128): cannot enable %d B of LDS", V_LDS_MAX); \
-        hipLaunchKernelGGL((gemm_ntw_kernel<E, AB>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a); \
+        if (a128) { \
+            static const int rc1__ = v_set_max_lds(gemm_ntw_kernel<E, AB, 1>, X_LDS); \
+            if (rc1__ != 0) VITK_FAIL(rc1__, "gemm_nt_bf16 (w128): cannot enable %d B of LDS", X_LDS); \
+            hipLaunchKernelGGL((gemm_ntw_kernel<E, AB, 1>), dim3((unsigned)grid), dim3(256), X_LDS, st, a); \
+        } else { \
+            static const int rc__ = v_set_max_lds(gemm_ntw_kernel<E, AB, 0>, V_LDS_MAX); \
+            if (rc__ != 0) VITK_FAIL(rc__, "gemm_nt_bf16 (w128): cannot enable %d B of LDS", V_LDS_MAX); \
+            hipLaunchKernelGGL((gemm_ntw_kernel<E, AB, 0>), dim3((unsigned)grid), dim3(256), lds_bytes, st, a); \
+        } \
     } while (0)
 #ifdef NTW_PROBE
 #define NTW_LAUNCH_ALL(E) do { \
