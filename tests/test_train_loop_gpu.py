@@ -128,12 +128,15 @@ def test_input_image_gradient_matches_the_oracle(kind, cfg_name):
 
 
 @pytest.mark.parametrize("kind", ["vit", "simple_vit"])
-def test_autocast_around_a_float32_model_runs_the_16bit_engine(kind):
+def test_autocast_around_a_float32_model_runs_the_16bit_engine(kind, monkeypatch):
     """`with torch.autocast("cuda", dtype=torch.bfloat16): model(x)` on float32 master weights -- mixed-precision training as accelerate
     sets it up around the reference (train_vit_decorr.py:74).  The fused engine runs on 16-bit copies of the parameters
-    (functional.autocast_aware): the logits are bit-identical to those of the same weights in a bfloat16 model, they come back in
+    (functional.autocast_aware).  With VITK_AUTOCAST_STREAM=16 (the residual streams in the parameter dtype, round 5's behaviour) the
+    logits are bit-identical to those of the same weights in a bfloat16 model; they come back in
     bfloat16 like the reference's autocast Linear gives them, the gradients arrive in float32 on the master parameters and equal the
-    bfloat16 model's (rounded to bf16 there), and a forward hook on the model fires once."""
+    bfloat16 model's (rounded to bf16 there), and a forward hook on the model fires once.  The DEFAULT (round 6: float32 residual streams,
+    like the reference under autocast) is held against the reference's own autocast run in tests/test_autocast_parity_gpu.py."""
+    monkeypatch.setenv("VITK_AUTOCAST_STREAM", "16")
     cfg = dict(CFG) if kind == "vit" else {k: v for k, v in CFG.items()}
     params = make_params(kind, cfg, 31)
     cls = ViT if kind == "vit" else SimpleViT
@@ -242,9 +245,10 @@ def test_torch_compile_runs_the_drop_in_eagerly_on_the_gpu():
     assert torch.equal(out, ref) and all(p.grad is not None for p in m.parameters() if p.numel())
 
 
-def test_autocast_around_the_standalone_transformer_block():
+def test_autocast_around_the_standalone_transformer_block(monkeypatch):
     """vit.Transformer used on its own (T2T-ViT builds its layers from it, t2t.py:45,57) with float32 parameters inside an autocast
-    region: the 16-bit engine on 16-bit parameter copies, like the whole model."""
+    region: the 16-bit engine on 16-bit parameter copies, like the whole model (bit-identical to the bfloat16 block with the streams in the
+    parameter dtype, VITK_AUTOCAST_STREAM=16; the default float32 streams stay within the bf16 rounding of it)."""
     from vit_pytorch_amd.vit import Transformer
     torch.manual_seed(3)
     t32 = Transformer(dim=256, depth=2, heads=4, dim_head=64, mlp_dim=512).to(DEV)
@@ -252,8 +256,12 @@ def test_autocast_around_the_standalone_transformer_block():
     t16.load_state_dict({k: v.to(torch.bfloat16) for k, v in t32.state_dict().items()})
     x = torch.randn(8, 197, 256, device=DEV)
     with torch.autocast("cuda", dtype=torch.bfloat16):
+        out_f32_streams = t32(x)
+    monkeypatch.setenv("VITK_AUTOCAST_STREAM", "16")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
         out = t32(x)
     out.float().square().mean().backward()
     ref = t16(x.to(torch.bfloat16))
     assert out.dtype == torch.bfloat16 and torch.equal(out, ref)
+    assert out_f32_streams.dtype == torch.bfloat16 and _rel(out_f32_streams, ref) < 2e-2
     assert all(p.grad is not None and p.grad.dtype == torch.float32 for p in t32.parameters())

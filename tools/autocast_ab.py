@@ -37,7 +37,12 @@ def timeit(fn):
 for f in (step16, step_ac):
     for _ in range(3):
         f()
-res = {"bf16": [], "autocast": []}
+res = {"bf16": [], "autocast": [], "autocast, VITK_AUTOCAST_STREAM=16 (round 5: streams in the parameter dtype)": []}
 for _ in range(3):
     res["bf16"].append(round(timeit(step16), 3)); res["autocast"].append(round(timeit(step_ac), 3))
+    os.environ["VITK_AUTOCAST_STREAM"] = "16"
+    step_ac()
+    res["autocast, VITK_AUTOCAST_STREAM=16 (round 5: streams in the parameter dtype)"].append(round(timeit(step_ac), 3))
+    del os.environ["VITK_AUTOCAST_STREAM"]
+    step_ac()
 print("ms/step", res, "peak GiB", round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))

@@ -255,6 +255,7 @@ class TransformerFn(torch.autograd.Function):
         dg_mode = bool(keep and depth and not recompute and drop_p == 0.0 and fp8 is None and lp[8] is not None
                        and ops.gelu_dg_ok(T, M, lp[7].shape[0], D))
         ctx.dg_mode = dg_mode
+        ctx.grad16 = ops.grad_stream_16()       # the backward's stream dtype is decided HERE (a per-call policy -- autocast -- is gone by backward time)
 
         def gemm8(a8, sc_a, w, out, Nn, Kd, epi, **kw):       # out (M, Nn) = a8 (M, Kd) e4m3 . e4m3(w)^T under the two per-tensor scales
             w8, wsc = fp8.weight(w)
@@ -361,7 +362,7 @@ class TransformerFn(torch.autograd.Function):
 
         # the residual stream of the backward: float32, or (16-bit parameters, no active dropout: ops.grad_stream_16) the parameter
         # dtype -- then the LayerNorm backward's 16-bit output IS the stream and the f32 tensors below do not exist
-        s16 = bf and drop_p == 0.0 and D % 4 == 0 and ops.grad_stream_16()
+        s16 = bf and drop_p == 0.0 and D % 4 == 0 and ctx.grad16
 
         def newg():
             g32 = None if s16 else ops.empty((M, D), F32, dy)
@@ -859,6 +860,7 @@ class PackedTransformerFn(torch.autograd.Function):
         att_drop = lambda li: site(li, 0) or (0.0, 0)
         dg_mode = bool(keep and depth and drop_p == 0.0 and lp[8] is not None and ops.gelu_dg_ok(T, Tn, lp[7].shape[0], D))     # see TransformerFn
         ctx.dg_mode = dg_mode
+        ctx.grad16 = ops.grad_stream_16()       # the backward's stream dtype is decided HERE (a per-call policy -- autocast -- is gone by backward time)
         for li in range(depth):
             ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
             a1 = ops.empty((Tn, D), T, xs)
@@ -908,7 +910,7 @@ class PackedTransformerFn(torch.autograd.Function):
         grads: List[Optional[Tensor]] = [None] * len(lp)
         fork = _Fork(dy.device)
 
-        s16 = T in ops.HALF and drop_p == 0.0 and D % 4 == 0 and ops.grad_stream_16()        # the backward's residual stream in the parameter dtype (same guards as TransformerFn.backward)
+        s16 = T in ops.HALF and drop_p == 0.0 and D % 4 == 0 and ctx.grad16        # the backward's residual stream in the parameter dtype (same guards as TransformerFn.backward)
 
         def newg():
             return (None if s16 else ops.empty((Tn, D), F32, dy)), ops.empty((Tn, D), T, dy)

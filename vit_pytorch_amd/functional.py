@@ -11,6 +11,8 @@ and `isinstance` checks are unchanged; only `forward` is replaced.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -181,7 +183,12 @@ def autocast_aware(forward):
         kwargs = {k: conv(v) for k, v in kwargs.items()}
         # (the swap is in place for the duration of the call: concurrent forwards of ONE module from several threads would see each
         # other's 16-bit tensors -- like torch.func.functional_call, not thread-safe per module)
-        with torch.autocast("cuda", enabled=False):
+        # The reference under autocast keeps its residual stream in float32 (only Linear / matmul run in 16 bit): so does this route --
+        # float32 forward and backward streams around the 16-bit GEMMs (ops.stream_policy) -- and lands at the reference-autocast's own
+        # distance from float32 (tests/test_autocast_parity_gpu.py: 3.6e-3 on ViT-B/16 logits, where the pure-bf16 model is at 9.2e-3).
+        # VITK_AUTOCAST_STREAM=16 keeps the parameter-dtype streams of a pure 16-bit model (faster by the two streams' bytes).
+        pol = ops.stream_policy() if os.environ.get("VITK_AUTOCAST_STREAM", "f32") == "16" else ops.stream_policy(fwd16=False, grad16=False)
+        with torch.autocast("cuda", enabled=False), pol:
             try:
                 from torch.nn.utils.stateless import _reparametrize_module
             except ImportError:       # public route: re-enters __call__ (hooks on the top-level module then fire twice)

@@ -14,6 +14,7 @@ dtype policy
 from __future__ import annotations
 
 import os
+import threading
 import weakref
 from typing import Optional, Tuple
 
@@ -119,11 +120,37 @@ def fold(part: Tensor, nparts: int, ld: int, cols: int, out: Tensor, accumulate:
         q.append((part, nparts, ld, cols, out, accumulate))
 
 
+class stream_policy:
+    """Per-thread override of the residual-stream dtypes for the calls made inside it (forward: fwd_stream_16, backward: grad_stream_16 --
+    the fused stages read the backward's at FORWARD time and keep it on their ctx).  functional.autocast_aware uses it: the reference under
+    torch.autocast keeps a float32 residual stream (LayerNorm outputs and `attn(x) + x` are float32 there, vit.py:80-81 under autocast)."""
+    _tls = threading.local()
+
+    def __init__(self, fwd16=None, grad16=None):
+        self.new = (fwd16, grad16)
+
+    def __enter__(self):
+        self.old = getattr(stream_policy._tls, "v", (None, None))
+        stream_policy._tls.v = self.new
+        return self
+
+    def __exit__(self, *exc):
+        stream_policy._tls.v = self.old
+        return False
+
+    @staticmethod
+    def current():
+        return getattr(stream_policy._tls, "v", (None, None))
+
+
 def grad_stream_16() -> bool:
     """The backward's residual stream (the gradient that flows through the `+ x` of vit.py:80-81) in the parameter dtype -- what
     torch autograd does when the reference runs in bfloat16 -- instead of float32: the LayerNorm backward, an HBM-bound kernel,
     moves 386 instead of 619 MB per launch (DESIGN_HISTORY.md, round 3).  On by default for 16-bit parameters without active
     dropout; VITK_GRAD_STREAM=f32 keeps the float32 stream (the forward stream is float32 either way)."""
+    ov = stream_policy.current()[1]
+    if ov is not None:
+        return bool(ov)
     return os.environ.get("VITK_GRAD_STREAM", "16") != "f32"
 
 
@@ -134,6 +161,9 @@ def fwd_stream_16(T=None) -> bool:
     ms per ViT-B/16 step; logits / gradients stay inside the 1.5x-of-the-reference's-own-bf16-error gate at full depth); IEEE half
     keeps the float32 stream (its gate is an absolute one, and a half stream can overflow where the f32 stream cannot).
     VITK_FWD_STREAM=f32 forces float32, =16 forces the parameter dtype for either 16-bit type."""
+    ov = stream_policy.current()[0]
+    if ov is not None:
+        return bool(ov)
     v = os.environ.get("VITK_FWD_STREAM", "auto")
     if v == "16":
         return True
