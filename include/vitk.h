@@ -14,8 +14,11 @@
  *   - return value: 0 = OK; < 0 = argument/shape/alignment error detected on the host before
  *     any launch (VITK_E_*); > 0 = hipError_t from the launch.  vitk_last_error() returns a
  *     thread-local human readable string for the last non-zero return on this thread.
- *   - thread safety: re-entrant; no global mutable state (error string is thread-local).
- *     Callable from the autograd worker thread.
+ *   - thread safety: re-entrant; the error string is thread-local.  Process-wide mutable state is limited to (1) the CU reserve
+ *     (vitk_set_cu_reserve: an atomic int; it changes how many workgroups the large GEMMs are LAUNCHED on and the split count
+ *     vitk_gemm_tn_splits() proposes -- never the layout of an output or of the column-sum partial rows, so a concurrent change
+ *     costs speed, not correctness), (2) the RCCL communicator behind vitk_comm_* (guarded by a mutex), and (3) the ticket words of
+ *     the dynamic tile order (one slot per launch, atomically claimed).  Callable from the autograd worker thread.
  *   - dtype tags: VITK_F32 = 0, VITK_BF16 = 1.  "T" below means the model dtype.  The same ABI ships twice:
  *     libvitk.so, where the 16-bit type is bfloat16, and libvitk_f16.so (same sources, -DVITK_HALF_IS_F16),
  *     where every "bf16" of this header is IEEE binary16 (model.half()): tag 1 then denotes half, the `_bf16` entry
@@ -245,8 +248,9 @@ int vitk_gemm_tn_fp8(const void* dY8, int64_t ldy, const void* X8, int64_t ldx, 
  * the strided one).  Split over M into `splits` slabs of f32 partials (ws: splits*N*K floats),
  * then reduced into dW (dtype odt, ld = ldo; accumulate: dW += ...).  N % 8 == 0, K % 8 == 0.  */
 int64_t vitk_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
-/* CUs the weight-gradient GEMMs leave to other kernels (train_vit_decorr.py:74-78,109: the gradient all-reduce that overlaps the
- * backward): vitk_gemm_tn_splits plans for 256 - cus workgroups.  Process-wide; 0 (default) = the whole chip.               */
+/* CUs the large GEMMs leave to other kernels (train_vit_decorr.py:74-78,109: the gradient all-reduce that overlaps the
+ * backward): vitk_gemm_tn_splits plans for 256 - cus workgroups, the persistent NT kernels are launched on 256 - cus workgroups
+ * (four-wave kernel) / draw their tiles by dynamic tickets (8-wave kernel).  Process-wide; 0 (default) = the whole chip.    */
 int vitk_set_cu_reserve(int cus);
 int vitk_get_cu_reserve(void);
 /* Test hook: hold `ncus` CUs for `ms` milliseconds on `stream` (a stand-in for a collective's resident kernel).            */

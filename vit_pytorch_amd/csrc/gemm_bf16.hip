@@ -855,19 +855,22 @@ extern "C" int vitk_gemm_nt_bf16_mul_aux8_colsum(const void* A, int64_t lda, con
 
 // ---- the persistent NT kernels: four-wave kernel (gemm_nt_w128.hip) on the full 256-row tiles of whole rounds, 8-wave kernel
 // (gemm_nt_persist.hip) on the remaining rows (the partial last m-tile and what would be a mostly idle last round, as 128-row tiles) ----
-// The row split is a function of (M, N, K), the CU count and vitk_set_cu_reserve() only: vitk_gemm_nt_colsum_rows() reports the partial
-// rows of both launches.  While another kernel is expected on the chip (cu_reserve > 0: the in-backward all-reduce) everything goes to the
-// 8-wave kernel, whose dynamic tile tickets keep a launch from waiting for CUs it does not get.
+// The row split is a function of (M, N, K) and the CU count only (and of the test switch VITK_NT_W128): vitk_gemm_nt_colsum_rows() reports the
+// partial rows of both launches, and the layout of those rows does NOT depend on vitk_set_cu_reserve() -- a caller that asks for the row
+// count, allocates, and launches while another thread changes the reserve still gets the rows it was promised.  While another
+// kernel is expected on the chip (cu_reserve = c > 0: the in-backward all-reduce) the four-wave kernel keeps its rows and is launched on
+// 256 - c workgroups (round 6; its per-XCD static tile lists take any multiple of 8: more tiles per workgroup, none waiting for a CU the
+// collective holds), and the 8-wave kernel draws its tiles by dynamic tickets as before.
 // VITK_NT_W128 = bit mask over VITK_EPI_* of the epilogues the four-wave kernel serves (0 = none: the 8-wave kernel alone; unset = NTW_EPIS)
 constexpr unsigned NTW_EPIS = 0xffu;
-static int ntw_tiles_m(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int epilogue) {
+static int ntw_tiles_m(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int epilogue, int grid = 0) {
     // (the 8-bit-factor pair follows the switches of its 16-bit twins)
     if (epilogue == VITK_EPI_BIAS_GELU_DG8) epilogue = VITK_EPI_BIAS_GELU_DG;
     if (epilogue == VITK_EPI_MUL_AUX8) epilogue = VITK_EPI_MUL_AUX;
     const char* e = vitk_switch("VITK_NT_W128");
     const unsigned mask = e ? (unsigned)strtoul(e, nullptr, 0) : NTW_EPIS;
-    if (!q.ok || !((mask >> epilogue) & 1u) || vitk_get_cu_reserve() > 0 || !gemm_ntw_serves(M, N, K)) return 0;
-    return gemm_ntw_split(M, N, K, q.grid);
+    if (!q.ok || !((mask >> epilogue) & 1u) || !gemm_ntw_serves(M, N, K)) return 0;
+    return gemm_ntw_split(M, N, K, grid > 0 ? grid : q.grid);
 }
 static int64_t nt_persist_colsum_rows(const NtpPlan& q, int64_t M, int64_t N, int64_t K, int64_t ldc) {
     // (the two epilogues with column sums, GELU_BWD and MUL_AUX, are switched together: one row count serves both entry points)
@@ -879,7 +882,13 @@ static int64_t nt_persist_colsum_rows(const NtpPlan& q, int64_t M, int64_t N, in
 static int nt_persist_dispatch(const NtpPlan& q, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
                                int64_t K, int epilogue, const void* bias, const float* resid, void* aux, float* csum, unsigned drop_t,
                                unsigned drop_seed, float inv_keep, void* stream) {
-    const int tmw = ntw_tiles_m(q, M, N, K, epilogue == VITK_EPI_GELU_BWD ? VITK_EPI_MUL_AUX : epilogue);
+    // the workgroups of the four-wave launch: one per CU that is expected to be free (a multiple of 8, at least a quarter of the chip)
+    const int reserve = vitk_get_cu_reserve();
+    int grid_w = q.grid - (reserve + 7) / 8 * 8;
+    if (grid_w < q.grid / 4) grid_w = q.grid / 4 / 8 * 8;
+    // the row split: with column-sum partial rows promised (csum) it is the full-chip one whatever the reserve; otherwise it follows the launch
+    // grid (whole rounds of 256 - c workgroups: at N = 768 the full-chip split would leave a third round two thirds empty)
+    const int tmw = ntw_tiles_m(q, M, N, K, epilogue == VITK_EPI_GELU_BWD ? VITK_EPI_MUL_AUX : epilogue, csum ? 0 : grid_w);
     const int64_t asz = (epilogue == VITK_EPI_BIAS_GELU_DG8 || epilogue == VITK_EPI_MUL_AUX8) ? 1 : 2;      // bytes per element of aux
     // fused dropout lives in the 8-wave kernel; only the epilogue with column sums has to keep the row split (its partial rows are promised)
     if (tmw == 0 || (drop_t && !(epilogue == VITK_EPI_GELU_BWD && csum)))
@@ -892,7 +901,7 @@ static int nt_persist_dispatch(const NtpPlan& q, const void* A, int64_t lda, con
         rc = gemm_ntp_launch(q1, A, lda, W, ldw, C, ldc, rows_w, N, K, epilogue, bias, resid, aux, csum, drop_t, drop_seed, inv_keep, stream);
     } else {
         if (256LL * (lda > ldw ? lda : ldw) * 2 + K * 2 >= (1LL << 31)) VITK_FAIL(VITK_E_SHAPE, "gemm_nt_bf16: row stride too large (lda %lld, ldw %lld)", (long long)lda, (long long)ldw);
-        rc = gemm_ntw_launch(tmw, q.grid, A, lda, W, ldw, C, ldc, N, K, epilogue, bias, resid, aux, csum, 0, 0, stream);
+        rc = gemm_ntw_launch(tmw, grid_w, A, lda, W, ldw, C, ldc, N, K, epilogue, bias, resid, aux, csum, 0, 0, stream);
     }
     if (rc != 0 || rest <= 0) return rc;
     const NtpPlan q2 = ntp_plan(rest, N, K, ldc, aux);

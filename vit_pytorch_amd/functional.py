@@ -172,15 +172,24 @@ def autocast_aware(forward):
             if b.dtype == F32 and b.is_cuda and b.is_floating_point():
                 swap[n] = _to(b, dt)
 
+        # Only the IMAGE argument is cast (the first positional argument, or the keyword the reference's forwards call it by): under the
+        # reference's torch.autocast every other tensor a wrapper passes along -- float32 targets, teacher logits, masks, temperatures --
+        # keeps its dtype, and only autocast-eligible ops downcast.
         def conv(v):
             if isinstance(v, torch.Tensor):
                 return cast(v, dt) if v.is_floating_point() else v
+            if isinstance(v, tuple) and hasattr(v, "_fields"):       # namedtuple: positional constructor
+                return type(v)(*(conv(u) for u in v))
             if isinstance(v, (list, tuple)):
                 return type(v)(conv(u) for u in v)
             return v
 
-        args = tuple(conv(a) for a in args)
-        kwargs = {k: conv(v) for k, v in kwargs.items()}
+        IMAGE_KEYS = ("img", "x", "images", "batched_images", "video")
+        if args:
+            args = (conv(args[0]),) + tuple(args[1:])
+            kwargs = dict(kwargs)
+        else:
+            kwargs = {k: (conv(v) if k in IMAGE_KEYS else v) for k, v in kwargs.items()}
         # (the swap is in place for the duration of the call: concurrent forwards of ONE module from several threads would see each
         # other's 16-bit tensors -- like torch.func.functional_call, not thread-safe per module)
         # The reference under autocast keeps its residual stream in float32 (only Linear / matmul run in 16 bit): so does this route --
