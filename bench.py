@@ -364,7 +364,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="vit_b16", choices=list(CONFIGS) + ["navit"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (invalidates the headline number)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the side measurements -- cpu_baseline, the fp16 leg and the box calibration -- so that a profiled run contains the timed workload only")
     ap.add_argument("--precision", choices=["bf16", "fp8"], default=None,
                     help="GEMM operand precision; default: the one BASELINE.json quotes the config in (vit_b16 / vit_l16: bf16, vit_h14 = config 5: fp8)")
     ap.add_argument("--fp8", action="store_true",
@@ -428,7 +429,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    box = box_calibration(dev) if rank == 0 else None
+    box = box_calibration(dev) if (rank == 0 and not args.no_cpu_baseline) else None
     for _ in range(args.warmup):
         step()
     # Shared GPU boxes show occasional multi-x slow phases (clock / power state; one measured run: 100.9, 39.6, 39.6 ms);
@@ -580,7 +581,7 @@ def main():
                                        "(FF1 at K = 768 with a 16-bit and an 8-bit output: 435 FLOP/B against 399; with two 16-bit outputs it was 339)",
                          "classes": others},
         }
-        if world == 1 and args.config == "vit_b16" and not args.fp8 and not args.batch:
+        if world == 1 and args.config == "vit_b16" and not args.fp8 and not args.batch and not args.no_cpu_baseline:
             del dp, model
             torch.cuda.empty_cache()
             line["fp16"] = fp16_leg(cfg, batch, dev)

@@ -1060,16 +1060,31 @@ extern "C" int vitk_set_cu_reserve(int cus) {
 }
 extern "C" int vitk_get_cu_reserve(void) { return g_cu_reserve.load(); }
 
+// M-splits of the four-wave weight-gradient kernel: every (256 x 256 tile, split) job is one workgroup that needs a whole CU, so the launch
+// runs in ROUNDS of `cus` jobs.  Rounds 1-5 took "about one job per CU" (s = 256 / tiles); at ViT-H/14's widths that rule gives 100 tiles x 3
+// = 300 jobs = two rounds, the second 17 % full (the weight gradients of `--config vit_h14 --precision bf16` ran at 0.38 of the MFMA peak
+// against 0.50 at ViT-B/16: VERDICT r05).  Now the split minimises a three-term model: rounds x (rows per job x 24 ns + 8 us of prologue and
+// slab store) + the fold's slab traffic (s f32 slabs written and read back at ~5 TB/s) [constants from the ViT-B/16 launches: 7,205 rows
+// per job in 175-181 us].  ViT-B/16 (36 tiles: 7) and ViT-L/16 (64 tiles: 4) keep their splits; 100 tiles at M = 147,712 take 5 (500 jobs =
+// 1.95 rounds) instead of 3.
+int64_t tn_pick_splits(int64_t tiles, int64_t M, int cus, long long slab_elems, double us_per_row, int64_t min_rows) {
+    const int64_t max_by_rows = (M + min_rows - 1) / min_rows;      // 16-bit kernel: at least 8 steps of 64 rows per split
+    int64_t best = 1;
+    double best_c = 1e30;
+    for (int64_t s = 1; s <= 64 && s <= max_by_rows; ++s) {
+        const int64_t rounds = (tiles * s + cus - 1) / cus;
+        const double job = (double)M / (double)s * us_per_row + 8.0;            // us
+        const double fold = (double)s * (double)slab_elems * 8.0 / 5.0e6;       // us
+        const double c = (double)rounds * job + fold;
+        if (c < best_c - 1e-9) { best_c = c; best = s; }
+    }
+    return best;
+}
+
 extern "C" int64_t vitk_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
     if (tn_large(M, N, K)) {
         const int64_t tiles = ((N + 255) / 256) * ((K + 255) / 256);
-        const int reserve = g_cu_reserve.load();
-        int64_t s = reserve ? (256 - reserve) / tiles : (256 + tiles / 2) / tiles;            // ~one workgroup per (available) CU
-        const int64_t max_by_rows = (M + 511) / 512;      // at least 8 steps of 64 rows per split
-        if (s > max_by_rows) s = max_by_rows;
-        if (s > 64) s = 64;
-        if (s < 1) s = 1;
-        return s;
+        return tn_pick_splits(tiles, M, 256 - g_cu_reserve.load(), (long long)N * K, 0.024, 512);
     }
     const int64_t tiles = ((N + BN - 1) / BN) * ((K + BM - 1) / BM);
     int64_t s = (768 + tiles - 1) / tiles;            // aim for ~3 blocks per CU
@@ -1120,12 +1135,7 @@ extern "C" int64_t vitk_gemm_tn_pair_splits(int64_t M, int64_t N0, int64_t K0, i
     // longer overlaps the attention backward) -- engine.TransformerFn pairs only when its side stream is off.
     if (vitk_switch("VITK_TN_PAIR") && atoi(vitk_switch("VITK_TN_PAIR")) == 0) return 0;
     const int64_t tiles = ((N0 + 255) / 256) * ((K0 + 255) / 256) + ((N1 + 255) / 256) * ((K1 + 255) / 256);
-    const int reserve = g_cu_reserve.load();
-    int64_t s = reserve ? (256 - reserve) / tiles : (256 + tiles / 2) / tiles;
-    const int64_t max_by_rows = (M + 511) / 512;
-    if (s > max_by_rows) s = max_by_rows;
-    if (s > 64) s = 64;
-    if (s < 1) s = 1;
+    const int64_t s = tn_pick_splits(tiles, M, 256 - g_cu_reserve.load(), (long long)N0 * K0 + (long long)N1 * K1, 0.024, 512);
     const int64_t ldmax = (N0 > K0 ? N0 : K0) > (N1 > K1 ? N1 : K1) ? (N0 > K0 ? N0 : K0) : (N1 > K1 ? N1 : K1);
     if (!gemm_tn_w128_serves(M, N0, K0, ldmax, ldmax, s)) return 0;
     return s;

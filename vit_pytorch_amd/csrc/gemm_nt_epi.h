@@ -38,14 +38,14 @@ __host__ __device__ constexpr int q_epi_younger(int f, int fmw, int d, int per_f
 template <int N_, typename T> __device__ __forceinline__ void q_wait_regs4(T& a, T& b, T& c, T& d) {
     if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
     Q_WAIT_CASE(4); Q_WAIT_CASE(6); Q_WAIT_CASE(8); Q_WAIT_CASE(10); Q_WAIT_CASE(12); Q_WAIT_CASE(16); Q_WAIT_CASE(20); Q_WAIT_CASE(24);
-    Q_WAIT_CASE(28); Q_WAIT_CASE(32); Q_WAIT_CASE(36); Q_WAIT_CASE(40);
+    Q_WAIT_CASE(28); Q_WAIT_CASE(32); Q_WAIT_CASE(36); Q_WAIT_CASE(40); Q_WAIT_CASE(44); Q_WAIT_CASE(48); Q_WAIT_CASE(52); Q_WAIT_CASE(56); Q_WAIT_CASE(60);
     else static_assert(N_ < 0, "unsupported vmcnt");
 }
 #define Q_WAIT2_CASE(n) else if constexpr (N_ == n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a), "+v"(b) :: "memory")
 template <int N_, typename T> __device__ __forceinline__ void q_wait_regs2(T& a, T& b) {
     if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) :: "memory");
     Q_WAIT2_CASE(2); Q_WAIT2_CASE(4); Q_WAIT2_CASE(6); Q_WAIT2_CASE(8); Q_WAIT2_CASE(10); Q_WAIT2_CASE(12);
-    Q_WAIT2_CASE(14); Q_WAIT2_CASE(16); Q_WAIT2_CASE(18); Q_WAIT2_CASE(20);
+    Q_WAIT2_CASE(14); Q_WAIT2_CASE(16); Q_WAIT2_CASE(18); Q_WAIT2_CASE(20); Q_WAIT2_CASE(22); Q_WAIT2_CASE(24); Q_WAIT2_CASE(26); Q_WAIT2_CASE(28); Q_WAIT2_CASE(30);
     else static_assert(N_ < 0, "unsupported vmcnt");
 }
 

@@ -410,6 +410,9 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
             const long long obase = (long long)(mrow0 + odd) * p.ldc + ncolw + 8 * (fi >> 1);      // + 16 f ldc + 64 qq + 2 pr ldc
             constexpr bool AUX_IN = q_aux_in<EPI>();      // an (M, N) operand read in the epilogue (16-bit; MUL_AUX8: 8-bit codes)
             constexpr bool AUX8 = (EPI == VITK_EPI_MUL_AUX8);
+            // [measured, round 6, one box, two interleaved runs (profiles/r06o_*): the codes of 4 / 8 / 16 fragment rows in flight (16 = the whole tile
+            //  requested before the first store, so that no wait for a load waits for a store's acknowledge): dFF1 248-250 / 250-252 / 258-260 us;
+            //  the 16-bit residual rows of EPI_RESID16 with 6 / 8 / 12 / 14 rows in flight: level.  4 and 6 stay.]
             constexpr int DP = AUX8 ? 4 : 6;
             using HPre = std::conditional_t<AUX8, q_u32x2, bf16x8>;
             HPre hpre[DP][2];

@@ -191,16 +191,14 @@ bool f8t_ok(int64_t M, int64_t N, int64_t K) { return M >= 1024 && N >= 256 && K
 
 extern "C" int vitk_get_cu_reserve(void);
 
+int64_t tn_pick_splits(int64_t tiles, int64_t M, int cus, long long slab_elems, double us_per_row, int64_t min_rows);      // gemm_bf16.hip
+
 extern "C" int64_t vitk_gemm_tn_fp8_splits(int64_t M, int64_t N, int64_t K, int flags) {
     if (!f8t_ok(M, N, K)) return 0;
     const int64_t bkm = (flags & 1) ? 128 : 64;
     const int64_t tiles = ((N + 255) / 256) * ((K + 255) / 256);
-    const int reserve = vitk_get_cu_reserve();
-    int64_t s = reserve ? (256 - reserve) / tiles : (256 + tiles / 2) / tiles;       // ~one workgroup per (available) CU
-    const int64_t max_by_rows = (M + 4 * bkm - 1) / (4 * bkm);                        // at least 4 LDS steps per split
-    if (s > max_by_rows) s = max_by_rows;
-    if (s > 64) s = 64;
-    if (s < 1) s = 1;
+    // rounds of (256 - reserve) one-CU jobs, like the 16-bit kernel (gemm_bf16.hip: tn_pick_splits); an fp8 job runs ~0.6 x the time per row
+    const int64_t s = tn_pick_splits(tiles, M, 256 - vitk_get_cu_reserve(), (long long)N * K, 0.015, 4 * bkm);
     return s;
 }
 
