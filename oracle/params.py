@@ -157,6 +157,10 @@ WIDE_CASES = {
     # FORCED ON (what config 5 takes at batch 256), so that path answers to the reference and not to the repo's own full-save run.
     "vit_h14_d4_b8": dict(kind="vit", batch=8, seed=24, sample=1024,
                           cfg=dict(image_size=336, patch_size=14, num_classes=1000, dim=1280, depth=4, heads=16, dim_head=80, mlp_dim=5120)),
+    # BASELINE config 5's architecture at its FULL depth of 32 (round 6), at a batch the reference finishes on the CPU (M = 8 * 577 = 4,616):
+    # the fp8 and bf16 engines are held to the reference through all 32 layers, not 4.  512 samples per gradient.
+    "vit_h14_full_b8": dict(kind="vit", batch=8, seed=25, sample=512,
+                            cfg=dict(image_size=336, patch_size=14, num_classes=1000, dim=1280, depth=32, heads=16, dim_head=80, mlp_dim=5120)),
 }
 GOLD_SAMPLE = 4096
 

@@ -253,3 +253,27 @@ def test_fp8_training_step_against_reference_golden(name, k128, wgrad, monkeypat
     for e, g in ((e2, g2), (e3, g3)):
         assert e < 3e-2 and g < 5e-2, (e, g)
     assert e3 > e16r                                                                   # fp8 did run (it cannot be as close as 16 bit)
+
+
+def test_fp8_training_step_full_depth_config5(monkeypatch):
+    """BASELINE config 5's architecture at its FULL depth (ViT-H/14 @ 336, 32 layers, dim_head 80) in its default fp8 setting (all twelve GEMMs of a
+    layer on fp8 operands, K = 128 MFMA), batch 8, against the reference's float32 run (tests/golden/vit_h14_full_b8.npz, round 6) -- the
+    depth-4 golden left 28 of the 32 layers' error accumulation unmeasured.  Stated tolerance: fp8 has no north-star figure; the gate is
+    self-stated -- logits <= 3e-2 and gradient samples <= 5e-2 relative L2, as at depth 4 -- and the reference's own bf16 distance is printed."""
+    name = "vit_h14_full_b8"
+    monkeypatch.setenv("VITK_FP8_K128", "1")
+    monkeypatch.setenv("VITK_FWD_STREAM", "f32")
+    monkeypatch.setenv("VITK_GELU_DG", "0")
+    case = WIDE_CASES[name]
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000).to(DEV, dtype=BF)
+    m = ViT(**case["cfg"]); m.load_state_dict(params, strict=True)
+    m = m.to(DEV, dtype=BF)
+    e16r, g16r, e_ref16, _ = _golden_errors(name, m, img, params, case)
+    enable_fp8(m, wgrad=True)
+    for _ in range(2):
+        _golden_errors(name, m, img, params, case)          # recording step, first fp8 step
+    e3, g3, _, _ = _golden_errors(name, m, img, params, case)
+    print(f"{name} fp8 (K = 128, all twelve GEMMs): logits {e3:.2e} grad samples {g3:.2e}; the bf16 engine {e16r:.2e} / {g16r:.2e}; reference's own bf16 logits {e_ref16:.2e}")
+    assert m.transformer._fp8.bwd_ready
+    assert e3 < 3e-2 and g3 < 5e-2, (e3, g3)
