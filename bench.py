@@ -134,8 +134,8 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
         (n0, k0), (n1, k1) = a[4].shape, a[9].shape
         return bracket(("tn", f"{n0}+{n1}", f"{k0}|{k1}"), 2.0 * a[10] * (n0 * k0 + n1 * k1), orig["gemm_tn_bf16_pair"], a, kw)
     K.gemm_tn_bf16_pair = tapped_pair
-    prev = os.environ.get("VITK_DW_STREAM")
-    os.environ["VITK_DW_STREAM"] = "0"          # serialized: engine._Fork reads it per backward
+    from vit_pytorch_amd import engine as E
+    E._Fork.serialize = True          # serialized launches (the fp8 path's side stream off): engine._Fork reads it per backward
     try:
         for _ in range(nsteps):
             step_fn()
@@ -143,10 +143,7 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
     finally:
         for n, f in orig.items():
             setattr(K, n, f)
-        if prev is None:
-            os.environ.pop("VITK_DW_STREAM", None)
-        else:
-            os.environ["VITK_DW_STREAM"] = prev
+        E._Fork.serialize = False
     return {key: (sum(e0.elapsed_time(e1) for e0, e1, _ in tl) / len(tl), tl[0][2], len(tl) // nsteps) for key, tl in taps.items()}
 
 

@@ -11,6 +11,7 @@ import torch
 from oracle import vit_oracle as O
 from oracle.params import make_params_for
 from vit_pytorch_amd import _lib as L
+from vit_pytorch_amd import engine as E
 from vit_pytorch_amd import kernels as K
 from vit_pytorch_amd.fp8 import SLOTS_PER_LAYER, enable_fp8, enable_fp8_forward
 from vit_pytorch_amd.vit import Transformer
@@ -131,7 +132,7 @@ def test_fp8_state_machine_and_formats(x, mode, monkeypatch):
     monkeypatch.setenv("VITK_FWD_STREAM", "f32")      # the fp8 path keeps the float32 stream: its recording step equals the 16-bit run under that stream
     monkeypatch.setenv("VITK_GELU_DG", "0")           # ... and saves the pre-activation (the 16-bit default stores the gelu' factor instead)
     lean = mode == "fwd+dx+dw"             # the forward's e4m3 copies are kept for the weight-gradient GEMMs (the default)
-    monkeypatch.setenv("VITK_FP8_LEAN", "1" if lean else "0")
+    monkeypatch.setattr(E, "FP8_LEAN", bool(lean))
     backward, wgrad = mode != "fwd", mode.startswith("fwd+dx+dw")
     m16, params = build(torch.bfloat16)
     y_ref, dx_ref, g_ref = reference(params, x)
@@ -215,7 +216,7 @@ def test_fp8_k128_switch_and_recompute(x, monkeypatch):
         assert len(f) == 8 * DEPTH and all(c[5] == (c[2] % 128 == 0) for c in f) and any(c[5] for c in f)
         tn = [c[1] for c in calls if c[0] == "gemm_tn_fp8"]
         assert len(tn) == 4 * DEPTH and all(c[3] for c in tn)             # every weight-gradient GEMM takes the K = 128 form (tokens are zero-padded)
-        monkeypatch.setenv("VITK_FP8_LEAN", "0")                           # the recompute policy matters where 16-bit activations are saved
+        monkeypatch.setattr(E, "FP8_LEAN", False)                           # the recompute policy matters where 16-bit activations are saved
         # the activation-recompute policy (engine._recompute_policy, what lets ViT-H/14 batch 256 fit) composes with fp8: the backward
         # rebuilds the LayerNorm / GELU outputs it no longer finds saved (the delayed scales moved by one step in between, so the
         # two runs agree to quantisation noise, not bit for bit)

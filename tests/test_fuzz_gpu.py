@@ -268,8 +268,8 @@ _FLAG_SETS = [
     {"VITK_RECOMPUTE": "1"},                                   # activation recompute (what config 5 takes at batch 256)
     {"VITK_FWD_STREAM": "f32", "VITK_GRAD_STREAM": "f32"},     # float32 residual streams in both directions (the round-1..3 layout)
     {"VITK_FWD_STREAM": "16"},                                 # 16-bit forward stream forced
-    {"VITK_GELU_DG": "0", "VITK_DW_STREAM": "1"},              # pre-activation saved instead of the gelu' factor; weight gradients on the side stream
-    {"VITK_RECOMPUTE": "1", "VITK_GRAD_STREAM": "f32", "VITK_DW_STREAM": "1"},
+    {"VITK_GELU_DG": "0"},                                     # pre-activation saved instead of the gelu' factor
+    {"VITK_RECOMPUTE": "1", "VITK_GRAD_STREAM": "f32"},
     {"VITK_GELU_DG": "16"},                                    # the gelu' factor in the 16-bit type (round 4) instead of the 8-bit codes
 ]
 

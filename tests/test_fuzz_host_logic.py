@@ -32,7 +32,6 @@ def _plain_f32_routes(monkeypatch):
     # float32 on the MFMA kernels (three-term bf16 split, ops.f32_on_mfma) and the hi + lo flash attention are compositions of GPU kernels
     # without doubles; the plain float32 routes run the same host logic
     monkeypatch.setenv("VITK_F32_MFMA", "0")
-    monkeypatch.setenv("VITK_F32_FLASH", "0")
 
 
 @pytest.mark.parametrize("seed", range(F.N_DRAWS))

@@ -36,8 +36,6 @@ def test_no_grad_forward_drops_activations_and_data_writes_need_invalidation(mon
     (2) a raw `.data` write is invisible to the K-blocked weight cache until invalidate_weight_caches()."""
     import vit_pytorch_amd
     from vit_pytorch_amd import ViT
-    monkeypatch.delenv("VITK_NTP_EPIS", raising=False)      # (other test modules set it; it turns the K-blocked weight copies off)
-    monkeypatch.delenv("VITK_PACK_W", raising=False)
     torch.manual_seed(0)
     m = ViT(image_size=224, patch_size=16, num_classes=10, dim=768, depth=6, heads=12, mlp_dim=3072).to("cuda", dtype=torch.bfloat16)
     x = torch.randn(32, 3, 224, 224, device="cuda").to(torch.bfloat16)

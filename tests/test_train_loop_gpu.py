@@ -43,8 +43,6 @@ def _train(opt_name, fp8, steps=4):
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("opt_name", ["sgd", "adamw_foreach", "adamw_fused"])
 def test_weight_caches_follow_the_optimizer(opt_name, fp8, monkeypatch):
-    monkeypatch.delenv("VITK_NTP_EPIS", raising=False)
-    monkeypatch.delenv("VITK_PACK_W", raising=False)
     monkeypatch.delenv("VITK_WEIGHT_CACHE", raising=False)
     losses, final, ps = _train(opt_name, fp8)
     monkeypatch.setenv("VITK_WEIGHT_CACHE", "0")

@@ -68,7 +68,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     VITK_BUILD_EXPERIMENTS=1 builds the EXPERIMENTS flavour instead -- the knobs of vitk_exp() in csrc/common.h compiled in (tile orders,
     cost-model constants, debug stamps: what the tools/ scripts switch) -- under its own names, libvitk_exp.so / libvitk_f16_exp.so, from its
     own object directory: the product libraries are never overwritten by it (a later product build used to see nothing stale and keep the
-    experiments flavour under the product name).  Load it with VITK_LIB=.../libvitk_exp.so (and VITK_LIB_F16)."""
+    experiments flavour under the product name).  Load it with VITK_LIB=.../libvitk_exp.so (the float16 sibling libvitk_f16_exp.so is found beside it)."""
     exp = os.environ.get("VITK_BUILD_EXPERIMENTS", "0") not in ("0", "")
     if exp:
         flags = ["-DVITK_EXPERIMENTS=1"]

@@ -11,7 +11,9 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITK_LIB") or os.path.join(HERE, "libvitk.so")     # VITK_LIB: A/B against another build of the library (tools)
-LIB_PATH_F16 = os.environ.get("VITK_LIB_F16") or os.path.join(HERE, "libvitk_f16.so")     # same ABI; its 16-bit type is IEEE half (model.half())
+# same ABI; its 16-bit type is IEEE half (model.half()).  With VITK_LIB set: the sibling of that file (libvitk*.so -> libvitk_f16*.so)
+LIB_PATH_F16 = (os.path.join(os.path.dirname(LIB_PATH), os.path.basename(LIB_PATH).replace("libvitk", "libvitk_f16", 1)) if os.environ.get("VITK_LIB")
+                else os.path.join(HERE, "libvitk_f16.so"))
 
 F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat16 in libvitk, half in libvitk_f16)
 HALF_TYPE_F16 = 2

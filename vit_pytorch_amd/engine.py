@@ -97,17 +97,16 @@ class _Fork:
     (measured: 146 GiB allocated, 287 GiB reserved, allocator retries, 4 s instead of 0.85 s per step).  Instead the inputs of
     the last LAG launches are held here, and before a launch's inputs are let go the MAIN stream waits for that launch's event:
     whatever main-stream kernel reuses the memory is ordered behind the side-stream reader by the streams themselves."""
-    LAG = int(__import__("os").environ.get("VITK_DW_LAG", "6"))    # launches (6 = a layer and a half) whose inputs stay referenced
+    LAG = 6                 # launches (a layer and a half) whose inputs stay referenced
+    serialize = False       # bench.py's per-class kernel timing sets it: a launch timed beside a concurrent GEMM measures the contention
 
     def __init__(self, device, fp8: bool = False):
-        import os
-        # bfloat16 / float16 weight gradients: OFF by default since round 4 (VITK_DW_STREAM=1 switches it on).  [measured, profiles/r04_dw_stream_ab.log, three interleaved pairs
-        # on one box] with the four-wave weight-gradient kernel (one workgroup needs a whole CU: 136 KB of LDS, 512 registers per wave) the
-        # side stream costs the ViT-B/16 step 0.46 ms (32.10 vs 31.64 ms): what it overlapped in rounds 1-3 -- the tails of the 8-wave
-        # kernels -- is gone, and two full-chip GEMMs time-slicing the CUs evict each other's operand panels from the L2s.
-        # fp8 weight gradients (gemm_tn256_f8_kernel, eight waves, 22 % of the ViT-H/14 step): ON by default -- that kernel still leaves the
-        # CU resources a second resident workgroup needs, and serializing it costs the fp8 step 7 % [measured, profiles/r04e_h14_dw_stream_ab.log].
-        self.enabled = device.type == "cuda" and os.environ.get("VITK_DW_STREAM", "1" if fp8 else "0") == "1"
+        # fp8 weight gradients ONLY (gemm_tn256_f8_kernel, eight waves, 22 % of the ViT-H/14 step): that kernel leaves the CU resources a
+        # second resident workgroup needs, and serializing it costs the fp8 step 7 % [measured, profiles/r04e_h14_dw_stream_ab.log].  The
+        # 16-bit weight-gradient kernel needs a whole CU per workgroup (136 KB of LDS, 512 registers per wave): beside it a side stream cost
+        # the ViT-B/16 step 0.3-0.46 ms in every A/B of rounds 4 and 5 (profiles/r04_dw_stream_ab.log, r05k2_switch_sweep.log), so since
+        # round 6 the 16-bit path has no side stream and no switch for one.
+        self.enabled = bool(fp8) and device.type == "cuda" and not _Fork.serialize
         self._held = []
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
@@ -155,6 +154,7 @@ def pack_layer_params(attn, ff) -> List[Optional[Tensor]]:
 
 
 NLP = 11  # tensors per layer in pack_layer_params
+FP8_LEAN = True     # fp8 with fp8 weight gradients: keep the e4m3 copies the forward GEMMs consumed INSTEAD of the 16-bit LayerNorm / GELU outputs (tests flip it)
 
 
 def _hash32(x: int) -> int:
@@ -247,7 +247,7 @@ class TransformerFn(torch.autograd.Function):
         # consumed ARE their activation operands -- they are kept (1 B / element) INSTEAD of the 16-bit LayerNorm / GELU outputs
         # (2 B / element), which nothing else in the backward reads: no re-quantisation pass, no recompute pass, less memory.
         # The scales they were made under are snapshotted (the fold at the end of this forward overwrites the live ones).
-        lean8 = bool(go8 and keep and bwd8 and fp8.wgrad and fp8.backward_will_be_fp8() and os.environ.get("VITK_FP8_LEAN", "1") != "0"
+        lean8 = bool(go8 and keep and bwd8 and fp8.wgrad and fp8.backward_will_be_fp8() and FP8_LEAN
                      and all(ops.fp8_tn_ok(M, n_, k_) for n_, k_ in ((D, lp[7].shape[0]), (lp[7].shape[0], D), (D, I), (3 * I, D))))
         scales_used = fp8.scales.clone() if lean8 else None
         # the FeedForward GEMM stores the gelu' factor instead of the pre-activation (ops.gelu_dg_ok) when the backward will want only

@@ -12,10 +12,10 @@ What runs on fp8 once the scales exist (the reference's four nn.Linear per layer
               dW of the same four layers         e5m2 gradients^T x e4m3 activations (gemm_tn_fp8.hip: ds_read_b64_tr_b8 fragments,
                                                  v_mfma_f32_16x16x32_bf8_fp8; `wgrad=False` keeps them 16-bit)
     16-bit    attention, LayerNorm, the residual streams.
-    saved     DEFAULT ("lean", VITK_FP8_LEAN=1, engine.TransformerFn `lean8`): when this step's dW GEMMs will run on fp8 operands, the e4m3
+    saved     DEFAULT ("lean", engine.FP8_LEAN, engine.TransformerFn `lean8`): when this step's dW GEMMs will run on fp8 operands, the e4m3
               copies the forward GEMMs just consumed ARE their activation operands -- they are kept (1 B / element, made under the
               PREVIOUS step's scale, snapshotted with it) INSTEAD of the 16-bit LayerNorm / GELU outputs; the backward raises if the fp8
-              state no longer allows fp8 weight gradients when it runs.  VITK_FP8_LEAN=0: the 16-bit activations are saved and the e4m3
+              state no longer allows fp8 weight gradients when it runs.  engine.FP8_LEAN = False: the 16-bit activations are saved and the e4m3
               operands re-made from them under this step's scales, one pass each (slightly different numerics: no stale-scale saturation).
 
 Every fp8 GEMM whose reduction extent is a multiple of 128 (every dW GEMM: tokens are zero-padded) runs on

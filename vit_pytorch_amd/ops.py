@@ -99,7 +99,7 @@ def flush_folds():
 class deferred_folds:
     def __enter__(self):
         self.prev = getattr(_FOLDS, "q", None)
-        _FOLDS.q = [] if os.environ.get("VITK_FOLD_DEFER", "1") != "0" else None       # =0: every fold its own launch (A/B runs)
+        _FOLDS.q = []
         return self
 
     def __exit__(self, exc_type, exc, tb):
@@ -374,10 +374,11 @@ def _persistent_nt(M: int, N: int, Kd: int) -> bool:
     return v
 
 
+PACK_W = True       # K-blocked weight copies for the persistent NT kernels (vitk_pack_w_nt); tests flip it to hold the row-major path against it
+
+
 def packed_weights_on() -> bool:
-    """K-blocked weight copies for the persistent NT kernel (VITK_PACK_W=0 turns them off; so does an explicit VITK_NTP_EPIS
-    mask, which may route an epilogue to the per-tile kernel that does not read them)."""
-    return _os.environ.get("VITK_PACK_W", "1") not in ("0", "") and "VITK_NTP_EPIS" not in _os.environ
+    return PACK_W
 
 
 def is_weight(W: Tensor) -> bool:
@@ -532,7 +533,7 @@ def linear_dw(dy: Tensor, x: Tensor, M: int, dW: Tensor, db: Optional[Tensor] = 
 
 def linear_dw_pair(dy0: Tensor, x0: Tensor, dW0: Tensor, dy1: Tensor, x1: Tensor, dW1: Tensor, M: int):
     """Two weight gradients over the same token rows (to_out's and to_qkv's of a layer) -- ONE launch of the split-M kernel where the
-    pair is served (K.gemm_tn_pair_splits: both large, 16-bit; VITK_TN_PAIR=0 switches it off): 36 tiles x 7 splits at ViT-B/16 instead of 27 x 9
+    pair is served (K.gemm_tn_pair_splits: both large, 16-bit; the library switch that turns pairing off is listed in README.md): 36 tiles x 7 splits at ViT-B/16 instead of 27 x 9
     and 9 x 28, i.e. half the f32 slabs, one launch and one fold less; otherwise two linear_dw calls."""
     (N0, K0), (N1, K1) = dW0.shape, dW1.shape
     if dy0.dtype in HALF and dy1.dtype == dy0.dtype and dW0.dtype == dW1.dtype and dW0.dtype in HALF + (F32,):
@@ -567,8 +568,8 @@ def attn_fast_ok(T, N: int, d: int) -> bool:
 def attn_x2_ok(T, N: int, d: int) -> bool:
     """f32 validation mode on the FLASH kernels (round 3): operands split into hi + lo 16-bit terms, three MFMAs per product, f32
     outputs -- the same staging / masking / online-softmax code as the 16-bit kernels (csrc/attention_pipe.hip, NS = 2), so the
-    1e-3 logic gate of the f32 mode covers them.  VITK_F32_FLASH=0 restores the materialising kernels."""
-    return T == torch.float32 and d == 64 and 32 < N <= 224 and os.environ.get("VITK_F32_FLASH", "1") != "0"
+    1e-3 logic gate of the f32 mode covers them.  VITK_F32_MFMA=0 (the f32 mode on the coverage kernels) restores the materialising kernels."""
+    return T == torch.float32 and d == 64 and 32 < N <= 224 and f32_on_mfma()
 
 
 def _split2(x: Tensor):
@@ -579,10 +580,7 @@ def _split2(x: Tensor):
 
 def attn_varlen_ok(T, d: int) -> bool:
     """chunked flash kernels (any N): 16-bit, dim_head 32 / 48 / 64 / 80 / 96 (ViT-H/14: dim_head 80, N = 577; vit.py:86 leaves dim_head
-    free -- the other widths a multiple of 16 up to 96 were instantiated in round 3).  VITK_ATTN_DH_EXT=0 keeps 32 / 48 / 96 on the
-    materialising path."""
-    if d in (32, 48, 96) and os.environ.get("VITK_ATTN_DH_EXT", "1") == "0":
-        return False
+    free -- the other widths a multiple of 16 up to 96 were instantiated in round 3)."""
     return T in HALF and d in (32, 48, 64, 80, 96)
 
 

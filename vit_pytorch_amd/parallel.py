@@ -70,25 +70,23 @@ class FlatGradSink:
         more transformer layers have been enqueued -- the weight-gradient GEMMs are planned for 256 - cu_reserve CUs
         (vitk_set_cu_reserve), so that their workgroups fit BESIDE the collective's resident kernel instead of queueing behind it
         as a second round ([measured on one GPU with a stand-in kernel, tools/cu_contention.py] 32 CUs held: 1.62x -> 1.02-1.10x per
-        layer; the persistent NT GEMMs adapt by themselves through their tile tickets).  Defaults 32 / 1, env VITK_DP_CU_RESERVE /
-        VITK_DP_RESERVE_LAYERS; 0 turns it off.
+        layer; the persistent NT GEMMs adapt too: the four-wave kernel is launched on 256 - cu_reserve workgroups, the 8-wave kernel draws
+        tile tickets).  Defaults 32 / 1; 0 turns it off.
         layers_per_chunk: transformer layers per in-backward all-reduce (0 = one message for the whole stack when its backward
-        ends); default 3, env VITK_DP_LAYERS_PER_CHUNK.  comm_priority: HIP stream priority of the side stream that carries the
-        collectives (lower = more urgent; default -1 so that RCCL's kernels are scheduled ahead of the GEMM workgroups that
-        would otherwise hold every CU), env VITK_DP_COMM_PRIORITY."""
+        ends); default 3.  comm_priority: HIP stream priority of the side stream that carries the collectives (lower = more urgent;
+        default -1 so that RCCL's kernels are scheduled ahead of the GEMM workgroups that would otherwise hold every CU).
+        Arguments left at None take the defaults, or the fields of ONE environment variable for runs that cannot pass arguments (the
+        driver's `bench.py --gpus N`):  VITK_DP="chunk=3,prio=-1,reserve=32,layers=1"  (any subset)."""
         import os
+        env = dict(kv.split("=", 1) for kv in os.environ.get("VITK_DP", "").replace(" ", "").split(",") if "=" in kv)
         self.model = model
         self.group = process_group
         self.average = average
         self.params, self.n_early, layer_end = _ordered_params(model)
-        if layers_per_chunk is None:
-            layers_per_chunk = int(os.environ.get("VITK_DP_LAYERS_PER_CHUNK", "3"))
-        if comm_priority is None:
-            comm_priority = int(os.environ.get("VITK_DP_COMM_PRIORITY", "-1"))
-        self.layers_per_chunk = layers_per_chunk
-        self.comm_priority = comm_priority
-        self.cu_reserve = int(os.environ.get("VITK_DP_CU_RESERVE", "32")) if cu_reserve is None else cu_reserve
-        self.reserve_layers = int(os.environ.get("VITK_DP_RESERVE_LAYERS", "1")) if reserve_layers is None else reserve_layers
+        self.layers_per_chunk = int(env.get("chunk", "3")) if layers_per_chunk is None else layers_per_chunk
+        self.comm_priority = int(env.get("prio", "-1")) if comm_priority is None else comm_priority
+        self.cu_reserve = int(env.get("reserve", "32")) if cu_reserve is None else cu_reserve
+        self.reserve_layers = int(env.get("layers", "1")) if reserve_layers is None else reserve_layers
         self._reserve_left = 0
         p0 = self.params[0]
         self.dtype, self.device = p0.dtype, p0.device
