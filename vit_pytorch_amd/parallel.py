@@ -108,7 +108,7 @@ class FlatGradSink:
         self._view_ptrs = {v.data_ptr() for v, p in zip(self.views, self.params) if p.numel()}
         self._filled = set()
         self._multi = set()
-        self.side = torch.cuda.Stream(device=self.device, priority=comm_priority) if self.device.type == "cuda" else None
+        self.side = torch.cuda.Stream(device=self.device, priority=self.comm_priority) if self.device.type == "cuda" else None
         self.log = None      # tests: list collecting (offset, length) of every all-reduce this rank issues
         self._early_launched = False
         self._late_launched = False
