@@ -147,7 +147,7 @@ def time_gemm_classes(step_fn, nsteps: int = 3):
     return {key: (sum(e0.elapsed_time(e1) for e0, e1, _ in tl) / len(tl), tl[0][2], len(tl) // nsteps) for key, tl in taps.items()}
 
 
-TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04h_pmc_traffic.json", "r04d_pmc_traffic.json", "r04c_pmc_traffic.json", "r04b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04h_pmc_traffic.json", "r04d_pmc_traffic.json", "r04c_pmc_traffic.json", "r04b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 # (class, N, K) of a ViT-B/16 GEMM -> the label tools/kprof.py / tools/pmc_traffic_json.py give its launch group
 TRAFFIC_LABELS = {("tn", 3072, 768): "dW ff1", ("tn", 2304, 768): "dW qkv", ("ff1", 3072, 768): "FF1 bias+GELU", ("dff1", 3072, 768): "dFF1 GELU'",
                   ("nt", 2304, 768): "QKV", ("nt_resid", 768, 3072): "FF2 +", ("nt_resid", 768, 768): "out-proj +", ("nt", 768, 3072): "dX of FF1"}
