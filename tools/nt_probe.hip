@@ -23,6 +23,10 @@
 #define gemm_ntw_split probe_ntw_split
 #define gemm_ntw_launch probe_ntw_launch
 #include "../vit_pytorch_amd/csrc/gemm_nt_w128.hip"
+#define NTX_PROBE
+#define gemm_ntx_serves probe_ntx_serves
+#define gemm_ntx_launch probe_ntx_launch
+#include "gemm_nt_x2.hip"
 
 #define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); exit(1); } } while (0)
 #define VK(x) do { int r__ = (x); if (r__ != 0) { printf("vitk error %d (%s) at %s:%d\n", r__, vitk_last_error(), __FILE__, __LINE__); exit(1); } } while (0)
@@ -211,6 +215,64 @@ int main(int argc, char** argv) {
             printf("  %-13s    with round 5's 64-byte activation pieces (VITK_NTW_A128=0): product path %7.1f us (128-byte rows x%.3f) | four-wave kernel alone %7.1f us (x%.3f)\n",
                    epi_name[epi], m5 * 1e3, m5 / mn, md5 * 1e3, md5 / md);
             if (epi == sh.epis[0] || epi == VITK_EPI_RESID16 || epi == VITK_EPI_BIAS_GELU_DG8 || epi == VITK_EPI_MUL_AUX8) { sum_old += mo; sum_new += mn; }
+            // ---- round 6: two wave groups of one workgroup swapping roles (csrc/gemm_nt_x2.hip): parity against the four-wave kernel alone, timing ----
+            const bool x2_epi = epi == VITK_EPI_NONE || epi == VITK_EPI_BIAS_GELU_DG || epi == VITK_EPI_BIAS_GELU_DG8 || epi == VITK_EPI_MUL_AUX || epi == VITK_EPI_MUL_AUX8;
+            if (x2_epi && probe_ntx_serves(M, N, K)) {
+                auto x2 = [&](int abl, int dbg) {
+                    void* aux = aux_is_in ? aux_in.p : (aux_is_out ? X0.p : nullptr);
+                    VK(probe_ntx_launch(tm_all, grid, A.p, K, Wp.p, 0, C0.p, N, N, K, epi, has_bias ? bias.p : nullptr, resid, aux,
+                                        aux_is_in ? (float*)cs0.p : nullptr, abl, dbg, nullptr));
+                };
+                const size_t cb = (size_t)256 * tm_all * N * 2;
+                CK(hipMemset(C0.p, 0xdd, cb)); CK(hipMemset(C1.p, 0xee, cb));
+                CK(hipMemset(X0.p, 0xdd, M * N * 2)); CK(hipMemset(X1.p, 0xee, M * N * 2));
+                CK(hipMemset(cs0.p, 0, cs0.n)); CK(hipMemset(cs1.p, 0, cs1.n));
+                x2(0, 0);
+                direct(tm_all, 0, 0);
+                CK(hipDeviceSynchronize());
+                std::vector<unsigned char> g0(cb), g1(cb);
+                CK(hipMemcpy(g0.data(), C0.p, cb, hipMemcpyDeviceToHost)); CK(hipMemcpy(g1.data(), C1.p, cb, hipMemcpyDeviceToHost));
+                size_t bx = 0, fbx = 0;
+                for (size_t i = 0; i < cb; ++i) if (g0[i] != g1[i]) { if (!bx) fbx = i; ++bx; }
+                size_t bax = 0, bcs = 0;
+                if (aux_is_out) {
+                    const size_t ab = (size_t)256 * tm_all * N * aux_sz;
+                    std::vector<unsigned char> y0(ab), y1(ab);
+                    CK(hipMemcpy(y0.data(), X0.p, ab, hipMemcpyDeviceToHost)); CK(hipMemcpy(y1.data(), X1.p, ab, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < ab; ++i) bax += y0[i] != y1[i];
+                }
+                if (aux_is_in) {
+                    const size_t sb = (size_t)2 * tm_all * N * 4;
+                    std::vector<unsigned char> y0(sb), y1(sb);
+                    CK(hipMemcpy(y0.data(), cs0.p, sb, hipMemcpyDeviceToHost)); CK(hipMemcpy(y1.data(), cs1.p, sb, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < sb; ++i) bcs += y0[i] != y1[i];
+                }
+                printf("  %-13s TWO GROUPS (x2) vs the four-wave kernel alone: C %s (%zu bytes differ", epi_name[epi], bx ? "MISMATCH" : "bit-identical", bx);
+                if (bx) printf(", first at row %zu col %zu", fbx / (N * 2), (fbx % (N * 2)) / 2);
+                printf(")");
+                if (aux_is_out) printf(", second output %s (%zu)", bax ? "MISMATCH" : "bit-identical", bax);
+                if (aux_is_in) printf(", column-sum rows %s (%zu)", bcs ? "MISMATCH" : "bit-identical", bcs);
+                printf("\n");
+                std::vector<float> tx, tw, txm;
+                for (int r = 0; r <= rounds; ++r) {
+                    const float a2 = time_ms([&] { x2(0, 0); }, 10);
+                    const float b2 = time_ms([&] { direct(tm_all, 0, 0); }, 10);
+                    const float c2 = time_ms([&] { x2(0, 1); }, 10);
+                    if (r) { tx.push_back(a2); tw.push_back(b2); txm.push_back(c2); }
+                }
+                printf("  %-13s TWO GROUPS (x2) %7.1f us %7.1f TF/s | four-wave kernel alone %7.1f us (x%.3f) | x2 main loops alone (no epilogue pieces) %7.1f us\n",
+                       epi_name[epi], median(tx) * 1e3, 2.0 * 256 * tm_all * N * K / median(tx) / 1e9, median(tw) * 1e3, median(tw) / median(tx), median(txm) * 1e3);
+                if (aux_is_out) {
+                    std::vector<float> t1, t2, t3;
+                    for (int r = 0; r < rounds; ++r) { t1.push_back(time_ms([&] { x2(0, 32); }, 10)); t2.push_back(time_ms([&] { x2(0, 64); }, 10)); t3.push_back(time_ms([&] { x2(0, 96); }, 10)); }
+                    printf("  %-13s x2 without the GELU arithmetic %7.1f us | without the stores %7.1f us | without both %7.1f us\n", epi_name[epi], median(t1) * 1e3, median(t2) * 1e3, median(t3) * 1e3);
+                }
+                if (epi == VITK_EPI_NONE) {
+                    std::vector<float> t1, t2;
+                    for (int r = 0; r < rounds; ++r) { t1.push_back(time_ms([&] { x2(1, 1); }, 10)); t2.push_back(time_ms([&] { direct(tm_all, 1, 1); }, 10)); }
+                    printf("  %-13s x2 main loops WITHOUT LDS-DMA (reads + MFMA + barriers) %7.1f us | four-wave kernel the same %7.1f us\n", epi_name[epi], median(t1) * 1e3, median(t2) * 1e3);
+                }
+            }
             if (quick) continue;
             // ---- ablations of the four-wave launch (all full tiles) ----
             if (epi == VITK_EPI_NONE) {
