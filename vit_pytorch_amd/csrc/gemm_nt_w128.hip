@@ -580,6 +580,13 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
     // about (vmcnt retires in order and counts to 63); the first tile has nothing but DMA pieces in flight
     constexpr int ST_ROW = (F32OUT || EPI == VITK_EPI_RESID16 || q_two_outputs<EPI>()) ? 4 : 2;   // stores per epilogue row
     constexpr int VM_RELAX = 16 + 16 * ST_ROW > 63 ? 63 : 16 + 16 * ST_ROW;
+    // What the exact count relies on: this wave's vector-memory operations retire IN ISSUE ORDER, loads and stores alike, so the DMA pieces the
+    // wait is about (older than the epilogue's stores) have landed once at most VM_RELAX younger operations are outstanding.  That is how gfx950's
+    // single vmcnt behaves for buffer / global operations of one wave (FLAT operations, which may resolve to LDS or scratch, are the documented
+    // out-of-order case; none is issued here) -- and it is the SAME property every counted wait of this file and of gemm_nt_epi.h already rests on
+    // (a residual row's exact-count wait passes stores issued before it).  Held empirically by the bit-identity of every epilogue against the 8-wave
+    // kernel over 2,364 tiles x 9-10 tiles per workgroup on random operands (tests/test_gemm_nt_w128_gpu.py, tools/nt_probe): a stale stage would
+    // show as a wrong tile.  dbg bit 1 (VITK_NTW_RELAX=n in the experiments build) makes every wait strict.
     // [measured, tools/nt_probe, strict vs exact-count waits: plain 16-bit stores (QKV) 155 vs 151 us; every epilogue that also READS rows
     //  or stores two tensors is level or better strict (FF1 shape 216 vs 231, dFF1 271 vs 275, out-projection 69.9 vs 76.6)]
     constexpr bool RELAX_OK = (EPI == VITK_EPI_NONE || (EPI == VITK_EPI_BIAS && !AW));      // (AW = 1: the bias loads of a tile sit behind the stores)
