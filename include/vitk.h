@@ -438,8 +438,8 @@ int vitk_copy_cols(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, i
 int vitk_split_bf16x3(const float* x, int64_t ldx, void* out, int64_t ld_out, int64_t block_stride, int64_t rows,
                       int64_t cols, int operand_b, void* stream);
 /* out[b, i, :] = (i < F ? front[i, :] : x[b, i - F, :]) + (pos ? pos[i, :] : 0) for i < Np + F: torch.cat((tokens, x), dim = 1)
- * + pos[:N] of vit.py:122-127 for all images in one launch; also the register tokens of
- * simple_vit_with_register_tokens.py:113-115 (placed in front: the transformer is equivariant to the token order).       */
+ * + pos[:N] of vit.py:122-127 for all images in one launch.  F < 0: the |F| extra tokens go BEHIND x, out[b, i, :] =
+ * (i < Np ? x[b, i, :] : front[i - Np, :]) + pos: pack([x, r]) of simple_vit_with_register_tokens.py:113-115.             */
 int vitk_concat_tokens(const void* x, const void* front, const void* pos, void* out, int dt, int64_t B, int64_t Np,
                        int64_t F, int64_t D, void* stream);
 /* scatter = 0: dst[b, j, :] = src[b, idx[b, j], :] (x[batch_indices, patch_indices_keep] of vit_with_patch_dropout.py:32);

@@ -438,10 +438,16 @@ def attn_varlen_bwd_bf16(q, k, v, o, dout, lse, delta, dq, dk, dv, cu_q, cu_k, q
 
 def concat_tokens(x, front, pos, out, B, Np, F, D):
     """out[b, i] = (i < F ? front[i] : x[b, i - F]) + (pos ? pos[i] : 0): torch.cat((tokens, x), dim=1) + pos[:N] (vit.py:122-127)."""
+    behind, F = F < 0, abs(F)       # F < 0: the extra tokens follow x (simple_vit_with_register_tokens.py:113-115)
     o = out.view(B, Np + F, D)
-    if F:
-        o[:, :F] = front.reshape(1, F, D).to(o.dtype)
-    o[:, F:] = x.reshape(B, Np, D)
+    if behind:
+        o[:, :Np] = x.reshape(B, Np, D)
+        if F:
+            o[:, Np:] = front.reshape(1, F, D).to(o.dtype)
+    else:
+        if F:
+            o[:, :F] = front.reshape(1, F, D).to(o.dtype)
+        o[:, F:] = x.reshape(B, Np, D)
     if pos is not None:
         o.copy_(o.float() + pos.reshape(-1, D)[:Np + F].float())
 

@@ -100,3 +100,24 @@ def test_register_tokens_do_not_change_the_pooled_token_count():
     assert tuple(seen[0]) == (2, 16 + 3, 64) and tuple(out.shape) == (2, 5)
     out.sum().backward()
     assert m.register_tokens.grad is not None and m.register_tokens.grad.abs().sum().item() > 0
+
+
+def test_register_tokens_follow_the_patch_tokens_like_the_reference_packs_them():
+    """simple_vit_with_register_tokens.py:113-115: `pack([x, r], 'b * d')` -- the registers come AFTER the patch tokens.  A forward
+    pre-hook on the transformer (what Extractor-style consumers attach) must see that order: the last R rows of every image are the
+    register parameters themselves, the first rows the position-encoded patch embeddings (rounds 4-5 had them in front)."""
+    from vit_pytorch_amd.simple_vit_with_register_tokens import SimpleViT
+    R = 3
+    m = SimpleViT(image_size=32, patch_size=8, num_classes=5, dim=64, depth=1, heads=2, mlp_dim=64, num_register_tokens=R).to(DEV)
+    seen = []
+    h = m.transformer.register_forward_pre_hook(lambda mod, args: seen.append(args[0].detach().clone()))
+    img = torch.randn(2, 3, 32, 32, device=DEV)
+    out = m(img)
+    h.remove()
+    x = seen[0]
+    assert tuple(x.shape) == (2, 16 + R, 64)
+    assert torch.equal(x[:, 16:], m.register_tokens.detach().expand(2, R, 64))
+    patches = m.to_patch_embedding(img) + m.pos_embedding.to(DEV)
+    assert torch.allclose(x[:, :16], patches, rtol=1e-5, atol=1e-6)
+    out.square().mean().backward()
+    assert m.register_tokens.grad is not None and m.register_tokens.grad.abs().sum().item() > 0

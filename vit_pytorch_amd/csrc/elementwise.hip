@@ -457,8 +457,9 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const T* __restrict__ sr
 }
 
 // out[b, i, :] = (i < F ? front[i, :] : x[b, i - F, :]) + (pos ? pos[i, :] : 0): torch.cat((front tokens, x), dim=1) (+ pos[:N])
-// for every image in ONE launch (vit.py:122-127 cls + pos; simple_vit_with_register_tokens.py:113-115 register tokens)
-template <typename T>
+// for every image in ONE launch (vit.py:122-127 cls + pos).  BEHIND: the extra tokens follow x -- pack([x, r]) of
+// simple_vit_with_register_tokens.py:113-115: out[b, i, :] = (i < Np ? x[b, i, :] : front[i - Np, :]) (+ pos)
+template <typename T, bool BEHIND>
 __global__ __launch_bounds__(256) void concat_tokens_kernel(const T* __restrict__ x, const T* __restrict__ front, const T* __restrict__ pos,
                                                              T* __restrict__ out, long long B, int Np, int F, int D4) {
     const int N = Np + F;
@@ -468,7 +469,9 @@ __global__ __launch_bounds__(256) void concat_tokens_kernel(const T* __restrict_
         const long long r = i / D4;
         const int t = (int)(r % N);
         const long long b = r / N;
-        f32x4 v = t < F ? load4<T>(front + ((long long)t * D4 + c) * 4) : load4<T>(x + ((b * Np + (t - F)) * D4 + c) * 4);
+        f32x4 v;
+        if constexpr (BEHIND) v = t < Np ? load4<T>(x + ((b * Np + t) * D4 + c) * 4) : load4<T>(front + ((long long)(t - Np) * D4 + c) * 4);
+        else v = t < F ? load4<T>(front + ((long long)t * D4 + c) * 4) : load4<T>(x + ((b * Np + (t - F)) * D4 + c) * 4);
         if (pos) v += load4<T>(pos + ((long long)t * D4 + c) * 4);
         store4<T>(out + i * 4, v);
     }
@@ -536,10 +539,17 @@ extern "C" int vitk_split_bf16x3(const float* x, int64_t ldx, void* out, int64_t
 
 extern "C" int vitk_concat_tokens(const void* x, const void* front, const void* pos, void* out, int dt, int64_t B, int64_t Np,
                                   int64_t F, int64_t D, void* stream) {
+    const bool behind = F < 0;          // F < 0: |F| extra tokens BEHIND x
+    if (behind) F = -F;
     if (!x || !out || (F > 0 && !front)) VITK_FAIL(VITK_E_ARG, "concat_tokens: null pointer");
-    if (B <= 0 || Np < 0 || F < 0 || Np + F <= 0 || D <= 0 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "concat_tokens: need D %% 4 == 0 and a non-empty sequence");
-    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((concat_tokens_kernel<T>), dim3(ew_blocks(B * (Np + F) * D / 4)), dim3(256), 0, (hipStream_t)stream,
-                                                (const T*)x, (const T*)front, (const T*)pos, (T*)out, (long long)B, (int)Np, (int)F, (int)(D / 4)));
+    if (B <= 0 || Np < 0 || Np + F <= 0 || D <= 0 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "concat_tokens: need D %% 4 == 0 and a non-empty sequence");
+    if (behind) {
+        VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((concat_tokens_kernel<T, true>), dim3(ew_blocks(B * (Np + F) * D / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                    (const T*)x, (const T*)front, (const T*)pos, (T*)out, (long long)B, (int)Np, (int)F, (int)(D / 4)));
+    } else {
+        VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((concat_tokens_kernel<T, false>), dim3(ew_blocks(B * (Np + F) * D / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                    (const T*)x, (const T*)front, (const T*)pos, (T*)out, (long long)B, (int)Np, (int)F, (int)(D / 4)));
+    }
     VITK_CHECK_LAUNCH("concat_tokens");
     return 0;
 }

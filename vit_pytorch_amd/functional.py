@@ -495,7 +495,8 @@ class ConcatTokensFn(torch.autograd.Function):
     the register tokens of simple_vit_with_register_tokens.py:113-115 (front / pos may be None).  One launch for all images."""
 
     @staticmethod
-    def forward(ctx, x, front, pos):
+    def forward(ctx, x, front, pos, behind):
+        """behind: the extra tokens FOLLOW x -- pack([x, r]) of simple_vit_with_register_tokens.py:113-115 -- instead of leading it."""
         K.require_device(x)
         x = x.contiguous()
         B, Np, D = x.shape
@@ -506,8 +507,9 @@ class ConcatTokensFn(torch.autograd.Function):
         fr = None if front is None or F_ == 0 else _to(front.reshape(F_, D), x.dtype)
         ps = None if pos is None else _to(pos[:N].contiguous(), x.dtype)
         out = torch.empty((B, N, D), dtype=x.dtype, device=x.device)
-        K.concat_tokens(x, fr, ps, out, B, Np, F_ if fr is not None else 0, D)
+        K.concat_tokens(x, fr, ps, out, B, Np, (-F_ if behind else F_) if fr is not None else 0, D)
         ctx.meta = (B, Np, F_, D, None if front is None else (front.shape, front.dtype), None if pos is None else (pos.shape, pos.dtype))
+        ctx.behind = bool(behind)
         return out
 
     @staticmethod
@@ -516,38 +518,42 @@ class ConcatTokensFn(torch.autograd.Function):
         N = Np + F_
         g = g.contiguous()
         dx = torch.empty((B, Np, D), dtype=g.dtype, device=g.device)
-        K.copy_cols(g.view(B, N * D)[:, F_ * D:], N * D, dx, Np * D, B, Np * D, Np * D)        # rows F.. of every image
+        x0 = 0 if ctx.behind else F_                                                            # first row of x inside every image
+        K.copy_cols(g.view(B, N * D)[:, x0 * D:], N * D, dx, Np * D, B, Np * D, Np * D)
         dfront = dpos = None
         if front_meta is not None or pos_meta is not None:
             gsum = torch.empty((N, D), dtype=g.dtype, device=g.device)
             ops.colsum(g, B, N * D, gsum)                                                     # sum over the batch
             if front_meta is not None:
-                dfront = _to(gsum[:F_].contiguous(), front_meta[1]).reshape(front_meta[0]) if F_ else torch.zeros(front_meta[0], dtype=front_meta[1], device=g.device)
+                gfr = gsum[Np:] if ctx.behind else gsum[:F_]
+                dfront = _to(gfr.contiguous(), front_meta[1]).reshape(front_meta[0]) if F_ else torch.zeros(front_meta[0], dtype=front_meta[1], device=g.device)
             if pos_meta is not None:
                 dpos = torch.zeros(pos_meta[0], dtype=pos_meta[1], device=g.device)
                 K.cast(gsum, dpos[:N])
-        return dx, dfront, dpos
+        return dx, dfront, dpos, None
 
 
 class TokenSliceFn(torch.autograd.Function):
-    """x[:, start:] as a contiguous tensor (unpack of the register tokens: simple_vit_with_register_tokens.py:119)."""
+    """x[:, start:stop] as a contiguous tensor (unpack of the register tokens: simple_vit_with_register_tokens.py:119)."""
 
     @staticmethod
-    def forward(ctx, x, start: int):
+    def forward(ctx, x, start: int, stop=None):
         x = x.contiguous()
         B, N, D = x.shape
-        out = torch.empty((B, N - start, D), dtype=x.dtype, device=x.device)
-        K.copy_cols(x.view(B, N * D)[:, start * D:], N * D, out, (N - start) * D, B, (N - start) * D, (N - start) * D)
-        ctx.meta = (B, N, D, start)
+        stop = N if stop is None else stop
+        n = stop - start
+        out = torch.empty((B, n, D), dtype=x.dtype, device=x.device)
+        K.copy_cols(x.view(B, N * D)[:, start * D:], N * D, out, n * D, B, n * D, n * D)
+        ctx.meta = (B, N, D, start, n)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, N, D, start = ctx.meta
+        B, N, D, start, n = ctx.meta
         g = g.contiguous()
         dx = torch.zeros((B, N, D), dtype=g.dtype, device=g.device)
-        K.copy_cols(g, (N - start) * D, dx.view(B, N * D)[:, start * D:], N * D, B, (N - start) * D, (N - start) * D)
-        return dx, None
+        K.copy_cols(g, n * D, dx.view(B, N * D)[:, start * D:], N * D, B, n * D, n * D)
+        return dx, None, None
 
 
 class GatherTokensFn(torch.autograd.Function):

@@ -143,7 +143,7 @@ class SimpleViT(nn.Module):
     @Fn.autocast_aware
     def forward(self, img):
         x = self.to_patch_embedding(img)
-        x = Fn.ConcatTokensFn.apply(x, None, self.pos_embedding.to(x.device, dtype=x.dtype))      # x += pos (simple_vit_with_qk_norm.py:134)
+        x = Fn.ConcatTokensFn.apply(x, None, self.pos_embedding.to(x.device, dtype=x.dtype), False)      # x += pos (simple_vit_with_qk_norm.py:134)
         x = self.transformer(x)
         x = Fn.MeanTokensFn.apply(x)
         x = self.to_latent(x)

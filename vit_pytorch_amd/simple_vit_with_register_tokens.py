@@ -4,9 +4,9 @@
 dropped again before the mean pool (simple_vit_with_register_tokens.py:102, 113-121).  Attention / FeedForward / Transformer are
 those of SimpleViT, so the stack runs in the fused engine (engine.TransformerFn) with N = patches + registers.
 
-The registers are placed IN FRONT of the patch tokens (the reference packs them behind): attention and the token-wise layers are
-equivariant to the order of the tokens and nothing position-dependent follows the concatenation, so the patch-token outputs, the
-pooled mean and every gradient are the same; the front placement lets one kernel (`vitk_concat_tokens`) build the sequence.
+The registers FOLLOW the patch tokens, as in the reference's `pack([x, r], 'b * d')` (since round 6: rounds 4-5 placed them in front --
+equivalent for the outputs, but a forward hook on the transformer saw another token order than under the reference); one kernel
+(`vitk_concat_tokens`, F < 0) builds the sequence and adds the positional table.
 """
 from __future__ import annotations
 
@@ -34,7 +34,7 @@ class SimpleViT(nn.Module):
         self.linear_head = Fn.Linear(dim, num_classes)
 
     def _pos_on(self, device, dtype):
-        """The sincos table with R zero rows in front (it is added to the patch tokens only), built ONCE per (device, dtype) -- the
+        """The sincos table with R zero rows behind it (it is added to the patch tokens only), built ONCE per (device, dtype) -- the
         reference converts / concatenates on every forward (simple_vit_with_register_tokens.py:139-142); no torch op on the data path."""
         slot = self.__dict__.setdefault("_pos_cache", {})
         key = (str(device), dtype)
@@ -42,7 +42,7 @@ class SimpleViT(nn.Module):
             slot.clear()
             pos = self.pos_embedding.to(device, dtype=dtype)
             R = self.register_tokens.shape[0]
-            slot[key] = torch.cat([pos.new_zeros(R, pos.shape[1]), pos], dim=0).contiguous()
+            slot[key] = torch.cat([pos, pos.new_zeros(R, pos.shape[1])], dim=0).contiguous()
         return slot[key]
 
     @Fn.autocast_aware
@@ -50,9 +50,10 @@ class SimpleViT(nn.Module):
         x = self.to_patch_embedding(img)
         R = self.register_tokens.shape[0]
         pos = self._pos_on(x.device, x.dtype)
-        x = Fn.ConcatTokensFn.apply(x, self.register_tokens, pos)               # (B, R + patches, dim)
+        P = x.shape[1]
+        x = Fn.ConcatTokensFn.apply(x, self.register_tokens, pos, True)         # (B, patches + R, dim): pack([x, r])
         x = self.transformer(x)
-        x = Fn.TokenSliceFn.apply(x, R) if R else x                             # unpack: the patch tokens
+        x = Fn.TokenSliceFn.apply(x, 0, P) if R else x                          # unpack: the patch tokens
         x = Fn.MeanTokensFn.apply(x)
         x = self.to_latent(x)
         return self.linear_head(x)

@@ -277,7 +277,7 @@ class _ClsRowFn(torch.autograd.Function):
 
 def _prepend_cls_add_pos(x, cls, pos):
     """cat(cls, x) + pos[:seq] (vit.py:122-127) for the non-fused embedding path: one launch for the whole batch."""
-    return Fn.ConcatTokensFn.apply(x, cls, pos)
+    return Fn.ConcatTokensFn.apply(x, cls, pos, False)
 
 
 Fn.eager_modules(globals())

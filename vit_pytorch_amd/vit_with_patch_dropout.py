@@ -70,9 +70,9 @@ class ViT(nn.Module):
     @Fn.autocast_aware
     def forward(self, img):
         x = self.to_patch_embedding(img)
-        x = Fn.ConcatTokensFn.apply(x, None, self.pos_embedding)                 # x += pos_embedding
+        x = Fn.ConcatTokensFn.apply(x, None, self.pos_embedding, False)                 # x += pos_embedding
         x = self.patch_dropout(x)
-        x = Fn.ConcatTokensFn.apply(x, self.cls_token.view(1, -1), None)         # cat(cls, x)
+        x = Fn.ConcatTokensFn.apply(x, self.cls_token.view(1, -1), None, False)         # cat(cls, x)
         x = self.dropout(x)
         x = self.transformer(x)
         x = Fn.MeanTokensFn.apply(x) if self.pool == 'mean' else _first_token(x)
