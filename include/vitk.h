@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 136
+#define VITK_VERSION 137
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -391,6 +391,10 @@ int vitk_patch_ln_bwd_params(const void* dy, const void* img, int dt, const floa
  * [row0, row0 + h*w) of a (T, C*p*p) matrix (leading dimension ld).                                           */
 int vitk_patchify_cpp(const void* img, void* out, int dt, int64_t C, int64_t H, int64_t W, int64_t p,
                       int64_t row0, int64_t ld, void* stream);
+/* Its adjoint -- the gradient of na_vit.py:300 with respect to the image (the reference is differentiable there): dimg (C, H, W)
+ * from rows [row0, row0 + h*w) of dpatch (leading dimension ld); every image element is written exactly once.     */
+int vitk_unpatchify_cpp(const void* dpatch, void* dimg, int dt, int64_t C, int64_t H, int64_t W, int64_t p,
+                        int64_t row0, int64_t ld, void* stream);
 /* out[t, :] = x[t, :] + A[ia[t], :] + B[ib[t], :]   (factorised 2-d positional embedding, na_vit.py:354-359)     */
 int vitk_gather_add2(const void* x, const void* A, const int32_t* ia, const void* B, const int32_t* ib, void* out, int dt,
                      int64_t T, int64_t D, void* stream);

@@ -372,6 +372,13 @@ def patchify_cpp(img, out, C, H, W, p, row0, ld):
     _rows(out, out.numel() // ld, C * p * p, ld)[row0:row0 + h * w] = img.reshape(C, h, p, w, p).permute(1, 3, 0, 2, 4).reshape(h * w, C * p * p)
 
 
+def unpatchify_cpp(dpatch, dimg, C, H, W, p, row0, ld):
+    """The adjoint of patchify_cpp: rows row0.. of a (T, ld) matrix back into a (C, H, W) image."""
+    h, w = H // p, W // p
+    rows = _rows(dpatch, dpatch.numel() // ld, C * p * p, ld)[row0:row0 + h * w]
+    dimg.reshape(C, H, W).copy_(rows.reshape(h, w, C, p, p).permute(2, 0, 3, 1, 4).reshape(C, H, W))
+
+
 def gather_add2(x, A, ia, B, ib, out, T, D):
     out.view(T, D).copy_(x.reshape(T, D).float() + A.reshape(-1, D)[ia.long()].float() + B.reshape(-1, D)[ib.long()].float())
 
@@ -550,7 +557,7 @@ _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_n
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials, fold_many=fold_many,
                   colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, cast_many=cast_many, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify, unpatchify=unpatchify, patch_ln_fwd=patch_ln_fwd, patch_ln_bwd_params=patch_ln_bwd_params,
                   copy_cols=copy_cols, write_cls_rows=write_cls_rows, mat=mat, gemm_generic=gemm_generic, concat_tokens=concat_tokens, hnd=hnd, attn_varlen_fwd_bf16=attn_varlen_fwd_bf16, attn_varlen_bwd_bf16=attn_varlen_bwd_bf16,
-                  patchify_cpp=patchify_cpp, gather_add2=gather_add2, csr_rowsum=csr_rowsum,
+                  patchify_cpp=patchify_cpp, unpatchify_cpp=unpatchify_cpp, gather_add2=gather_add2, csr_rowsum=csr_rowsum,
                   rmsnorm_heads_fwd=rmsnorm_heads_fwd, rmsnorm_heads_bwd=rmsnorm_heads_bwd,
                   softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd, mean_pool_fwd=mean_pool_fwd, mean_pool_bwd=mean_pool_bwd,
                   require_device=require_device)

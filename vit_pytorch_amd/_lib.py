@@ -19,7 +19,7 @@ F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat1
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD, EPI_RESID16, EPI_BIAS_GELU_DG, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6, 7
 EPI_BIAS_GELU_DG8, EPI_MUL_AUX8 = 8, 9       # the gelu' factor as 8-bit codes (include/vitk.h)
-VITK_VERSION = 136
+VITK_VERSION = 137
 
 
 class RowMap(C.Structure):
@@ -113,6 +113,7 @@ SIGNATURES = {
     "vitk_patchify": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "vitk_unpatchify": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "vitk_patchify_cpp": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "vitk_unpatchify_cpp": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "vitk_patch_ln_serves": (_i, [_i, _i64, _i64, _i64, _i64, _i64]),
     "vitk_patch_ln_bwd_blocks": (_i64, [_i64]),
     "vitk_patch_ln_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),

@@ -420,6 +420,26 @@ __global__ __launch_bounds__(256) void patchify_cpp_kernel(const T* __restrict__
     }
 }
 
+// the adjoint of patchify_cpp_kernel: dimg[c][ph p + i][pw p + j] = dpatch[(row0 + row) ld + e] (every image element belongs to exactly one patch)
+template <typename T>
+__global__ __launch_bounds__(256) void unpatchify_cpp_kernel(const T* __restrict__ dpatch, T* __restrict__ dimg, int C, int H, int W, int p,
+                                                              long long row0, long long ld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hp = H / p, wp = W / p;
+    const int P = C * p * p;
+    for (int row = blockIdx.x * 4 + wave; row < hp * wp; row += gridDim.x * 4) {
+        const int ph = row / wp, pw = row % wp;
+        T* dst = dimg + (long long)(ph * p) * W + pw * p;
+        const T* src = dpatch + (row0 + row) * ld;
+        for (int e = lane; e < P; e += 64) {
+            const int j = e % p;
+            const int ci = e / p;
+            const int i = ci % p, c = ci / p;
+            dst[(long long)c * H * W + (long long)i * W + j] = src[e];
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gather_add2_kernel(const T* __restrict__ x, const T* __restrict__ A, const int* __restrict__ ia,
                                                            const T* __restrict__ B, const int* __restrict__ ib, T* __restrict__ out,
@@ -879,6 +899,17 @@ extern "C" int vitk_patchify_cpp(const void* img, void* out, int dt, int64_t C, 
     VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((patchify_cpp_kernel<T>), dim3(ew_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                                                 (const T*)img, (T*)out, (int)C, (int)H, (int)W, (int)p, (long long)row0, (long long)ld));
     VITK_CHECK_LAUNCH("patchify_cpp");
+    return 0;
+}
+
+extern "C" int vitk_unpatchify_cpp(const void* dpatch, void* dimg, int dt, int64_t C, int64_t H, int64_t W, int64_t p, int64_t row0,
+                                   int64_t ld, void* stream) {
+    if (!dpatch || !dimg) VITK_FAIL(VITK_E_ARG, "unpatchify_cpp: null pointer");
+    if (C <= 0 || p <= 0 || H <= 0 || W <= 0 || H % p || W % p) VITK_FAIL(VITK_E_SHAPE, "unpatchify_cpp: image not divisible by patch");
+    const long long rows = (H / p) * (W / p);
+    VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((unpatchify_cpp_kernel<T>), dim3(ew_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)dpatch, (T*)dimg, (int)C, (int)H, (int)W, (int)p, (long long)row0, (long long)ld));
+    VITK_CHECK_LAUNCH("unpatchify_cpp");
     return 0;
 }
 

@@ -430,6 +430,10 @@ def patchify_cpp(img: Tensor, out: Tensor, C: int, H: int, W: int, p: int, row0:
     check(_lib_for(img, out).vitk_patchify_cpp(_p(img), _p(out), dt(img), C, H, W, p, row0, ld, _stream()), "patchify_cpp")
 
 
+def unpatchify_cpp(dpatch: Tensor, dimg: Tensor, C: int, H: int, W: int, p: int, row0: int, ld: int):
+    check(_lib_for(dpatch, dimg).vitk_unpatchify_cpp(_p(dpatch), _p(dimg), dt(dpatch), C, H, W, p, row0, ld, _stream()), "unpatchify_cpp")
+
+
 def gather_add2(x: Tensor, A: Tensor, ia: Tensor, B: Tensor, ib: Tensor, out: Tensor, T: int, D: int):
     check(_lib_for(x, A, ia, B, ib, out).vitk_gather_add2(_p(x), _p(A), _p(ia), _p(B), _p(ib), _p(out), dt(x), T, D, _stream()), "gather_add2")
 

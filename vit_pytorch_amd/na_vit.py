@@ -155,6 +155,58 @@ class _QKNormAttnFn(torch.autograd.Function):
         return dq, dkv, dgq.view(gq_shape), dgk.view(gk_shape), None, None, None, None
 
 
+class _PackPatchesFn(torch.autograd.Function):
+    """The packed (T, C p p) patch matrix of a list of images -- `rearrange(image, 'c (h p1) (w p2) -> (h w) (c p1 p2)')` per image
+    (na_vit.py:300), token dropout's `patches[keep]` (:306-314) and the concatenation, written straight into one matrix -- as ONE autograd
+    node over the images, so that `image.requires_grad_()` gets its gradient like under the reference (round 6; it used to raise): the
+    backward scatters the kept rows back (dropped patches: zero) and un-patchifies per image (vitk_unpatchify_cpp)."""
+
+    @staticmethod
+    def forward(ctx, meta, *images):
+        c, p, keeps, lens, dtype, device = meta
+        P = c * p * p
+        T = int(sum(lens))
+        patches = torch.empty((T, P), dtype=dtype, device=device)
+        row0 = 0
+        for image, keep, n in zip(images, keeps, lens):
+            image = image.contiguous()
+            ih, iw = image.shape[-2:]
+            if keep is None:
+                K.patchify_cpp(image, patches, c, ih, iw, p, row0, P)
+            else:
+                full = torch.empty(((ih // p) * (iw // p), P), dtype=dtype, device=device)
+                K.patchify_cpp(image, full, c, ih, iw, p, 0, P)
+                ptr = torch.arange(n + 1, dtype=torch.int32, device=device)
+                K.csr_rowsum(full, ptr, keep.to(torch.int32), patches[row0:row0 + n], n, P)   # row gather
+            row0 += n
+        ctx.meta = meta
+        ctx.shapes = [tuple(im.shape) for im in images]
+        return patches
+
+    @staticmethod
+    def backward(ctx, g):
+        c, p, keeps, lens, dtype, device = ctx.meta
+        P = c * p * p
+        g = g.contiguous()
+        grads = []
+        row0 = 0
+        for i, (shape, keep, n) in enumerate(zip(ctx.shapes, keeps, lens)):
+            if not ctx.needs_input_grad[1 + i]:
+                grads.append(None); row0 += n
+                continue
+            ih, iw = shape[-2:]
+            dimg = torch.empty(shape, dtype=g.dtype, device=g.device)
+            if keep is None:
+                K.unpatchify_cpp(g, dimg, c, ih, iw, p, row0, P)
+            else:       # the dropped patches' rows are zero
+                full = torch.zeros((1, (ih // p) * (iw // p), P), dtype=g.dtype, device=g.device)
+                K.gather_tokens(g[row0:row0 + n].contiguous().view(1, n, P), keep.to(torch.int32).view(1, n), full, 1, (ih // p) * (iw // p), n, P, scatter=True)
+                K.unpatchify_cpp(full, dimg, c, ih, iw, p, 0, P)
+            grads.append(dimg)
+            row0 += n
+        return (None, *grads)
+
+
 class _PosEmbedFn(torch.autograd.Function):
     """x + pos_embed_height[h_idx] + pos_embed_width[w_idx] (na_vit.py:354-359); deterministic backward
     through CSR lists of the tokens that use each table row."""
@@ -488,25 +540,11 @@ class NaViT(nn.Module):
         h_idx, w_idx = torch.from_numpy(h_all).to(device), torch.from_numpy(w_all).to(device)
         h_csr, w_csr = csr(h_all, self.pos_embed_height.shape[0]), csr(w_all, self.pos_embed_width.shape[0])
 
-        # ---- patches: 'c (h p1) (w p2) -> (h w) (c p1 p2)' written straight into the packed (T, P) matrix ----
-        patches = torch.empty((T, P), dtype=dtype, device=device)
-        row0 = 0
-        for image, keep, n in zip(images, keeps, lens):
+        # ---- patches: 'c (h p1) (w p2) -> (h w) (c p1 p2)' written straight into the packed (T, P) matrix (one autograd node over the images) ----
+        for image in images:
             if image.dtype != dtype:
                 raise VitkError(f"image dtype {image.dtype} != parameter dtype {dtype}")
-            if image.requires_grad and torch.is_grad_enabled():
-                # the patches are gathered outside autograd: say so instead of handing back an image without a gradient
-                raise VitkError("NaViT: the gradient with respect to the input images is not implemented (vit.ViT / SimpleViT provide it)")
-            image = image.contiguous()
-            ih, iw = image.shape[-2:]
-            if keep is None:
-                K.patchify_cpp(image, patches, c, ih, iw, p, row0, P)
-            else:
-                full = torch.empty(((ih // p) * (iw // p), P), dtype=dtype, device=device)
-                K.patchify_cpp(image, full, c, ih, iw, p, 0, P)
-                ptr = torch.arange(n + 1, dtype=torch.int32, device=device)
-                K.csr_rowsum(full, ptr, keep.to(torch.int32), patches[row0:row0 + n], n, P)   # row gather
-            row0 += n
+        patches = _PackPatchesFn.apply((c, p, keeps, lens, dtype, device), *images)
 
         x = self.to_patch_embedding(patches)
         x = _PosEmbedFn.apply(x, self.pos_embed_height, self.pos_embed_width, h_idx, w_idx, h_csr, w_csr)
