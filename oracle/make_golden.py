@@ -201,7 +201,7 @@ def main_navit_wide():
             continue
         params = make_navit_params(case["cfg"], case["seed"])
         images = make_navit_images(case["cfg"], case["sizes"], case["seed"] + 1000)
-        assert sum((h // 16) * (w // 16) for (h, w) in case["sizes"][0]) == 4096
+        assert sum((h // 16) * (w // 16) for (h, w) in case["sizes"][0]) == case.get("tokens", 4096)
         res = {}
         for dtype in (torch.float32, torch.bfloat16):
             model = mod.NaViT(**case["cfg"])

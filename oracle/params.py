@@ -318,5 +318,12 @@ NAVIT_WIDE_CASES = {
                 (256, 128), (256, 256), (128, 64), (64, 64), (256, 256), (128, 128), (256, 256), (64, 64), (256, 128), (256, 256),
                 (128, 64), (64, 64)]],
         cfg=dict(image_size=256, patch_size=16, num_classes=1000, dim=1024, depth=2, heads=16, mlp_dim=4096)),
+    # BASELINE config 4's architecture at its FULL depth of 24 (round 6): one pack of 2,048 tokens (16 images of four resolutions) -- what the
+    # reference's dense masked attention lets the host hold at 24 layers (the bench draw's 9 packs of 4,096 tokens stop at depth 12).
+    "navit_cfg4_full_depth": dict(
+        seed=42, sample=512, tokens=2048,
+        sizes=[[(256, 256), (128, 128), (256, 128), (64, 64), (256, 256), (128, 64), (256, 256), (64, 64), (256, 256), (128, 128),
+                (256, 256), (64, 64), (256, 128), (256, 256), (128, 64), (64, 64)]],
+        cfg=dict(image_size=256, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096)),
 }
 

@@ -143,7 +143,12 @@ def test_navit_oracle_matches_reference_golden(name, dtype):
         assert rel_l2(g, torch.from_numpy(gold["grad::" + k])) <= 2e-5, k
 
 
-@pytest.mark.parametrize("name", list(NAVIT_WIDE_CASES))
+# (the full-depth case -- 24 layers on the CPU, ~2 minutes -- is held by the GPU suite against the same golden; here only with VITK_TEST_SLOW=1,
+#  so that the CPU suite stays within a few minutes)
+_NAVIT_WIDE_CPU = [n for n in NAVIT_WIDE_CASES if NAVIT_WIDE_CASES[n]["cfg"]["depth"] <= 4 or os.environ.get("VITK_TEST_SLOW") == "1"]
+
+
+@pytest.mark.parametrize("name", _NAVIT_WIDE_CPU)
 def test_navit_oracle_matches_compact_golden_at_config4_width(name):
     """BASELINE config 4 at its real width (dim 1024, 16 heads, one pack of 4,096 tokens from 32 images, depth 2): the restatement
     against the compact golden the reference produced (full logits; per gradient its norm and a fixed 1024-element sample)."""
