@@ -54,11 +54,11 @@ template <int N_, typename T> __device__ __forceinline__ void q_wait_regs2(T& a,
 // per pair with a stall slot after every step.
 typedef float q_f32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ q_f32x8 q_splat8(float v) { return q_f32x8{v, v, v, v, v, v, v, v}; }
-__device__ __forceinline__ q_f32x8 q_phi8(q_f32x8 x) {
-    q_f32x8 xc;
+// Phi of x clamped to [-4.5, 4.5]; also hands back the clamped x and its square (the density term of the derivative reuses them)
+__device__ __forceinline__ q_f32x8 q_phi_parts8(q_f32x8 x, q_f32x8& xc, q_f32x8& u) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) xc[e] = __builtin_amdgcn_fmed3f(x[e], -4.5f, 4.5f);
-    const q_f32x8 u = xc * xc;
+    u = xc * xc;
     q_f32x8 q = __builtin_elementwise_fma(u, q_splat8(3.619783835e-11f), q_splat8(-3.842468662e-09f));
     q = __builtin_elementwise_fma(q, u, q_splat8(1.789582063e-07f));
     q = __builtin_elementwise_fma(q, u, q_splat8(-4.853476327e-06f));
@@ -69,24 +69,31 @@ __device__ __forceinline__ q_f32x8 q_phi8(q_f32x8 x) {
     q = __builtin_elementwise_fma(q, u, q_splat8(3.988530737e-01f));
     return __builtin_elementwise_fma(xc, q, q_splat8(0.5f));
 }
+__device__ __forceinline__ q_f32x8 q_phi8(q_f32x8 x) { q_f32x8 xc, u; return q_phi_parts8(x, xc, u); }
 __device__ __forceinline__ q_f32x8 q_gelu8(q_f32x8 x) { return x * q_phi8(x); }
+// x phi(x) of the derivative on the CLAMPED x (round 6: the square and the clamp are Phi's own -- 8 VALU instructions per 8 values fewer in
+// the VALU-bound FF1 epilogue): identical to the unclamped form for |x| <= 4.5; beyond, |x phi(x)| < 8e-5 either way (the 8-bit code's
+// step is 5e-3, a bf16's at 1.0 is 4e-3)
 __device__ __forceinline__ q_f32x8 q_gelu_grad8(q_f32x8 x) {
-    const q_f32x8 w = x * x * q_splat8(-0.72134752044448170368f);
+    q_f32x8 xc, u;
+    const q_f32x8 ph = q_phi_parts8(x, xc, u);
+    const q_f32x8 w = u * q_splat8(-0.72134752044448170368f);
     q_f32x8 e;
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(w[i]);
-    return __builtin_elementwise_fma(x * q_splat8(0.39894228040143267794f), e, q_phi8(x));
+    return __builtin_elementwise_fma(xc * q_splat8(0.39894228040143267794f), e, ph);
 }
 // GELU and its derivative of the same 8 values with ONE evaluation of Phi (the BIAS_GELU_DG epilogue: the forward GEMM stores gelu'(pre) for
 // the backward instead of pre, so that the backward's epilogue is a multiplication -- same operations per element as q_gelu8 / q_gelu_grad8)
 __device__ __forceinline__ void q_gelu_both8(q_f32x8 x, q_f32x8& g, q_f32x8& dg) {
-    const q_f32x8 ph = q_phi8(x);
-    const q_f32x8 w = x * x * q_splat8(-0.72134752044448170368f);
+    q_f32x8 xc, u;
+    const q_f32x8 ph = q_phi_parts8(x, xc, u);
+    const q_f32x8 w = u * q_splat8(-0.72134752044448170368f);
     q_f32x8 e;
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(w[i]);
     g = x * ph;
-    dg = __builtin_elementwise_fma(x * q_splat8(0.39894228040143267794f), e, ph);
+    dg = __builtin_elementwise_fma(xc * q_splat8(0.39894228040143267794f), e, ph);
 }
 __device__ __forceinline__ q_f32x8 q_widen8(bf16x8 v) {
     q_f32x8 r;
@@ -122,8 +129,12 @@ __device__ __forceinline__ q_u32x2 q_dg_encode8(q_f32x8 dg) {
         const float te = t[e];          // (a __builtin_bit_cast of the vector-element expression itself reads element 0 with this clang)
         b[e] = __builtin_bit_cast(unsigned, te);
     }
-    return q_u32x2{(b[0] & 0xffu) | ((b[1] & 0xffu) << 8) | ((b[2] & 0xffu) << 16) | (b[3] << 24),
-                   (b[4] & 0xffu) | ((b[5] & 0xffu) << 8) | ((b[6] & 0xffu) << 16) | (b[7] << 24)};
+    // the low bytes of four words into one word: two byte permutes + one OR (v_perm_b32: selector 0..3 = bytes of the second operand,
+    // 4..7 = bytes of the first, 0x0c = 0x00) -- 6 instructions per 8 codes instead of 12 shifts / masks / ors
+    auto low4 = [](unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+        return __builtin_amdgcn_perm(w1, w0, 0x0c0c0400u) | __builtin_amdgcn_perm(w3, w2, 0x04000c0cu);
+    };
+    return q_u32x2{low4(b[0], b[1], b[2], b[3]), low4(b[4], b[5], b[6], b[7])};
 }
 __device__ __forceinline__ q_f32x8 q_dg_decode8(q_u32x2 c) {
     q_f32x8 r;
@@ -140,6 +151,14 @@ __device__ __forceinline__ unsigned q_dpp_xor1(unsigned v) {       // value of l
 __device__ __forceinline__ unsigned q_pack2(float a, float b) {
     const bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, v);
+}
+// two accumulator values (+ their bias) rounded to the 16-bit type and packed: the adds as ONE packed add, and none at all in the epilogues
+// without a bias (an `acc + 0.f` is not dropped by the compiler: it turns a -0 into +0)
+template <bool HAS_BIAS> __device__ __forceinline__ unsigned q_pack2b(float a, float b, float ba, float bb) {
+    if constexpr (HAS_BIAS) {
+        const f32x2 t = f32x2{a, b} + f32x2{ba, bb};
+        return q_pack2(t[0], t[1]);
+    } else return q_pack2(a, b);
 }
 typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
 

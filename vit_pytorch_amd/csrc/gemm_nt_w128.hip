@@ -448,10 +448,10 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
                     // rows j0 = 2 pr and j0 + 1 of this lane's 4 columns, rounded to the 16-bit type
                     const int j0 = 2 * pr;
                     const f32x4 bq = b4[qq];
-                    const unsigned a0 = q_pack2(acc[4 * qq + 0][f][j0] + bq[0], acc[4 * qq + 1][f][j0] + bq[1]);
-                    const unsigned a1 = q_pack2(acc[4 * qq + 2][f][j0] + bq[2], acc[4 * qq + 3][f][j0] + bq[3]);
-                    const unsigned c0 = q_pack2(acc[4 * qq + 0][f][j0 + 1] + bq[0], acc[4 * qq + 1][f][j0 + 1] + bq[1]);
-                    const unsigned c1 = q_pack2(acc[4 * qq + 2][f][j0 + 1] + bq[2], acc[4 * qq + 3][f][j0 + 1] + bq[3]);
+                    const unsigned a0 = q_pack2b<q_has_bias<EPI>()>(acc[4 * qq + 0][f][j0], acc[4 * qq + 1][f][j0], bq[0], bq[1]);
+                    const unsigned a1 = q_pack2b<q_has_bias<EPI>()>(acc[4 * qq + 2][f][j0], acc[4 * qq + 3][f][j0], bq[2], bq[3]);
+                    const unsigned c0 = q_pack2b<q_has_bias<EPI>()>(acc[4 * qq + 0][f][j0 + 1], acc[4 * qq + 1][f][j0 + 1], bq[0], bq[1]);
+                    const unsigned c1 = q_pack2b<q_has_bias<EPI>()>(acc[4 * qq + 2][f][j0 + 1], acc[4 * qq + 3][f][j0 + 1], bq[2], bq[3]);
                     // even lane keeps row j0 and receives the neighbour's 4 columns of it; odd lane likewise for row j0 + 1
                     const unsigned r0 = q_dpp_xor1(odd ? a0 : c0), r1 = q_dpp_xor1(odd ? a1 : c1);
                     const unsigned k0 = odd ? c0 : a0, k1 = odd ? c1 : a1;
