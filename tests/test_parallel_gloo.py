@@ -413,3 +413,19 @@ def test_torch_ddp_around_the_fused_stage_two_ranks_gloo():
     single-process full-batch run (float32, doubles)."""
     port = _free_port()
     mp.spawn(_torch_ddp_worker, args=(2, port), nprocs=2, join=True)
+
+
+def test_sink_defaults_follow_the_one_environment_variable(monkeypatch):
+    """VITK_DP="chunk=…,prio=…,reserve=…,layers=…" (any subset) sets the data-parallel sink's defaults for runs that cannot pass arguments --
+    the driver's `bench.py --gpus N`; explicit constructor arguments win.  (Round 6: one variable instead of four VITK_DP_* names.)"""
+    from vit_pytorch_amd.parallel import FlatGradSink
+    m = _EngineModel()
+    monkeypatch.delenv("VITK_DP", raising=False)
+    s = FlatGradSink(m)
+    assert (s.layers_per_chunk, s.comm_priority, s.cu_reserve, s.reserve_layers) == (3, -1, 32, 1)
+    monkeypatch.setenv("VITK_DP", "chunk=0, reserve=48")
+    s = FlatGradSink(m)
+    assert (s.layers_per_chunk, s.comm_priority, s.cu_reserve, s.reserve_layers) == (0, -1, 48, 1)
+    monkeypatch.setenv("VITK_DP", "chunk=2,prio=0,reserve=16,layers=2")
+    s = FlatGradSink(m, layers_per_chunk=5, cu_reserve=0)
+    assert (s.layers_per_chunk, s.comm_priority, s.cu_reserve, s.reserve_layers) == (5, 0, 0, 2)
