@@ -36,6 +36,7 @@ constexpr int AT_THREADS = 512;  // 8 waves per (batch, head): query / key tiles
 constexpr int AT_WAVES = AT_THREADS / 64;
 
 struct BHND { __bf16* p; long long s_b, s_h, s_n; };
+typedef unsigned q4u __attribute__((ext_vector_type(4)));
 
 // Two tiles at once with every global load of a batch in flight before the first LDS store: a plain
 // load -> store loop is serialised by the compiler (s_waitcnt vmcnt(0) per 16 bytes), which at ~2 us of
@@ -194,10 +195,21 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
             const int qi = (t0 + r) * 16 + fi;
             const float ls = accl[r][0];        // every row of 1^T P^T is the same sum
             const float inv = inv_keep / ls;    // kept entries are scaled by 1 / (1 - p)
-            if (qi < N) {
-                __bf16* op = o.p + b * o.s_b + h * o.s_h + (long long)qi * o.s_n + 4 * fg;
+            // [round 6] a lane holds 4 columns of each of the row's four 16-column blocks: lane pairs (fg, fg ^ 1) exchange halves
+            // (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second) so that every lane stores TWO 16-byte
+            // pieces -- 8 consecutive columns of two blocks -- instead of four 8-byte ones (MI355X guide T21: the store tail is issue-bound)
+            const bf16x8 x01 = pack8(acc[r][0] * inv, acc[r][1] * inv), x23 = pack8(acc[r][2] * inv, acc[r][3] * inv);
+            const q4u xa = __builtin_bit_cast(q4u, x01), xb = __builtin_bit_cast(q4u, x23);
+            unsigned pa[4], pb2[4];
 #pragma unroll
-                for (int fd = 0; fd < 4; ++fd) store4<__bf16>(op + fd * 16, acc[r][fd] * inv);
+            for (int d = 0; d < 4; ++d) {
+                auto sw = __builtin_amdgcn_permlane16_swap(xa[d], xb[d], false, false);
+                pa[d] = (unsigned)sw[0]; pb2[d] = (unsigned)sw[1];
+            }
+            if (qi < N) {
+                __bf16* op = o.p + b * o.s_b + h * o.s_h + (long long)qi * o.s_n + ((fg & 1) ? 32 : 0) + 4 * (fg & 2);
+                *reinterpret_cast<q4u*>(op) = q4u{pa[0], pa[1], pb2[0], pb2[1]};
+                *reinterpret_cast<q4u*>(op + 16) = q4u{pa[2], pa[3], pb2[2], pb2[3]};
                 if (fg == 0) lse[(long long)bh * N + qi] = (mref[r] + log2f(ls)) * LN2;
             }
         }

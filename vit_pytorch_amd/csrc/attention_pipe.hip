@@ -1054,11 +1054,28 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
                 const int key = (kvw * KT + t) * 16 + fi_o;
-                if (key < N) {
-                    __bf16* dkp = reinterpret_cast<__bf16*>(dkb + (unsigned)(key * ((int)a.dk.s_n * 2) + 8 * fg_o));
-                    __bf16* dvp = reinterpret_cast<__bf16*>(dvb + (unsigned)(key * ((int)a.dv.s_n * 2) + 8 * fg_o));
+                // [round 6] lane pairs (fg, fg ^ 1) exchange halves (v_permlane16_swap) so that a lane stores two 16-byte pieces -- 8 consecutive
+                // columns of two 16-column blocks -- per tensor instead of four 8-byte ones (as in attention.hip's forward)
+                typedef unsigned fb_u4 __attribute__((ext_vector_type(4)));
+                const fb_u4 kx = __builtin_bit_cast(fb_u4, pack8(accK[t][0] * a.scale, accK[t][1] * a.scale)), ky = __builtin_bit_cast(fb_u4, pack8(accK[t][2] * a.scale, accK[t][3] * a.scale));
+                const fb_u4 vx = __builtin_bit_cast(fb_u4, pack8(accV[t][0], accV[t][1])), vy = __builtin_bit_cast(fb_u4, pack8(accV[t][2], accV[t][3]));
+                unsigned ka[4], kb[4], va[4], vb[4];
 #pragma unroll
-                    for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[t][fd] * a.scale); store4<__bf16>(dvp + fd * 16, accV[t][fd]); }
+                for (int d = 0; d < 4; ++d) {
+                    auto sk = __builtin_amdgcn_permlane16_swap(kx[d], ky[d], false, false);
+                    auto sv = __builtin_amdgcn_permlane16_swap(vx[d], vy[d], false, false);
+                    ka[d] = (unsigned)sk[0]; kb[d] = (unsigned)sk[1]; va[d] = (unsigned)sv[0]; vb[d] = (unsigned)sv[1];
+                }
+                if (key < N) {
+                    const unsigned col = ((fg_o & 1) ? 64u : 0u) + 8u * (fg_o & 2);          // bytes: block 2 / 0, + 8 columns for fg 2, 3
+                    char* dkp = dkb + (unsigned)(key * ((int)a.dk.s_n * 2)) + col;
+                    char* dvp = dvb + (unsigned)(key * ((int)a.dv.s_n * 2)) + col;
+                    // [measured: a second exchange level that makes each instruction's pieces of a row contiguous (64 bytes) is level -- it is
+                    //  the NUMBER of store instructions queued behind the producer's DMA stream that counted (profiles/r06ab_store_widening_ab.log)]
+                    *reinterpret_cast<fb_u4*>(dkp) = fb_u4{ka[0], ka[1], kb[0], kb[1]};
+                    *reinterpret_cast<fb_u4*>(dkp + 32) = fb_u4{ka[2], ka[3], kb[2], kb[3]};
+                    *reinterpret_cast<fb_u4*>(dvp) = fb_u4{va[0], va[1], vb[0], vb[1]};
+                    *reinterpret_cast<fb_u4*>(dvp + 32) = fb_u4{va[2], va[3], vb[2], vb[3]};
                 }
             }
         }
