@@ -1,5 +1,5 @@
-"""A/B of the attention kernels at BASELINE config-2 size (B=256, H=12, N=197): python tools/attn_ab.py  (run once per setting of
-VITK_ATTN_PIPE; prints forward / backward time with HIP events, 30 launches each after 5 warm-ups)."""
+"""A/B of the attention kernels at BASELINE config-2 size (B=256, H=12, N=197): python tools/attn_ab.py [B [N]]  (run once per setting of
+VITK_ATTN_PIPE / VITK_LIB; prints forward / backward time with HIP events, 30 launches each after 5 warm-ups)."""
 import sys
 import torch
 from vit_pytorch_amd import kernels as K
@@ -22,7 +22,7 @@ def timeit(fn, iters=30, warm=5):
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-H, N, d = 12, 197, 64
+H, N, d = 12, (int(sys.argv[2]) if len(sys.argv) > 2 else 197), 64
 I = H * d
 qkv = torch.randn(B, N, 3 * I, device=dev).to(BF); o = torch.empty(B, N, I, dtype=BF, device=dev)
 lse = torch.empty(B, H, N, device=dev); delta = torch.empty(B, H, N, device=dev)
@@ -34,7 +34,7 @@ tf = timeit(lambda: K.attn_fwd_bf16(q_, k_, v_, o_, lse, B, H, N, d, d ** -0.5))
 tb = timeit(lambda: K.attn_bwd_bf16(q_, k_, v_, o_, K.bhnd(do, N * I, d, I), lse, delta, K.bhnd(dqkv, sb, sh, sn), K.bhnd(dqkv, sb, sh, sn, offset=I),
                                     K.bhnd(dqkv, sb, sh, sn, offset=2 * I), B, H, N, d, d ** -0.5))
 import os
-print(f"VITK_ATTN_PIPE={os.environ.get('VITK_ATTN_PIPE', '(default)')} B={B}: fwd {tf:.1f} us  bwd {tb:.1f} us")
+print(f"VITK_ATTN_PIPE={os.environ.get('VITK_ATTN_PIPE', '(default)')} B={B} N={N}: fwd {tf:.1f} us  bwd {tb:.1f} us")
 if int(os.environ.get("VITK_ATTN_DBG", "0")) & 24:
     # the fused backward's cycle stamps (workgroup 0): per-role totals in the (otherwise unused) delta buffer
     torch.cuda.synchronize()

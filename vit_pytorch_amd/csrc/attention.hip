@@ -312,11 +312,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k,
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int qi = (t0 + r) * 16 + fi;
-            if (qi < N) {
-                __bf16* dqp = dq.p + b * dq.s_b + h * dq.s_h + (long long)qi * dq.s_n + 4 * fg;
-#pragma unroll
-                for (int fd = 0; fd < 4; ++fd) store4<__bf16>(dqp + fd * 16, acc[r][fd] * scale);
-            }
+            store_rows16<4>(dq.p + b * dq.s_b + h * dq.s_h + (long long)(qi < N ? qi : 0) * dq.s_n, acc[r], scale, fg, qi < N);
         }
         t0 += AT_WAVES * R;
         if (t0 < nqt) load_rows(t0);
@@ -426,12 +422,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int ki = (t0 + r) * 16 + fi;
-            if (ki < N) {
-                __bf16* dkp = dk.p + b * dk.s_b + h * dk.s_h + (long long)ki * dk.s_n + 4 * fg;
-                __bf16* dvp = dv.p + b * dv.s_b + h * dv.s_h + (long long)ki * dv.s_n + 4 * fg;
-#pragma unroll
-                for (int fd = 0; fd < 4; ++fd) { store4<__bf16>(dkp + fd * 16, accK[r][fd] * scale); store4<__bf16>(dvp + fd * 16, accV[r][fd]); }
-            }
+            store_rows16<4>(dk.p + b * dk.s_b + h * dk.s_h + (long long)(ki < N ? ki : 0) * dk.s_n, accK[r], scale, fg, ki < N);
+            store_rows16<4>(dv.p + b * dv.s_b + h * dv.s_h + (long long)(ki < N ? ki : 0) * dv.s_n, accV[r], 1.f, fg, ki < N);
         }
         t0 += AT_WAVES * R;
         if (t0 < nkt) load_rows(t0);

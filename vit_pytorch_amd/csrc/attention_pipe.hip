@@ -450,7 +450,9 @@ __global__ __launch_bounds__(1024) void attn_dq_pipe_kernel(const DqArgs<NS> a) 
             // pin the adoption (and with it the wait for the row loads) IN FRONT of this item's stores: hipcc otherwise sinks it
             // below them and its vmcnt(0) then waits for the stores' write round trip
             if constexpr (NS == 1) asm volatile("" :: "v"(qf[0].t[0]), "v"(qf[1].t[0]), "v"(df[0].t[0]), "v"(df[1].t[0]), "v"(l2), "v"(dl) : "memory");
-            if (qi < N) {
+            if constexpr (NS == 1) {
+                store_rows16<4>(reinterpret_cast<__bf16*>(a.dq.p) + (b * a.dq.s_b + h * a.dq.s_h) + (qi < N ? qi : 0) * (int)a.dq.s_n, acc, a.scale, fg, qi < N);
+            } else if (qi < N) {
                 TO* dqp = reinterpret_cast<TO*>(a.dq.p) + (b * a.dq.s_b + h * a.dq.s_h) + (qi * (int)a.dq.s_n + 4 * fg);
 #pragma unroll
                 for (int fd = 0; fd < 4; ++fd) store4<TO>(dqp + fd * 16, acc[fd] * a.scale);
@@ -585,7 +587,10 @@ __global__ __launch_bounds__(1024) void attn_dkv_pipe_kernel(const DkvArgs<NS> a
                 }
             }
             if (item + stride < a.nitems) fetch_rows(item + stride);     // (an earlier fetch into spare registers, as in the dQ kernel, does not fit in 128 VGPRs here)
-            if (ki < N) {
+            if constexpr (NS == 1) {
+                store_rows16<4>(reinterpret_cast<__bf16*>(a.dk.p) + (b * a.dk.s_b + h * a.dk.s_h) + (ki < N ? ki : 0) * (int)a.dk.s_n, accK, a.scale, fg, ki < N);
+                store_rows16<4>(reinterpret_cast<__bf16*>(a.dv.p) + (b * a.dv.s_b + h * a.dv.s_h) + (ki < N ? ki : 0) * (int)a.dv.s_n, accV, 1.f, fg, ki < N);
+            } else if (ki < N) {
                 TO* dkp = reinterpret_cast<TO*>(a.dk.p) + (b * a.dk.s_b + h * a.dk.s_h) + (ki * (int)a.dk.s_n + 4 * fg);
                 TO* dvp = reinterpret_cast<TO*>(a.dv.p) + (b * a.dv.s_b + h * a.dv.s_h) + (ki * (int)a.dv.s_n + 4 * fg);
 #pragma unroll

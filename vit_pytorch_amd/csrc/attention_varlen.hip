@@ -342,14 +342,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DH <= 80 && !DROP && !VL_EARLY
     if (!wave_active) return;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        if (tl.row(r) < nq) {
-            const float ls = accl[r][0];        // every row of 1^T P^T is the same sum
-            const float inv = inv_keep / ls;    // kept entries are scaled by 1 / (1 - p)
-            __bf16* op = o.p + (long long)tl.grow(r) * o.s_n + h * o.s_h + 4 * fg;
-#pragma unroll
-            for (int fd = 0; fd < NFD; ++fd) store4<__bf16>(op + fd * 16, acc[r][fd] * inv);
-            if (fg == 0) lse[(long long)h * tq_total + tl.grow(r)] = (mref[r] + log2f(ls)) * LN2;
-        }
+        const bool ok = tl.row(r) < nq;
+        const float ls = accl[r][0];        // every row of 1^T P^T is the same sum
+        const float inv = inv_keep / ls;    // kept entries are scaled by 1 / (1 - p)
+        store_rows16<NFD>(o.p + (long long)tl.grow(r) * o.s_n + h * o.s_h, acc[r], inv, fg, ok);
+        if (ok && fg == 0) lse[(long long)h * tq_total + tl.grow(r)] = (mref[r] + log2f(ls)) * LN2;
     }
 }
 
@@ -473,6 +470,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH <= 80 && !VL_EARLY_TR) ? 3 
     if (!wave_active) return;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+        // (8-byte stores here: with store_rows16 the d = 80 dropout instance of this kernel spills inside its key loop)
         if (tl.row(r) < nq) {
             __bf16* dqp = dq.p + (long long)tl.grow(r) * dq.s_n + h * dq.s_h + 4 * fg;
 #pragma unroll
@@ -622,12 +620,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_varlen_bwd_dkv_kernel(
     if (!wave_active) return;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        if (tl.row(r) < nk) {
-            __bf16* dkp = dk.p + (long long)tl.grow(r) * dk.s_n + h * dk.s_h + 4 * fg;
-            __bf16* dvp = dv.p + (long long)tl.grow(r) * dv.s_n + h * dv.s_h + 4 * fg;
-#pragma unroll
-            for (int fd = 0; fd < NFD; ++fd) { store4<__bf16>(dkp + fd * 16, accK[r][fd] * scale); store4<__bf16>(dvp + fd * 16, accV[r][fd]); }
-        }
+        const bool ok = tl.row(r) < nk;
+        store_rows16<NFD>(dk.p + (long long)tl.grow(r) * dk.s_n + h * dk.s_h, accK[r], scale, fg, ok);
+        store_rows16<NFD>(dv.p + (long long)tl.grow(r) * dv.s_n + h * dv.s_h, accV[r], 1.f, fg, ok);
     }
 }
 
