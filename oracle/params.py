@@ -123,6 +123,9 @@ CASES = {
     "vit_identity_out": dict(  # heads == 1 and dim_head == dim: to_out is nn.Identity, no out-projection parameters (vit.py:34,49)
         kind="vit", batch=3, seed=4,
         cfg=dict(image_size=32, patch_size=8, num_classes=5, dim=64, depth=2, heads=1, dim_head=64, mlp_dim=96, pool="cls")),
+    "vit_dim30": dict(  # a width that is not a multiple of 4 (missing 5): the any-width kernels, op by op
+        kind="vit", batch=3, seed=6,
+        cfg=dict(image_size=32, patch_size=8, num_classes=5, dim=30, depth=2, heads=2, dim_head=16, mlp_dim=50, pool="cls")),
     "vit_tokens_small_input": dict(  # num_classes=0 -> tokens out; input smaller than image_size (vit.py:125-127)
         kind="vit", batch=2, seed=3, image=(16, 24),
         cfg=dict(image_size=32, patch_size=8, num_classes=0, dim=32, depth=1, heads=2, dim_head=16,

@@ -195,3 +195,22 @@ def test_torch_compile_runs_the_drop_in_eagerly():
         refw = w(img)
         outw = torch.compile(w, backend="eager")(img)
         assert torch.allclose(outw, refw, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+def test_a_batch_of_zero_images_returns_empty_logits_and_zero_gradients(kind):
+    """The reference is shape-agnostic in the batch (vit.py:118-138): model(torch.empty(0, 3, H, W)) is a (0, classes) tensor and
+    backward() leaves zero gradients.  The drop-in answers the same way without a kernel launch on the empty batch (functional._empty_batch_forward)."""
+    case = CASES["vit_cls_tiny" if kind == "vit" else "cfg1_simple_vit_tiny"]
+    m = (ViT if kind == "vit" else SimpleViT)(**case["cfg"])
+    img = make_images(case["cfg"], 1, 5)[:0].clone().requires_grad_(True)
+    with KD.installed():
+        out = m(img)
+        assert tuple(out.shape) == (0, case["cfg"]["num_classes"]) and out.dtype == torch.float32
+        out.sum().backward()
+        with torch.no_grad():
+            assert tuple(m(img).shape) == (0, case["cfg"]["num_classes"])
+        assert tuple(m(img=img).shape) == (0, case["cfg"]["num_classes"])           # by keyword, like a trainer's model(**batch)
+    assert tuple(img.grad.shape) == tuple(img.shape)
+    for k, p in m.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().sum()) == 0.0, k

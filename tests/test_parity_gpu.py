@@ -502,3 +502,21 @@ def test_fused_dropout_layer_matches_masked_reference():
     assert e < 1e-2 and g < 2e-2 and worst < 6e-2
     blk.eval()
     assert blk._dropout_p() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["vit", "simple_vit"])
+def test_a_batch_of_zero_images(kind, dtype):
+    """vit.py:118-138 is shape-agnostic in the batch: an empty batch gives (0, classes) logits and zero gradients (missing 5)."""
+    case = CASES["vit_cls_tiny" if kind == "vit" else "cfg1_simple_vit_tiny"]
+    m = (ViT if kind == "vit" else SimpleViT)(**case["cfg"]).to("cuda").to(dtype)
+    img = torch.zeros((0, 3, 32, 32), device="cuda", dtype=dtype, requires_grad=True)
+    out = m(img)
+    assert tuple(out.shape) == (0, case["cfg"]["num_classes"]) and out.dtype == dtype
+    out.float().sum().backward()
+    assert tuple(img.grad.shape) == (0, 3, 32, 32)
+    for k, p in m.named_parameters():
+        assert p.grad is not None and float(p.grad.float().abs().sum()) == 0.0, k
+    if dtype == torch.float32:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert tuple(m(img).shape) == (0, case["cfg"]["num_classes"])

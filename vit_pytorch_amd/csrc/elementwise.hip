@@ -497,6 +497,25 @@ __global__ __launch_bounds__(256) void concat_tokens_kernel(const T* __restrict_
     }
 }
 
+// the same for a width that is not a multiple of 4 (rows are not 8-byte aligned: one element per thread)
+template <typename T, bool BEHIND>
+__global__ __launch_bounds__(256) void concat_tokens_any_kernel(const T* __restrict__ x, const T* __restrict__ front, const T* __restrict__ pos,
+                                                                 T* __restrict__ out, long long B, int Np, int F, int D) {
+    const int N = Np + F;
+    const long long total = B * N * D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % D);
+        const long long r = i / D;
+        const int t = (int)(r % N);
+        const long long b = r / N;
+        float v;
+        if constexpr (BEHIND) v = t < Np ? (float)x[(b * Np + t) * D + c] : (float)front[(long long)(t - Np) * D + c];
+        else v = t < F ? (float)front[(long long)t * D + c] : (float)x[(b * Np + (t - F)) * D + c];
+        if (pos) v += (float)pos[(long long)t * D + c];
+        out[i] = (T)v;
+    }
+}
+
 // out[b, j, :] = x[b, idx[b, j], :]  (PatchDropout: vit_with_patch_dropout.py:28-32) and its adjoint dx[b, idx[b, j], :] = g[b, j, :]
 // (the indices of one image are distinct, dx is zeroed by the caller)
 template <typename T, bool SCATTER>
@@ -562,7 +581,18 @@ extern "C" int vitk_concat_tokens(const void* x, const void* front, const void* 
     const bool behind = F < 0;          // F < 0: |F| extra tokens BEHIND x
     if (behind) F = -F;
     if (!x || !out || (F > 0 && !front)) VITK_FAIL(VITK_E_ARG, "concat_tokens: null pointer");
-    if (B <= 0 || Np < 0 || Np + F <= 0 || D <= 0 || (D & 3)) VITK_FAIL(VITK_E_SHAPE, "concat_tokens: need D %% 4 == 0 and a non-empty sequence");
+    if (B <= 0 || Np < 0 || Np + F <= 0 || D <= 0) VITK_FAIL(VITK_E_SHAPE, "concat_tokens: need a non-empty sequence");
+    if (D & 3) {        // any width (ViT(dim = 30): the reference has no such constraint), one element per thread
+        if (behind) {
+            VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((concat_tokens_any_kernel<T, true>), dim3(ew_blocks(B * (Np + F) * D)), dim3(256), 0, (hipStream_t)stream,
+                                                        (const T*)x, (const T*)front, (const T*)pos, (T*)out, (long long)B, (int)Np, (int)F, (int)D));
+        } else {
+            VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((concat_tokens_any_kernel<T, false>), dim3(ew_blocks(B * (Np + F) * D)), dim3(256), 0, (hipStream_t)stream,
+                                                        (const T*)x, (const T*)front, (const T*)pos, (T*)out, (long long)B, (int)Np, (int)F, (int)D));
+        }
+        VITK_CHECK_LAUNCH("concat_tokens");
+        return 0;
+    }
     if (behind) {
         VITK_DISPATCH_DT(dt, T, hipLaunchKernelGGL((concat_tokens_kernel<T, true>), dim3(ew_blocks(B * (Np + F) * D / 4)), dim3(256), 0, (hipStream_t)stream,
                                                     (const T*)x, (const T*)front, (const T*)pos, (T*)out, (long long)B, (int)Np, (int)F, (int)(D / 4)));

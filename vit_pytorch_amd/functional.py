@@ -137,6 +137,38 @@ def _autocast_dtype():
     return d if d in (torch.bfloat16, torch.float16) else None
 
 
+def _empty_batch_forward(call, module, v, args, kwargs):
+    """A batch of ZERO images (the reference returns an empty (0, ...) result and zero gradients: vit.py:118-138 is shape-agnostic in the
+    batch).  No kernel has anything to do; the result's trailing shape and dtype are read off a one-image stand-in run without autograd, and
+    the empty result is tied to the input and the parameters so that backward() delivers (empty / zero) gradients like the reference's."""
+    one = v.new_zeros((1,) + tuple(v.shape[1:]))
+    was_training = module.training
+    with torch.no_grad():
+        if args:
+            out = call(module, one, *args[1:], **kwargs)
+        else:
+            key = next(k for k in kwargs if kwargs[k] is v)
+            out = call(module, **{**kwargs, key: one})
+    assert module.training == was_training
+    link = None
+    if torch.is_grad_enabled():
+        terms = [t for t in [v] + list(module.parameters()) if t.requires_grad]
+        if terms:
+            link = sum(t.float().sum() for t in terms) * 0.0
+
+    def empty(o):
+        if isinstance(o, torch.Tensor) and o.dim() >= 1 and o.shape[0] == 1:
+            z = o.new_zeros((0,) + tuple(o.shape[1:]))
+            return z if link is None or not z.is_floating_point() else z + link.to(z.dtype)
+        if isinstance(o, tuple) and hasattr(o, "_fields"):
+            return type(o)(*(empty(u) for u in o))
+        if isinstance(o, (list, tuple)):
+            return type(o)(empty(u) for u in o)
+        return o
+
+    return empty(out)
+
+
 def autocast_aware(forward):
     """Decorator of a top-level model's forward.  The reference under `torch.autocast("cuda", dtype=torch.bfloat16)` -- or accelerate's
     mixed precision around train_vit_decorr.py:74 -- keeps float32 master parameters and runs its Linear layers on 16-bit copies.  The
@@ -146,8 +178,13 @@ def autocast_aware(forward):
     and calls outside autocast, go straight through."""
     import functools
 
+    IMAGE_KEYS = ("img", "x", "images", "batched_images", "video")
+
     @functools.wraps(forward)
     def wrapped(self, *args, **kwargs):      # (every argument may come by keyword: model(img=t), a trainer's model(**batch))
+        v = args[0] if args else next((kwargs[k] for k in IMAGE_KEYS if k in kwargs), None)
+        if isinstance(v, torch.Tensor) and v.dim() >= 2 and v.shape[0] == 0:
+            return _empty_batch_forward(wrapped, self, v, args, kwargs)
         with model_grad_scope():             # torch.no_grad() around the call is seen by every fused stage, not just the transformer
             return inner(self, *args, **kwargs)
 
@@ -184,7 +221,6 @@ def autocast_aware(forward):
                 return type(v)(conv(u) for u in v)
             return v
 
-        IMAGE_KEYS = ("img", "x", "images", "batched_images", "video")
         if args:
             args = (conv(args[0]),) + tuple(args[1:])
             kwargs = dict(kwargs)
@@ -502,8 +538,6 @@ class ConcatTokensFn(torch.autograd.Function):
         B, Np, D = x.shape
         F_ = 0 if front is None else front.shape[0]
         N = Np + F_
-        if D % 4:
-            raise VitkError(f"token width {D} must be a multiple of 4")
         fr = None if front is None or F_ == 0 else _to(front.reshape(F_, D), x.dtype)
         ps = None if pos is None else _to(pos[:N].contiguous(), x.dtype)
         out = torch.empty((B, N, D), dtype=x.dtype, device=x.device)

@@ -227,7 +227,7 @@ class ViT(Module):
             return False
         if any(_has_fwd_hooks(m) for m in pe.modules()):
             return False
-        if pe[1].weight.shape[0] % 4:        # patch_dim off the 16-byte rows of the fused stage (7 x 7 x 3 = 147): op by op on the any-width kernels
+        if pe[1].weight.shape[0] % 4 or pe[2].weight.shape[0] % 4:   # patch_dim (7 x 7 x 3 = 147) or dim (ViT(dim = 30)) off the 16-byte rows of the fused stage: op by op on the any-width kernels
             return False
         return not (self.training and self.dropout.p > 0.) and not _has_fwd_hooks(self.dropout)
 
