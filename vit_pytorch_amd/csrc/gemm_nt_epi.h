@@ -161,5 +161,32 @@ template <bool HAS_BIAS> __device__ __forceinline__ unsigned q_pack2b(float a, f
     } else return q_pack2(a, b);
 }
 typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
+// Column sums of the ROUNDED outputs (what a later colsum(C) would read): cs[e] += (float)g8[e], one v_dot2c_f32 per element -- the pair
+// against (1, 0) or (0, 1), accumulated in f32 -- instead of an unpack and an add (round 6).  The products are exact and the other
+// lane of the pair contributes 0 x value: a NON-FINITE value in the neighbouring column therefore turns this column's sum into NaN
+// too (0 x Inf); a step with a non-finite gradient is lost either way.
+__device__ __forceinline__ void q_cs_add8(float (&cs)[8], bf16x8 g8) {
+    typedef __bf16 q_h2 __attribute__((ext_vector_type(2)));
+    // the unit pairs as OPAQUE register values: hipcc folds a literal {1, 0} pair into the inline constant "1.0", which the instruction
+    // reads as the 32-bit pattern 0x3f800000 = the pair (0, 1) [measured: both sums then collect the odd column]
+#ifdef VITK_HALF_IS_F16
+    unsigned k0 = 0x00003c00u, k1 = 0x3c000000u;
+#else
+    unsigned k0 = 0x00003f80u, k1 = 0x3f800000u;
+#endif
+    asm volatile("" : "+s"(k0), "+s"(k1));
+    const q_h2 e0 = __builtin_bit_cast(q_h2, k0), e1 = __builtin_bit_cast(q_h2, k1);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const q_h2 v = {g8[e], g8[e + 1]};
+#ifdef VITK_HALF_IS_F16
+        cs[e] = __builtin_amdgcn_fdot2(v, e0, cs[e], false);
+        cs[e + 1] = __builtin_amdgcn_fdot2(v, e1, cs[e + 1], false);
+#else
+        cs[e] = __builtin_amdgcn_fdot2_f32_bf16(v, e0, cs[e], false);
+        cs[e + 1] = __builtin_amdgcn_fdot2_f32_bf16(v, e1, cs[e + 1], false);
+#endif
+    }
+}
 
 }  // namespace

@@ -590,8 +590,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const NtpArgs p) {
                             const bf16x8 g8 = q_narrow8(g);
                             if (ok) {
                                 *reinterpret_cast<bf16x8*>(Cb + o) = g8;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) cs[e] += (float)g8[e];     // of the ROUNDED values: what colsum(C) would read
+                                q_cs_add8(cs, g8);                      // of the ROUNDED values: what colsum(C) would read
                             }
                         }
                     }

@@ -487,8 +487,7 @@ __global__ __launch_bounds__(256) void gemm_ntw_kernel(const NtwArgs p) {
                         if (p.dbg & 64) asm volatile("" :: "v"(g8)); else       // experiments (timing only): bit 6 = no stores
 #endif
                         *reinterpret_cast<bf16x8*>(Cb + o) = g8;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) cs[qq][e] += (float)g8[e];     // of the ROUNDED values: what colsum(C) would read
+                        q_cs_add8(cs[qq], g8);                          // of the ROUNDED values: what colsum(C) would read
                     }
                 }
                 if constexpr (AUX_IN) {
