@@ -225,10 +225,14 @@ def test_fp8_k128_switch_and_recompute(x, monkeypatch):
         assert rel(y_b, y_a) < 2e-2 and rel(dx_b, dx_a) < 6e-2 and worst_grad(g_b, g_a) < 1e-1     # a routing error shows as O(1)
 
 
-def test_fp8_needs_16bit_parameters_and_a_transformer():
+def test_fp8_needs_16bit_operands_and_a_transformer(x):
+    # a float32 model may be switched (its 16-bit operands exist under torch.autocast: functional.autocast_aware), but a float32
+    # FORWARD with the switch on raises instead of silently ignoring it
     m, _ = build(torch.float32)
-    with pytest.raises(L.VitkError):
-        enable_fp8(m)
+    enable_fp8(m)
+    assert m._fp8 is not None
+    with KD.installed(), pytest.raises(L.VitkError, match="autocast"):
+        m(x.float())
     with pytest.raises(L.VitkError):
         enable_fp8(torch.nn.Linear(4, 4).to(torch.bfloat16))
     m16, _ = build(torch.bfloat16)

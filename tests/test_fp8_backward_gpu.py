@@ -284,3 +284,43 @@ def test_fp8_training_step_full_depth_config5(monkeypatch):
     g_ref16 = rel(torch.cat([torch.from_numpy(gold["bf16::gsample::" + k]).float() for k in keys]), torch.cat([torch.from_numpy(gold["gsample::" + k]).float() for k in keys]))
     assert e3 <= 4.0 * e_ref16 and g3 <= g_ref16 + 1e-2, (e3, e_ref16, g3, g_ref16)
     assert e3 > e16r
+
+
+def test_fp8_on_a_float32_model_under_autocast(monkeypatch):
+    """`enable_fp8` on float32 master parameters (missing 5): under torch.autocast the model's forward runs on 16-bit copies
+    of the parameters (functional.autocast_aware), and the fp8 state machine works on those -- the e4m3 weight copies keyed on the MASTER
+    parameter's value, so that they are requantised once per optimizer step and nothing is left behind for the per-step copies.
+    Same stated fp8 tolerance as the 16-bit model (logits 3e-2, gradient sample 5e-2 of the reference's float32 run); float32 gradients."""
+    name = "vit_b16_width"
+    case = WIDE_CASES[name]
+    params = make_params(case["kind"], case["cfg"], case["seed"])
+    img = make_images(case["cfg"], case["batch"], case["seed"] + 1000).to(DEV)
+    m = ViT(**case["cfg"]); m.load_state_dict(params, strict=True)
+    m = m.to(DEV)                                        # float32 master parameters
+    enable_fp8(m)
+    st = m.transformer._fp8
+    with pytest.raises(L.VitkError, match="autocast"):   # a float32 forward must not silently ignore the switch
+        m(img)
+    errs = []
+    for step in range(3):
+        with torch.autocast("cuda", dtype=BF):
+            e, g, _, out = _golden_errors(name, m, img, params, case)
+        assert out.dtype == BF and all(p.grad is not None and p.grad.dtype == torch.float32 for p in m.parameters() if p.numel())
+        errs.append((e, g))
+        n_w = (len(st._w), len(st._wt))
+        if step == 1:
+            kept = n_w
+            w8_before = next(iter(st._w.values()))[1]
+    assert st.ready and st.bwd_ready
+    assert n_w == kept, (n_w, kept)                      # one entry per weight, not one per step
+    assert next(iter(st._w.values()))[1] is w8_before    # unchanged master -> the e4m3 copy is reused
+    print(f"{name} float32 master + autocast + fp8: logits / gradient sample vs reference f32 per step {errs}")
+    for e, g in errs[1:]:
+        assert e < 3e-2 and g < 5e-2, (e, g)
+    assert errs[2][0] > 4e-3                             # fp8 did run (the autocast-bf16 route is at 3.7e-3 on this case)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.0)                                  # an "optimizer step": the version counter moves
+    with torch.autocast("cuda", dtype=BF):
+        m(img)
+    assert next(iter(st._w.values()))[1] is not w8_before and (len(st._w), len(st._wt)) == kept

@@ -239,6 +239,9 @@ class TransformerFn(torch.autograd.Function):
             raise VitkError("TransformerFn: this shape does not take the fused dropout path (caller must check dropout_fusable)")
         site = (lambda li, k: (drop_p, _hash32(drop_seed + 4 * li + k))) if drop_p > 0.0 else (lambda li, k: None)
         # fp8 (fp8.py): e4m3 operands for QKV / out-projection / FF1 / FF2 once the delayed scales exist; the first call only records amax
+        if fp8 is not None and T not in ops.HALF:
+            raise VitkError("enable_fp8: fp8 replaces 16-bit GEMM operands -- call this float32 model inside torch.autocast('cuda', dtype=torch.bfloat16) "
+                            "(or convert it with .bfloat16()); a float32 forward would silently ignore the switch")
         use8 = fp8 is not None and T in ops.HALF and drop_p == 0.0 and depth > 0 and lp[8] is not None and ops.fp8_gemm_ok(M, D, I, lp[7].shape[0])
         go8 = use8 and fp8.ready
         out8 = use8 and lp[3] is not None and ops.fp8_out_ok(M, D, I)       # the out-projection takes an e4m3 copy of the attention output

@@ -57,6 +57,14 @@ E4M3_MAX = 448.0
 E5M2_MAX_USED = 28672.0                   # 57344 / 2: one-step-old gradient scales keep a factor 2 of headroom
 
 
+def _identity(w: torch.Tensor):
+    """(cache slot, staleness key) of a weight.  A 16-bit copy functional.autocast_aware made of a float32 master parameter for ONE forward
+    carries the master's identity (`_vitk_master`): the e4m3 copies then live as long as the master keeps its value (gradient
+    accumulation: one quantisation per optimizer step), and no entry is left behind for a tensor that died with its step."""
+    m = getattr(w, "_vitk_master", None)
+    return m if m is not None else (id(w), weight_key(w))
+
+
 class Fp8State:
     """Delayed-scaling state of one Transformer: scales / amax records per (layer, tensor) and the e4m3 weight caches."""
 
@@ -83,8 +91,8 @@ class Fp8State:
 
     def weight(self, w: torch.Tensor):
         """e4m3 copy of a (N, K) weight and its scale pair; re-quantised when the parameter changed."""
-        key = weight_key(w)       # data_ptr, torch version counter AND the epoch the fused optimizer bumps (it writes through raw pointers)
-        ent = self._w.get(id(w))
+        ident, key = _identity(w)       # data_ptr, torch version counter AND the epoch the fused optimizer bumps (it writes through raw pointers)
+        ent = self._w.get(ident)
         # while a HIP graph is captured the quantisation must be part of the graph (replays then see the current weights)
         if ent is None or ent[0] != key or ent[1].device != w.device or torch.cuda.is_current_stream_capturing():
             sc = torch.empty(2, dtype=torch.float32, device=w.device)
@@ -92,20 +100,20 @@ class Fp8State:
             K.fp8_amax_scale(w, sc)
             K.quantize_fp8(w, w8, scale_dev=sc)
             ent = (key, w8, sc)
-            self._w[id(w)] = ent
+            self._w[ident] = ent
         return ent[1], ent[2]
 
     def weight_t(self, w: torch.Tensor):
         """e4m3 copy of W^T (K, N) -- the "W" operand that makes dX = dY . W an NT GEMM -- under the SAME scale as `weight(w)`."""
         w8, sc = self.weight(w)
-        key = weight_key(w)
-        ent = self._wt.get(id(w))
+        ident, key = _identity(w)
+        ent = self._wt.get(ident)
         if ent is None or ent[0] != key or ent[1].device != w.device or torch.cuda.is_current_stream_capturing():
             wt = ops.transpose_weight(w)                       # 16-bit (K, N), cached per parameter value
             w8t = torch.empty(wt.shape, dtype=torch.uint8, device=w.device)
             K.quantize_fp8(wt, w8t, scale_dev=sc)
             ent = (key, w8t)
-            self._wt[id(w)] = ent
+            self._wt[ident] = ent
         return ent[1], sc
 
     def backward_will_be_fp8(self) -> bool:
@@ -133,8 +141,10 @@ def enable_fp8(model: torch.nn.Module, enabled: bool = True, backward: bool = Tr
     for m in model.modules():
         if isinstance(m, (Transformer, SimpleTransformer)):
             p = next(m.parameters())
-            if enabled and p.dtype not in (torch.bfloat16, torch.float16):
-                raise VitkError("enable_fp8: the model must be bfloat16 or float16 (fp8 replaces the 16-bit GEMM operands)")
+            # a float32 model: fp8 takes effect where its forward runs on 16-bit operands, i.e. inside torch.autocast (the reference's
+            # accelerate mixed precision: train_vit_decorr.py:74-78); outside autocast the forward raises (engine.TransformerFn)
+            if enabled and p.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+                raise VitkError("enable_fp8: the model must be bfloat16, float16, or float32 run under torch.autocast (fp8 replaces the 16-bit GEMM operands)")
             m._fp8 = Fp8State(len(m.layers), p.device, backward, wgrad) if enabled else None
             found = True
     if not found:

@@ -19,7 +19,7 @@ from torch import nn
 from . import kernels as K
 from . import ops
 from ._lib import VitkError
-from ._epoch import model_grad_scope
+from ._epoch import model_grad_scope, weight_key
 
 Tensor = torch.Tensor
 F32 = torch.float32
@@ -201,8 +201,9 @@ def autocast_aware(forward):
         for _, p in named:
             uniq.setdefault(id(p), p)
         cast_all = CastParamsFn.apply(dt, *uniq.values())
-        for c in cast_all:
+        for p_, c in zip(uniq.values(), cast_all):
             c._vitk_weight = True            # ops.is_weight: these get the K-blocked / transposed copies a Parameter gets
+            c._vitk_master = (id(p_), weight_key(p_))      # fp8.Fp8State keys its e4m3 weight copies on the MASTER parameter's value
         by_id = dict(zip(uniq.keys(), cast_all))
         swap = {n: by_id[id(p)] for n, p in named}
         for n, b in self.named_buffers(remove_duplicate=False):
