@@ -223,6 +223,18 @@ def test_fp8_k128_switch_and_recompute(x, monkeypatch):
         monkeypatch.setenv("VITK_RECOMPUTE", "1")
         y_b, dx_b, g_b = run(m8, x)
         assert rel(y_b, y_a) < 2e-2 and rel(dx_b, dx_a) < 6e-2 and worst_grad(g_b, g_a) < 1e-1     # a routing error shows as O(1)
+        # round 6: with the lean saving ON the same switch (or a stack that would not fit: _recompute_policy with frac = 0.70) makes the
+        # lean saving give way to the recompute -- no e4m3 activation is kept, the weight-gradient GEMMs re-make their operands
+        monkeypatch.setattr(E, "FP8_LEAN", True)
+        kept = []
+        orig = E._recompute_policy
+        monkeypatch.setattr(E, "_recompute_policy", lambda b, d, frac=0.45: (kept.append(frac), orig(b, d, frac))[1])
+        y_c, dx_c, g_c = run(m8, x)
+        assert 0.70 in kept                                                  # the lean question was asked ...
+        assert rel(y_c, y_a) < 2e-2 and rel(dx_c, dx_a) < 6e-2 and worst_grad(g_c, g_a) < 1e-1
+        monkeypatch.setenv("VITK_RECOMPUTE", "0")                           # ... and with the switch off the lean saving stays
+        y_d, dx_d, g_d = run(m8, x)
+        assert rel(y_d, y_a) < 2e-2 and worst_grad(g_d, g_a) < 1e-1
 
 
 def test_fp8_needs_16bit_operands_and_a_transformer(x):

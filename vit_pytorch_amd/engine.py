@@ -174,13 +174,16 @@ def dropout_fusable(T, B: int, N: int, D: int, heads: int, dim_head: int, F: int
             and ops.fused_dropout_ok(T, M, F, D) and ops.fused_dropout_ok(T, M, D, F))
 
 
-def _recompute_policy(saved_bytes: int, device) -> bool:
+def _recompute_policy(saved_bytes: int, device, frac: float = 0.45) -> bool:
     """Keep every activation of the stack (the default: 1.4 GB / layer at ViT-B/16 batch 256, nothing but the attention
     probabilities is ever recomputed) unless that would not fit: when the activations a forward pass is about to save exceed
     45 % of the device memory -- BASELINE config 5, ViT-H/14 at 336 px and batch 256 / GPU: 6.8 GB x 32 layers = 217 GB of 288 --
     the three cheapest-to-rebuild tensors of a layer are dropped and rebuilt in its backward: the GELU output (one elementwise pass
     over the saved pre-activation) and the two LayerNorm outputs (one LayerNorm forward each from the saved residual stream):
-    2.3 of the 6.8 GB.  VITK_RECOMPUTE=0 / 1 overrides."""
+    2.3 of the 6.8 GB.  VITK_RECOMPUTE=0 / 1 overrides.  The fp8 path (round 6): its lean saving (e4m3 copies instead of the 16-bit
+    LayerNorm / GELU outputs: 5.9 GB a layer at config 5, 187 GiB in all) is kept while it fits -- `frac` = 0.70 of the device for that
+    question -- and gives way to the same recompute (4.5 GB a layer, 145 GiB; the e4m3 operands of the weight-gradient GEMMs are then
+    re-made from the rebuilt 16-bit tensors) beyond it or under VITK_RECOMPUTE=1."""
     import os
     v = os.environ.get("VITK_RECOMPUTE")
     if v is not None:
@@ -189,7 +192,7 @@ def _recompute_policy(saved_bytes: int, device) -> bool:
         total = torch.cuda.get_device_properties(device).total_memory
     except Exception:
         return False
-    return saved_bytes > 0.45 * total
+    return saved_bytes > frac * total
 
 
 def forward_stream_is_16bit(T, M: int, D: int, I: int, Fh: int, depth: int, drop_p: float, fp8, has_out: bool, has_b1: bool) -> bool:
@@ -252,6 +255,10 @@ class TransformerFn(torch.autograd.Function):
         # The scales they were made under are snapshotted (the fold at the end of this forward overwrites the live ones).
         lean8 = bool(go8 and keep and bwd8 and fp8.wgrad and fp8.backward_will_be_fp8() and FP8_LEAN
                      and all(ops.fp8_tn_ok(M, n_, k_) for n_, k_ in ((D, lp[7].shape[0]), (lp[7].shape[0], D), (D, I), (3 * I, D))))
+        if lean8:       # ... while it fits (see _recompute_policy): xs, x2 (f32) + three e4m3 activations + the e4m3 attention output + qkv, o, pre (16 bit)
+            lean_layer = M * (10 * D + Fh0 + I + (4 * I + Fh0) * esz)
+            if _recompute_policy(lean_layer * depth, xs.device, frac=0.70):
+                lean8, recompute = False, True
         scales_used = fp8.scales.clone() if lean8 else None
         # the FeedForward GEMM stores the gelu' factor instead of the pre-activation (ops.gelu_dg_ok) when the backward will want only
         # that of it: not under recompute (the GELU output is rebuilt from the pre-activation), fp8 or active dropout
