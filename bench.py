@@ -23,9 +23,10 @@ Extra objects in the line:
                 peak = 2516.6 TFLOP/s dense bf16 MFMA.  `traffic` is STATIC (profiles/rNN_pmc_traffic.json, see `traffic_source`).
   weight_cache_rebuild_ms
                 the timed steady state never changes the weights, so the K-blocked / transposed weight copies are built once;
-                a real training step (optimizer after every backward) rebuilds them every step.  This is the extra time of ONE
-                step right after `invalidate_weight_caches()` (what every step of a real run pays), measured after the timed
-                region: `ms_per_step + weight_cache_rebuild_ms` is the fwd+bwd time inside a training loop.
+                a real training step (optimizer after every backward) rebuilds them every step.  This is the extra time per
+                step of a 10-step window that calls `invalidate_weight_caches()` before every step (what every step of a real
+                run pays; round 6: all copies of the stack in one table launch, vitk_pack_w_nt_many), measured after the timed
+                region against a steady window: `ms_per_step + weight_cache_rebuild_ms` is the fwd+bwd time inside a training loop.
   model         whole-step algorithmic TFLOP/s (105.383 GF/img for ViT-B/16) and its fraction of peak.
   box           a ~60 ms calibration of THIS box before the timed region, with plain torch ops (not the product): a bf16 torch.mm
                 (hipBLASLt) of 8192^3 on random data in TFLOP/s, a 1 GiB fill and a 1 GiB copy in TB/s.  The pool's boxes differ by +-5 % on the
@@ -463,16 +464,19 @@ def main():
     # one step with every weight-derived cache invalidated (= what each step of a real training loop pays) vs a steady step
     from vit_pytorch_amd import invalidate_weight_caches
 
-    def one_step_ms(invalidate: bool) -> float:
+    # (windows of 10 steps, the CPU running ahead of the GPU as in a real loop: a single synchronised step would add the host-side
+    #  allocation of the copies to the GPU's time)
+    def window_ms(invalidate: bool, n: int = 10) -> float:
         sync()
-        if invalidate:
-            invalidate_weight_caches()
         t0 = time.perf_counter()
-        step()
+        for _ in range(n):
+            if invalidate:
+                invalidate_weight_caches()
+            step()
         sync()
-        return (time.perf_counter() - t0) * 1e3
-    one_step_ms(False)
-    rebuild = [one_step_ms(True) - one_step_ms(False) for _ in range(3)]
+        return (time.perf_counter() - t0) * 1e3 / n
+    window_ms(True, 2)
+    rebuild = [window_ms(True) - window_ms(False) for _ in range(3)]
     weight_cache_rebuild_ms = sorted(rebuild)[1]
 
     if rank == 0:

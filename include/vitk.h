@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VITK_VERSION 137
+#define VITK_VERSION 138
 
 #define VITK_F32 0
 #define VITK_BF16 1          /* the library's 16-bit float type: bfloat16 (libvitk.so) or IEEE half (libvitk_f16.so) */
@@ -173,6 +173,10 @@ int vitk_gemm_nt_plan(int64_t M, int64_t N, int64_t K, int64_t ldc, int32_t* out
  * kernel's LDS stage, so its LDS-DMA reads whole 128-byte lines (see gemm_nt_persist.hip).                                    */
 int64_t vitk_pack_w_nt_bytes(int64_t rows, int64_t reduction);
 int vitk_pack_w_nt(const void* W, int64_t ldw, int64_t N, int64_t K, void* out, void* out_t, void* stream);
+/* The same for a table of `count` weights in ceil(jobs / 96) launches (a job = one non-null out / out_t): what a training step does
+ * once per optimizer step for every Linear of the stack.  Row t: W[t] (N[t] x K[t], leading dimension ldw[t]), out[t], out_t[t]. */
+int vitk_pack_w_nt_many(const void* const* W, const int64_t* ldw, const int64_t* N, const int64_t* K, void* const* out,
+                        void* const* out_t, int64_t count, void* stream);
 int vitk_gemm_nt_bf16_gelu_bwd_colsum(const void* A, int64_t lda, const void* W, int64_t ldw,
                                       void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                       void* aux, float* colsum_partials, void* stream);

@@ -166,6 +166,12 @@ def pack_w_nt(W, ldw, N, Kd, out, out_t):
         out_t[:N * Kd] = W.reshape(N, Kd).t().contiguous().flatten()
 
 
+def pack_w_nt_many(rows):
+    CALLS.append(("pack_w_nt_many", len(rows)))
+    for W, N, Kd, out, out_t in rows:
+        pack_w_nt(W, Kd, N, Kd, out, out_t)
+
+
 def gemm_tn_bf16_pair(dY0, ldy0, X0, ldx0, dW0, dY1, ldy1, X1, ldx1, dW1, M, ws, splits, accumulate0=False, accumulate1=False):
     (N0, K0), (N1, K1) = dW0.shape, dW1.shape
     gemm_tn_bf16(dY0, ldy0, X0, ldx0, dW0, K0, M, N0, K0, ws, splits, accumulate0)
@@ -552,7 +558,7 @@ def require_device(*ts):
 
 
 _K_DOUBLES = dict(gemm_nt_bf16=gemm_nt_bf16, gemm_nt_bf16_gelu_bwd_colsum=gemm_nt_bf16_gelu_bwd_colsum, gemm_nt_bf16_mul_aux_colsum=gemm_nt_bf16_mul_aux_colsum, gemm_nt_bf16_mul_aux8_colsum=gemm_nt_bf16_mul_aux8_colsum, gemm_nt_fp8_v2=gemm_nt_fp8_v2,
-                  gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_bf16_pair=gemm_tn_bf16_pair, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
+                  gemm_nt_fp8_ex=gemm_nt_fp8_ex, pack_w_nt=pack_w_nt, pack_w_nt_many=pack_w_nt_many, gemm_tn_bf16=gemm_tn_bf16, gemm_tn_bf16_pair=gemm_tn_bf16_pair, gemm_tn_fp8=gemm_tn_fp8, layernorm_fwd=layernorm_fwd,
                   fp8_amax_scale=fp8_amax_scale, quantize_fp8=quantize_fp8, quantize_fp8_delayed=quantize_fp8_delayed,
                   fp8_update_scales_fmt=fp8_update_scales_fmt, fp8_update_scales=fp8_update_scales, colsum_partials=colsum_partials, fold_many=fold_many,
                   colsum=colsum, transpose=transpose, add_rows=add_rows, cast=cast, cast_many=cast_many, gelu_fwd=gelu_fwd, gelu_bwd=gelu_bwd, patchify=patchify, unpatchify=unpatchify, patch_ln_fwd=patch_ln_fwd, patch_ln_bwd_params=patch_ln_bwd_params,

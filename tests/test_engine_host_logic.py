@@ -13,6 +13,7 @@ from oracle.params import make_params_for
 from vit_pytorch_amd import _lib as L
 from vit_pytorch_amd import engine as E
 from vit_pytorch_amd import kernels as K
+from vit_pytorch_amd import ops
 from vit_pytorch_amd.fp8 import SLOTS_PER_LAYER, enable_fp8, enable_fp8_forward
 from vit_pytorch_amd.vit import Transformer
 
@@ -279,3 +280,23 @@ def test_fp8_on_the_simple_vit_stack(x, monkeypatch):
         assert "gemm_tn_bf16" not in names and "gemm_nt_bf16" not in names
     assert set(g8) == set(g16) and all(v is not None for v in g8.values())
     assert rel(y8, y16) < 6e-2 and rel(dx8, dx16) < 1.2e-1 and worst_grad(g8, g16) < 1.5e-1
+
+
+def test_a_step_packs_the_weights_of_the_stack_in_one_table_call(x, monkeypatch):
+    """ops.prepack_weights (round 6): the K-blocked copies of a step go out as ONE vitk_pack_w_nt_many table at the top of the stage --
+    forward and transposed packs of the four Linear weights of every layer -- and a second step on unchanged weights packs nothing."""
+    monkeypatch.setattr(ops, "_persistent_nt", lambda M, N, Kd: True)
+    m, _ = build(torch.bfloat16)
+    with KD.installed() as calls:
+        run(m, x)
+        tables = [c for c in calls if c[0] == "pack_w_nt_many"]
+        assert [c[1] for c in tables] == [4 * DEPTH], tables
+        del calls[:]
+        run(m, x)
+        assert not [c for c in calls if c[0] == "pack_w_nt_many"]
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.0)                                  # an optimizer step: version counters move
+        del calls[:]
+        run(m, x)
+        assert [c[1] for c in calls if c[0] == "pack_w_nt_many"] == [4 * DEPTH]

@@ -226,3 +226,32 @@ def test_gelu_factor_epilogue_pair(M, N, Kd):
     assert rel(dx, ref) < 4e-3
     assert rel(db, dx.double().sum(0)) < 4e-3              # column sums of the ROUNDED output, like GELU_BWD
     assert rel(dx, dx0.double()) < 6e-3                     # vs the pair it replaces: one more rounding of the factor
+
+
+def test_pack_w_nt_many_equals_the_single_packs():
+    """vitk_pack_w_nt_many (round 6): a table of weights per launch -- 13 layers' worth (104 weights, 195 packs: more than one 96-job table) of
+    mixed shapes, some with one side only -- byte for byte what vitk_pack_w_nt writes for each."""
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (1000, 96), (520, 32), (96, 1024), (264, 64)] * 13
+    rows, refs = [], []
+    for i, (N, Kd) in enumerate(shapes):
+        W = (rnd(N, Kd, seed=300 + i) * Kd ** -0.5).to(BF)
+        want_f = Kd % 32 == 0 and i % 5 != 4
+        want_t = N % 32 == 0 and i % 7 != 6
+        if not (want_f or want_t):
+            want_f = True
+        pf = torch.full((K.pack_w_nt_bytes(N, Kd) // 2,), -7.0, dtype=BF, device=DEV) if want_f else None
+        pt = torch.full((K.pack_w_nt_bytes(Kd, N) // 2,), -7.0, dtype=BF, device=DEV) if want_t else None
+        rf = torch.empty_like(pf) if want_f else None
+        rt = torch.empty_like(pt) if want_t else None
+        K.pack_w_nt(W, Kd, N, Kd, rf, rt)
+        rows.append((W, N, Kd, pf, pt)); refs.append((rf, rt))
+    assert sum((r[3] is not None) + (r[4] is not None) for r in rows) > 96
+    K.pack_w_nt_many(rows)
+    for (W, N, Kd, pf, pt), (rf, rt) in zip(rows, refs):
+        if pf is not None:
+            assert torch.equal(pf.view(torch.int16), rf.view(torch.int16)), (N, Kd, "forward pack")
+        if pt is not None:
+            assert torch.equal(pt.view(torch.int16), rt.view(torch.int16)), (N, Kd, "transposed pack")
+    K.pack_w_nt_many([])                                   # an empty table is nothing
+    with pytest.raises(L.VitkError):
+        K.pack_w_nt_many([(rows[4][0], 1000, 96, None, torch.empty(8, dtype=BF, device=DEV))])      # N = 1000: no transposed pack (N % 32)

@@ -19,7 +19,7 @@ F32, BF16 = 0, 1          # dtype tags; 1 = "the library's 16-bit type" (bfloat1
 HALF_TYPE_F16 = 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESID, EPI_GELU_BWD, EPI_RESID16, EPI_BIAS_GELU_DG, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6, 7
 EPI_BIAS_GELU_DG8, EPI_MUL_AUX8 = 8, 9       # the gelu' factor as 8-bit codes (include/vitk.h)
-VITK_VERSION = 137
+VITK_VERSION = 138
 
 
 class RowMap(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "vitk_comm_destroy": (_i, [_vp]),
     "vitk_pack_w_nt_bytes": (_i64, [_i64, _i64]),
     "vitk_pack_w_nt": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "vitk_pack_w_nt_many": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vitk_gemm_nt_bf16_gelu_bwd_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_nt_bf16_mul_aux_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "vitk_gemm_nt_bf16_mul_aux8_colsum": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -876,12 +876,10 @@ int gemm_ntp_launch(const NtpPlan& pl, const void* A, int64_t lda, const void* W
 // (rows past N repeat row N - 1), and position s of the row holds its 16-byte chunk s ^ q_swz(R >> 2) of K-step kt.
 // The transposed flavour packs W^T (K x N) -- the operand of dX = dY . W -- straight from W.
 namespace {
-template <bool TR>
-__global__ __launch_bounds__(256) void pack_w_kernel(const __bf16* __restrict__ W, long long ldw, int N, int K, char* __restrict__ out) {
-    // logical operand: rows = TR ? K : N ("n"), reduction = TR ? N : K ("k")
+// logical operand: rows = TR ? K : N ("n"), reduction = TR ? N : K ("k")
+__device__ __forceinline__ void pack_w_chunk(const __bf16* __restrict__ W, long long ldw, int N, int K, char* __restrict__ out, bool TR, long long chunk) {
     const int rows = TR ? K : N, red = TR ? N : K;
     const int nt = red >> 5;
-    const long long chunk = (long long)blockIdx.x * 256 + threadIdx.x;       // one 16-byte chunk per thread
     const long long total = (long long)((rows + 255) >> 8) * nt * 1024;
     if (chunk >= total) return;
     const int spos = (int)(chunk & 3), R = (int)((chunk >> 2) & 255);
@@ -897,6 +895,22 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const __bf16* __restrict__ 
         for (int e = 0; e < 8; ++e) v[e] = W[(long long)(k0 + e) * ldw + n];
     }
     *reinterpret_cast<bf16x8*>(out + chunk * 16) = v;
+}
+template <bool TR>
+__global__ __launch_bounds__(256) void pack_w_kernel(const __bf16* __restrict__ W, long long ldw, int N, int K, char* __restrict__ out) {
+    pack_w_chunk(W, ldw, N, K, out, TR, (long long)blockIdx.x * 256 + threadIdx.x);       // one 16-byte chunk per thread
+}
+}  // namespace
+
+namespace {
+// the same for a TABLE of weights in one launch (a training step re-packs every weight of the stack: 96 launches of ~5 us at ViT-B/16)
+constexpr int PM_MAX = 96;
+struct PackMany { const __bf16* W[PM_MAX]; char* out[PM_MAX]; int ldw[PM_MAX], N[PM_MAX], K[PM_MAX]; int blk0[PM_MAX + 1]; int count; unsigned tr[PM_MAX / 32]; };
+__global__ __launch_bounds__(256) void pack_w_many_kernel(PackMany a) {
+    int lo = 0, hi = a.count;                  // uniform binary search: blk0[lo] <= blockIdx.x < blk0[lo + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= a.blk0[mid]) lo = mid; else hi = mid; }
+    const bool tr = (a.tr[lo >> 5] >> (lo & 31)) & 1u;
+    pack_w_chunk(a.W[lo], a.ldw[lo], a.N[lo], a.K[lo], a.out[lo], tr, (long long)((int)blockIdx.x - a.blk0[lo]) * 256 + threadIdx.x);
 }
 }  // namespace
 
@@ -921,4 +935,42 @@ extern "C" int vitk_pack_w_nt(const void* W, int64_t ldw, int64_t N, int64_t K, 
     }
     VITK_CHECK_LAUNCH("pack_w_nt");
     return 0;
+}
+
+extern "C" int vitk_pack_w_nt_many(const void* const* W, const int64_t* ldw, const int64_t* N, const int64_t* K, void* const* out,
+                                   void* const* out_t, int64_t count, void* stream) {
+    if (count <= 0) return 0;
+    if (!W || !ldw || !N || !K || !out || !out_t) VITK_FAIL(VITK_E_ARG, "pack_w_nt_many: null table");
+    hipStream_t st = (hipStream_t)stream;
+    PackMany a;
+    a.count = 0; a.blk0[0] = 0;
+    for (int i = 0; i < PM_MAX / 32; ++i) a.tr[i] = 0u;
+    auto flush = [&]() -> int {
+        if (a.count == 0) return 0;
+        hipLaunchKernelGGL(pack_w_many_kernel, dim3((unsigned)a.blk0[a.count]), dim3(256), 0, st, a);
+        VITK_CHECK_LAUNCH("pack_w_nt_many");
+        a.count = 0; a.blk0[0] = 0;
+        for (int i = 0; i < PM_MAX / 32; ++i) a.tr[i] = 0u;
+        return 0;
+    };
+    for (int64_t t = 0; t < count; ++t) {
+        if (!W[t] || (!out[t] && !out_t[t])) VITK_FAIL(VITK_E_ARG, "pack_w_nt_many: null pointer in row %lld", (long long)t);
+        if (N[t] <= 0 || K[t] <= 0 || ldw[t] < K[t] || (ldw[t] & 7) || N[t] > (1 << 24) || K[t] > (1 << 24))
+            VITK_FAIL(VITK_E_SHAPE, "pack_w_nt_many: bad shape N=%lld K=%lld ldw=%lld", (long long)N[t], (long long)K[t], (long long)ldw[t]);
+        if ((out[t] && (K[t] & 31)) || (out_t[t] && (N[t] & 31))) VITK_FAIL(VITK_E_SHAPE, "pack_w_nt_many: the reduction dimension must be a multiple of 32");
+        if (!aligned16(W[t]) || (out[t] && !aligned16(out[t])) || (out_t[t] && !aligned16(out_t[t]))) VITK_FAIL(VITK_E_ALIGN, "pack_w_nt_many: 16-byte aligned pointers required");
+        for (int tr = 0; tr < 2; ++tr) {
+            void* o = tr ? out_t[t] : out[t];
+            if (!o) continue;
+            const long long chunks = (tr ? vitk_pack_w_nt_bytes(K[t], N[t]) : vitk_pack_w_nt_bytes(N[t], K[t])) / 16;
+            const long long blocks = (chunks + 255) / 256;
+            if (a.count == PM_MAX || a.blk0[a.count] + blocks > 0x3fffffff) { if (int rc = flush()) return rc; }
+            const int j = a.count;
+            a.W[j] = (const __bf16*)W[t]; a.out[j] = (char*)o; a.ldw[j] = (int)ldw[t]; a.N[j] = (int)N[t]; a.K[j] = (int)K[t];
+            if (tr) a.tr[j >> 5] |= 1u << (j & 31);
+            a.blk0[j + 1] = a.blk0[j] + (int)blocks;
+            ++a.count;
+        }
+    }
+    return flush();
 }

@@ -271,6 +271,8 @@ class TransformerFn(torch.autograd.Function):
             w8, wsc = fp8.weight(w)
             K.gemm_nt_fp8_v2(a8, Kd, w8, Kd, out, Nn, M, Nn, Kd, epi, a_kind=K.A_E4M3, alpha_a=sc_a[1:], alpha_w=wsc[1:],
                              k128=fp8.k128 and Kd % 128 == 0, **kw)
+        if T in ops.HALF and fp8 is None:       # every K-blocked weight copy this step will ask for, in one launch (after an optimizer step: all of them)
+            ops.prepack_weights([lp[li * NLP + j] for li in range(depth) for j in (2, 3, 7, 9)], M)
         for li in range(depth):
             ln1w, ln1b, wqkv, wout, bout, ln2w, ln2b, w1, b1, w2, b2 = lp[li * NLP:(li + 1) * NLP]
             a1 = ops.empty((M, D), T, xs)

@@ -183,6 +183,23 @@ def pack_w_nt(W: Tensor, ldw: int, N: int, Kd: int, out: Optional[Tensor], out_t
     check(_lib_for(W, out, out_t).vitk_pack_w_nt(_p(W), ldw, N, Kd, _p(out), _p(out_t), _stream()), "pack_w_nt")
 
 
+def pack_w_nt_many(rows):
+    """rows: list of (W, N, Kd, out or None, out_t or None) -- vitk_pack_w_nt for all of them in ceil(jobs / 96) launches."""
+    import ctypes
+    rows = [r for r in rows if r[3] is not None or r[4] is not None]
+    if not rows:
+        return
+    n = len(rows)
+    pw = (ctypes.c_void_p * n)(*[r[0].data_ptr() for r in rows])
+    ld = (ctypes.c_int64 * n)(*[r[2] for r in rows])
+    nn = (ctypes.c_int64 * n)(*[r[1] for r in rows])
+    kk = (ctypes.c_int64 * n)(*[r[2] for r in rows])
+    po = (ctypes.c_void_p * n)(*[(r[3].data_ptr() if r[3] is not None else None) for r in rows])
+    pt = (ctypes.c_void_p * n)(*[(r[4].data_ptr() if r[4] is not None else None) for r in rows])
+    c = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    check(_lib_for(*[r[0] for r in rows]).vitk_pack_w_nt_many(c(pw), c(ld), c(nn), c(kk), c(po), c(pt), n, _stream()), "pack_w_nt_many")
+
+
 def gemm_nt_bf16_gelu_bwd_colsum(A: Tensor, lda: int, W: Tensor, ldw: int, C: Tensor, ldc: int, M: int, N: int, K: int,
                                  aux: Tensor, partials: Tensor):
     check(_lib_for(A, W, C, aux, partials).vitk_gemm_nt_bf16_gelu_bwd_colsum(_p(A), lda, _p(W), ldw, _p(C), ldc, M, N, K, _p(aux), _p(partials),

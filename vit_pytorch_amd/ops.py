@@ -424,6 +424,43 @@ def nt_weight(W: Tensor, M: int, transposed: bool):
     return W, Kd
 
 
+def prepack_weights(Ws, M: int) -> int:
+    """The K-blocked copies nt_weight() would make one by one during this step -- forward pack and, when the caller wants gradients,
+    the transposed pack of every weight in `Ws` whose cache entry is missing or stale -- in ONE table-driven launch per 96 packs
+    (vitk_pack_w_nt_many): a training step re-packs every Linear of the stack after each optimizer step, 8 launches a layer before.
+    Same conditions, same cache entries as nt_weight(); returns the number of packs made."""
+    if not packed_weights_on() or torch.cuda.is_current_stream_capturing():
+        return 0
+    rows, ents = [], []
+    want_grad = caller_grad_mode()
+    for W in Ws:
+        if W is None or W.dtype not in HALF or not is_weight(W) or not W.is_contiguous():
+            continue
+        N, Kd = W.shape
+        key = weight_key(W)
+        ent = _WP_CACHE.get(id(W))
+        if ent is None or ent[0]() is not W or ent[1] != key:
+            wid = id(W)
+            ent = [weakref.ref(W, lambda _r, wid=wid: _WP_CACHE.pop(wid, None)), key, None, None]
+            _WP_CACHE[wid] = ent
+        want_f = ent[2] is None and Kd % 32 == 0 and _persistent_nt(M, N, Kd)
+        want_t = ent[3] is None and want_grad and W.requires_grad and N % 32 == 0 and _persistent_nt(M, Kd, N)
+        if not (want_f or want_t):
+            continue
+        pf = empty((K.pack_w_nt_bytes(N, Kd) // 2,), W.dtype, W) if want_f else None
+        pt = empty((K.pack_w_nt_bytes(Kd, N) // 2,), W.dtype, W) if want_t else None
+        rows.append((W, N, Kd, pf, pt)); ents.append(ent)
+    if not rows:
+        return 0
+    K.pack_w_nt_many(rows)
+    for (W, N, Kd, pf, pt), ent in zip(rows, ents):
+        if pf is not None:
+            ent[2] = pf
+        if pt is not None:
+            ent[3] = pt
+    return sum((r[3] is not None) + (r[4] is not None) for r in rows)
+
+
 def transpose_weight(W: Tensor, pad_to: int = 0) -> Tensor:
     """W (N, K) -> W^T (K, N) (optionally with zero columns up to pad_to): the operand that makes dX = dY . W an NT GEMM.
     Cached per parameter until its values change (weight_key: data_ptr, torch version counter, and the epoch this package's
