@@ -156,8 +156,9 @@ def test_gpu_only_helpers_refuse_cpu_models():
     from vit_pytorch_amd.optim import Adam
     from vit_pytorch_amd.parallel import DataParallel
     m = ViT(image_size=32, patch_size=8, num_classes=10, dim=64, depth=1, heads=2, mlp_dim=128)
+    import copy
     with pytest.raises(VitkError):
-        enable_fp8_forward(m)                                        # float32 model: fp8 replaces 16-bit operands only
+        enable_fp8_forward(copy.deepcopy(m).double())               # fp8 replaces 16-bit operands: bf16 / f16 models, or f32 ones run under autocast (round 6)
     with pytest.raises(VitkError):
         Adam(DataParallel(m))                                        # parameters on the CPU
     with pytest.raises(VitkError):
