@@ -873,6 +873,8 @@ class PackedTransformerFn(torch.autograd.Function):
         dg_mode = bool(keep and depth and drop_p == 0.0 and lp[8] is not None and ops.gelu_dg_ok(T, Tn, lp[7].shape[0], D))     # see TransformerFn
         ctx.dg_mode = dg_mode
         ctx.grad16 = ops.grad_stream_16()       # the backward's stream dtype is decided HERE (a per-call policy -- autocast -- is gone by backward time)
+        if T in ops.HALF:       # the K-blocked weight copies of the step in one launch (see TransformerFn)
+            ops.prepack_weights([lp[li * NLP_NAVIT + j] for li in range(depth) for j in (5, 7, 9)], Tn)       # (q | kv go through _cat_rows: their concatenation is the GEMM operand)
         for li in range(depth):
             ln1g, wq, wkv, gq, gk, wout, ln2g, w1, b1, w2, b2 = lp[li * NLP_NAVIT:(li + 1) * NLP_NAVIT]
             a1 = ops.empty((Tn, D), T, xs)
