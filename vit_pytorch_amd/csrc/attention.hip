@@ -85,7 +85,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int col0, 
 // R = 16-row query tiles a wave carries at once: every K / V fragment read from LDS feeds R MFMAs, so R = 2 halves
 // the LDS traffic per flop and gives the scheduler two independent softmax chains; with 8 waves it also covers
 // N <= 256 (ViT-B/L: 13 tiles) in ONE pass instead of two unbalanced ones.
-template <int R>
+// DROP: attention dropout compiled in (round 6: a template parameter -- the runtime test cost two VALU instructions and a branch per tile
+// and key step in the instance every inference / p = 0 training step runs)
+template <int R, bool DROP = true>
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BHND v, BHND o, float* __restrict__ lse,
                                                         int H, int N, float scale_log2e, unsigned drop_t, unsigned drop_seed,
                                                         float inv_keep) {
@@ -117,8 +119,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
     };
     auto compute = [&]() {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    asm volatile("" : "+v"(ones));          // four live registers: hipcc otherwise keeps one and rebuilds the operand (3 moves) in front of every row-sum MFMA
     const float c = scale_log2e;            // > 0 (checked on the host): max() commutes with the scaling
+    const float inv_c = 1.0f / c;
     while (t0 < nqt) {
         // Softmax bookkeeping is kept off the VALU, which is the busy pipe of this kernel (measured: 12 VALU
         // instructions per MFMA before, VALU 55-60 % busy vs MFMA 16 %):
@@ -127,10 +131,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
         //    exceeds it by more than 2^8 -- exp2(s - mref) <= 256 is harmless in f32 / bf16 -- so after the first
         //    step the rescale and its cross-lane reduction almost never run (wave-uniform branch on a ballot);
         //  * scale and -mref are folded into the exp2 argument as one FMA.
-        float mref[R];
+        float mref[R], thr[R];              // thr = (mref + 8) / c: the lazy test on the raw score maximum (one compare a step)
         f32x4 acc[R][4], accl[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { mref[r] = -INFINITY; accl[r] = z4; acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = z4; }
+        for (int r = 0; r < R; ++r) { mref[r] = -INFINITY; thr[r] = -INFINITY; accl[r] = z4; acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = z4; }
         for (int s = 0; s < nks; ++s) {
             bf16x8 kf[2][2];
 #pragma unroll
@@ -158,13 +162,14 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
                 mloc = fmaxf(fmaxf(mloc, st[0][3]), st[1][0]);
                 mloc = fmaxf(fmaxf(mloc, st[1][1]), st[1][2]);
                 mloc = fmaxf(mloc, st[1][3]);
-                if (__builtin_amdgcn_ballot_w64(mloc * c > mref[r] + 8.0f) != 0) {
+                if (__builtin_amdgcn_ballot_w64(mloc > thr[r]) != 0) {
                     const float m_new = fmaxf(mref[r], groups_max(mloc) * c);
                     const float alpha = __builtin_amdgcn_exp2f(mref[r] - m_new);
 #pragma unroll
                     for (int fd = 0; fd < 4; ++fd) acc[r][fd] *= alpha;
                     accl[r] *= alpha;
                     mref[r] = m_new;
+                    thr[r] = (m_new + 8.0f) * inv_c;
                 }
                 const float nm = -mref[r];
 #pragma unroll
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
                     for (int e = 0; e < 4; ++e) st[hh][e] = __builtin_amdgcn_exp2f(fmaf(st[hh][e], c, nm));
                 pb[r] = pack8(st[0], st[1]);
                 accl[r] = MFMA(ones, pb[r], accl[r]);          // softmax denominators: of the UNDROPPED probabilities
-                if (drop_t) {                                  // nn.Dropout on the attention matrix (vit.py:60): zero P entries for P.V
+                if (DROP && drop_t) {                          // nn.Dropout on the attention matrix (vit.py:60): zero P entries for P.V
                     const unsigned hrow = drop_row((unsigned)(bh * N + (t0 + r) * 16 + fi), drop_seed);
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh)
@@ -619,9 +624,13 @@ extern "C" int vitk_attn_fwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vi
     }
     const int rows_pad = (int)((N + 31) / 32 * 32);
     const int r = tiles_per_wave("VITK_ATTN_R_FWD", true, N);
-    ATTN_LAUNCH(attn_fwd_kernel, "attn_fwd_bf16", r, (unsigned)(B * H), (size_t)2 * rows_pad * AT_LD, (hipStream_t)stream, to_bhnd(q),
-                to_bhnd(k), to_bhnd(v), to_bhnd(o), lse, (int)H, (int)N, scale * LOG2E, drop_thresh(drop_p), drop_seed,
-                1.0f / (1.0f - drop_p));
+#define ATTN_FWD_LAUNCH(RR, DD) do { SET_LDS((attn_fwd_kernel<RR, DD>), "attn_fwd_bf16"); \
+        hipLaunchKernelGGL((attn_fwd_kernel<RR, DD>), dim3((unsigned)(B * H)), dim3(AT_THREADS), (size_t)2 * rows_pad * AT_LD, (hipStream_t)stream, to_bhnd(q), \
+                to_bhnd(k), to_bhnd(v), to_bhnd(o), lse, (int)H, (int)N, scale * LOG2E, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p)); } while (0)
+    const bool drop = drop_thresh(drop_p) != 0;
+    if (r == 2) { if (drop) ATTN_FWD_LAUNCH(2, true); else ATTN_FWD_LAUNCH(2, false); }
+    else        { if (drop) ATTN_FWD_LAUNCH(1, true); else ATTN_FWD_LAUNCH(1, false); }
+#undef ATTN_FWD_LAUNCH
     VITK_CHECK_LAUNCH("attn_fwd_bf16");
     return 0;
 }

@@ -245,13 +245,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DH <= 80 && !DROP && !VL_EARLY
 #pragma unroll
     for (int r = 0; r < R; ++r) load_row_frags<DH, NKS>(qf[r], q.p + (long long)tl.grow(r) * q.s_n + h * q.s_h, fg);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    asm volatile("" : "+v"(ones));                    // four live registers (hipcc otherwise rebuilds the operand in front of every row-sum MFMA)
     const float c = scale_log2e;                      // > 0 (host check)
-    float mref[R];                                    // lazy reference maximum, row sums by MFMA: see attn_fwd_kernel (attention.hip)
+    const float inv_c = 1.0f / c;
+    float mref[R], thr[R];                            // lazy reference maximum, row sums by MFMA: see attn_fwd_kernel (attention.hip); thr = (mref + 8) / c
     f32x4 acc[R][NFD], accl[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        mref[r] = -INFINITY; accl[r] = z4;
+        mref[r] = -INFINITY; thr[r] = -INFINITY; accl[r] = z4;
 #pragma unroll
         for (int fd = 0; fd < NFD; ++fd) acc[r][fd] = z4;
     }
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DH <= 80 && !DROP && !VL_EARLY
                 m = fmaxf(fmaxf(m, st[r][0][3]), st[r][1][0]);
                 m = fmaxf(fmaxf(m, st[r][1][1]), st[r][1][2]);
                 mloc[r] = fmaxf(m, st[r][1][3]);
-                raise = raise || (mloc[r] * c > mref[r] + 8.0f);
+                raise = raise || (mloc[r] > thr[r]);
             }
             if (__builtin_amdgcn_ballot_w64(raise) != 0) {
 #pragma unroll
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && DH <= 80 && !DROP && !VL_EARLY
                     for (int fd = 0; fd < NFD; ++fd) acc[r][fd] *= alpha;
                     accl[r] *= alpha;
                     mref[r] = m_new;
+                    thr[r] = (m_new + 8.0f) * inv_c;
                 }
             }
 #pragma unroll
