@@ -227,7 +227,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(BHND q, BHND k, BH
     compute();
 }
 
-template <int R>
+template <int R, bool DROP = true>      // DROP: see attn_fwd_kernel
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k, BHND v, BHND o, BHND dout,
                                                            const float* __restrict__ lse, float* __restrict__ delta,
                                                            BHND dq, int H, int N, float scale, unsigned drop_t,
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k,
                     st = MFMA(k1, qf[r][1], st);
                     f32x4 dp = MFMA(v0, df[r][0], z4);
                     dp = MFMA(v1, df[r][1], dp);
-                    if (drop_t) {                     // dP = dP_dropped * keep / (1 - p)
+                    if (DROP && drop_t) {             // dP = dP_dropped * keep / (1 - p)
                         const unsigned hrow = drop_row((unsigned)(bh * N + (t0 + r) * 16 + fi), drop_seed);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(BHND q, BHND k,
     compute();
 }
 
-template <int R>
+template <int R, bool DROP = true>      // DROP: see attn_fwd_kernel
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k, BHND v, BHND dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             BHND dk, BHND dv, int H, int N, float scale, unsigned drop_t,
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(BHND q, BHND k
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         p[r][hh][e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale_log2e, l4[e]));
-                        if (drop_t) {               // dV takes P * keep / (1 - p); dP = dP_dropped * keep / (1 - p)
+                        if (DROP && drop_t) {       // dV takes P * keep / (1 - p); dP = dP_dropped * keep / (1 - p)
                             const float km = drop_keep(hq_s[row0 + 4 * fg + e], (unsigned)((t0 + r) * 16 + fi), drop_t) ? inv_keep : 0.f;
                             ds[r][hh][e] = p[r][hh][e] * (dp[e] * km + d4[e]);
                             p[r][hh][e] *= km;
@@ -598,10 +598,6 @@ int tiles_per_wave(const char* env, bool prefer2, int64_t N) {
     if (const char* e = vitk_switch(env)) return atoi(e) == 2 ? 2 : 1;
     return prefer2 && (N + 15) / 16 > AT_WAVES ? 2 : 1;
 }
-#define ATTN_LAUNCH(KERNEL, name, r, grid, lds, st, ...) do { \
-    if (r == 2) { SET_LDS(KERNEL<2>, name); hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(AT_THREADS), lds, st, __VA_ARGS__); } \
-    else        { SET_LDS(KERNEL<1>, name); hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(AT_THREADS), lds, st, __VA_ARGS__); } \
-    } while (0)
 
 }  // namespace
 
@@ -664,15 +660,24 @@ extern "C" int vitk_attn_bwd_bf16_drop(vitk_bhnd q, vitk_bhnd k, vitk_bhnd v, vi
     const size_t lds2 = lds1 + (size_t)3 * rows_pad * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int r1 = tiles_per_wave("VITK_ATTN_R_DQ", false, N), r2 = tiles_per_wave("VITK_ATTN_R_DKV", false, N);
+    const bool drop = drop_thresh(drop_p) != 0;
     if (pipe & 1) { if (int rc = attn_pipe_bwd(pa, stream, 1)) return rc; }
     else {
-        ATTN_LAUNCH(attn_bwd_dq_kernel, "attn_bwd_dq", r1, (unsigned)(B * H), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(o),
-                    to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
+#define ATTN_DQ_LAUNCH(RR, DD) do { SET_LDS((attn_bwd_dq_kernel<RR, DD>), "attn_bwd_dq"); \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<RR, DD>), dim3((unsigned)(B * H)), dim3(AT_THREADS), lds1, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(o), \
+                    to_bhnd(dout), lse, delta, to_bhnd(dq), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p)); } while (0)
+        if (r1 == 2) { if (drop) ATTN_DQ_LAUNCH(2, true); else ATTN_DQ_LAUNCH(2, false); }
+        else         { if (drop) ATTN_DQ_LAUNCH(1, true); else ATTN_DQ_LAUNCH(1, false); }
+#undef ATTN_DQ_LAUNCH
         VITK_CHECK_LAUNCH("attn_bwd_dq");
     }
     if (pipe & 2) return attn_pipe_bwd(pa, stream, 2);
-    ATTN_LAUNCH(attn_bwd_dkv_kernel, "attn_bwd_dkv", r2, (unsigned)(B * H), lds2, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(dout),
-                lse, delta, to_bhnd(dk), to_bhnd(dv), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
+#define ATTN_DKV_LAUNCH(RR, DD) do { SET_LDS((attn_bwd_dkv_kernel<RR, DD>), "attn_bwd_dkv"); \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<RR, DD>), dim3((unsigned)(B * H)), dim3(AT_THREADS), lds2, st, to_bhnd(q), to_bhnd(k), to_bhnd(v), to_bhnd(dout), \
+                lse, delta, to_bhnd(dk), to_bhnd(dv), (int)H, (int)N, scale, drop_thresh(drop_p), drop_seed, 1.0f / (1.0f - drop_p)); } while (0)
+    if (r2 == 2) { if (drop) ATTN_DKV_LAUNCH(2, true); else ATTN_DKV_LAUNCH(2, false); }
+    else         { if (drop) ATTN_DKV_LAUNCH(1, true); else ATTN_DKV_LAUNCH(1, false); }
+#undef ATTN_DKV_LAUNCH
     VITK_CHECK_LAUNCH("attn_bwd_dkv");
     return 0;
 }
