@@ -34,6 +34,15 @@
 #include <string.h>
 #include <type_traits>
 
+// The experiment bits of the kernels' argument structs (VITK_ATTN_DBG: ablations, cycle stamps) exist in the experiments flavour of the library
+// only (round 6): in the product build they are the constant 0, so that the stamp code, its registers and its per-step branches -- basic-block
+// boundaries in the middle of every step -- are not compiled into the kernels that run.
+#ifdef VITK_EXPERIMENTS
+#define AP_DBG(a) ((a).dbg)
+#else
+#define AP_DBG(a) 0
+#endif
+
 namespace {
 
 
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
                                              (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
         };
         auto issue_stage = [&](int g) {              // 9 pieces: Q 4, dO 4, lse 1 (steps past the end re-load the last one: uniform counts)
-            if (a.dbg & 1) return;
+            if (AP_DBG(a) & 1) return;
             const int gg = g < G ? g : G - 1;
             const int it = gg / FB_NKS, s = gg - it * FB_NKS;
             const int item = item_of(it), b = item / H, h = item - b * H;
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
                                              (void __attribute__((address_space(3)))*)(st + 8192), 4, 0, 0);
         };
         auto issue_kv = [&](int it, int part) {      // 13 pieces: part 0..3 of the 52 row groups of K (26) and V (26) of item `it` (clamped)
-            if (a.dbg & 1) return;
+            if (AP_DBG(a) & 1) return;
             const int itc = it < nit ? it : nit - 1;
             const int item = item_of(itc), b = item / H, h = item - b * H;
             const char* kb = reinterpret_cast<const char*>(a.k.p + b * a.k.s_b + h * a.k.s_h);
@@ -761,7 +770,7 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
         AP_WAIT_DMA();
         AP_BARRIER();          // P: stage 0 (and 1) visible -> the dQ waves form delta(0)
         AP_BARRIER();          // b_0
-        const bool prof = (a.dbg & 24) && blockIdx.x == 0;
+        const bool prof = (AP_DBG(a) & 24) && blockIdx.x == 0;
         unsigned long long tp[3] = {0, 0, 0}, t0 = 0, t1 = 0, t2 = 0;
         for (int g = 0; g <= G + 1; ++g) {
             const int s = g % FB_NKS, it = g / FB_NKS;
@@ -850,12 +859,12 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
         constexpr int KREG = 5;                                    // K^T key steps held in registers per item (the same fragments serve all 7 query
                                                                    // steps); the rest is re-read from LDS each step: 128 registers a lane
         bf16x8 ktf[KREG][2];
-        const bool prof = blockIdx.x == 0 && (((a.dbg & 8) && qt == 0) || (a.dbg & 16));
+        const bool prof = blockIdx.x == 0 && (((AP_DBG(a) & 8) && qt == 0) || (AP_DBG(a) & 16));
         unsigned long long tp[3] = {0, 0, 0}, t0 = 0, t1 = 0, t2 = 0;
         for (int g = 0; g <= G + 1; ++g) {
             if (prof) t0 = fb_now();
             const ORow req = o_rows(g + 3);                        // requested now, used two steps from now
-            if (g >= 1 && g <= G && !(a.dbg & 4)) {                // dQ of step g - 1: dS K over all keys, columns 32 qt .. 32 qt + 31 of d
+            if (g >= 1 && g <= G && !(AP_DBG(a) & 4)) {                // dQ of step g - 1: dS K over all keys, columns 32 qt .. 32 qt + 31 of d
                 const int gp = g - 1, itp = gp / FB_NKS;
                 const char* dsb = smem + FB_OFF_DS + (gp & 1) * FB_DS;
                 const char* Ks = smem + FB_OFF_K + (itp & 1) * FB_TILE;
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
         }
         if (prof && lane == 0) {
             unsigned long long* o = reinterpret_cast<unsigned long long*>(a.delta);
-            if (a.dbg & 16) o[20 + wave] = tp[2];
+            if (AP_DBG(a) & 16) o[20 + wave] = tp[2];
             if (qt == 0) { o[8] = tp[0]; o[9] = tp[1]; o[10] = tp[2]; }
         }
         return;
@@ -1086,8 +1095,8 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
         }
     };
 
-    const bool work = !(a.dbg & 2);
-    const bool prof = blockIdx.x == 0 && (((a.dbg & 8) && wave == 2) || (a.dbg & 16));
+    const bool work = !(AP_DBG(a) & 2);
+    const bool prof = blockIdx.x == 0 && (((AP_DBG(a) & 8) && wave == 2) || (AP_DBG(a) & 16));
     unsigned long long tp[4] = {0, 0, 0, 0}, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int g = 0; g <= G + 1; ++g) {
         if (prof) t0 = fb_now();
@@ -1103,7 +1112,7 @@ __global__ __launch_bounds__(fb_threads(KT)) void attn_bwd_fused_kernel(const Fu
     }
     if (prof && lane == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(a.delta);
-        if (a.dbg & 16) o[20 + wave] = tp[3];
+        if (AP_DBG(a) & 16) o[20 + wave] = tp[3];
         if (wave == 2) { o[0] = tp[0]; o[1] = tp[1]; o[2] = tp[2]; o[3] = tp[3]; o[4] = (unsigned long long)G; }
     }
 }
