@@ -851,3 +851,26 @@ def test_fused_backward_with_deferred_folds_equals_immediate_folds():
     finally:
         OPS.deferred_folds = real
     assert all(torch.equal(a, b) for a, b in zip(g1, g0))
+
+
+@pytest.mark.parametrize("nparts", [1, 15, 16, 17, 127, 128, 129, 144, 394, 1000])
+def test_fold_walk_sums_in_row_order_with_loads_in_flight(nparts):
+    """layernorm.hip fold_walk (round 6: eight loads in flight per thread): out[c] = sum_p partials[p][c] is formed as 16 phase sums (rows ph, ph + 16, ...
+    added in row order, float32) that are then added in phase order -- emulated here operation by operation, so the match is BIT-exact for every
+    batch / tail split of the walk (full batches of 8, a tail of 0..7 rows, fewer rows than phases)."""
+    cols = 200                                             # 3 full 64-column blocks + a partial one
+    g = torch.Generator(device="cuda").manual_seed(nparts)
+    part = torch.randn(nparts, cols, device="cuda", generator=g) * torch.logspace(-3, 3, cols, device="cuda")
+    out = torch.empty(cols, device="cuda")
+    K.colsum_partials(part, nparts, cols, cols, out)
+    phase = torch.zeros(16, cols, device="cuda")
+    for ph in range(16):
+        for p in range(ph, nparts, 16):
+            phase[ph] = phase[ph] + part[p]                # float32 adds, row order
+    ref = torch.zeros(cols, device="cuda")
+    for ph in range(16):
+        ref = ref + phase[ph]
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    jobs = [(part, nparts, cols, cols, torch.empty(cols, device="cuda"), False)]
+    K.fold_many(jobs)
+    assert torch.equal(jobs[0][4], ref)
